@@ -1,0 +1,36 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_index():
+    return json.loads((GOLDEN / "files" / "index.json").read_text())
+
+
+def golden_names(small_only=True):
+    idx = golden_index()
+    return sorted(n for n, m in idx.items() if not (small_only and "sampled" in m))
+
+
+@pytest.fixture(scope="session")
+def gindex():
+    return golden_index()
+
+
+def load_golden(name):
+    raw = (GOLDEN / "files" / f"{name}.jpg").read_bytes()
+    vec = np.load(GOLDEN / "files" / f"{name}.npz")
+    return raw, vec

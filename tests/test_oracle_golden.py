@@ -1,0 +1,69 @@
+"""Pins the CPU oracle (oracle/jpeg_oracle.c) against vectors captured from the reference itself
+(tools/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_index, golden_names, load_golden
+from oracle import oracle
+
+
+def test_idct_table_matches_reference_table():
+    ref = np.load(GOLDEN / "idct_table.npy")
+    assert ref.shape == (8, 8, 8, 8) and ref.dtype == np.float64
+    # bit-for-bit, not allclose: rounding at exact ties depends on the last ulp
+    assert np.array_equal(oracle.idct_table().view(np.uint64), ref.view(np.uint64))
+
+
+def test_idct_known_answers_including_ties():
+    g = np.load(GOLDEN / "idct_blocks.npz")
+    out = oracle.idct_xy(g["blocks"])
+    assert np.array_equal(out, g["out"])
+    # F6: DC*q = 4 rounds away from zero (0.5 -> 1), -4 -> -1
+    assert g["out"][0, 0, 0] == 129 and g["out"][1, 0, 0] == 127
+
+
+@pytest.mark.parametrize("dst", [(16, 16), (16, 8), (8, 16)])
+def test_upsample_known_answers(dst):
+    g = np.load(GOLDEN / "resize_blocks.npz")
+    ins, outs = g[f"in_{dst[0]}x{dst[1]}"], g[f"out_{dst[0]}x{dst[1]}"]
+    for i in range(ins.shape[0]):
+        assert np.array_equal(oracle.upsample(ins[i], dst), outs[i])
+
+
+def test_upsample_operator_shape():
+    for dst in [(16, 16), (16, 8), (8, 16)]:
+        W = oracle.load_W((8, 8), dst)
+        assert W.shape == (dst[0] * dst[1], 64)
+        assert (W.sum(1) == 15).all() and ((W != 0).sum(1) <= 3).all() and W.min() >= 0
+
+
+def test_ycbcr_to_rgb_known_answers_including_ties():
+    g = np.load(GOLDEN / "ycc_rgb.npz")
+    assert np.array_equal(oracle.ycbcr_to_rgb(g["ycc"]), g["rgb"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_file_fixture_every_seam(name):
+    raw, vec = load_golden(name)
+    meta = golden_index()[name]
+    out = oracle.decode(raw, want_idct=True)
+    parsed = out["parsed"]
+    assert np.array_equal(out["coef"], vec["coef"]), "G1 zig-zag coefficients"
+    # G2: dequantised blocks
+    deq = []
+    bpm_comp = []
+    scan = parsed.scans[0]
+    comps = [parsed.color_components[c] for c in scan.component_ids]
+    for c in comps:
+        bpm_comp += [c.quantization_table_id] * (c.repeat if len(comps) > 1 else 1)
+    for i in range(out["coef"].shape[0]):
+        q = parsed.quantization_tables[bpm_comp[i % len(bpm_comp)]]
+        d, _ = oracle.dequant_idct(out["coef"][i], q)
+        deq.append(d[0])
+    assert np.array_equal(np.stack(deq), vec["deq"]), "G2 dequantised blocks"
+    assert np.array_equal(out["idct"], vec["idct"]), "G3 IDCT output"
+    assert np.array_equal(out["planes"], vec["planes"]), "G5 YCbCr planes"
+    assert np.array_equal(out["rgb"], vec["rgb"]), "G6 image_array"
+    assert out["rgb"].dtype == np.uint8 and list(out["rgb"].shape) == meta["image_array_shape"]
+    # file_header after the scan: the reference ends on EOI handling (+2 marker, +2 bogus length read)
+    assert out["end_pos"] == scan.entropy_end
