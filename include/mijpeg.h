@@ -1,0 +1,173 @@
+/*
+ * mijpeg.h — C ABI of libmijpeg.so: the MI355X (gfx950) replacement for the per-MCU hot path of
+ * tbpaolini/PyJpegDecoder.
+ *
+ * The reference is one Python class with no FFI; the seam this library plugs into is method level
+ * (SURVEY.md §8b).  Each entry point names the reference code it replaces (all citations are into
+ * /root/reference/jpeg_decoder.py):
+ *
+ *   mj_plan_create / mj_plan_execute    JpegDecoder.baseline_dct_scan       :697-906   (Huffman decode,
+ *                                       + InverseDCT.__call__               :1561-1573  dequantise, IDCT,
+ *                                       + ResizeGrid.__call__               :1588-1626  upsample,
+ *                                       + end_of_image crop / YCbCr_to_RGB  :1373-1386, :1683-1700  colour)
+ *   mj_decode_baseline_batch            the same, one call (create + execute + sync + read back)
+ *   mj_idct_batch                       the same minus the entropy decoder: caller supplies the zig-zag
+ *                                       coefficients seen at :869 (BASELINE.json configs[1], "host Huffman")
+ *
+ * Inputs are exactly what start_of_scan (:505-650) has prepared when it calls the scan decoder: the
+ * file bytes, the offset of the first entropy-coded byte, per-component table selectors, the DHT
+ * BITS/HUFFVAL lists, the DQT tables, the restart interval and the MCU geometry — plus the offsets of
+ * the restart segments, because stage 1 decodes one restart segment per wavefront.
+ *
+ * Conventions
+ *   - plain C, no torch / numpy types; every pointer is either host or device memory as said by the
+ *     accompanying MJ_MEM_* flag; the caller owns every buffer it passes and the library never frees it.
+ *   - every function returns MJ_OK (0) or a negative MJ_ERR_*; mj_last_error() gives the text.
+ *   - per-image decode outcomes go to status[] (MJ_ST_*), they are not API errors.
+ *   - one context per GPU per host thread; a context is not thread safe.
+ *   - mj_plan_execute is asynchronous on the plan's stream; everything else is synchronous at return.
+ *   - there is NO CPU fallback anywhere in this library.
+ */
+#ifndef MIJPEG_H
+#define MIJPEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJ_VERSION 1
+
+/* API results */
+#define MJ_OK               0
+#define MJ_ERR_INVALID     (-1)   /* bad argument / inconsistent description */
+#define MJ_ERR_HIP         (-2)   /* a HIP runtime call failed (no GPU, OOM, launch failure, ...) */
+#define MJ_ERR_UNSUPPORTED (-3)   /* sampling layout / feature outside the MI355X path */
+
+/* per-image status */
+#define MJ_ST_OK          0
+#define MJ_ST_BAD_CODE    1   /* no Huffman code within 16 bits: the reference raises CorruptedJpeg (:718-719) */
+#define MJ_ST_OVERRUN     2   /* a segment needed more bits than it holds (reference: IndexError / garbage)     */
+#define MJ_ST_DESYNC      3   /* a segment's MCUs end before its next RSTn: the reference's count-driven restart
+                                 (:667-669, :898-900) would lose synchronisation here                           */
+
+/* memory spaces */
+#define MJ_MEM_NONE   0
+#define MJ_MEM_HOST   1
+#define MJ_MEM_DEVICE 2
+
+/* pixel layouts of the RGB / grey output */
+#define MJ_LAYOUT_XMAJOR   0   /* reference image_array: (W, H, C), x-major */
+#define MJ_LAYOUT_ROWMAJOR 1   /* (H, W, C) */
+
+/* flags of mj_batch.flags */
+#define MJ_FLAG_KEEP_COEF    1u   /* keep the zig-zag coefficient array (:869 seam) readable after execute */
+#define MJ_FLAG_KEEP_PLANES  2u   /* also produce the cropped int16 YCbCr planes (:1373 seam)               */
+#define MJ_FLAG_KEEP_IDCT    4u   /* also produce the per-block IDCT output (:872 return value)             */
+#define MJ_FLAG_EXACT_ONLY   8u   /* stage 2: use only the exact-order fp64 summation (no fast path)        */
+
+typedef struct mj_context mj_context;
+typedef struct mj_plan mj_plan;
+
+/* One DHT table (:293-324): BITS[16] then HUFFVAL. */
+typedef struct {
+    uint8_t bits[16];
+    uint8_t vals[256];
+} mj_huff_spec;
+
+/* One image = one interleaved baseline scan (or a single-component greyscale scan). */
+typedef struct {
+    int32_t width, height;        /* image_width, image_height (:160-169)                                    */
+    int32_t ncomp;                /* 1 or 3 (:177-183)                                                        */
+    int32_t hs[3], vs[3];         /* sampling factors in frame order Y, Cb, Cr (:205-207)                     */
+    int32_t qt_sel[3];            /* index into mj_batch.qt of each component's table (:212)                  */
+    int32_t dc_sel[3], ac_sel[3]; /* index into mj_batch.huff of each component's DC / AC table (:543-544)    */
+    int32_t restart_interval;     /* MCUs per restart segment, 0 = none (:476)                                */
+    int32_t mcu_count_h, mcu_count_v; /* (:609-619)                                                           */
+    int32_t n_segments;           /* number of restart segments = ceil(mcu_count / restart_interval) or 1     */
+    int64_t first_segment;        /* index of this image's first entry in seg_begin / seg_end                 */
+} mj_image_desc;
+
+typedef struct {
+    int32_t n_images;
+    const mj_image_desc *images;          /* host */
+
+    const uint8_t *blob;                  /* the file bytes of all images, back to back or not              */
+    int64_t blob_len;
+    int32_t blob_mem;                     /* MJ_MEM_HOST or MJ_MEM_DEVICE (device: must stay valid for the plan) */
+
+    int64_t n_segments;                   /* total entries of the two arrays below                          */
+    const int64_t *seg_begin;             /* host: blob offset of the first entropy byte of each segment    */
+    const int64_t *seg_end;               /* host: blob offset one past its last entropy byte (= position of
+                                             the RSTn / next marker)                                         */
+    int32_t n_huff;
+    const mj_huff_spec *huff;             /* host */
+    int32_t n_qt;
+    const uint16_t *qt;                   /* host: n_qt tables of 64 entries in zig-zag (file) order (:454)  */
+
+    int32_t layout;                       /* MJ_LAYOUT_*                                                     */
+    uint32_t flags;                       /* MJ_FLAG_*                                                       */
+} mj_batch;
+
+/* Sizes and per-image offsets of a plan's outputs (all outputs are packed image after image). */
+typedef struct {
+    int64_t total_blocks;                 /* coefficient blocks in the batch                                 */
+    int64_t total_mcus;
+    int64_t total_pixels;                 /* sum of width*height                                              */
+    int64_t rgb_bytes;                    /* sum of width*height*ncomp                                        */
+    int64_t entropy_bytes;                /* sum of segment lengths                                           */
+} mj_plan_info;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int mj_create(int device_id, mj_context **out);
+void mj_destroy(mj_context *ctx);
+const char *mj_last_error(const mj_context *ctx);   /* ctx may be NULL: error of the failed mj_create */
+int mj_version(void);
+
+/* ---- plan: upload once, execute many times (bench.py times mj_plan_execute only) ------------------ */
+int mj_plan_create(mj_context *ctx, const mj_batch *batch, mj_plan **out);
+void mj_plan_destroy(mj_plan *plan);
+int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
+/* offsets (in elements of the respective output) of image i inside the packed outputs */
+int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off, int64_t *rgb_off);
+
+/* Launch stage 1 (Huffman) + stage 2 (dequant/IDCT/upsample/colour) on `stream` (a hipStream_t passed as
+ * void*, NULL = the context's own stream).  `rgb_device` is a device buffer of rgb_bytes bytes, or NULL to
+ * use a plan-owned one.  Asynchronous. */
+int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
+/* The two stages separately (profiling, config 2). */
+int mj_plan_execute_stage1(mj_plan *plan, void *stream);
+int mj_plan_execute_stage2(mj_plan *plan, void *stream, uint8_t *rgb_device);
+int mj_plan_sync(mj_plan *plan);
+
+/* Device pointers of plan-owned buffers (valid until mj_plan_destroy): zero-copy hand-off to torch etc. */
+int mj_plan_device_buffers(mj_plan *plan, int16_t **coef, uint8_t **rgb, int16_t **planes, int16_t **idct);
+
+/* Copy results to host memory (after mj_plan_sync).  Any pointer may be NULL. */
+int mj_plan_read(mj_plan *plan, uint8_t *rgb_host, int16_t *coef_host, int16_t *planes_host,
+                 int16_t *idct_host, int32_t *status_host);
+/* Replace the plan's coefficient array (config 2: coefficients decoded elsewhere). mem = MJ_MEM_*. */
+int mj_plan_write_coef(mj_plan *plan, const int16_t *coef, int32_t mem);
+
+/* ---- one-shot conveniences ----------------------------------------------------------------------- */
+/* create + execute + sync + read + destroy; rgb_out/status_out host, coef_out may be NULL. */
+int mj_decode_baseline_batch(mj_context *ctx, const mj_batch *batch, uint8_t *rgb_out, int16_t *coef_out,
+                             int32_t *status_out);
+/* Stage 2 only on caller-supplied coefficients (host), descriptors as above (segment fields ignored). */
+int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, uint8_t *rgb_out);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* Average device time (ms) of each stage's kernel over `iters` back-to-back launches on the plan's
+ * stream, measured with HIP events recorded on that stream. */
+int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms);
+
+/* ---- host-side helper (no GPU needed) -------------------------------------------------------------- */
+/* The IDCT table as the library builds it: 4096 doubles laid out [u*8+v][x*8+y], the transpose of the
+ * reference's InverseDCT.idct_table (:1541-1553).  Lets CPU tests pin it bit-for-bit. */
+void mj_host_idct_table(double *tt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIJPEG_H */

@@ -1,2 +1,15 @@
-"""MI355X-native batched JPEG block-decode behind the reference's ``JpegDecoder`` class surface."""
+"""MI355X-native batched JPEG block-decode behind the reference's ``JpegDecoder`` class surface.
+
+    from pyjpegdecoder_amd import JpegDecoder          # drop-in for the reference class (one file)
+    from pyjpegdecoder_amd import BatchDecoder         # many files per launch on one GPU
+
+The pixel path lives in ``libmijpeg.so`` (hand-written HIP for gfx950, C ABI in ``include/mijpeg.h``);
+importing this package does not need a GPU, decoding does — there is no CPU fallback.
+"""
 from .errors import BackendError, CorruptedJpeg, JpegError, NotJpeg, UnsupportedJpeg  # noqa: F401
+from ._parse import ColorComponent, HuffmanTable, parse_jpeg  # noqa: F401
+from .jpeg_decoder import JpegDecoder  # noqa: F401
+from .batch import BatchDecoder, prepare_batch  # noqa: F401
+
+__all__ = ["JpegDecoder", "BatchDecoder", "prepare_batch", "parse_jpeg", "ColorComponent", "HuffmanTable",
+           "JpegError", "NotJpeg", "CorruptedJpeg", "UnsupportedJpeg", "BackendError"]

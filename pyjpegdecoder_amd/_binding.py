@@ -1,0 +1,204 @@
+"""ctypes binding of libmijpeg.so (include/mijpeg.h).  Fails loudly when the HIP library is missing or
+no GPU is present — there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from .errors import BackendError
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libmijpeg.so"
+
+MJ_OK, MJ_ERR_INVALID, MJ_ERR_HIP, MJ_ERR_UNSUPPORTED = 0, -1, -2, -3
+MJ_ST_OK, MJ_ST_BAD_CODE, MJ_ST_OVERRUN, MJ_ST_DESYNC = 0, 1, 2, 3
+MJ_MEM_NONE, MJ_MEM_HOST, MJ_MEM_DEVICE = 0, 1, 2
+MJ_LAYOUT_XMAJOR, MJ_LAYOUT_ROWMAJOR = 0, 1
+MJ_FLAG_KEEP_COEF, MJ_FLAG_KEEP_PLANES, MJ_FLAG_KEEP_IDCT, MJ_FLAG_EXACT_ONLY = 1, 2, 4, 8
+
+# every symbol include/mijpeg.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "mj_create", "mj_destroy", "mj_last_error", "mj_version",
+    "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
+    "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
+    "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table",
+)
+
+
+class HuffSpecC(ctypes.Structure):
+    _fields_ = [("bits", ctypes.c_uint8 * 16), ("vals", ctypes.c_uint8 * 256)]
+
+
+class ImageDescC(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ncomp", ctypes.c_int32),
+                ("hs", ctypes.c_int32 * 3), ("vs", ctypes.c_int32 * 3), ("qt_sel", ctypes.c_int32 * 3),
+                ("dc_sel", ctypes.c_int32 * 3), ("ac_sel", ctypes.c_int32 * 3),
+                ("restart_interval", ctypes.c_int32),
+                ("mcu_count_h", ctypes.c_int32), ("mcu_count_v", ctypes.c_int32),
+                ("n_segments", ctypes.c_int32), ("first_segment", ctypes.c_int64)]
+
+
+class BatchC(ctypes.Structure):
+    _fields_ = [("n_images", ctypes.c_int32), ("images", ctypes.POINTER(ImageDescC)),
+                ("blob", ctypes.c_void_p), ("blob_len", ctypes.c_int64), ("blob_mem", ctypes.c_int32),
+                ("n_segments", ctypes.c_int64), ("seg_begin", ctypes.c_void_p), ("seg_end", ctypes.c_void_p),
+                ("n_huff", ctypes.c_int32), ("huff", ctypes.POINTER(HuffSpecC)),
+                ("n_qt", ctypes.c_int32), ("qt", ctypes.c_void_p),
+                ("layout", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+
+
+class PlanInfoC(ctypes.Structure):
+    _fields_ = [("total_blocks", ctypes.c_int64), ("total_mcus", ctypes.c_int64), ("total_pixels", ctypes.c_int64),
+                ("rgb_bytes", ctypes.c_int64), ("entropy_bytes", ctypes.c_int64)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmijpeg.so and declare the prototypes.  Raises BackendError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise BackendError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C pyjpegdecoder_amd/csrc`). There is no CPU fallback.")
+    try:
+        L = ctypes.CDLL(str(LIB_PATH))
+    except OSError as exc:
+        raise BackendError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.mj_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.mj_destroy.argtypes = [vp]
+    L.mj_destroy.restype = None
+    L.mj_last_error.argtypes = [vp]
+    L.mj_last_error.restype = ctypes.c_char_p
+    L.mj_plan_create.argtypes = [vp, ctypes.POINTER(BatchC), ctypes.POINTER(vp)]
+    L.mj_plan_destroy.argtypes = [vp]
+    L.mj_plan_destroy.restype = None
+    L.mj_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfoC)]
+    L.mj_plan_image_offsets.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.mj_plan_execute.argtypes = [vp, vp, vp]
+    L.mj_plan_execute_stage1.argtypes = [vp, vp]
+    L.mj_plan_execute_stage2.argtypes = [vp, vp, vp]
+    L.mj_plan_sync.argtypes = [vp]
+    L.mj_plan_device_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.mj_plan_read.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.mj_plan_write_coef.argtypes = [vp, vp, i32]
+    L.mj_decode_baseline_batch.argtypes = [vp, ctypes.POINTER(BatchC), vp, vp, vp]
+    L.mj_idct_batch.argtypes = [vp, ctypes.POINTER(BatchC), vp, vp]
+    L.mj_plan_time_stages.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.mj_host_idct_table.argtypes = [vp]
+    L.mj_host_idct_table.restype = None
+    _lib = L
+    return L
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """mj_context: one per GPU per thread."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.mj_create(device, ctypes.byref(h))
+        if rc != MJ_OK:
+            raise BackendError(self.lib.mj_last_error(None).decode() or f"mj_create failed ({rc})")
+        self.handle = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc != MJ_OK:
+            msg = self.lib.mj_last_error(self.handle).decode()
+            if rc == MJ_ERR_UNSUPPORTED:
+                from .errors import UnsupportedJpeg
+                raise UnsupportedJpeg(msg)
+            raise BackendError(f"libmijpeg error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mj_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """mj_plan over a prepared batch (see batch.PreparedBatch)."""
+
+    def __init__(self, ctx: Context, batch_c: BatchC, keepalive):
+        self.ctx = ctx
+        self._keep = keepalive
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.mj_plan_create(ctx.handle, ctypes.byref(batch_c), ctypes.byref(h)))
+        self.handle = h
+        info = PlanInfoC()
+        ctx.check(ctx.lib.mj_plan_get_info(h, ctypes.byref(info)))
+        self.info = info
+
+    def execute(self, stream: int = 0, rgb_device: int = 0):
+        self.ctx.check(self.ctx.lib.mj_plan_execute(self.handle, stream or None, rgb_device or None))
+
+    def execute_stage1(self, stream: int = 0):
+        self.ctx.check(self.ctx.lib.mj_plan_execute_stage1(self.handle, stream or None))
+
+    def execute_stage2(self, stream: int = 0, rgb_device: int = 0):
+        self.ctx.check(self.ctx.lib.mj_plan_execute_stage2(self.handle, stream or None, rgb_device or None))
+
+    def sync(self):
+        self.ctx.check(self.ctx.lib.mj_plan_sync(self.handle))
+
+    def write_coef(self, coef: np.ndarray):
+        coef = np.ascontiguousarray(coef, dtype=np.int16)
+        assert coef.size == self.info.total_blocks * 64
+        self.ctx.check(self.ctx.lib.mj_plan_write_coef(self.handle, _ptr(coef), MJ_MEM_HOST))
+
+    def read(self, rgb=True, coef=False, planes=False, idct=False):
+        out = {}
+        a_rgb = np.empty(self.info.rgb_bytes, dtype=np.uint8) if rgb else None
+        a_coef = np.empty((self.info.total_blocks, 64), dtype=np.int16) if coef else None
+        a_pl = np.empty(self.info.rgb_bytes, dtype=np.int16) if planes else None
+        a_id = np.empty((self.info.total_blocks, 64), dtype=np.int16) if idct else None
+        n_images = self._keep["n_images"]
+        st = np.zeros(n_images, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.mj_plan_read(self.handle, _ptr(a_rgb), _ptr(a_coef), _ptr(a_pl), _ptr(a_id), _ptr(st)))
+        out.update(rgb=a_rgb, coef=a_coef, planes=a_pl, idct=a_id, status=st)
+        return out
+
+    def image_offsets(self, i: int):
+        b, r = ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.mj_plan_image_offsets(self.handle, i, ctypes.byref(b), ctypes.byref(r)))
+        return b.value, r.value
+
+    def device_buffers(self):
+        c, r, p, d = (ctypes.c_void_p() for _ in range(4))
+        self.ctx.check(self.ctx.lib.mj_plan_device_buffers(self.handle, ctypes.byref(c), ctypes.byref(r), ctypes.byref(p), ctypes.byref(d)))
+        return {"coef": c.value, "rgb": r.value, "planes": p.value, "idct": d.value}
+
+    def time_stages(self, iters: int = 10, rgb_device: int = 0):
+        s1, s2 = ctypes.c_float(), ctypes.c_float()
+        self.ctx.check(self.ctx.lib.mj_plan_time_stages(self.handle, iters, rgb_device or None, ctypes.byref(s1), ctypes.byref(s2)))
+        return s1.value, s2.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.mj_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,225 @@
+"""Batched decode: many JPEG files -> one plan on one MI355X.
+
+Python host code (header parsing + restart segmentation, `_parse.py`) prepares the arrays the C ABI
+takes (`include/mijpeg.h`); all pixel work happens in libmijpeg.so's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _binding as B
+from ._parse import ParsedJpeg, ScanInfo, parse_jpeg
+from .errors import CorruptedJpeg, UnsupportedJpeg
+
+_STATUS_TEXT = {
+    B.MJ_ST_BAD_CODE: "Failed to decode image (no Huffman code within 16 bits).",
+    B.MJ_ST_OVERRUN: "Failed to decode image (a restart segment ends before its MCUs do).",
+    B.MJ_ST_DESYNC: "Failed to decode image (restart markers are not where the restart interval puts them).",
+}
+
+
+def check_supported(p: ParsedJpeg) -> ScanInfo:
+    """What the MI355X path accepts: one interleaved baseline scan covering all frame components."""
+    if p.scan_mode != "baseline_dct":
+        raise UnsupportedJpeg("Encoding mode not supported by the MI355X path yet. Only 'Baseline DCT' is.")
+    if not p.scans:
+        raise CorruptedJpeg("No scan found in the file.")
+    if len(p.scans) != 1 or len(p.scans[0].component_ids) != len(p.color_components):
+        raise UnsupportedJpeg("Non-interleaved baseline scans are not supported by the MI355X path.")
+    return p.scans[0]
+
+
+@dataclass
+class PreparedBatch:
+    """Host-side arrays of one mj_batch (kept alive for the life of the plan)."""
+    parsed: List[ParsedJpeg]
+    blob: np.ndarray
+    file_offsets: np.ndarray
+    descs: ctypes.Array
+    seg_begin: np.ndarray
+    seg_end: np.ndarray
+    huff: ctypes.Array
+    n_huff: int
+    qt: np.ndarray
+    layout: int
+    flags: int
+    shapes: List[Tuple[int, int, int]] = field(default_factory=list)   # (W, H, ncomp)
+
+    def to_c(self, blob_device_ptr: int = 0) -> B.BatchC:
+        b = B.BatchC()
+        b.n_images = len(self.parsed)
+        b.images = ctypes.cast(self.descs, ctypes.POINTER(B.ImageDescC))
+        if blob_device_ptr:
+            b.blob, b.blob_mem = blob_device_ptr, B.MJ_MEM_DEVICE
+        else:
+            b.blob, b.blob_mem = self.blob.ctypes.data, B.MJ_MEM_HOST
+        b.blob_len = int(self.blob.size)
+        b.n_segments = int(self.seg_begin.size)
+        b.seg_begin, b.seg_end = self.seg_begin.ctypes.data, self.seg_end.ctypes.data
+        b.n_huff = self.n_huff
+        b.huff = ctypes.cast(self.huff, ctypes.POINTER(B.HuffSpecC))
+        b.n_qt = self.qt.shape[0]
+        b.qt = self.qt.ctypes.data
+        b.layout, b.flags = self.layout, self.flags
+        return b
+
+
+def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flags: int = 0,
+                  parsed: Optional[List[ParsedJpeg]] = None) -> PreparedBatch:
+    """Parse every file and build the descriptor / table / segment arrays of include/mijpeg.h."""
+    if parsed is None:
+        parsed = [parse_jpeg(f) for f in files]
+    n = len(parsed)
+    sizes = np.array([len(p.raw) for p in parsed], dtype=np.int64)
+    # keep every file 4-byte aligned inside the blob (stage 1 fetches aligned dwords)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum((sizes + 3) & ~3)
+    blob = np.zeros(int(offs[-1]) + 4, dtype=np.uint8)
+    descs = (B.ImageDescC * n)()
+    huff_ids: Dict[bytes, int] = {}
+    huff_list: List[Tuple[np.ndarray, np.ndarray]] = []
+    qt_ids: Dict[bytes, int] = {}
+    qt_list: List[np.ndarray] = []
+    seg_b: List[np.ndarray] = []
+    seg_e: List[np.ndarray] = []
+    n_seg_total = 0
+    shapes = []
+
+    def huff_id(spec) -> int:
+        key = spec.bits.tobytes() + spec.vals.tobytes()
+        if key not in huff_ids:
+            huff_ids[key] = len(huff_list)
+            huff_list.append((spec.bits, spec.vals))
+        return huff_ids[key]
+
+    def qt_id(zz: np.ndarray) -> int:
+        key = zz.tobytes()
+        if key not in qt_ids:
+            qt_ids[key] = len(qt_list)
+            qt_list.append(zz.astype(np.uint16))
+        return qt_ids[key]
+
+    for i, p in enumerate(parsed):
+        scan = check_supported(p)
+        blob[offs[i]:offs[i] + sizes[i]] = np.frombuffer(p.raw, dtype=np.uint8)
+        d = descs[i]
+        d.width, d.height, d.ncomp = p.image_width, p.image_height, len(scan.component_ids)
+        for c, cid in enumerate(scan.component_ids):
+            comp = p.color_components[cid]
+            d.hs[c], d.vs[c] = comp.horizontal_sampling, comp.vertical_sampling
+            if comp.quantization_table_id not in p.quantization_zz:
+                raise CorruptedJpeg("Scan uses a quantization table that the file does not define.")
+            d.qt_sel[c] = qt_id(p.quantization_zz[comp.quantization_table_id])
+            tabs = scan.huffman_tables_id[cid]
+            if tabs.dc not in scan.huffman or tabs.ac not in scan.huffman:
+                raise CorruptedJpeg("Scan uses a Huffman table that the file does not define.")
+            d.dc_sel[c] = huff_id(scan.huffman[tabs.dc])
+            d.ac_sel[c] = huff_id(scan.huffman[tabs.ac])
+        if d.ncomp == 1:
+            d.hs[0] = d.vs[0] = 1     # a single-component scan is always 8x8 MCUs (jpeg_decoder.py:595-598)
+        d.restart_interval = scan.restart_interval
+        d.mcu_count_h, d.mcu_count_v = scan.mcu_count_h, scan.mcu_count_v
+        so = scan.segment_offsets
+        if scan.restart_interval > 0:
+            want = -(-scan.mcu_count // scan.restart_interval)
+            if so.size - 1 != want:
+                raise CorruptedJpeg(
+                    f"Failed to decode image ({so.size - 2} restart markers found, {want - 1} expected).")
+            b = so[:-1].copy()
+            e = np.concatenate([so[1:-1] - 2, so[-1:]])
+        else:
+            b = np.array([scan.entropy_start], dtype=np.int64)
+            e = np.array([scan.entropy_end], dtype=np.int64)
+        d.n_segments = int(b.size)
+        d.first_segment = n_seg_total
+        n_seg_total += int(b.size)
+        seg_b.append(b + offs[i])
+        seg_e.append(e + offs[i])
+        shapes.append((p.image_width, p.image_height, d.ncomp))
+
+    huff = (B.HuffSpecC * max(1, len(huff_list)))()
+    for k, (bits, vals) in enumerate(huff_list):
+        huff[k].bits[:] = bits.tolist()
+        v = np.zeros(256, dtype=np.uint8)
+        v[:min(256, vals.size)] = vals[:256]
+        huff[k].vals[:] = v.tolist()
+    qt = np.ascontiguousarray(np.stack(qt_list), dtype=np.uint16)
+    return PreparedBatch(parsed=parsed, blob=blob, file_offsets=offs, descs=descs,
+                         seg_begin=np.ascontiguousarray(np.concatenate(seg_b), dtype=np.int64),
+                         seg_end=np.ascontiguousarray(np.concatenate(seg_e), dtype=np.int64),
+                         huff=huff, n_huff=len(huff_list), qt=qt, layout=layout, flags=flags, shapes=shapes)
+
+
+def raise_for_status(status: np.ndarray):
+    bad = np.flatnonzero(status)
+    if bad.size:
+        i = int(bad[0])
+        raise CorruptedJpeg(f"image {i}: {_STATUS_TEXT.get(int(status[i]), 'decode failed')}")
+
+
+class BatchDecoder:
+    """Decode lists of baseline JPEG files on one GPU.
+
+    >>> dec = BatchDecoder(device=0)
+    >>> images = dec.decode([open(p, 'rb').read() for p in paths])      # list of uint8 (W,H,3) arrays
+    """
+
+    def __init__(self, device: int = 0, layout: str = "xmajor"):
+        self.ctx = B.Context(device)
+        self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
+
+    def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
+        prep = prepare_batch(files, self.layout, flags)
+        plan = B.Plan(self.ctx, prep.to_c(blob_device_ptr), {"prep": prep, "n_images": len(prep.parsed)})
+        return prep, plan
+
+    def split_outputs(self, prep: PreparedBatch, flat: np.ndarray, per_pixel: int = 1) -> List[np.ndarray]:
+        out, off = [], 0
+        for (w, h, nc) in prep.shapes:
+            n = w * h * nc * per_pixel
+            a = flat[off:off + n]
+            shape = (w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)
+            out.append(a.reshape(shape + ((nc,) if nc == 3 else ())))
+            off += n
+        return out
+
+    def decode(self, files: Sequence[bytes], return_seams: bool = False):
+        """Decode files that may mix sampling layouts (one plan per layout)."""
+        parsed = [parse_jpeg(f) for f in files]
+        groups: Dict[tuple, List[int]] = {}
+        for i, p in enumerate(parsed):
+            scan = check_supported(p)
+            comps = [p.color_components[c] for c in scan.component_ids]
+            key = (len(comps),) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            groups.setdefault(key, []).append(i)
+        results: List[Optional[np.ndarray]] = [None] * len(files)
+        seams: List[Optional[dict]] = [None] * len(files)
+        flags = (B.MJ_FLAG_KEEP_PLANES | B.MJ_FLAG_KEEP_IDCT) if return_seams else 0
+        for idxs in groups.values():
+            prep = prepare_batch([files[i] for i in idxs], self.layout, flags, [parsed[i] for i in idxs])
+            plan = B.Plan(self.ctx, prep.to_c(), {"prep": prep, "n_images": len(idxs)})
+            try:
+                plan.execute()
+                plan.sync()
+                out = plan.read(rgb=True, coef=return_seams, planes=return_seams, idct=return_seams)
+                raise_for_status(out["status"])
+                imgs = self.split_outputs(prep, out["rgb"])
+                for k, i in enumerate(idxs):
+                    results[i] = imgs[k]
+                    if return_seams:
+                        b0, _ = plan.image_offsets(k)
+                        b1 = plan.image_offsets(k + 1)[0] if k + 1 < len(idxs) else plan.info.total_blocks
+                        w, h, nc = prep.shapes[k]
+                        po = sum(s[0] * s[1] * s[2] for s in prep.shapes[:k])
+                        seams[i] = {"coef": out["coef"][b0:b1], "idct": out["idct"][b0:b1].reshape(-1, 8, 8),
+                                    "planes": out["planes"][po:po + w * h * nc].reshape(w, h, nc)}
+            finally:
+                plan.close()
+        return (results, seams) if return_seams else results
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,472 @@
+// C ABI of libmijpeg.so: context, plan (upload once / execute many), one-shot helpers.
+// Host-side only; the kernels are in huffman.hip and reconstruct.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "mijpeg_internal.h"
+
+struct mj_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
+    std::string err;
+};
+
+static std::string g_create_err;
+
+struct mj_plan {
+    mj_context *ctx = nullptr;
+    int32_t n_images = 0;
+    int32_t layout = 0;
+    uint32_t flags = 0;
+    int hmax = 1, vmax = 1, ncomp = 3;
+    int lut_slots = 1;
+    bool uniform = false;
+    int32_t mcus_per_image = 0;
+    mj_plan_info info{};
+    std::vector<mj::DevImage> h_images;
+    // device
+    uint8_t *d_blob_owned = nullptr;
+    const uint8_t *d_blob = nullptr;
+    mj::DevSegment *d_segs = nullptr;
+    int64_t n_segs = 0;
+    mj::DevImage *d_images = nullptr;
+    mj::DevHuff *d_huff = nullptr;
+    uint16_t *d_qt = nullptr;
+    int64_t *d_mcu_prefix = nullptr;
+    int16_t *d_coef = nullptr;
+    uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
+    int16_t *d_planes = nullptr;
+    int16_t *d_idct = nullptr;
+    int32_t *d_status = nullptr;
+    uint8_t *last_rgb = nullptr;    // where the most recent execute wrote
+};
+
+namespace {
+
+int fail(mj_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define MJ_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((ctx), MJ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// InverseDCT.idct_table (jpeg_decoder.py:1541-1553): 0.25*Cu*Cv*cos((2x+1)*pi*u/16)*cos((2y+1)*pi*v/16),
+// left to right in IEEE doubles with libm cos (= Python's math.cos).  Stored transposed: [u*8+v][x*8+y].
+void build_idct_tt(double *tt) {
+    const double pi = 3.141592653589793;
+    const double isq2 = pow(2.0, -0.5);
+    for (int x = 0; x < 8; x++)
+        for (int y = 0; y < 8; y++)
+            for (int u = 0; u < 8; u++)
+                for (int v = 0; v < 8; v++) {
+                    volatile double t = 0.25 * (u == 0 ? isq2 : 1.0);
+                    t = t * (v == 0 ? isq2 : 1.0);
+                    volatile double ca = cos(((double)(2 * x + 1) * pi) * (double)u / 16.0);
+                    volatile double cb = cos(((double)(2 * y + 1) * pi) * (double)v / 16.0);
+                    t = t * ca;
+                    t = t * cb;
+                    tt[(u * 8 + v) * 64 + (x * 8 + y)] = t;
+                }
+}
+
+// DHT -> canonical code book + 9-bit LUT (jpeg_decoder.py:366-377)
+void build_dev_huff(const mj_huff_spec &spec, mj::DevHuff &h) {
+    memset(&h, 0, sizeof(h));
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code <<= 1;
+        h.first_code[l] = code;
+        h.count[l] = spec.bits[l - 1];
+        h.first_sym[l] = k;
+        for (int i = 0; i < spec.bits[l - 1] && k < 256; ++i, ++k, ++code) {
+            h.vals[k] = spec.vals[k];
+            if (l <= mj::kLutBits && code < (1 << l)) {
+                int shift = mj::kLutBits - l;
+                for (int f = 0; f < (1 << shift); ++f) {
+                    int idx = (code << shift) | f;
+                    if (h.lut[idx] == 0) h.lut[idx] = (uint16_t)((l << 8) | spec.vals[k]);   // first (shortest) key wins
+                }
+            }
+        }
+    }
+}
+
+bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
+    if (d.ncomp == 1) { hmax = vmax = 1; return true; }
+    if (d.ncomp != 3) return false;
+    if (d.hs[1] != 1 || d.vs[1] != 1 || d.hs[2] != 1 || d.vs[2] != 1) return false;
+    hmax = d.hs[0]; vmax = d.vs[0];
+    return (hmax == 1 || hmax == 2) && (vmax == 1 || vmax == 2);
+}
+
+template <typename T>
+int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
+    MJ_HIP(ctx, hipMalloc((void **)dst, n * sizeof(T) + pad_bytes + 16));
+    if (pad_bytes) MJ_HIP(ctx, hipMemset((char *)*dst + n * sizeof(T), 0, pad_bytes));
+    if (n) MJ_HIP(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return MJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mj_version(void) { return MJ_VERSION; }
+
+const char *mj_last_error(const mj_context *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mj_create(int device_id, mj_context **out) {
+    if (!out) return fail(nullptr, MJ_ERR_INVALID, "mj_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, MJ_ERR_HIP, "mj_create: no HIP device available (%s); libmijpeg has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, MJ_ERR_INVALID, "mj_create: device %d of %d", device_id, n);
+    mj_context *ctx = new mj_context();
+    ctx->device = device_id;
+    MJ_HIP(nullptr, hipSetDevice(device_id));
+    MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    std::vector<double> tt(64 * 64);
+    build_idct_tt(tt.data());
+    MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
+    MJ_HIP(nullptr, hipMemcpy(ctx->d_idct_tt, tt.data(), tt.size() * sizeof(double), hipMemcpyHostToDevice));
+    *out = ctx;
+    return MJ_OK;
+}
+
+void mj_destroy(mj_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+/* Host-side table export for tests: the IDCT table exactly as the library builds it ([u*8+v][x*8+y]). */
+void mj_host_idct_table(double *tt) { build_idct_tt(tt); }
+
+void mj_plan_destroy(mj_plan *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_qt, p->d_mcu_prefix, p->d_coef,
+                    p->d_rgb, p->d_planes, p->d_idct, p->d_status};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
+    if (!ctx) return MJ_ERR_INVALID;
+    if (!b || !out) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: NULL argument");
+    *out = nullptr;
+    if (b->n_images <= 0 || !b->images) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: empty batch");
+    if (b->layout != MJ_LAYOUT_XMAJOR && b->layout != MJ_LAYOUT_ROWMAJOR)
+        return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: unknown layout %d", b->layout);
+    if (b->n_qt <= 0 || !b->qt) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: no quantisation tables");
+    MJ_HIP(ctx, hipSetDevice(ctx->device));
+
+    mj_plan *p = new mj_plan();
+    p->ctx = ctx;
+    p->n_images = b->n_images;
+    p->layout = b->layout;
+    p->flags = b->flags;
+    struct Guard { mj_plan *p; ~Guard() { if (p) mj_plan_destroy(p); } } guard{p};
+
+    const bool have_entropy = b->blob_mem != MJ_MEM_NONE && b->blob != nullptr;
+    if (have_entropy && (b->n_huff <= 0 || !b->huff || !b->seg_begin || !b->seg_end))
+        return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: entropy data without Huffman tables / segment offsets");
+
+    std::vector<mj::DevImage> &imgs = p->h_images;
+    std::vector<mj::DevSegment> segs;
+    std::vector<int64_t> mcu_prefix(b->n_images + 1, 0);
+    imgs.resize(b->n_images);
+    int64_t blk = 0, mcu = 0, rgb = 0, pix = 0, ent = 0;
+    p->uniform = true;
+    p->lut_slots = 1;
+    for (int i = 0; i < b->n_images; ++i) {
+        const mj_image_desc &d = b->images[i];
+        mj::DevImage &im = imgs[i];
+        memset(&im, 0, sizeof(im));
+        int hmax, vmax;
+        if (d.width <= 0 || d.height <= 0 || d.width > 65535 || d.height > 65535)
+            return fail(ctx, MJ_ERR_INVALID, "image %d: bad dimensions %dx%d", i, d.width, d.height);
+        if (!sampling_class(d, hmax, vmax))
+            return fail(ctx, MJ_ERR_UNSUPPORTED,
+                        "image %d: sampling layout not supported by the MI355X path (ncomp=%d, Y %dx%d, Cb %dx%d, Cr %dx%d); "
+                        "supported: greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0", i, d.ncomp, d.hs[0], d.vs[0], d.hs[1], d.vs[1], d.hs[2], d.vs[2]);
+        if (i == 0) { p->hmax = hmax; p->vmax = vmax; p->ncomp = d.ncomp; }
+        else if (hmax != p->hmax || vmax != p->vmax || d.ncomp != p->ncomp)
+            return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: a plan holds one sampling layout; split the batch by layout", i);
+        const int mw = d.ncomp == 1 ? 8 : 8 * hmax, mh = d.ncomp == 1 ? 8 : 8 * vmax;
+        if (d.mcu_count_h != (d.width + mw - 1) / mw || d.mcu_count_v != (d.height + mh - 1) / mh)
+            return fail(ctx, MJ_ERR_INVALID, "image %d: MCU counts %dx%d do not match %dx%d with %dx%d MCUs", i,
+                        d.mcu_count_h, d.mcu_count_v, d.width, d.height, mw, mh);
+        im.width = d.width; im.height = d.height; im.ncomp = d.ncomp;
+        im.hmax = hmax; im.vmax = vmax;
+        im.blocks_per_mcu = d.ncomp == 1 ? 1 : hmax * vmax + 2;
+        im.mcu_count_h = d.mcu_count_h; im.mcu_count_v = d.mcu_count_v;
+        im.restart_interval = d.restart_interval;
+        const int64_t mcus = (int64_t)d.mcu_count_h * d.mcu_count_v;
+        // per-block component / table slots, decode order (jpeg_decoder.py:774, :805)
+        int nb = 0;
+        for (int c = 0; c < d.ncomp; ++c) {
+            if (d.qt_sel[c] < 0 || d.qt_sel[c] >= b->n_qt) return fail(ctx, MJ_ERR_INVALID, "image %d: qt_sel out of range", i);
+            im.qt_index[c] = d.qt_sel[c];
+            int dslot = 0, aslot = 0;
+            if (have_entropy) {
+                if (d.dc_sel[c] < 0 || d.dc_sel[c] >= b->n_huff || d.ac_sel[c] < 0 || d.ac_sel[c] >= b->n_huff)
+                    return fail(ctx, MJ_ERR_INVALID, "image %d: Huffman table selector out of range", i);
+                auto slot_of = [&](int t) {
+                    for (int s = 0; s < im.n_tabs; ++s) if (im.tab_index[s] == t) return s;
+                    im.tab_index[im.n_tabs] = t;
+                    return im.n_tabs++;
+                };
+                dslot = slot_of(d.dc_sel[c]);
+                aslot = slot_of(d.ac_sel[c]);
+            }
+            const int rep = d.ncomp == 1 ? 1 : (c == 0 ? hmax * vmax : 1);
+            for (int r = 0; r < rep; ++r, ++nb) {
+                im.blk_comp[nb] = (uint8_t)c; im.blk_dc_slot[nb] = (uint8_t)dslot; im.blk_ac_slot[nb] = (uint8_t)aslot;
+            }
+        }
+        if (im.n_tabs > p->lut_slots) p->lut_slots = im.n_tabs;
+        im.block_off = blk; im.mcu_off = mcu; im.rgb_off = rgb; im.pix_off = pix;
+        mcu_prefix[i] = mcu;
+        if (i > 0 && (d.width != b->images[0].width || d.height != b->images[0].height)) p->uniform = false;
+        if (have_entropy) {
+            const int64_t want = d.restart_interval > 0 ? (mcus + d.restart_interval - 1) / d.restart_interval : 1;
+            if (d.n_segments != want)
+                return fail(ctx, MJ_ERR_INVALID, "image %d: %d restart segments given, %lld expected (restart interval %d, %lld MCUs)",
+                            i, d.n_segments, (long long)want, d.restart_interval, (long long)mcus);
+            if (d.first_segment < 0 || d.first_segment + d.n_segments > b->n_segments)
+                return fail(ctx, MJ_ERR_INVALID, "image %d: segment range outside seg_begin/seg_end", i);
+            for (int s = 0; s < d.n_segments; ++s) {
+                const int64_t sb = b->seg_begin[d.first_segment + s], se = b->seg_end[d.first_segment + s];
+                if (sb < 0 || se < sb || se > b->blob_len || se - sb > 0x7fff0000)
+                    return fail(ctx, MJ_ERR_INVALID, "image %d segment %d: bad byte range [%lld, %lld)", i, s, (long long)sb, (long long)se);
+                mj::DevSegment g{};
+                g.begin = sb; g.len = (int32_t)(se - sb); g.image = i;
+                g.mcu0 = d.restart_interval > 0 ? s * d.restart_interval : 0;
+                g.n_mcu = (int32_t)(d.restart_interval > 0 ? std::min<int64_t>(d.restart_interval, mcus - g.mcu0) : mcus);
+                g.last = s == d.n_segments - 1;
+                segs.push_back(g);
+                ent += se - sb;
+            }
+        }
+        blk += mcus * im.blocks_per_mcu;
+        mcu += mcus;
+        rgb += (int64_t)d.width * d.height * d.ncomp;
+        pix += (int64_t)d.width * d.height;
+    }
+    mcu_prefix[b->n_images] = mcu;
+    p->mcus_per_image = (int32_t)(mcu / b->n_images);
+    p->info.total_blocks = blk; p->info.total_mcus = mcu; p->info.total_pixels = pix;
+    p->info.rgb_bytes = rgb; p->info.entropy_bytes = ent;
+    p->n_segs = (int64_t)segs.size();
+
+    int rc;
+    if ((rc = upload(ctx, &p->d_images, imgs.data(), imgs.size())) != MJ_OK) return rc;
+    if ((rc = upload(ctx, &p->d_mcu_prefix, mcu_prefix.data(), mcu_prefix.size())) != MJ_OK) return rc;
+    if ((rc = upload(ctx, &p->d_qt, b->qt, (size_t)b->n_qt * 64)) != MJ_OK) return rc;
+    if (have_entropy) {
+        std::vector<mj::DevHuff> hh(b->n_huff);
+        for (int t = 0; t < b->n_huff; ++t) build_dev_huff(b->huff[t], hh[t]);
+        if ((rc = upload(ctx, &p->d_huff, hh.data(), hh.size())) != MJ_OK) return rc;
+        if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
+        if (b->blob_mem == MJ_MEM_HOST) {
+            if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
+            p->d_blob = p->d_blob_owned;
+        } else {
+            if (((uintptr_t)b->blob & 3) != 0) return fail(ctx, MJ_ERR_INVALID, "device blob must be 4-byte aligned");
+            p->d_blob = b->blob;
+        }
+    }
+    MJ_HIP(ctx, hipMalloc((void **)&p->d_coef, (size_t)blk * 64 * sizeof(int16_t) + 16));
+    MJ_HIP(ctx, hipMemset(p->d_coef, 0, (size_t)blk * 64 * sizeof(int16_t)));
+    MJ_HIP(ctx, hipMalloc((void **)&p->d_status, (size_t)b->n_images * sizeof(int32_t)));
+    MJ_HIP(ctx, hipMemset(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t)));
+    if (b->flags & MJ_FLAG_KEEP_PLANES) MJ_HIP(ctx, hipMalloc((void **)&p->d_planes, (size_t)rgb * sizeof(int16_t) + 16));
+    if (b->flags & MJ_FLAG_KEEP_IDCT) MJ_HIP(ctx, hipMalloc((void **)&p->d_idct, (size_t)blk * 64 * sizeof(int16_t) + 16));
+    guard.p = nullptr;
+    *out = p;
+    return MJ_OK;
+}
+
+int mj_plan_get_info(const mj_plan *p, mj_plan_info *info) {
+    if (!p || !info) return MJ_ERR_INVALID;
+    *info = p->info;
+    return MJ_OK;
+}
+
+int mj_plan_image_offsets(const mj_plan *p, int32_t image, int64_t *block_off, int64_t *rgb_off) {
+    if (!p || image < 0 || image >= p->n_images) return MJ_ERR_INVALID;
+    if (block_off) *block_off = p->h_images[image].block_off;
+    if (rgb_off) *rgb_off = p->h_images[image].rgb_off;
+    return MJ_OK;
+}
+
+int mj_plan_execute_stage1(mj_plan *p, void *stream) {
+    if (!p) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data (stage 1 unavailable)");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
+    MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
+                                   p->d_status, p->lut_slots));
+    return MJ_OK;
+}
+
+int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (!p) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (!rgb_device) {
+        if (!p->d_rgb) MJ_HIP(ctx, hipMalloc((void **)&p->d_rgb, (size_t)p->info.rgb_bytes + 16));
+        rgb_device = p->d_rgb;
+    }
+    p->last_rgb = rgb_device;
+    mj::ReconArgs a{};
+    a.images = p->d_images; a.n_images = p->n_images; a.mcu_prefix = p->d_mcu_prefix;
+    a.total_mcus = p->info.total_mcus; a.coef = p->d_coef; a.qt = p->d_qt; a.idct_tt = ctx->d_idct_tt;
+    a.up_taps = nullptr; a.rgb = rgb_device; a.planes = p->d_planes; a.idct_out = p->d_idct;
+    a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
+    a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
+    MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
+    return MJ_OK;
+}
+
+int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    int rc = mj_plan_execute_stage1(p, stream);
+    if (rc != MJ_OK) return rc;
+    return mj_plan_execute_stage2(p, stream, rgb_device);
+}
+
+int mj_plan_sync(mj_plan *p) {
+    if (!p) return MJ_ERR_INVALID;
+    MJ_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    return MJ_OK;
+}
+
+int mj_plan_device_buffers(mj_plan *p, int16_t **coef, uint8_t **rgb, int16_t **planes, int16_t **idct) {
+    if (!p) return MJ_ERR_INVALID;
+    if (coef) *coef = p->d_coef;
+    if (rgb) *rgb = p->last_rgb ? p->last_rgb : p->d_rgb;
+    if (planes) *planes = p->d_planes;
+    if (idct) *idct = p->d_idct;
+    return MJ_OK;
+}
+
+int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *planes_host, int16_t *idct_host,
+                 int32_t *status_host) {
+    if (!p) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    MJ_HIP(ctx, hipDeviceSynchronize());
+    if (rgb_host) {
+        if (!p->last_rgb) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: nothing executed yet");
+        MJ_HIP(ctx, hipMemcpy(rgb_host, p->last_rgb, (size_t)p->info.rgb_bytes, hipMemcpyDeviceToHost));
+    }
+    if (coef_host) MJ_HIP(ctx, hipMemcpy(coef_host, p->d_coef, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
+    if (planes_host) {
+        if (!p->d_planes) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: plan was created without MJ_FLAG_KEEP_PLANES");
+        MJ_HIP(ctx, hipMemcpy(planes_host, p->d_planes, (size_t)p->info.rgb_bytes * 2, hipMemcpyDeviceToHost));
+    }
+    if (idct_host) {
+        if (!p->d_idct) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: plan was created without MJ_FLAG_KEEP_IDCT");
+        MJ_HIP(ctx, hipMemcpy(idct_host, p->d_idct, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
+    }
+    if (status_host) MJ_HIP(ctx, hipMemcpy(status_host, p->d_status, (size_t)p->n_images * 4, hipMemcpyDeviceToHost));
+    return MJ_OK;
+}
+
+int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
+    if (!p || !coef) return MJ_ERR_INVALID;
+    MJ_HIP(p->ctx, hipMemcpy(p->d_coef, coef, (size_t)p->info.total_blocks * 128,
+                             mem == MJ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return MJ_OK;
+}
+
+int mj_decode_baseline_batch(mj_context *ctx, const mj_batch *batch, uint8_t *rgb_out, int16_t *coef_out,
+                             int32_t *status_out) {
+    mj_plan *p = nullptr;
+    int rc = mj_plan_create(ctx, batch, &p);
+    if (rc != MJ_OK) return rc;
+    rc = mj_plan_execute(p, nullptr, nullptr);
+    if (rc == MJ_OK) rc = mj_plan_sync(p);
+    if (rc == MJ_OK) rc = mj_plan_read(p, rgb_out, coef_out, nullptr, nullptr, status_out);
+    mj_plan_destroy(p);
+    return rc;
+}
+
+int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, uint8_t *rgb_out) {
+    if (!batch || !coef) return fail(ctx, MJ_ERR_INVALID, "mj_idct_batch: NULL argument");
+    mj_batch b = *batch;
+    b.blob = nullptr; b.blob_mem = MJ_MEM_NONE;
+    mj_plan *p = nullptr;
+    int rc = mj_plan_create(ctx, &b, &p);
+    if (rc != MJ_OK) return rc;
+    rc = mj_plan_write_coef(p, coef, MJ_MEM_HOST);
+    if (rc == MJ_OK) rc = mj_plan_execute_stage2(p, nullptr, nullptr);
+    if (rc == MJ_OK) rc = mj_plan_sync(p);
+    if (rc == MJ_OK) rc = mj_plan_read(p, rgb_out, nullptr, nullptr, nullptr, nullptr);
+    mj_plan_destroy(p);
+    return rc;
+}
+
+int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms) {
+    if (!p || iters <= 0) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = ctx->stream;
+    hipEvent_t e0, e1;
+    MJ_HIP(ctx, hipEventCreate(&e0));
+    MJ_HIP(ctx, hipEventCreate(&e1));
+    int rc = MJ_OK;
+    float ms = 0.f;
+    if (stage1_ms) {
+        *stage1_ms = 0.f;
+        if (p->d_blob) {
+            if ((rc = mj_plan_execute_stage1(p, s)) != MJ_OK) return rc;   // warm
+            MJ_HIP(ctx, hipEventRecord(e0, s));
+            for (int i = 0; i < iters && rc == MJ_OK; ++i)
+                rc = mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
+                                        p->d_status, p->lut_slots) == hipSuccess ? MJ_OK : MJ_ERR_HIP;
+            MJ_HIP(ctx, hipEventRecord(e1, s));
+            MJ_HIP(ctx, hipEventSynchronize(e1));
+            MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            *stage1_ms = ms / iters;
+        }
+    }
+    if (stage2_ms && rc == MJ_OK) {
+        if ((rc = mj_plan_execute_stage2(p, s, rgb_device)) != MJ_OK) return rc;   // warm
+        MJ_HIP(ctx, hipEventRecord(e0, s));
+        for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = mj_plan_execute_stage2(p, s, rgb_device);
+        MJ_HIP(ctx, hipEventRecord(e1, s));
+        MJ_HIP(ctx, hipEventSynchronize(e1));
+        MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *stage2_ms = ms / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// Stage 1 — baseline Huffman entropy decode on gfx950: one wavefront per restart segment.
+//
+// Replaces the entropy part of JpegDecoder.baseline_dct_scan (jpeg_decoder.py:734-866, :894-900) with its
+// helpers get_bits (:654-695), next_huffval (:712-722) and bin_twos_complement (:1636-1646).
+//
+// Mapping to the machine
+//   * A restart segment is the largest unit with no serial dependence on its neighbours (DC predictors
+//     reset, bit reader re-aligned, :898-900), so each wavefront owns one segment and walks it serially.
+//     The walk is wave-uniform: the bit buffer, positions, run/size arithmetic all live in SGPRs and
+//     issue on the scalar unit; 8 waves per SIMD hide the dependent-lookup latency of each other.
+//   * The 64 lanes are used for what is parallel:
+//       - the bitstream is fetched 256 B at a time, one dword per lane, and the serial walker pulls
+//         dwords out of that register with v_readlane (no LDS or memory access on the critical path);
+//         the next 256 B are already in flight while the current ones are consumed;
+//       - lane l owns zig-zag coefficient l of the current block: a decoded value is "scattered" with a
+//         single compare+select, and the finished block leaves as one coalesced 128-B store.
+//   * Huffman tables: the 9-bit primary LUT of every table the image uses is copied into LDS once per
+//     wave (1 KiB each); codes longer than 9 bits (rare) take a canonical search through L2-resident
+//     first_code/count arrays with scalar loads.
+//   * Byte stuffing follows the reference literally: whatever follows a 0xFF byte is skipped (:676-677).
+//     Four bytes are consumed per refill when none of them is 0xFF, else the refill goes byte-wise.
+//   * Restart handling is count-driven in the reference (:667-669); here the host has located the RSTn
+//     markers, and a segment whose MCUs do not end exactly at its marker is reported (MJ_ST_DESYNC /
+//     MJ_ST_OVERRUN) instead of silently decoding garbage.
+#include "mijpeg_internal.h"
+
+namespace mj {
+
+namespace {
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct BitReader {
+    // all members are wave-uniform
+    const uint32_t *words;   // 4-byte aligned start of the stream
+    uint32_t cur, nxt;       // per-lane: dwords [cd0 + lane] and [cd0 + 63 + lane]
+    int cd0;                 // dword index of lane 0 of `cur`
+    int pos;                 // next byte to load, relative to `words`
+    int end;                 // one past the last byte of the segment, relative to `words`
+    uint64_t bb;             // bit buffer, next bit = bit 63
+    int bc;                  // valid bits in bb
+    int pad;                 // bits of zero padding appended past `end`
+    int lane;
+
+    __device__ __forceinline__ void init(const uint8_t *blob, int64_t begin, int len, int lane_) {
+        lane = lane_;
+        int64_t abase = begin & ~(int64_t)3;
+        words = reinterpret_cast<const uint32_t *>(blob + abase);
+        pos = (int)(begin - abase);
+        end = pos + len;
+        cd0 = 0;
+        cur = words[lane];
+        nxt = words[63 + lane];
+        bb = 0;
+        bc = 0;
+        pad = 0;
+    }
+
+    // dwords [i], [i+1] of the stream around byte `p`, shifted so that byte p is the low byte
+    __device__ __forceinline__ uint32_t peek_raw(int p) {
+        int i = (p >> 2) - cd0;
+        if (i >= 63) {            // uniform branch: step to the next 252-byte window
+            cd0 += 63;
+            cur = nxt;
+            nxt = words[cd0 + 63 + lane];
+            i -= 63;
+        }
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cur, i);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cur, i + 1);
+        uint64_t w = ((uint64_t)hi << 32) | lo;
+        return (uint32_t)(w >> ((p & 3) * 8));
+    }
+
+    // make at least 32 bits available (zero-padded past the end of the segment)
+    __device__ __forceinline__ void refill() {
+        while (bc <= 32) {
+            if (pos + 4 <= end) {
+                uint32_t w = peek_raw(pos);
+                // any byte == 0xFF ?  (zero byte in ~w)
+                uint32_t nw = ~w;
+                if (((nw - 0x01010101u) & ~nw & 0x80808080u) == 0) {
+                    uint32_t be = __builtin_bswap32(w);
+                    bb |= (uint64_t)be << (32 - bc);
+                    bc += 32;
+                    pos += 4;
+                    continue;
+                }
+                uint32_t b = w & 0xFFu;                 // byte-wise, reference semantics (:673-677)
+                pos += (b == 0xFFu) ? 2 : 1;
+                bb |= (uint64_t)b << (56 - bc);
+                bc += 8;
+            } else if (pos < end) {
+                uint32_t b = peek_raw(pos) & 0xFFu;
+                pos += (b == 0xFFu) ? 2 : 1;
+                bb |= (uint64_t)b << (56 - bc);
+                bc += 8;
+            } else {
+                pad += 8;                                // past the end: feed zeros, remember how many
+                bc += 8;
+            }
+        }
+    }
+
+    __device__ __forceinline__ uint32_t peek16() const { return (uint32_t)(bb >> 48); }
+    __device__ __forceinline__ void skip(int n) { bb <<= n; bc -= n; }
+    __device__ __forceinline__ uint32_t take(int n) {   // 1 <= n <= 16
+        uint32_t v = (uint32_t)(bb >> (64 - n));
+        bb <<= n;
+        bc -= n;
+        return v;
+    }
+};
+
+// next_huffval (:712-722).  Returns the symbol, or -1 if no code matches within 16 bits.
+__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut, const DevHuff *tab) {
+    uint32_t p16 = br.peek16();
+    int e = rfl((int)lut[p16 >> (16 - kLutBits)]);
+    int len = e >> 8;
+    int sym = e & 0xFF;
+    if (len == 0) {
+        sym = -1;
+        for (int l = kLutBits + 1; l <= 16; ++l) {
+            int d = (int)(p16 >> (16 - l)) - tab->first_code[l];
+            if (d >= 0 && d < tab->count[l]) {
+                sym = tab->vals[tab->first_sym[l] + d];
+                len = l;
+                break;
+            }
+        }
+        if (sym < 0) return -1;
+    }
+    br.skip(len);
+    return sym;
+}
+
+// bin_twos_complement (:1636-1646)
+__device__ __forceinline__ int extend(uint32_t raw, int n) {
+    return (raw >> (n - 1)) ? (int)raw : (int)raw - ((1 << n) - 1);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blob,
+                                                 const DevSegment *__restrict__ segs, int64_t n_segs,
+                                                 const DevImage *__restrict__ images,
+                                                 const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
+                                                 int32_t *__restrict__ status, int lut_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][lut_slots][kLutSize]
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int64_t seg_id = (int64_t)blockIdx.x * 4 + wave;
+    if (seg_id >= n_segs) return;
+
+    const DevSegment *sg = segs + seg_id;
+    const int image = sg->image;
+    const DevImage *im = images + image;
+    const int n_tabs = im->n_tabs;
+    uint16_t *my_lut = s_lut + (size_t)wave * lut_slots * kLutSize;
+
+    // stage this image's primary LUTs: 1 KiB each = one 16-byte load per lane
+    for (int t = 0; t < n_tabs; ++t) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(huff[im->tab_index[t]].lut);
+        reinterpret_cast<uint4 *>(my_lut + t * kLutSize)[lane] = src[lane];
+    }
+
+    BitReader br;
+    br.init(blob, sg->begin, sg->len, lane);
+
+    const int bpm = im->blocks_per_mcu;
+    const int n_mcu = sg->n_mcu;
+    // per-block tables packed into scalars: 8 blocks x 8 bits each
+    const uint64_t comp_pk = *reinterpret_cast<const uint64_t *>(im->blk_comp);
+    const uint64_t dc_pk = *reinterpret_cast<const uint64_t *>(im->blk_dc_slot);
+    const uint64_t ac_pk = *reinterpret_cast<const uint64_t *>(im->blk_ac_slot);
+
+    int16_t *out = coef + (im->block_off + (int64_t)sg->mcu0 * bpm) * 64 + lane;
+    int pred0 = 0, pred1 = 0, pred2 = 0;   // previous_dc (:735), int16 arithmetic
+    int err = 0;
+
+    for (int m = 0; m < n_mcu; ++m) {
+        for (int b = 0; b < bpm; ++b) {
+            const int comp = (int)((comp_pk >> (8 * b)) & 0xFF);
+            const int dslot = (int)((dc_pk >> (8 * b)) & 0xFF);
+            const int aslot = (int)((ac_pk >> (8 * b)) & 0xFF);
+            const uint16_t *dc_lut = my_lut + dslot * kLutSize;
+            const uint16_t *ac_lut = my_lut + aslot * kLutSize;
+            const DevHuff *dc_tab = huff + im->tab_index[dslot];
+            const DevHuff *ac_tab = huff + im->tab_index[aslot];
+            int v = 0;   // this lane's coefficient of the block (lane = zig-zag index)
+
+            // ---- DC (:810-820)
+            br.refill();
+            int s = decode_symbol(br, dc_lut, dc_tab);
+            if (s < 0 || s > 16) { err = MJ_ST_BAD_CODE; s = 0; }
+            int diff = 0;
+            if (s > 0) diff = extend(br.take(s), s);
+            int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
+            int dcv = (int)(int16_t)(diff + pred);
+            if (comp == 0) pred0 = dcv; else if (comp == 1) pred1 = dcv; else pred2 = dcv;
+            if (lane == 0) v = dcv;
+
+            // ---- AC (:833-866)
+            int k = 1;
+            while (k < 64) {
+                br.refill();
+                int hv = decode_symbol(br, ac_lut, ac_tab);
+                if (hv < 0) { err = MJ_ST_BAD_CODE; break; }
+                if (hv == 0) break;                 // EOB
+                k += hv >> 4;
+                if (k >= 64) break;
+                int n = hv & 15;
+                if (n > 0) {
+                    int val = extend(br.take(n), n);
+                    if (lane == k) v = val;
+                }
+                ++k;
+            }
+            *out = (int16_t)v;
+            out += 64;
+            if (err) break;
+        }
+        if (err) break;
+    }
+
+    if (!err) {
+        if (br.pad > 0 && br.bc < br.pad) err = MJ_ST_OVERRUN;             // consumed bits that are not there
+        else if (!sg->last && (((br.bc - br.pad) >> 3) > 0 || br.pos < br.end)) err = MJ_ST_DESYNC;
+    }
+    if (err && lane == 0) atomicMax(status + image, err);
+}
+
+hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+                          const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
+                          int lut_slots) {
+    if (n_segs == 0) return hipSuccess;
+    const int64_t blocks = (n_segs + 3) / 4;
+    const size_t lds = (size_t)4 * lut_slots * kLutSize * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_huffman, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
+                       coef, status, lut_slots);
+    return hipGetLastError();
+}
+
+}  // namespace mj

@@ -1,0 +1,87 @@
+// Internal device/host structures of libmijpeg.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mijpeg.h"
+
+namespace mj {
+
+constexpr int kWave = 64;               // CDNA4 wavefront
+constexpr int kLutBits = 9;             // primary Huffman LUT: codes up to 9 bits resolve in one LDS read
+constexpr int kLutSize = 1 << kLutBits;
+constexpr int kMaxBlocksPerMcu = 6;     // 4:2:0 = 4 Y + Cb + Cr; every supported layout has <= 6
+constexpr int kMaxTabsPerImage = 6;     // DC+AC for up to three components
+
+// One Huffman table on the device.  `lut` is staged into LDS by the stage-1 kernel; the long-code
+// side (codes of 10..16 bits, a few percent of symbols) stays in global memory / L2.
+struct DevHuff {
+    uint16_t lut[kLutSize];   // (len << 8) | symbol for codes <= kLutBits bits, 0 = longer code
+    int32_t first_code[17];   // canonical code book per length (jpeg_decoder.py:366-377)
+    int32_t count[17];
+    int32_t first_sym[17];
+    uint8_t vals[256];
+    uint8_t pad[4];
+};
+static_assert(sizeof(DevHuff) % 8 == 0, "DevHuff must keep 8-byte alignment in arrays");
+
+// Per-image description used by both kernels.
+struct DevImage {
+    int32_t width, height, ncomp;
+    int32_t hmax, vmax;               // MCU = (8*hmax) x (8*vmax) pixels
+    int32_t blocks_per_mcu;
+    int32_t mcu_count_h, mcu_count_v;
+    int32_t restart_interval;
+    int32_t n_tabs;                   // distinct Huffman tables of this image (<= kMaxTabsPerImage)
+    int32_t tab_index[kMaxTabsPerImage];   // indices into the batch's DevHuff array
+    // for each block of an MCU, in decode order (jpeg_decoder.py:774, :805):
+    uint8_t blk_comp[8];              // component 0..2
+    uint8_t blk_dc_slot[8];           // slot (0..n_tabs-1) of its DC table in the wave's LDS copy
+    uint8_t blk_ac_slot[8];
+    int32_t qt_index[3];              // per component, into the batch's quantisation tables
+    int32_t pad0;
+    int64_t block_off;                // first coefficient block of this image in the packed coef array
+    int64_t mcu_off;                  // first MCU of this image in the batch-wide MCU numbering
+    int64_t rgb_off;                  // byte offset of this image in the packed RGB output
+    int64_t pix_off;                  // pixel offset (for the planes output: *ncomp int16 each)
+};
+
+// One restart segment = the unit of work of one stage-1 wavefront.
+struct DevSegment {
+    int64_t begin;        // blob offset of the first entropy-coded byte
+    int32_t len;          // bytes up to the terminating marker
+    int32_t image;
+    int32_t mcu0;         // first MCU (within the image) of the segment
+    int32_t n_mcu;
+    int32_t last;         // 1 = last segment of its image (trailing bytes are not a desync)
+    int32_t pad;
+};
+
+}  // namespace mj
+
+// stage-1 / stage-2 launchers (defined in huffman.hip / reconstruct.hip)
+namespace mj {
+hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+                          const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
+                          int lut_slots);
+
+struct ReconArgs {
+    const DevImage *images;
+    int32_t n_images;
+    const int64_t *mcu_prefix;   // [n_images + 1]
+    int64_t total_mcus;
+    const int16_t *coef;
+    const uint16_t *qt;          // [n_qt][64] zig-zag order
+    const double *idct_tt;       // [64 (u*8+v)][64 (x*8+y)] transposed reference table
+    const uint32_t *up_taps;     // packed upsample taps, see reconstruct.hip
+    uint8_t *rgb;
+    int16_t *planes;             // optional
+    int16_t *idct_out;           // optional
+    int32_t layout;
+    int32_t exact_only;
+    // homogeneous-batch shortcut: all images share one geometry
+    int32_t uniform_geometry;
+    int32_t mcus_per_image;
+};
+hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);
+}  // namespace mj

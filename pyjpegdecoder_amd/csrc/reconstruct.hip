@@ -1,0 +1,292 @@
+// Stage 2 — dequantise + 8x8 inverse DCT + chroma upsample + YCbCr->RGB, fused, on gfx950.
+//
+// Replaces, per MCU, jpeg_decoder.py:869 (undo_zigzag * quantization_table), InverseDCT.__call__
+// (:1561-1573), the block placement (:875-879), ResizeGrid.__call__ (:1588-1626), the store (:889-891),
+// the crop (:1373) and YCbCr_to_RGB (:1683-1700) / the greyscale clip (:1384-1386).
+//
+// Work unit: one MCU per wavefront pass (grid-stride).  HBM traffic is the algorithmic minimum: each
+// coefficient block is read once (128 B, coalesced, lane = zig-zag index) and each output pixel is
+// written once; everything in between lives in registers and LDS.
+//
+// Bit-exactness:
+//   * IDCT: out[x,y] = np.sum(block * T[x,y]) is NumPy's pairwise sum: eight running sums r[v] over
+//     u = 0..7 (flat index u*8+v), then ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), float64, products and sums
+//     rounded separately.  Lane (x*8+y) reproduces exactly that sequence, skipping terms whose
+//     coefficient is zero (x + 0.0 == x, so the skipped sequence is bitwise the same).  The table T is
+//     the reference's own 4096 doubles, transposed to [u*8+v][x*8+y] so a wave reads 512 contiguous bytes.
+//   * upsample: round(sum(n_i*v_i)/15) with the taps captured from the reference; exact in integers
+//     because a multiple of 1/15 is never a half-integer.
+//   * colour: evaluated in integers — 1.402 c = 701c/500, 1.772 c = 443c/250, 0.34414 a + 0.71414 b =
+//     (17207a + 35707b)/50000 — which equals the float64 result whenever the real value is not an exact
+//     half-integer (distance to the nearest tie >= 2e-5 >> float64 error ~1e-11); exact ties (and
+//     out-of-range chroma) take the reference's float64 expression verbatim, contraction disabled.
+#include "mijpeg_internal.h"
+#include "upsample_taps.h"
+
+#pragma clang fp contract(off)
+
+namespace mj {
+
+namespace {
+
+// natural (u*8+v) -> zig-zag index: value at [x=u][y=v] of undo_zigzag is zz[ZZ_GRID[v][u]] (:1652-1662)
+__constant__ uint8_t c_zz_of_nat[64] = {
+    0, 2, 3, 9, 10, 20, 21, 35,
+    1, 4, 8, 11, 19, 22, 34, 36,
+    5, 7, 12, 18, 23, 33, 37, 48,
+    6, 13, 17, 24, 32, 38, 47, 49,
+    14, 16, 25, 31, 39, 46, 50, 57,
+    15, 26, 30, 40, 45, 51, 56, 58,
+    27, 29, 41, 44, 52, 55, 59, 62,
+    28, 42, 43, 53, 54, 60, 61, 63};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// floor((t) / den) for |t| < bias*den
+template <int DEN, int BIAS>
+__device__ __forceinline__ int floordiv(int t) {
+    return (int)((unsigned)(t + DEN * BIAS) / (unsigned)DEN) - BIAS;
+}
+
+// YCbCr_to_RGB (:1693-1700) exactly as written, float64, no contraction.
+__device__ __noinline__ void ycc_to_rgb_f64(int Y, int Cb, int Cr, int &R, int &G, int &B) {
+    double y = (double)Y, cb = (double)Cb - 128.0, cr = (double)Cr - 128.0;
+    double r = y + 1.402 * cr;
+    double g = (y - 0.34414 * cb) - 0.71414 * cr;
+    double b = y + 1.772 * cb;
+    r = fmin(fmax(r, 0.0), 255.0);
+    g = fmin(fmax(g, 0.0), 255.0);
+    b = fmin(fmax(b, 0.0), 255.0);
+    R = (int)__builtin_rint(r);
+    G = (int)__builtin_rint(g);
+    B = (int)__builtin_rint(b);
+}
+
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__device__ __forceinline__ void ycc_to_rgb(int Y, int Cb, int Cr, int &R, int &G, int &B) {
+    int cb = Cb - 128, cr = Cr - 128;
+    bool slow = (unsigned)(cb + 2048) > 4096u || (unsigned)(cr + 2048) > 4096u;
+    int tr = 701 * cr + 250;                       // round(701 cr / 500)
+    int qr = floordiv<500, 8192>(tr);
+    int tb = 443 * cb + 125;                       // round(443 cb / 250)
+    int qb = floordiv<250, 8192>(tb);
+    int tg = 17207 * cb + 35707 * cr + 25000;      // round((17207 cb + 35707 cr) / 50000), subtracted
+    int qg = floordiv<50000, 4096>(tg);
+    // exact half-integers: remainder 0 after adding the half
+    slow |= (tr - qr * 500 == 0) | (tb - qb * 250 == 0) | (tg - qg * 50000 == 0);
+    if (slow) {
+        ycc_to_rgb_f64(Y, Cb, Cr, R, G, B);
+        return;
+    }
+    // G = Y - g where g is rounded to nearest; round(Y - g_real) = Y - round_half_down(g_real) — no tie here,
+    // so nearest(−g) = −nearest(g)
+    R = clamp255(Y + qr);
+    B = clamp255(Y + qb);
+    int tgn = -(17207 * cb + 35707 * cr) + 25000;
+    G = clamp255(Y + floordiv<50000, 4096>(tgn));
+}
+
+template <int HS, int VS, int NC>
+struct Geo {
+    static constexpr int NBY = HS * VS;
+    static constexpr int NB = NC == 1 ? 1 : NBY + 2;
+    static constexpr int MW = NC == 1 ? 8 : 8 * HS;
+    static constexpr int MH = NC == 1 ? 8 : 8 * VS;
+    static constexpr int NPIX = MW * MH;
+    static constexpr int PPL = NPIX / 64;           // pixels per lane
+    static constexpr bool SUB = NC == 3 && NBY > 1; // chroma needs upsampling
+};
+
+}  // namespace
+
+template <int HS, int VS, int NC, int LAYOUT>
+__global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
+    using G = Geo<HS, VS, NC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_tt = reinterpret_cast<double *>(smem);                                  // 32 KiB
+    uint32_t *s_taps = reinterpret_cast<uint32_t *>(smem + 64 * 64 * sizeof(double)); // NPIX words (or 64)
+    int16_t *s_mcu_all = reinterpret_cast<int16_t *>(smem + 64 * 64 * sizeof(double) + 256 * sizeof(uint32_t));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    int16_t *s_mcu = s_mcu_all + wave * (G::NB * 64);
+
+    for (int i = tid; i < 64 * 64; i += 256) s_tt[i] = a.idct_tt[i];
+    if constexpr (G::SUB) {
+        const uint32_t *taps = (HS == 2 && VS == 2) ? UP_TAPS_16x16 : (HS == 2 ? UP_TAPS_16x8 : UP_TAPS_8x16);
+        for (int i = tid; i < G::NPIX; i += 256) s_taps[i] = taps[i];
+    }
+    __syncthreads();
+
+    const int zz_of_lane = c_zz_of_nat[lane];
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < a.total_mcus; g += n_waves) {
+        // ---- which image / MCU (wave-uniform)
+        int img;
+        int m;
+        if (a.uniform_geometry) {
+            img = (int)(g / a.mcus_per_image);
+            m = (int)(g - (int64_t)img * a.mcus_per_image);
+        } else {
+            int lo = 0, hi = a.n_images;            // largest img with mcu_prefix[img] <= g
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (a.mcu_prefix[mid] <= g) lo = mid; else hi = mid;
+            }
+            img = lo;
+            m = (int)(g - a.mcu_prefix[img]);
+        }
+        const DevImage *im = a.images + img;
+        const int W = im->width, H = im->height;
+        const int mcu_y = m / im->mcu_count_h, mcu_x = m - mcu_y * im->mcu_count_h;
+        const int64_t blk0 = im->block_off + (int64_t)m * G::NB;
+        const int16_t *cp = a.coef + blk0 * 64 + lane;
+
+        int craw[G::NB];
+#pragma unroll
+        for (int b = 0; b < G::NB; ++b) craw[b] = cp[b * 64];
+
+#pragma unroll
+        for (int b = 0; b < G::NB; ++b) {
+            const int comp = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
+            const int q = a.qt[im->qt_index[comp] * 64 + lane];
+            const int dzz = (int)(int16_t)(craw[b] * q);                 // int16 * int16 -> int16 (:869)
+            const int dn = __shfl(dzz, zz_of_lane);                      // lane n = u*8+v holds block[u][v]
+            const uint64_t mask = __ballot(dn != 0);
+
+            double r[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                r[v] = 0.0;
+                const uint32_t cm = (uint32_t)((mask >> v) & 0x0101010101010101ull ? 1 : 0);
+                if (cm) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = s_tt[(u * 8 + v) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if ((mask >> (u * 8 + v)) & 1) {
+                            const int c = __builtin_amdgcn_readlane(dn, u * 8 + v);
+                            const double p = (double)c * t[u];
+                            r[v] = r[v] + p;
+                        }
+                    }
+                }
+            }
+            const double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);   // :1573
+            s_mcu[b * 64 + lane] = (int16_t)val;
+            if (a.idct_out) a.idct_out[(blk0 + b) * 64 + lane] = (int16_t)val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pixels of the MCU: PPL consecutive pixels per lane along the contiguous axis
+        unsigned char bytes[G::PPL * NC];
+        int px[G::PPL], py[G::PPL];
+#pragma unroll
+        for (int j = 0; j < G::PPL; ++j) {
+            const int p = lane * G::PPL + j;
+            int x, y;
+            if (LAYOUT == MJ_LAYOUT_XMAJOR) { x = p / G::MH; y = p % G::MH; }
+            else                            { y = p / G::MW; x = p % G::MW; }
+            px[j] = x; py[j] = y;
+            const int yblk = (NC == 1) ? 0 : (y >> 3) * HS + (x >> 3);
+            const int Yv = s_mcu[yblk * 64 + (x & 7) * 8 + (y & 7)];
+            int Cbv = 0, Crv = 0;
+            if constexpr (NC == 3) {
+                const int16_t *cbp = s_mcu + G::NBY * 64, *crp = cbp + 64;
+                if constexpr (G::SUB) {
+                    const uint32_t tp = s_taps[x * G::MH + y];
+                    int sb = 0, sr = 0;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int idx = (tp >> (10 * t)) & 63, w = (tp >> (10 * t + 6)) & 15;
+                        sb += w * cbp[idx];
+                        sr += w * crp[idx];
+                    }
+                    Cbv = (int)(int16_t)floordiv<30, 65536>(2 * sb + 15);   // round(s/15), never a tie
+                    Crv = (int)(int16_t)floordiv<30, 65536>(2 * sr + 15);
+                } else {
+                    Cbv = cbp[x * 8 + y];
+                    Crv = crp[x * 8 + y];
+                }
+            }
+            const int gx = mcu_x * G::MW + x, gy = mcu_y * G::MH + y;
+            if (a.planes && gx < W && gy < H) {
+                int16_t *pl = a.planes + (im->pix_off + (int64_t)gx * H + gy) * NC;
+                pl[0] = (int16_t)Yv;
+                if constexpr (NC == 3) { pl[1] = (int16_t)Cbv; pl[2] = (int16_t)Crv; }
+            }
+            if constexpr (NC == 3) {
+                int R, Gc, B;
+                ycc_to_rgb(Yv, Cbv, Crv, R, Gc, B);
+                bytes[j * 3 + 0] = (unsigned char)R;
+                bytes[j * 3 + 1] = (unsigned char)Gc;
+                bytes[j * 3 + 2] = (unsigned char)B;
+            } else {
+                bytes[j] = (unsigned char)clamp255(Yv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // all reads of s_mcu done before the next pass overwrites it
+
+        // ---- store
+        const int gx0 = mcu_x * G::MW + px[0], gy0 = mcu_y * G::MH + py[0];
+        int64_t off0;
+        bool full;
+        if (LAYOUT == MJ_LAYOUT_XMAJOR) {
+            off0 = im->rgb_off + ((int64_t)gx0 * H + gy0) * NC;
+            full = gx0 < W && gy0 + G::PPL <= H;
+        } else {
+            off0 = im->rgb_off + ((int64_t)gy0 * W + gx0) * NC;
+            full = gy0 < H && gx0 + G::PPL <= W;
+        }
+        constexpr int NBYTES = G::PPL * NC;
+        unsigned char *dst = a.rgb + off0;
+        if (NBYTES % 4 == 0 && full && ((uintptr_t)dst & 3) == 0) {
+#pragma unroll
+            for (int k = 0; k < NBYTES / 4; ++k) {
+                uint32_t wv = bytes[4 * k] | (bytes[4 * k + 1] << 8) | (bytes[4 * k + 2] << 16) | ((uint32_t)bytes[4 * k + 3] << 24);
+                reinterpret_cast<uint32_t *>(dst)[k] = wv;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::PPL; ++j) {
+                const int gx = mcu_x * G::MW + px[j], gy = mcu_y * G::MH + py[j];
+                if (gx < W && gy < H) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dst[j * NC + c] = bytes[j * NC + c];
+                }
+            }
+        }
+    }
+}
+
+template <int HS, int VS, int NC>
+static hipError_t launch_t(hipStream_t stream, const ReconArgs &a) {
+    using G = Geo<HS, VS, NC>;
+    const size_t lds = 64 * 64 * sizeof(double) + 256 * sizeof(uint32_t) + (size_t)4 * G::NB * 64 * sizeof(int16_t);
+    int64_t want = (a.total_mcus + 3) / 4;
+    int64_t cap = 256 * 4;   // 256 CUs x 4 workgroups (LDS: ~36 KiB each)
+    unsigned blocks = (unsigned)(want < cap ? want : cap);
+    if (blocks == 0) return hipSuccess;
+    if (a.layout == MJ_LAYOUT_XMAJOR)
+        hipLaunchKernelGGL((k_reconstruct<HS, VS, NC, MJ_LAYOUT_XMAJOR>), dim3(blocks), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((k_reconstruct<HS, VS, NC, MJ_LAYOUT_ROWMAJOR>), dim3(blocks), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp) {
+    if (ncomp == 1) return launch_t<1, 1, 1>(stream, a);
+    if (hmax == 1 && vmax == 1) return launch_t<1, 1, 3>(stream, a);
+    if (hmax == 2 && vmax == 1) return launch_t<2, 1, 3>(stream, a);
+    if (hmax == 1 && vmax == 2) return launch_t<1, 2, 3>(stream, a);
+    if (hmax == 2 && vmax == 2) return launch_t<2, 2, 3>(stream, a);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mj

@@ -1,0 +1,69 @@
+"""The C-ABI library loads and exports every symbol include/mijpeg.h declares; host-side pieces of it
+are pinned against the reference's goldens.  No compute calls; CPU only."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from pyjpegdecoder_amd import _binding as B
+    if not B.LIB_PATH.exists():
+        g.build()
+    return B.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    from pyjpegdecoder_amd import _binding as B
+    header = (ROOT / "include" / "mijpeg.h").read_text()
+    declared = set(re.findall(r"\b(mj_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(B.EXPORTS), declared ^ set(B.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mj_version() == 1
+
+
+def test_library_idct_table_is_the_reference_table(lib):
+    tt = np.empty(4096, dtype=np.float64)
+    lib.mj_host_idct_table(tt.ctypes.data_as(ctypes.c_void_p))
+    ref = np.load(GOLDEN / "idct_table.npy")            # [x,y,u,v]
+    want = ref.transpose(2, 3, 0, 1).reshape(4096)      # [u*8+v][x*8+y]
+    assert np.array_equal(tt.view(np.uint64), want.view(np.uint64))
+
+
+def test_upsample_taps_header_matches_captured_operator():
+    txt = (ROOT / "pyjpegdecoder_amd" / "csrc" / "upsample_taps.h").read_text()
+    for dst, name in (((16, 16), "UP_TAPS_16x16"), ((16, 8), "UP_TAPS_16x8"), ((8, 16), "UP_TAPS_8x16")):
+        body = re.search(name + r"\[\d+\] = \{(.*?)\};", txt, re.S).group(1)
+        words = [int(w.rstrip("u"), 16) for w in re.findall(r"0x[0-9a-f]+u", body)]
+        W = np.load(GOLDEN / f"upsample_W_8x8_{dst[0]}x{dst[1]}.npy")
+        assert len(words) == W.shape[0]
+        for o, word in enumerate(words):
+            row = np.zeros(64, dtype=int)
+            for t in range(3):
+                idx, w = (word >> (10 * t)) & 63, (word >> (10 * t + 6)) & 15
+                row[idx] += w
+            assert np.array_equal(row, W[o]), (name, o)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pyjpegdecoder_amd import BackendError, BatchDecoder
+    with pytest.raises(BackendError):
+        BatchDecoder(device=0)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = ROOT / "pyjpegdecoder_amd"
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
+        src = f.read_text()
+        assert "oracle" not in src.lower() or f.name in (), f"{f} mentions the oracle"
+    assert "oracle" not in (ROOT / "include" / "mijpeg.h").read_text().lower()

@@ -1,0 +1,249 @@
+"""Parity of the HIP path (through the C ABI) with the reference's goldens and with the CPU oracle.
+Needs a real MI355X: run with `-m gpu`."""
+import hashlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_index, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from pyjpegdecoder_amd import BatchDecoder
+    d = BatchDecoder(device=0)
+    yield d
+    d.close()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fixture_every_seam_bit_exact(dec, name):
+    """G1 coefficients, G3 IDCT output, G5 planes, G6 RGB — all bit-exact against the reference."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], vec["coef"]), "G1 coefficients (bit-exact bar)"
+    assert np.array_equal(seam["idct"], vec["idct"]), "G3 IDCT output"
+    assert np.array_equal(seam["planes"], vec["planes"]), "G5 YCbCr planes"
+    assert img.dtype == np.uint8 and img.shape == vec["rgb"].shape
+    assert np.array_equal(img, vec["rgb"]), "G6 RGB (bar is +-1; we are exact)"
+
+
+def test_all_fixtures_in_one_mixed_batch(dec):
+    names = golden_names()
+    raws = [load_golden(n)[0] for n in names]
+    imgs = dec.decode(raws)
+    for n, img in zip(names, imgs):
+        assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
+
+
+def test_full_size_1080p_dri_against_reference_hashes(dec):
+    """BASELINE config 3 image: SHA-256 of every seam as the reference produced it."""
+    name = "c3_1920x1080_420_dri120"
+    raw, vec = load_golden(name)
+    meta = golden_index()[name]
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert sha(seam["coef"]) == meta["sha256"]["coef"]
+    assert sha(seam["idct"]) == meta["sha256"]["idct"]
+    assert sha(seam["planes"]) == meta["sha256"]["planes"]
+    assert sha(img) == meta["sha256"]["rgb"]
+    st = meta["sampled"]
+    assert np.array_equal(img[::st["x_stride"], ::st["y_stride"]], vec["rgb"])
+
+
+def test_rowmajor_layout_is_the_transpose(dec):
+    from pyjpegdecoder_amd import BatchDecoder
+    d2 = BatchDecoder(device=0, layout="rowmajor")
+    try:
+        for name in ("70x50_420_pil_opt", "64x48_422_pil", "48x80_440", "50x70_grey_dri4", "40x40_444_dri5"):
+            raw, vec = load_golden(name)
+            (img,) = d2.decode([raw])
+            assert np.array_equal(np.swapaxes(img, 0, 1), vec["rgb"]), name
+    finally:
+        d2.close()
+
+
+@pytest.mark.parametrize("ss,w,h,ri,q", [
+    ("420", 333, 211, 5, 85), ("420", 16, 16, 0, 50), ("420", 17, 9, 1, 95), ("422", 250, 130, 9, 90),
+    ("440", 130, 250, 4, 75), ("444", 99, 101, 13, 92), ("grey", 123, 77, 6, 88), ("420", 640, 480, 40, 85),
+    ("420", 1, 1, 0, 85), ("444", 8, 8, 1, 30), ("420", 1024, 64, 64, 100),
+])
+def test_random_sizes_against_oracle(dec, ss, w, h, ri, q):
+    """Seeded synthetic files at sizes the oracle finishes in well under a second; bit-exact on G1 and G6."""
+    from oracle import oracle
+    from tools import synth
+    sigma = 40.0 if q >= 95 else 12.0
+    raw = synth.encode_rgb(synth.synth_rgb(w * 1000 + h, w, h, sigma), q, ss, ri)
+    ref = oracle.decode(raw)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"])
+    assert np.array_equal(seam["planes"], ref["planes"])
+    assert np.array_equal(img, ref["rgb"])
+
+
+def test_config2_idct_only_on_host_decoded_coefficients(dec):
+    """BASELINE configs[1]: 512x512 4:2:0 files, entropy decode on the host (here: the oracle's), stage 2
+    alone on the GPU through mj_idct_batch's plan path."""
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import synth
+    raws = [synth.synth_jpeg(100 + i, 512, 512, 85, "420", 0) for i in range(8)]
+    raws[0] = load_golden("c2_512x512_420")[0]
+    prep = prepare_batch(raws)
+    coefs, want = [], []
+    for r in raws:
+        o = oracle.decode(r)
+        coefs.append(o["coef"]); want.append(o["rgb"])
+    coef = np.concatenate(coefs)
+    bc = prep.to_c()
+    rgb = np.empty(sum(x.size for x in want), dtype=np.uint8)
+    rc = dec.ctx.lib.mj_idct_batch(dec.ctx.handle, bc, coef.ctypes.data, rgb.ctypes.data)
+    dec.ctx.check(rc)
+    got = dec.split_outputs(prep, rgb)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    assert np.array_equal(got[0], load_golden("c2_512x512_420")[1]["rgb"])
+
+
+def test_idct_tie_blocks_through_the_kernel(dec):
+    """The F6/F7 exact-tie blocks: feed the golden dequantised blocks as coefficients with an all-ones
+    quantisation table through stage 2 and compare the IDCT seam."""
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    import ctypes
+    g = np.load(GOLDEN / "idct_blocks.npz")
+    blocks, want = g["blocks"], g["out"]          # [n,8,8] in [x,y] order
+    n = blocks.shape[0]
+    # zig-zag them: coef_zz[ZZ_GRID[y][x]] = block[x][y]
+    from pyjpegdecoder_amd._parse import ZZ_GRID
+    zz = np.zeros((n, 64), dtype=np.int16)
+    for x in range(8):
+        for y in range(8):
+            zz[:, ZZ_GRID[y, x]] = blocks[:, x, y]
+    # a greyscale "image" of n blocks: width 8*n, height 8
+    d = (B.ImageDescC * 1)()
+    d[0].width, d[0].height, d[0].ncomp = 8 * n, 8, 1
+    d[0].hs[0] = d[0].vs[0] = 1
+    d[0].mcu_count_h, d[0].mcu_count_v = n, 1
+    d[0].n_segments = 1
+    qt = np.ones((1, 64), dtype=np.uint16)
+    bc = B.BatchC()
+    bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
+    bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
+    bc.n_qt = 1; bc.qt = qt.ctypes.data
+    bc.layout = B.MJ_LAYOUT_XMAJOR; bc.flags = B.MJ_FLAG_KEEP_IDCT | B.MJ_FLAG_KEEP_PLANES
+    plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
+    try:
+        plan.write_coef(zz)
+        plan.execute_stage2()
+        plan.sync()
+        out = plan.read(rgb=True, idct=True)
+    finally:
+        plan.close()
+    assert np.array_equal(out["idct"].reshape(n, 8, 8), want)
+
+
+def test_colour_conversion_ties_through_the_kernel(dec):
+    """YCbCr_to_RGB golden triples (incl. exact .5 ties): build 4:4:4 DC-only blocks whose IDCT gives the
+    wanted Y/Cb/Cr (DC*q = 8*(v-128) -> every sample = v), then compare the RGB."""
+    from pyjpegdecoder_amd import _binding as B
+    import ctypes
+    g = np.load(GOLDEN / "ycc_rgb.npz")
+    ycc, want = g["ycc"].astype(np.int32), g["rgb"]
+    ok = (np.abs(ycc - 128) < 4000).all(axis=1)
+    ycc, want = ycc[ok], want[ok]
+    n = ycc.shape[0]
+    coef = np.zeros((n, 3, 64), dtype=np.int16)
+    coef[:, :, 0] = (ycc - 128) * 8
+    d = (B.ImageDescC * 1)()
+    d[0].width, d[0].height, d[0].ncomp = 8 * n, 8, 3
+    for c in range(3):
+        d[0].hs[c] = d[0].vs[c] = 1
+    d[0].mcu_count_h, d[0].mcu_count_v = n, 1
+    d[0].n_segments = 1
+    qt = np.ones((1, 64), dtype=np.uint16)
+    bc = B.BatchC()
+    bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
+    bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
+    bc.n_qt = 1; bc.qt = qt.ctypes.data
+    bc.layout = B.MJ_LAYOUT_XMAJOR; bc.flags = B.MJ_FLAG_KEEP_PLANES
+    plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
+    try:
+        plan.write_coef(coef.reshape(-1, 64))
+        plan.execute_stage2()
+        plan.sync()
+        out = plan.read(rgb=True, planes=True)
+    finally:
+        plan.close()
+    planes = out["planes"].reshape(8 * n, 8, 3)
+    assert np.array_equal(planes[::8, 0, :], ycc.astype(np.int16)), "DC-only construction"
+    rgb = out["rgb"].reshape(8 * n, 8, 3)
+    assert np.array_equal(rgb[::8, 0, :], want)
+    assert np.array_equal(rgb[3::8, 5, :], want)
+
+
+def test_jpegdecoder_class_surface(tmp_path):
+    from pyjpegdecoder_amd import JpegDecoder
+    for name in ("c1_64x64_444_pil", "70x50_420_pil_opt", "50x70_grey_dri4", "128x64_420_dri3"):
+        raw, vec = load_golden(name)
+        meta = golden_index()[name]
+        f = tmp_path / f"{name}.jpg"
+        f.write_bytes(raw)
+        d = JpegDecoder(f)
+        assert np.array_equal(d.image_array, vec["rgb"]) and d.image_array.dtype == np.uint8
+        for k in ("file_size", "file_header", "scan_finished", "scan_mode", "image_width", "image_height",
+                  "restart_interval", "scan_count", "scan_amount", "mcu_width", "mcu_height", "mcu_count_h",
+                  "mcu_count_v", "mcu_count", "array_width", "array_height", "array_depth"):
+            assert getattr(d, k) == meta[k], k
+        assert list(d.sample_shape) == meta["sample_shape"] and list(d.mcu_shape) == meta["mcu_shape"]
+        assert {str(k): v for k, v in d.huffman_tables.items()} == meta["huffman_tables"]
+        assert not hasattr(d, "raw_file") and d.file_path == f
+        assert set(d.handlers) == {b"\xFF\xC4", b"\xFF\xDB", b"\xFF\xDD", b"\xFF\xC0", b"\xFF\xC2", b"\xFF\xDA", b"\xFF\xD9"}
+    with pytest.raises(AttributeError):
+        JpegDecoder(str(f), verbose=True)     # the reference needs a Path too (`file.name`, :41)
+
+
+def test_corrupt_streams_raise_like_the_reference(dec):
+    from pyjpegdecoder_amd import CorruptedJpeg, parse_jpeg
+    raw, _ = load_golden("128x64_420_dri3")
+    p = parse_jpeg(raw)
+    s = p.scans[0]
+    # (a) drop one restart marker -> host sees the wrong number of segments
+    off = int(s.segment_offsets[2])
+    bad = raw[:off - 2] + raw[off:]
+    with pytest.raises(CorruptedJpeg):
+        dec.decode([bad])
+    # (b) move a restart marker by inserting two data bytes before it -> count-driven restart desyncs
+    bad = raw[:off - 2] + b"\x12\x34" + raw[off - 2:]
+    with pytest.raises(CorruptedJpeg):
+        dec.decode([bad])
+    # (c) truncate a segment hard -> it runs out of bits
+    off1 = int(s.segment_offsets[1])
+    bad = raw[:int(s.entropy_start) + 3] + raw[off1 - 2:]
+    with pytest.raises(CorruptedJpeg):
+        dec.decode([bad])
+    # a good file still decodes afterwards on the same context
+    assert np.array_equal(dec.decode([raw])[0], load_golden("128x64_420_dri3")[1]["rgb"])
+
+
+def test_batch_of_1080p_roundtrip_properties(dec):
+    """BASELINE-size batch properties that need no oracle run: determinism across launches and images,
+    and equality with the same files decoded one by one."""
+    from tools import synth
+    blob, offs = synth.synth_batch(6, 7000, 1920, 1080, 85, "420", 120)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(6)]
+    a = dec.decode(raws)
+    b = dec.decode(raws[::-1])[::-1]
+    for x, y in zip(a, b):
+        assert x.shape == (1920, 1080, 3) and np.array_equal(x, y)
+    single = dec.decode([raws[3]])[0]
+    assert np.array_equal(single, a[3])
+    from oracle import oracle
+    assert np.array_equal(oracle.decode(raws[5])["rgb"], a[5])

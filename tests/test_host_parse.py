@@ -1,0 +1,71 @@
+"""Host logic (container parser, scan segmentation) against the attribute surface captured from the
+reference.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden_index, golden_names, load_golden
+from pyjpegdecoder_amd import _parse
+from pyjpegdecoder_amd.errors import CorruptedJpeg, NotJpeg, UnsupportedJpeg
+
+
+@pytest.mark.parametrize("name", golden_names(small_only=False))
+def test_attribute_surface_matches_reference(name):
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    p = _parse.parse_jpeg(raw)
+    scan = p.scans[0]
+    assert p.scan_mode == meta["scan_mode"]
+    assert (p.image_width, p.image_height) == (meta["image_width"], meta["image_height"])
+    assert {str(k): list(v) for k, v in p.color_components.items()} == \
+        {k: [tuple(x) if isinstance(x, list) else x for x in v] for k, v in meta["color_components"].items()} or \
+        {str(k): [list(x) if isinstance(x, tuple) else x for x in v] for k, v in p.color_components.items()} == meta["color_components"]
+    assert list(p.sample_shape) == meta["sample_shape"]
+    assert {str(k): dict(v.tree) for k, v in p.huffman.items()} == meta["huffman_tables"]
+    assert {str(k): v.tolist() for k, v in p.quantization_tables.items()} == meta["quantization_tables"]
+    assert p.restart_interval == meta["restart_interval"]
+    assert p.scan_amount == meta["scan_amount"]
+    assert (scan.mcu_width, scan.mcu_height) == (meta["mcu_width"], meta["mcu_height"])
+    assert (scan.mcu_count_h, scan.mcu_count_v, scan.mcu_count) == (meta["mcu_count_h"], meta["mcu_count_v"], meta["mcu_count"])
+    assert (p.array_width, p.array_height, p.array_depth) == (meta["array_width"], meta["array_height"], meta["array_depth"])
+    assert p.file_header == meta["file_header"]
+    assert p.reached_eoi == meta["scan_finished"]
+
+
+@pytest.mark.parametrize("name", golden_names(small_only=False))
+def test_restart_segmentation(name):
+    raw, _ = load_golden(name)
+    p = _parse.parse_jpeg(raw)
+    scan = p.scans[0]
+    so = scan.segment_offsets
+    assert so[0] == scan.entropy_start and so[-1] == scan.entropy_end
+    if scan.restart_interval:
+        assert so.size - 1 == -(-scan.mcu_count // scan.restart_interval)
+        for k, off in enumerate(so[1:-1]):
+            assert raw[off - 2] == 0xFF and raw[off - 1] == 0xD0 + (k % 8)
+    assert raw[scan.entropy_end:scan.entropy_end + 2] == b"\xFF\xD9"
+
+
+def test_not_jpeg():
+    with pytest.raises(NotJpeg):
+        _parse.parse_jpeg(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+
+
+def test_unsupported_and_corrupt_headers():
+    raw, _ = load_golden("c1_64x64_444_pil")
+    i = raw.index(b"\xFF\xC0")
+    bad = bytearray(raw); bad[i + 4] = 12                      # precision 12
+    with pytest.raises(UnsupportedJpeg):
+        _parse.parse_jpeg(bytes(bad))
+    bad = bytearray(raw); bad[i + 9] = 4                       # 4 components
+    with pytest.raises(UnsupportedJpeg):
+        _parse.parse_jpeg(bytes(bad))
+    bad = bytearray(raw); bad[i + 7] = 0; bad[i + 8] = 0       # width 0
+    with pytest.raises(CorruptedJpeg):
+        _parse.parse_jpeg(bytes(bad))
+
+
+def test_undo_zigzag_is_the_reference_layout():
+    zz = np.arange(64)
+    xy = _parse.undo_zigzag(zz)
+    # [x, y]: x = horizontal; zig-zag 1 is the first horizontal frequency, 2 the first vertical one
+    assert xy[1, 0] == 1 and xy[0, 1] == 2 and xy[7, 7] == 63 and xy[2, 0] == 5
