@@ -160,13 +160,15 @@ def test_colour_conversion_ties_through_the_kernel(dec):
     ok = (np.abs(ycc - 128) < 4000).all(axis=1)
     ycc, want = ycc[ok], want[ok]
     n = ycc.shape[0]
-    coef = np.zeros((n, 3, 64), dtype=np.int16)
-    coef[:, :, 0] = (ycc - 128) * 8
+    cols = 1024
+    rows = -(-n // cols)
+    coef = np.zeros((rows * cols, 3, 64), dtype=np.int16)
+    coef[:n, :, 0] = (ycc - 128) * 8
     d = (B.ImageDescC * 1)()
-    d[0].width, d[0].height, d[0].ncomp = 8 * n, 8, 3
+    d[0].width, d[0].height, d[0].ncomp = 8 * cols, 8 * rows, 3
     for c in range(3):
         d[0].hs[c] = d[0].vs[c] = 1
-    d[0].mcu_count_h, d[0].mcu_count_v = n, 1
+    d[0].mcu_count_h, d[0].mcu_count_v = cols, rows
     d[0].n_segments = 1
     qt = np.ones((1, 64), dtype=np.uint16)
     bc = B.BatchC()
@@ -182,11 +184,14 @@ def test_colour_conversion_ties_through_the_kernel(dec):
         out = plan.read(rgb=True, planes=True)
     finally:
         plan.close()
-    planes = out["planes"].reshape(8 * n, 8, 3)
-    assert np.array_equal(planes[::8, 0, :], ycc.astype(np.int16)), "DC-only construction"
-    rgb = out["rgb"].reshape(8 * n, 8, 3)
-    assert np.array_equal(rgb[::8, 0, :], want)
-    assert np.array_equal(rgb[3::8, 5, :], want)
+    planes = out["planes"].reshape(8 * cols, 8 * rows, 3)
+    rgb = out["rgb"].reshape(8 * cols, 8 * rows, 3)
+    # block i sits at MCU (i % cols, i // cols); sample two pixels of each block
+    i = np.arange(n)
+    bx, by = (i % cols) * 8, (i // cols) * 8
+    assert np.array_equal(planes[bx, by, :], ycc.astype(np.int16)), "DC-only construction"
+    assert np.array_equal(rgb[bx, by, :], want)
+    assert np.array_equal(rgb[bx + 3, by + 5, :], want)
 
 
 def test_jpegdecoder_class_surface(tmp_path):
