@@ -168,12 +168,14 @@ class BatchDecoder:
     >>> images = dec.decode([open(p, 'rb').read() for p in paths])      # list of uint8 (W,H,3) arrays
     """
 
-    def __init__(self, device: int = 0, layout: str = "xmajor"):
+    def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False):
         self.ctx = B.Context(device)
         self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
+        # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
+        self.base_flags = B.MJ_FLAG_EXACT_ONLY if exact_only else 0
 
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
-        prep = prepare_batch(files, self.layout, flags)
+        prep = prepare_batch(files, self.layout, flags | self.base_flags)
         plan = B.Plan(self.ctx, prep.to_c(blob_device_ptr), {"prep": prep, "n_images": len(prep.parsed)})
         return prep, plan
 
@@ -198,7 +200,7 @@ class BatchDecoder:
             groups.setdefault(key, []).append(i)
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)
-        flags = (B.MJ_FLAG_KEEP_PLANES | B.MJ_FLAG_KEEP_IDCT) if return_seams else 0
+        flags = ((B.MJ_FLAG_KEEP_PLANES | B.MJ_FLAG_KEEP_IDCT) if return_seams else 0) | self.base_flags
         for idxs in groups.values():
             prep = prepare_batch([files[i] for i in idxs], self.layout, flags, [parsed[i] for i in idxs])
             plan = B.Plan(self.ctx, prep.to_c(), {"prep": prep, "n_images": len(idxs)})

@@ -40,6 +40,10 @@ struct mj_plan {
     mj::DevHuff *d_huff = nullptr;
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
+    int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
+    int64_t total_tiles = 0;
+    int32_t tiles_per_image = 0;
+    int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
     int16_t *d_planes = nullptr;
@@ -108,6 +112,14 @@ void build_dev_huff(const mj_huff_spec &spec, mj::DevHuff &h) {
     }
 }
 
+// zig-zag index -> natural index v*8+u (row = vertical frequency); blocks and quantisation tables live on the
+// device in this order (see huffman.hip / reconstruct_fast.hip)
+const uint8_t kNatOfZz[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
 bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
     if (d.ncomp == 1) { hmax = vmax = 1; return true; }
     if (d.ncomp != 3) return false;
@@ -125,6 +137,32 @@ int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 
 }
 
 }  // namespace
+
+namespace mj {
+__constant__ uint8_t c_nat[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__global__ void k_permute_blocks(const int16_t *__restrict__ src, int16_t *__restrict__ dst, int64_t n_blocks,
+                                 int to_natural) {
+    const uint8_t *nat = c_nat;
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < n_blocks;
+         b += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        if (to_natural) dst[b * 64 + nat[lane]] = src[b * 64 + lane];   // lane = zig-zag index
+        else dst[b * 64 + lane] = src[b * 64 + nat[lane]];
+    }
+}
+hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural) {
+    if (n_blocks == 0) return hipSuccess;
+    int64_t want = (n_blocks + 3) / 4;
+    unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_permute_blocks, dim3(blocks), dim3(256), 0, stream, src, dst, n_blocks, to_natural);
+    return hipGetLastError();
+}
+}  // namespace mj
 
 extern "C" {
 
@@ -168,7 +206,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_qt, p->d_mcu_prefix, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -287,7 +325,21 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     int rc;
     if ((rc = upload(ctx, &p->d_images, imgs.data(), imgs.size())) != MJ_OK) return rc;
     if ((rc = upload(ctx, &p->d_mcu_prefix, mcu_prefix.data(), mcu_prefix.size())) != MJ_OK) return rc;
-    if ((rc = upload(ctx, &p->d_qt, b->qt, (size_t)b->n_qt * 64)) != MJ_OK) return rc;
+    {
+        std::vector<uint16_t> qn((size_t)b->n_qt * 64);
+        for (int t = 0; t < b->n_qt; ++t)
+            for (int z = 0; z < 64; ++z) qn[(size_t)t * 64 + kNatOfZz[z]] = b->qt[(size_t)t * 64 + z];
+        if ((rc = upload(ctx, &p->d_qt, qn.data(), qn.size())) != MJ_OK) return rc;
+        const int tm = mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp);
+        std::vector<int64_t> tp(b->n_images + 1, 0);
+        for (int i = 0; i < b->n_images; ++i) {
+            const int64_t mcus = (int64_t)imgs[i].mcu_count_h * imgs[i].mcu_count_v;
+            tp[i + 1] = tp[i] + (mcus + tm - 1) / tm;
+        }
+        p->total_tiles = tp[b->n_images];
+        p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
+        if ((rc = upload(ctx, &p->d_tile_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
+    }
     if (have_entropy) {
         std::vector<mj::DevHuff> hh(b->n_huff);
         for (int t = 0; t < b->n_huff; ++t) build_dev_huff(b->huff[t], hh[t]);
@@ -351,7 +403,11 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.up_taps = nullptr; a.rgb = rgb_device; a.planes = p->d_planes; a.idct_out = p->d_idct;
     a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
-    MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
+    if (p->layout == MJ_LAYOUT_XMAJOR && !a.exact_only)
+        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,
+                                               p->tiles_per_image));
+    else
+        MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
     return MJ_OK;
 }
 
@@ -385,7 +441,12 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
         if (!p->last_rgb) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: nothing executed yet");
         MJ_HIP(ctx, hipMemcpy(rgb_host, p->last_rgb, (size_t)p->info.rgb_bytes, hipMemcpyDeviceToHost));
     }
-    if (coef_host) MJ_HIP(ctx, hipMemcpy(coef_host, p->d_coef, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
+    if (coef_host) {   // the :869 seam is in zig-zag order; the device keeps blocks in natural order
+        if (!p->d_tmp_coef) MJ_HIP(ctx, hipMalloc((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
+        MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, p->d_coef, p->d_tmp_coef, p->info.total_blocks, 0));
+        MJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MJ_HIP(ctx, hipMemcpy(coef_host, p->d_tmp_coef, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
+    }
     if (planes_host) {
         if (!p->d_planes) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: plan was created without MJ_FLAG_KEEP_PLANES");
         MJ_HIP(ctx, hipMemcpy(planes_host, p->d_planes, (size_t)p->info.rgb_bytes * 2, hipMemcpyDeviceToHost));
@@ -400,8 +461,16 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
 
 int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
     if (!p || !coef) return MJ_ERR_INVALID;
-    MJ_HIP(p->ctx, hipMemcpy(p->d_coef, coef, (size_t)p->info.total_blocks * 128,
-                             mem == MJ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    mj_context *ctx = p->ctx;
+    const int16_t *src = coef;
+    if (mem != MJ_MEM_DEVICE) {
+        if (!p->d_tmp_coef) MJ_HIP(ctx, hipMalloc((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
+        MJ_HIP(ctx, hipMemcpy(p->d_tmp_coef, coef, (size_t)p->info.total_blocks * 128, hipMemcpyHostToDevice));
+        src = p->d_tmp_coef;
+    }
+    MJ_HIP(ctx, hipDeviceSynchronize());
+    MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, src, p->d_coef, p->info.total_blocks, 1));   // zig-zag -> natural
+    MJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MJ_OK;
 }
 

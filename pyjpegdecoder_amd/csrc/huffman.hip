@@ -13,7 +13,8 @@
 //         dwords out of that register with v_readlane (no LDS or memory access on the critical path);
 //         the next 256 B are already in flight while the current ones are consumed;
 //       - lane l owns zig-zag coefficient l of the current block: a decoded value is "scattered" with a
-//         single compare+select, and the finished block leaves as one coalesced 128-B store.
+//         single compare+select, and the finished block leaves as one 128-B line (lanes permuted to the
+//         natural [v][u] order stage 2 wants).
 //   * Huffman tables: the 9-bit primary LUT of every table the image uses is copied into LDS once per
 //     wave (1 KiB each); codes longer than 9 bits (rare) take a canonical search through L2-resident
 //     first_code/count arrays with scalar loads.
@@ -27,6 +28,14 @@
 namespace mj {
 
 namespace {
+
+// zig-zag index -> position inside the stored block.  Blocks are kept in HBM as [v][u] (row = vertical
+// frequency, the usual "natural order"), which is what stage 2's 8-lane groups load 16 bytes at a time.
+__constant__ uint8_t c_nat_of_zz[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
     const uint64_t dc_pk = *reinterpret_cast<const uint64_t *>(im->blk_dc_slot);
     const uint64_t ac_pk = *reinterpret_cast<const uint64_t *>(im->blk_ac_slot);
 
-    int16_t *out = coef + (im->block_off + (int64_t)sg->mcu0 * bpm) * 64 + lane;
+    int16_t *out = coef + (im->block_off + (int64_t)sg->mcu0 * bpm) * 64 + c_nat_of_zz[lane];
     int pred0 = 0, pred1 = 0, pred2 = 0;   // previous_dc (:735), int16 arithmetic
     int err = 0;
 

@@ -71,7 +71,7 @@ struct ReconArgs {
     const int64_t *mcu_prefix;   // [n_images + 1]
     int64_t total_mcus;
     const int16_t *coef;
-    const uint16_t *qt;          // [n_qt][64] zig-zag order
+    const uint16_t *qt;          // [n_qt][64] natural order [v][u] (same layout as the coefficient blocks)
     const double *idct_tt;       // [64 (u*8+v)][64 (x*8+y)] transposed reference table
     const uint32_t *up_taps;     // packed upsample taps, see reconstruct.hip
     uint8_t *rgb;
@@ -84,4 +84,10 @@ struct ReconArgs {
     int32_t mcus_per_image;
 };
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);
+// fast form (x-major output): tiles of fast_tile_mcus() MCUs in column-major MCU order
+int fast_tile_mcus(int hmax, int vmax, int ncomp);
+hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp,
+                                   const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image);
+// 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]
+hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural);
 }  // namespace mj

@@ -5,7 +5,7 @@
 // the crop (:1373) and YCbCr_to_RGB (:1683-1700) / the greyscale clip (:1384-1386).
 //
 // Work unit: one MCU per wavefront pass (grid-stride).  HBM traffic is the algorithmic minimum: each
-// coefficient block is read once (128 B, coalesced, lane = zig-zag index) and each output pixel is
+// coefficient block is read once (128 B, one line per wave) and each output pixel is
 // written once; everything in between lives in registers and LDS.
 //
 // Bit-exactness:
@@ -28,17 +28,6 @@
 namespace mj {
 
 namespace {
-
-// natural (u*8+v) -> zig-zag index: value at [x=u][y=v] of undo_zigzag is zz[ZZ_GRID[v][u]] (:1652-1662)
-__constant__ uint8_t c_zz_of_nat[64] = {
-    0, 2, 3, 9, 10, 20, 21, 35,
-    1, 4, 8, 11, 19, 22, 34, 36,
-    5, 7, 12, 18, 23, 33, 37, 48,
-    6, 13, 17, 24, 32, 38, 47, 49,
-    14, 16, 25, 31, 39, 46, 50, 57,
-    15, 26, 30, 40, 45, 51, 56, 58,
-    27, 29, 41, 44, 52, 55, 59, 62,
-    28, 42, 43, 53, 54, 60, 61, 63};
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -120,7 +109,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
     }
     __syncthreads();
 
-    const int zz_of_lane = c_zz_of_nat[lane];
+    // lane n = u*8+v holds block[u][v] (reference [x][y] order); blocks are stored [v][u] by stage 1
+    const int src_of_lane = (lane & 7) * 8 + (lane >> 3);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
 
     for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < a.total_mcus; g += n_waves) {
@@ -143,7 +133,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
         const int W = im->width, H = im->height;
         const int mcu_y = m / im->mcu_count_h, mcu_x = m - mcu_y * im->mcu_count_h;
         const int64_t blk0 = im->block_off + (int64_t)m * G::NB;
-        const int16_t *cp = a.coef + blk0 * 64 + lane;
+        const int16_t *cp = a.coef + blk0 * 64 + src_of_lane;
 
         int craw[G::NB];
 #pragma unroll
@@ -152,9 +142,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
 #pragma unroll
         for (int b = 0; b < G::NB; ++b) {
             const int comp = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
-            const int q = a.qt[im->qt_index[comp] * 64 + lane];
-            const int dzz = (int)(int16_t)(craw[b] * q);                 // int16 * int16 -> int16 (:869)
-            const int dn = __shfl(dzz, zz_of_lane);                      // lane n = u*8+v holds block[u][v]
+            const int q = a.qt[im->qt_index[comp] * 64 + src_of_lane];
+            const int dn = (int)(int16_t)(craw[b] * q);                  // int16 * int16 -> int16 (:869)
             const uint64_t mask = __ballot(dn != 0);
 
             double r[8];

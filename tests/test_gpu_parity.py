@@ -19,6 +19,14 @@ def dec():
     d.close()
 
 
+@pytest.fixture(scope="module")
+def dec_exact():
+    from pyjpegdecoder_amd import BatchDecoder
+    d = BatchDecoder(device=0, exact_only=True)
+    yield d
+    d.close()
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -33,6 +41,15 @@ def test_fixture_every_seam_bit_exact(dec, name):
     assert np.array_equal(seam["planes"], vec["planes"]), "G5 YCbCr planes"
     assert img.dtype == np.uint8 and img.shape == vec["rgb"].shape
     assert np.array_equal(img, vec["rgb"]), "G6 RGB (bar is +-1; we are exact)"
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fixture_exact_order_kernel(dec_exact, name):
+    """The exact-order stage-2 kernel (MJ_FLAG_EXACT_ONLY) alone — the fast kernel's referee."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec_exact.decode([raw], return_seams=True)
+    assert np.array_equal(seam["idct"], vec["idct"]) and np.array_equal(seam["planes"], vec["planes"])
+    assert np.array_equal(img, vec["rgb"])
 
 
 def test_all_fixtures_in_one_mixed_batch(dec):
