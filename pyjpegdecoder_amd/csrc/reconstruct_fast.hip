@@ -14,16 +14,18 @@
 //               sum at all: every sample is round(DC*q * T[0,0,0,0]) — one product, same as the reference
 //               whose 63 other products are zeros.
 //
-// Work decomposition (256 threads = 32 groups of 8 lanes):
-//   phase A  a tile of TM MCUs along the contiguous output axis; each 8-lane group transforms one block:
-//            lane v loads row v of the coefficient block (16 B; stage 1 writes blocks as [v][u]), so the
-//            first pass needs no cross-lane traffic; the 8x8 transpose between the passes goes through a
-//            conflict-free LDS scratch (row stride 72 B, group stride 576 B).  Results land in an LDS tile
-//            as int16 [x][y] blocks.
-//   phase B  thread (x, k) owns the MH consecutive pixels of column x of MCU k: 16-byte LDS reads for Y and
-//            for the two chroma source rows it needs, upsample from the four cell-corner weights, colour
-//            conversion, and 3*MH contiguous output bytes; neighbouring lanes (k+1) continue the same
-//            image column, so a 16-lane group writes 768 contiguous bytes.
+// Work decomposition: every wavefront works alone on a strip of TMW vertically adjacent MCUs (no block-wide
+// barriers; a workgroup is just four such waves sharing an LDS weight table).
+//   phase A  8-lane groups, one block each: lane v loads row v of the coefficient block (16 B; stage 1
+//            writes blocks as [v][u]), so the first pass needs no cross-lane traffic; the 8x8 transpose
+//            between the passes goes through a conflict-free LDS scratch (row stride 72 B, group stride
+//            576 B).  Results land in the wave's LDS strip as int16 [x][y] blocks.
+//   phase B  lane (x, k) owns the MH consecutive pixels of column x of MCU k: 16-byte LDS reads for Y and
+//            for the two chroma source rows it needs; upsample (four cell-corner weights) and colour run in
+//            fp32 where fp32 is provably exact, bytes are packed with v_cvt_pk_u8_f32, and the lane writes
+//            3*MH contiguous bytes; lanes k+1.. continue the same image column.
+//   The colour conversion is the reference's float64 expression whenever a pixel sits on (or outside the
+//   range where we can rule out) an exact rounding tie — see the comments in phase B and DESIGN.md.
 #include "mijpeg_internal.h"
 #include "upsample_taps.h"
 
@@ -62,15 +64,10 @@ __device__ __forceinline__ void idct8(const double f[8], double t[8]) {
     t[3] = e3 + o[3]; t[4] = e3 - o[3];
 }
 
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
-
-template <int DEN, int BIAS>
-__device__ __forceinline__ int floordiv(int t) {
-    return (int)((unsigned)(t + DEN * BIAS) / (unsigned)DEN) - BIAS;
-}
+__device__ __forceinline__ int deq(int c, uint32_t q) { return (int)(int16_t)__mul24(c, (int)q); }   // int16 wrap (:869)
 
 // YCbCr_to_RGB (jpeg_decoder.py:1693-1700) exactly as written: float64, no contraction.
 __device__ __forceinline__ uint32_t ycc_to_rgb_f64(int Y, int Cb, int Cr) {
@@ -84,72 +81,132 @@ __device__ __forceinline__ uint32_t ycc_to_rgb_f64(int Y, int Cb, int Cr) {
     return (uint32_t)(int)__builtin_rint(r) | ((uint32_t)(int)__builtin_rint(g) << 8) | ((uint32_t)(int)__builtin_rint(b) << 16);
 }
 
-// Integer/fp32 form, equal to the float64 expression except at exact half-integers, which go to the f64 form
-// (DESIGN.md "colour conversion"): 1.402c = 701c/500, 1.772c = 443c/250, 0.34414a+0.71414b = (17207a+35707b)/50000.
-__device__ __forceinline__ uint32_t ycc_to_rgb(int Y, int Cb, int Cr) {
-    const int cb = Cb - 128, cr = Cr - 128;
-    const float fr = (float)cr * 1.402f, fb = (float)cb * 1.772f;
-    const float rr = __builtin_rintf(fr), rb = __builtin_rintf(fb);
-    const int tg = 25000 - (17207 * cb + 35707 * cr);
-    const int qg = floordiv<50000, 2048>(tg);
-    bool slow = (unsigned)(cb + 1024) > 2048u || (unsigned)(cr + 1024) > 2048u;
-    slow |= __builtin_fabsf(fr - rr) > 0.4993f;
-    slow |= __builtin_fabsf(fb - rb) > 0.4985f;
-    slow |= (tg - qg * 50000) == 0;
-    if (slow) return ycc_to_rgb_f64(Y, Cb, Cr);
-    const int R = clamp255(Y + (int)rr), G = clamp255(Y + qg), B = clamp255(Y + (int)rb);
-    return (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
-}
-
 template <int HS, int VS, int NC>
 struct FGeo {
     static constexpr int NBY = HS * VS;
     static constexpr int NB = NC == 1 ? 1 : NBY + 2;
     static constexpr int MW = NC == 1 ? 8 : 8 * HS;
     static constexpr int MH = NC == 1 ? 8 : 8 * VS;
-    static constexpr int TM = 256 / MW;                  // MCUs per tile
-    static constexpr int ROUNDS = TM * NB / 32;          // 32 blocks per round
+    static constexpr int TMW = 64 / MW;                  // MCUs per wave strip
+    static constexpr int ROUNDS = TMW * NB / 8;          // 8 blocks per round
     static constexpr int MCU_STRIDE = NB * 64 + 8;       // int16 elements, +16 B so that MCUs start on different banks
     static constexpr bool SUB = NC == 3 && NBY > 1;
-    static constexpr int TILE_BYTES = TM * MCU_STRIDE * 2;
-    static constexpr int SCRATCH_BYTES = 4 * 8 * 576;
-    static constexpr int LDS_BYTES = TILE_BYTES + SCRATCH_BYTES + 16 + TM * NB * 4;
-    static_assert(TM * NB % 32 == 0, "tile must be a whole number of 32-block rounds");
+    static constexpr int STRIP_BYTES = TMW * MCU_STRIDE * 2;
+    static constexpr int SCR_BYTES = 8 * 576;
+    static constexpr int WAVE_BYTES = STRIP_BYTES + SCR_BYTES;
+    static constexpr int WTS_BYTES = SUB ? MW * MH * 16 : 0;
+    static constexpr int LDS_BYTES = 4 * WAVE_BYTES + WTS_BYTES;
+    static_assert(TMW * NB % 8 == 0, "strip must be a whole number of 8-block rounds");
+    static_assert(WAVE_BYTES % 16 == 0, "16-byte LDS accesses");
 };
+
+// Upsampled chroma of pixel (column px, row y) from the two source rows, integer form (exact):
+// round(sum(n_i*v_i)/15) — jpeg_decoder.py:1624-1626 through the captured operator.
+template <int HS, int VS>
+__device__ __forceinline__ int upsample_int(const int16_t *cp, int sx0, int sx1, int y, uint32_t w) {
+    const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
+    const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
+    const int w00 = w & 15, w01 = (w >> 4) & 15, w10 = (w >> 8) & 15, w11 = w >> 12;
+    const int s = w00 * cp[sx0 * 8 + sy0] + w01 * cp[sx0 * 8 + sy1] + w10 * cp[sx1 * 8 + sy0] + w11 * cp[sx1 * 8 + sy1];
+    return (int)(int16_t)((int)((unsigned)(2 * s + 15 + 30 * 65536) / 30u) - 65536);
+}
+
+// Slow, always-exact version of one lane's pixel run (rare): integer upsample + float64 colour, straight from
+// the LDS strip to global memory.  Also serves the seam outputs (planes) of the parity tests.
+template <int HS, int VS, int NC>
+__device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned char *dst, int nrows,
+                                             int16_t *planes /* or null */) {
+    using G = FGeo<HS, VS, NC>;
+    const uint16_t *w4 = (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
+    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+    const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
+#pragma unroll 1
+    for (int y = 0; y < nrows; ++y) {
+        const int yb = NC == 1 ? 0 : (y >> 3) * HS + (px >> 3);
+        const int Yv = mt[yb * 64 + (px & 7) * 8 + (y & 7)];
+        if constexpr (NC == 3) {
+            int Cbv, Crv;
+            if constexpr (G::SUB) {
+                const uint32_t w = w4[px * G::MH + y];
+                Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
+                Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
+            } else {
+                Cbv = mt[G::NBY * 64 + px * 8 + y];
+                Crv = mt[(G::NBY + 1) * 64 + px * 8 + y];
+            }
+            if (planes) { planes[3 * y] = (int16_t)Yv; planes[3 * y + 1] = (int16_t)Cbv; planes[3 * y + 2] = (int16_t)Crv; }
+            const uint32_t p = ycc_to_rgb_f64(Yv, Cbv, Crv);
+            dst[3 * y] = (unsigned char)p; dst[3 * y + 1] = (unsigned char)(p >> 8); dst[3 * y + 2] = (unsigned char)(p >> 16);
+        } else {
+            if (planes) planes[y] = (int16_t)Yv;
+            dst[y] = (unsigned char)clamp255(Yv);
+        }
+    }
+}
+
+// Exact-order IDCT of one block by a whole wave (lane = x*8+y), result into the LDS strip.
+__device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qblk, const double *tt, int16_t *out_lds,
+                                         int16_t *idct_out /* or null */) {
+    const int lane = threadIdx.x & 63;
+    const int u = lane >> 3, v = lane & 7;
+    const int dn = deq(cblk[v * 8 + u], qblk[v * 8 + u]);
+    const uint64_t mask = __ballot(dn != 0);
+    // r[v] accumulates u = 0..7 in order (NumPy pairwise sum); zero terms are skipped (x + 0.0 == x)
+    double rsum[8];
+#pragma unroll
+    for (int vv = 0; vv < 8; ++vv) rsum[vv] = 0.0;
+#pragma unroll 1
+    for (int uu = 0; uu < 8; ++uu) {
+        const uint32_t rowbits = (uint32_t)(mask >> (uu * 8)) & 0xFFu;
+        if (rowbits == 0) continue;
+#pragma unroll
+        for (int vv = 0; vv < 8; ++vv) {
+            if ((rowbits >> vv) & 1) {
+                const int cc = __builtin_amdgcn_readlane(dn, uu * 8 + vv);
+                const double p = (double)cc * tt[(uu * 8 + vv) * 64 + lane];
+                rsum[vv] = rsum[vv] + p;
+            }
+        }
+    }
+    const double s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
+    const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);
+    out_lds[lane] = (int16_t)val;
+    if (idct_out) idct_out[lane] = (int16_t)val;
+}
 
 }  // namespace
 
-template <int HS, int VS, int NC>
+template <int HS, int VS, int NC, bool SEAMS>
 __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
                                                           int64_t total_tiles, int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int16_t *s_tile = reinterpret_cast<int16_t *>(smem);
-    double *s_scr = reinterpret_cast<double *>(smem + G::TILE_BYTES);
-    int *s_nsusp = reinterpret_cast<int *>(smem + G::TILE_BYTES + G::SCRATCH_BYTES);
-    int *s_list = s_nsusp + 4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = tid >> 3, j = tid & 7;
-    double *scr = s_scr + wave * (8 * 72) + (lane >> 3) * 72;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int16_t *s_strip = reinterpret_cast<int16_t *>(smem + wave * G::WAVE_BYTES);
+    double *scr = reinterpret_cast<double *>(smem + wave * G::WAVE_BYTES + G::STRIP_BYTES) + (lane >> 3) * 72;
+    const float4 *s_wts = reinterpret_cast<const float4 *>(smem + 4 * G::WAVE_BYTES);
+    const int grp = lane >> 3, j = lane & 7;
     const double T0 = a.idct_tt[0];     // T[x,y,0,0], identical for every (x,y)
 
-    // phase-B identity of this thread: column x of MCU k
-    const int px = tid / G::TM, pk = tid % G::TM;
-    uint32_t wpk[G::MH / 2];
-    if constexpr (G::SUB) {
+    if constexpr (G::SUB) {             // four corner weights / 15 as floats, [x][y]
         const uint16_t *w4 = (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
-#pragma unroll
-        for (int i = 0; i < G::MH / 2; ++i)
-            wpk[i] = (uint32_t)w4[px * G::MH + 2 * i] | ((uint32_t)w4[px * G::MH + 2 * i + 1] << 16);
+        float4 *wt = reinterpret_cast<float4 *>(smem + 4 * G::WAVE_BYTES);
+        for (int i = tid; i < G::MW * G::MH; i += 256) {
+            const uint32_t w = w4[i];
+            wt[i] = make_float4((float)(w & 15) / 15.0f, (float)((w >> 4) & 15) / 15.0f, (float)((w >> 8) & 15) / 15.0f,
+                                (float)(w >> 12) / 15.0f);
+        }
+        __syncthreads();
     }
-    if (tid == 0) *s_nsusp = 0;
-    __syncthreads();
 
-    for (int64_t tg = blockIdx.x; tg < total_tiles; tg += gridDim.x) {
-        // ---- tile -> image (uniform)
-        int img;
-        int tile;
+    // phase-B identity of this lane: column px of MCU pk of the strip
+    const int px = lane / G::TMW, pk = lane % G::TMW;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    for (int64_t tg = (int64_t)blockIdx.x * 4 + wave; tg < total_tiles; tg += n_waves) {
+        // ---- strip -> image (wave-uniform)
+        int img, tile;
         if (a.uniform_geometry) {
             img = (int)(tg / tiles_per_image);
             tile = (int)(tg - (int64_t)img * tiles_per_image);
@@ -165,28 +222,37 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
         const DevImage *im = a.images + img;
         const int W = im->width, H = im->height;
         const int mch = im->mcu_count_h, mcv = im->mcu_count_v;
-        const int mcus = mch * mcv;
-        const int first = tile * G::TM;                       // in column-major MCU order
-        const int n_valid = min(G::TM, mcus - first);
+        const int first = tile * G::TMW;                      // in column-major MCU order
+        const int n_valid = min(G::TMW, mch * mcv - first);
+        const int64_t block_off = im->block_off;
+        const uint16_t *qbase = a.qt;
+        const int q0i = im->qt_index[0] * 64, q1i = im->qt_index[NC == 3 ? 1 : 0] * 64, q2i = im->qt_index[NC == 3 ? 2 : 0] * 64;
 
         // ================= phase A: blocks ==================
-#pragma unroll 1
+        // all rounds' coefficient rows are requested up front (ROUNDS x 16 B per lane in flight)
+        uint4 cw[G::ROUNDS];
+        int64_t blk_r[G::ROUNDS];
+#pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
-            const int bt = r * 32 + grp;
+            const int bt = r * 8 + grp;
             const int k = bt / G::NB, b = bt - k * G::NB;
-            const bool valid = k < n_valid;
-            const int mp = first + (valid ? k : 0);
+            const int mp = first + (k < n_valid ? k : 0);
             const int mcu_x = mp / mcv, mcu_y = mp - mcu_x * mcv;
-            const int64_t blk = im->block_off + (int64_t)(mcu_y * mch + mcu_x) * G::NB + b;
-            const int comp = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
-            uint4 cw = make_uint4(0, 0, 0, 0);
-            if (valid) cw = *reinterpret_cast<const uint4 *>(a.coef + blk * 64 + j * 8);
-            const uint4 qw = *reinterpret_cast<const uint4 *>(a.qt + im->qt_index[comp] * 64 + j * 8);
+            blk_r[r] = block_off + (int64_t)(mcu_y * mch + mcu_x) * G::NB + b;
+            cw[r] = *reinterpret_cast<const uint4 *>(a.coef + blk_r[r] * 64 + j * 8);
+        }
+        uint32_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r) {
+            const int bt = r * 8 + grp;
+            const int k = bt / G::NB, b = bt - k * G::NB;
+            const int qi = (NC == 1 || b < G::NBY) ? q0i : (b == G::NBY ? q1i : q2i);
+            const uint4 qw = *reinterpret_cast<const uint4 *>(qbase + qi + j * 8);
             int d[8];
-            d[0] = (int)(int16_t)(lo16(cw.x) * (int)(qw.x & 0xFFFF)); d[1] = (int)(int16_t)(hi16(cw.x) * (int)(qw.x >> 16));
-            d[2] = (int)(int16_t)(lo16(cw.y) * (int)(qw.y & 0xFFFF)); d[3] = (int)(int16_t)(hi16(cw.y) * (int)(qw.y >> 16));
-            d[4] = (int)(int16_t)(lo16(cw.z) * (int)(qw.z & 0xFFFF)); d[5] = (int)(int16_t)(hi16(cw.z) * (int)(qw.z >> 16));
-            d[6] = (int)(int16_t)(lo16(cw.w) * (int)(qw.w & 0xFFFF)); d[7] = (int)(int16_t)(hi16(cw.w) * (int)(qw.w >> 16));
+            d[0] = deq(lo16(cw[r].x), qw.x & 0xFFFF); d[1] = deq(hi16(cw[r].x), qw.x >> 16);
+            d[2] = deq(lo16(cw[r].y), qw.y & 0xFFFF); d[3] = deq(hi16(cw[r].y), qw.y >> 16);
+            d[4] = deq(lo16(cw[r].z), qw.z & 0xFFFF); d[5] = deq(hi16(cw[r].z), qw.z >> 16);
+            d[6] = deq(lo16(cw[r].w), qw.w & 0xFFFF); d[7] = deq(hi16(cw[r].w), qw.w >> 16);
 
             const int ac = d[1] | d[2] | d[3] | d[4] | d[5] | d[6] | d[7] | (j == 0 ? 0 : d[0]);
             const uint64_t acb = __ballot(ac != 0);
@@ -216,59 +282,36 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
 #pragma unroll
                 for (int y = 0; y < 8; ++y) o[y] = vdc;
             }
-            const bool susp = valid && !dconly && err > (0.5 - 9.5367431640625e-07);
+            const bool susp = !dconly && err > (0.5 - 9.5367431640625e-07);
             const uint64_t sb = __ballot(susp);
-            if (((sb >> (lane & 56)) & 0xFF) != 0 && j == 0) s_list[atomicAdd(s_nsusp, 1)] = bt;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8)
+                if ((sb >> (8 * g8)) & 0xFF) susp_bits |= 1u << (r * 8 + g8);
 
             uint4 ow;
             ow.x = (uint32_t)(o[0] & 0xFFFF) | ((uint32_t)o[1] << 16);
             ow.y = (uint32_t)(o[2] & 0xFFFF) | ((uint32_t)o[3] << 16);
             ow.z = (uint32_t)(o[4] & 0xFFFF) | ((uint32_t)o[5] << 16);
             ow.w = (uint32_t)(o[6] & 0xFFFF) | ((uint32_t)o[7] << 16);
-            *reinterpret_cast<uint4 *>(s_tile + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
-            if (a.idct_out && valid) *reinterpret_cast<uint4 *>(a.idct_out + blk * 64 + j * 8) = ow;
+            *reinterpret_cast<uint4 *>(s_strip + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
+            if constexpr (SEAMS) {
+                if (a.idct_out && k < n_valid) *reinterpret_cast<uint4 *>(a.idct_out + blk_r[r] * 64 + j * 8) = ow;
+            }
         }
-        __syncthreads();
 
         // ---- rare: blocks with a sample too close to a rounding boundary -> exact-order recompute
-        const int nsusp = *s_nsusp;
-        if (nsusp > 0) {
-            for (int i = wave; i < nsusp; i += 4) {
-                const int bt = s_list[i];
-                const int k = bt / G::NB, b = bt - k * G::NB;
-                const int mp = first + k;
-                const int mcu_x = mp / mcv, mcu_y = mp - mcu_x * mcv;
-                const int64_t blk = im->block_off + (int64_t)(mcu_y * mch + mcu_x) * G::NB + b;
-                const int comp = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
-                const int u = lane >> 3, v = lane & 7;
-                const int c = a.coef[blk * 64 + v * 8 + u];
-                const int q = a.qt[im->qt_index[comp] * 64 + v * 8 + u];
-                const int dn = (int)(int16_t)(c * q);
-                const uint64_t mask = __ballot(dn != 0);
-                // r[v] accumulates u = 0..7 in order; the u loop stays rolled (this path is rare, keep it small)
-                double rsum[8];
-#pragma unroll
-                for (int vv = 0; vv < 8; ++vv) rsum[vv] = 0.0;
-#pragma unroll 1
-                for (int uu = 0; uu < 8; ++uu) {
-                    const uint32_t rowbits = (uint32_t)(mask >> (uu * 8)) & 0xFFu;
-                    if (rowbits == 0) continue;
-#pragma unroll
-                    for (int vv = 0; vv < 8; ++vv) {
-                        if ((rowbits >> vv) & 1) {
-                            const int cc = __builtin_amdgcn_readlane(dn, uu * 8 + vv);
-                            const double p = (double)cc * a.idct_tt[(uu * 8 + vv) * 64 + lane];
-                            rsum[vv] = rsum[vv] + p;
-                        }
-                    }
-                }
-                const double s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
-                const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);
-                s_tile[k * G::MCU_STRIDE + b * 64 + lane] = (int16_t)val;
-                if (a.idct_out) a.idct_out[blk * 64 + lane] = (int16_t)val;
-            }
-            __syncthreads();
-            if (tid == 0) *s_nsusp = 0;
+        susp_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)susp_bits);
+        while (susp_bits) {
+            const int bt = __builtin_ctz(susp_bits);
+            susp_bits &= susp_bits - 1;
+            const int k = bt / G::NB, b = bt - k * G::NB;
+            if (k >= n_valid) continue;
+            const int mp = first + k;
+            const int mcu_x = mp / mcv, mcu_y = mp - mcu_x * mcv;
+            const int64_t blk = block_off + (int64_t)(mcu_y * mch + mcu_x) * G::NB + b;
+            const int qi = (NC == 1 || b < G::NBY) ? q0i : (b == G::NBY ? q1i : q2i);
+            block_exact(a.coef + blk * 64, qbase + qi, a.idct_tt, s_strip + k * G::MCU_STRIDE + b * 64,
+                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr);
         }
 
         // ================= phase B: pixels ==================
@@ -276,85 +319,98 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
             const int mp = first + pk;
             const int mcu_x = mp / mcv, mcu_y = mp - mcu_x * mcv;
             const int gx = mcu_x * G::MW + px, gy0 = mcu_y * G::MH;
-            const int16_t *mt = s_tile + pk * G::MCU_STRIDE;
-            // chroma source rows sx0, sx0+1 of this thread's column, unpacked once
-            int cA[2][8], cB[2][8];
-            if constexpr (NC == 3) {
-                const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
-                const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int16_t *cp = mt + (G::NBY + c) * 64;
-                    const uint4 wa = *reinterpret_cast<const uint4 *>(cp + sx0 * 8);
-                    cA[c][0] = lo16(wa.x); cA[c][1] = hi16(wa.x); cA[c][2] = lo16(wa.y); cA[c][3] = hi16(wa.y);
-                    cA[c][4] = lo16(wa.z); cA[c][5] = hi16(wa.z); cA[c][6] = lo16(wa.w); cA[c][7] = hi16(wa.w);
-                    if constexpr (HS == 2) {
-                        const uint4 wb = *reinterpret_cast<const uint4 *>(cp + sx1 * 8);
-                        cB[c][0] = lo16(wb.x); cB[c][1] = hi16(wb.x); cB[c][2] = lo16(wb.y); cB[c][3] = hi16(wb.y);
-                        cB[c][4] = lo16(wb.z); cB[c][5] = hi16(wb.z); cB[c][6] = lo16(wb.w); cB[c][7] = hi16(wb.w);
-                    }
-                }
-            }
+            const int16_t *mt = s_strip + pk * G::MCU_STRIDE;
+            const int nrows = min(G::MH, H - gy0);
+            unsigned char *dst = a.rgb + im->rgb_off + ((int64_t)gx * H + gy0) * NC;
             constexpr int NBYTES = G::MH * NC;
-            uint32_t ob[(NBYTES + 3) / 4];
-            const bool want_planes = a.planes != nullptr;
+
+            if constexpr (SEAMS) {
+                if (gx < W)
+                    pixel_run_exact<HS, VS, NC>(mt, px, dst, nrows,
+                                                a.planes ? a.planes + (im->pix_off + (int64_t)gx * H + gy0) * NC : nullptr);
+            } else {
+                uint32_t ob[(NBYTES + 3) / 4];
 #pragma unroll
-            for (int by = 0; by < G::MH / 8; ++by) {
-                const int yb = NC == 1 ? 0 : by * HS + (px >> 3);
-                const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
-                const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
-                uint32_t pix[8];
+                for (int i = 0; i < (NBYTES + 3) / 4; ++i) ob[i] = 0;
+                bool slow = false;
+                if constexpr (NC == 3) {
+                    // chroma source rows sx0, sx0+1 of this lane's column, as floats
+                    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+                    const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
+                    float cA[2][8], cB[2][8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int y = by * 8 + i;
-                    const int Yv = (i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]);
-                    int Cbv = 0, Crv = 0;
-                    if constexpr (NC == 3) {
-                        if constexpr (G::SUB) {
-                            const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
-                            const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
-                            const uint32_t w = (wpk[y >> 1] >> (16 * (y & 1))) & 0xFFFFu;
-                            const int w00 = w & 15, w01 = (w >> 4) & 15, w10 = (w >> 8) & 15, w11 = w >> 12;
-                            int sb = w00 * cA[0][sy0] + w01 * cA[0][sy1];
-                            int sr = w00 * cA[1][sy0] + w01 * cA[1][sy1];
-                            if constexpr (HS == 2) {
-                                sb += w10 * cB[0][sy0] + w11 * cB[0][sy1];
-                                sr += w10 * cB[1][sy0] + w11 * cB[1][sy1];
-                            }
-                            // round(s/15): s/15 is never a half-integer and |s| < 2^19, so fp32 is exact here
-                            Cbv = (int)(int16_t)(int)__builtin_rintf((float)sb * (1.0f / 15.0f));
-                            Crv = (int)(int16_t)(int)__builtin_rintf((float)sr * (1.0f / 15.0f));
-                        } else {
-                            Cbv = cA[0][y];
-                            Crv = cA[1][y];
+                    for (int c = 0; c < 2; ++c) {
+                        const int16_t *cp = mt + (G::NBY + c) * 64;
+                        const uint4 wa = *reinterpret_cast<const uint4 *>(cp + sx0 * 8);
+                        cA[c][0] = (float)lo16(wa.x); cA[c][1] = (float)hi16(wa.x); cA[c][2] = (float)lo16(wa.y); cA[c][3] = (float)hi16(wa.y);
+                        cA[c][4] = (float)lo16(wa.z); cA[c][5] = (float)hi16(wa.z); cA[c][6] = (float)lo16(wa.w); cA[c][7] = (float)hi16(wa.w);
+                        if constexpr (HS == 2) {
+                            const uint4 wb = *reinterpret_cast<const uint4 *>(cp + sx1 * 8);
+                            cB[c][0] = (float)lo16(wb.x); cB[c][1] = (float)hi16(wb.x); cB[c][2] = (float)lo16(wb.y); cB[c][3] = (float)hi16(wb.y);
+                            cB[c][4] = (float)lo16(wb.z); cB[c][5] = (float)hi16(wb.z); cB[c][6] = (float)lo16(wb.w); cB[c][7] = (float)hi16(wb.w);
                         }
                     }
-                    if (want_planes && gx < W && gy0 + y < H) {
-                        int16_t *pl = a.planes + (im->pix_off + (int64_t)gx * H + gy0 + y) * NC;
-                        pl[0] = (int16_t)Yv;
-                        if constexpr (NC == 3) { pl[1] = (int16_t)Cbv; pl[2] = (int16_t)Crv; }
-                    }
-                    if constexpr (NC == 3) pix[i] = ycc_to_rgb(Yv, Cbv, Crv);
-                    else pix[i] = (uint32_t)clamp255(Yv);
-                }
-                if constexpr (NC == 3) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 2; ++q4) {       // 4 pixels (12 bytes) -> 3 dwords
-                        const uint32_t p0 = pix[4 * q4], p1 = pix[4 * q4 + 1], p2 = pix[4 * q4 + 2], p3 = pix[4 * q4 + 3];
-                        ob[by * 6 + 3 * q4 + 0] = p0 | (p1 << 24);
-                        ob[by * 6 + 3 * q4 + 1] = (p1 >> 8) | (p2 << 16);
-                        ob[by * 6 + 3 * q4 + 2] = (p2 >> 16) | (p3 << 8);
+                    for (int by = 0; by < G::MH / 8; ++by) {
+                        const int yb = by * HS + (px >> 3);
+                        const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
+                        const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int y = by * 8 + i;
+                            const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
+                            float Cbf, Crf;
+                            if constexpr (G::SUB) {
+                                // sum(n_i v_i)/15 is never within 1/30 of a half-integer and the fp32 evaluation is
+                                // within 0.012 of it for any int16 inputs, so rintf() returns the reference's value
+                                const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
+                                const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
+                                const float4 wq = s_wts[px * G::MH + y];
+                                float sb = wq.x * cA[0][sy0], sr = wq.x * cA[1][sy0];
+                                sb = __builtin_fmaf(wq.y, cA[0][sy1], sb); sr = __builtin_fmaf(wq.y, cA[1][sy1], sr);
+                                if constexpr (HS == 2) {
+                                    sb = __builtin_fmaf(wq.z, cB[0][sy0], sb); sr = __builtin_fmaf(wq.z, cB[1][sy0], sr);
+                                    sb = __builtin_fmaf(wq.w, cB[0][sy1], sb); sr = __builtin_fmaf(wq.w, cB[1][sy1], sr);
+                                }
+                                Cbf = __builtin_rintf(sb);
+                                Crf = __builtin_rintf(sr);
+                            } else {
+                                Cbf = cA[0][y];
+                                Crf = cA[1][y];
+                            }
+                            // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact: 1.402c = 701c/500 and
+                            // 1.772c = 443c/250 have their first exact .5 at |c| = 250 resp. 125 and are otherwise >= 0.002
+                            // away from one; N = 17207cb + 35707cr is an exact fp32 integer for |c| <= 255 and its
+                            // remainder against 50000 is obtained exactly with one fma.
+                            const float cb = Cbf - 128.0f, cr = Crf - 128.0f;
+                            const float Rf = Yf + __builtin_rintf(cr * 1.402f);
+                            const float Bf = Yf + __builtin_rintf(cb * 1.772f);
+                            const float N = __builtin_fmaf(35707.0f, cr, 17207.0f * cb);
+                            float q = __builtin_rintf(N * 2e-5f);
+                            const float rem = __builtin_fmaf(-50000.0f, q, N);
+                            q += (rem > 25000.0f ? 1.0f : 0.0f) - (rem < -25000.0f ? 1.0f : 0.0f);
+                            const float Gf = Yf - q;
+                            slow |= (__builtin_fabsf(cb) > 255.0f) | (__builtin_fabsf(cr) >= 250.0f) |
+                                    (__builtin_fabsf(cb) == 125.0f) | (__builtin_fabsf(rem) == 25000.0f);
+                            const int o0 = 3 * y, o1 = 3 * y + 1, o2 = 3 * y + 2;
+                            ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Rf, o0 & 3, ob[o0 >> 2]);
+                            ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
+                            ob[o2 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Bf, o2 & 3, ob[o2 >> 2]);
+                        }
                     }
                 } else {
-                    ob[by * 2 + 0] = pix[0] | (pix[1] << 8) | (pix[2] << 16) | (pix[3] << 24);
-                    ob[by * 2 + 1] = pix[4] | (pix[5] << 8) | (pix[6] << 16) | (pix[7] << 24);
+                    const uint4 yw = *reinterpret_cast<const uint4 *>(mt + (px & 7) * 8);
+                    const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
+                        ob[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Yf, i & 3, ob[i >> 2]);
+                    }
                 }
-            }
-            if (gx < W) {
-                unsigned char *dst = a.rgb + im->rgb_off + ((int64_t)gx * H + gy0) * NC;
-                const int nrows = min(G::MH, H - gy0);
-                if (nrows == G::MH && ((uintptr_t)dst & 3) == 0) {
-                    if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                if (gx < W) {
+                    if (slow || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
+                        pixel_run_exact<HS, VS, NC>(mt, px, dst, nrows, nullptr);
+                    } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
 #pragma unroll
                         for (int i = 0; i < NBYTES / 16; ++i)
                             reinterpret_cast<uint4 *>(dst)[i] = make_uint4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
@@ -366,15 +422,10 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
 #pragma unroll
                         for (int i = 0; i < NBYTES / 4; ++i) reinterpret_cast<uint32_t *>(dst)[i] = ob[i];
                     }
-                } else {
-                    const int nb = nrows * NC;
-#pragma unroll
-                    for (int i = 0; i < NBYTES; ++i)
-                        if (i < nb) dst[i] = (unsigned char)(ob[i >> 2] >> (8 * (i & 3)));
                 }
             }
         }
-        __syncthreads();   // tile buffer is reused by the next tile
+        // the strip is private to this wave and LDS operations of one wave complete in order: no barrier
     }
 }
 
@@ -383,14 +434,19 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
                                 int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
     if (total_tiles == 0) return hipSuccess;
+    const int64_t want = (total_tiles + 3) / 4;
     const int64_t cap = 256 * 5;
-    const unsigned blocks = (unsigned)(total_tiles < cap ? total_tiles : cap);
-    hipLaunchKernelGGL((k_reconstruct_fast<HS, VS, NC>), dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, tile_prefix,
-                       total_tiles, tiles_per_image);
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    if (a.planes || a.idct_out)
+        hipLaunchKernelGGL((k_reconstruct_fast<HS, VS, NC, true>), dim3(blocks), dim3(256), G::LDS_BYTES, stream, a,
+                           tile_prefix, total_tiles, tiles_per_image);
+    else
+        hipLaunchKernelGGL((k_reconstruct_fast<HS, VS, NC, false>), dim3(blocks), dim3(256), G::LDS_BYTES, stream, a,
+                           tile_prefix, total_tiles, tiles_per_image);
     return hipGetLastError();
 }
 
-int fast_tile_mcus(int hmax, int vmax, int ncomp) { return 256 / (ncomp == 1 ? 8 : 8 * hmax); }
+int fast_tile_mcus(int hmax, int vmax, int ncomp) { return 64 / (ncomp == 1 ? 8 : 8 * hmax); }
 
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp,
                                    const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image) {

@@ -52,6 +52,13 @@ def test_fixture_exact_order_kernel(dec_exact, name):
     assert np.array_equal(img, vec["rgb"])
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_fixture_production_launch(dec, name):
+    """Same files through the launch that produces no seam outputs (fast pixel path)."""
+    raw, vec = load_golden(name)
+    assert np.array_equal(dec.decode([raw])[0], vec["rgb"])
+
+
 def test_all_fixtures_in_one_mixed_batch(dec):
     names = golden_names()
     raws = [load_golden(n)[0] for n in names]
@@ -102,6 +109,8 @@ def test_random_sizes_against_oracle(dec, ss, w, h, ri, q):
     assert np.array_equal(seam["coef"], ref["coef"])
     assert np.array_equal(seam["planes"], ref["planes"])
     assert np.array_equal(img, ref["rgb"])
+    # the production launch (no seam outputs) takes the fp32 upsample/colour fast path: same pixels
+    assert np.array_equal(dec.decode([raw])[0], ref["rgb"])
 
 
 def test_config2_idct_only_on_host_decoded_coefficients(dec):
@@ -203,6 +212,17 @@ def test_colour_conversion_ties_through_the_kernel(dec):
         plan.close()
     planes = out["planes"].reshape(8 * cols, 8 * rows, 3)
     rgb = out["rgb"].reshape(8 * cols, 8 * rows, 3)
+    # and once more through the production launch (fp32 fast colour path with its tie detection)
+    bc.flags = 0
+    plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
+    try:
+        plan.write_coef(coef.reshape(-1, 64))
+        plan.execute_stage2()
+        plan.sync()
+        rgb2 = plan.read(rgb=True)["rgb"].reshape(8 * cols, 8 * rows, 3)
+    finally:
+        plan.close()
+    assert np.array_equal(rgb2, rgb)
     # block i sits at MCU (i % cols, i // cols); sample two pixels of each block
     i = np.arange(n)
     bx, by = (i % cols) * 8, (i // cols) * 8
