@@ -334,8 +334,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         const int tm = mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp);
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
-            const int64_t mcus = (int64_t)imgs[i].mcu_count_h * imgs[i].mcu_count_v;
-            tp[i + 1] = tp[i] + (mcus + tm - 1) / tm;
+            tp[i + 1] = tp[i] + (int64_t)imgs[i].mcu_count_h * ((imgs[i].mcu_count_v + tm - 1) / tm);   // column strips
         }
         p->total_tiles = tp[b->n_images];
         p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
@@ -403,6 +402,7 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.total_mcus = p->info.total_mcus; a.coef = p->d_coef; a.qt = p->d_qt; a.idct_tt = ctx->d_idct_tt;
     a.up_taps = nullptr; a.rgb = rgb_device; a.planes = p->d_planes; a.idct_out = p->d_idct;
     a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
+    a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
     if (p->layout == MJ_LAYOUT_XMAJOR && !a.exact_only)
         MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,

@@ -79,6 +79,7 @@ struct ReconArgs {
     int16_t *idct_out;           // optional
     int32_t layout;
     int32_t exact_only;
+    int32_t debug;               // profiling ablations (MJ_DEBUG_STAGE2 env): 1 = no phase A, 2 = no phase B, 3 = no stores
     // homogeneous-batch shortcut: all images share one geometry
     int32_t uniform_geometry;
     int32_t mcus_per_image;
