@@ -39,6 +39,9 @@ struct mj_plan {
     int64_t n_segs = 0;
     mj::DevImage *d_images = nullptr;
     mj::DevHuff *d_huff = nullptr;
+    uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
+    int n_huff = 0;
+    bool use_lanes = false;
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
     int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
@@ -207,7 +210,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -344,6 +347,32 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         std::vector<mj::DevHuff> hh(b->n_huff);
         for (int t = 0; t < b->n_huff; ++t) build_dev_huff(b->huff[t], hh[t]);
         if ((rc = upload(ctx, &p->d_huff, hh.data(), hh.size())) != MJ_OK) return rc;
+        p->n_huff = b->n_huff;
+        {   // 11-bit LUTs for the lane-parallel kernel
+            const int LB = mj::kLaneLutBits, LS = 1 << LB;
+            std::vector<uint16_t> l11((size_t)b->n_huff * LS, 0);
+            for (int t = 0; t < b->n_huff; ++t) {
+                int code = 0, k = 0;
+                for (int l = 1; l <= 16; ++l) {
+                    code <<= 1;
+                    for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                        if (l <= LB && code < (1 << l)) {
+                            const int shift = LB - l;
+                            for (int f = 0; f < (1 << shift); ++f) {
+                                uint16_t &e = l11[(size_t)t * LS + ((code << shift) | f)];
+                                if (e == 0) e = (uint16_t)((l << 8) | b->huff[t].vals[k]);
+                            }
+                        }
+                    }
+                }
+            }
+            if ((rc = upload(ctx, &p->d_lut11, l11.data(), l11.size())) != MJ_OK) return rc;
+        }
+        // one segment per lane pays off once there are enough segments to fill the chip that way
+        const char *force = getenv("MJ_HUFFMAN");
+        p->use_lanes = b->n_huff <= mj::kMaxLaneTables && (int64_t)segs.size() >= 8192;
+        if (force && !strcmp(force, "wave")) p->use_lanes = false;
+        if (force && !strcmp(force, "lanes") && b->n_huff <= mj::kMaxLaneTables) p->use_lanes = true;
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
@@ -383,8 +412,12 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
     if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data (stage 1 unavailable)");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
-    MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
-                                   p->d_status, p->lut_slots));
+    if (p->use_lanes)
+        MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
+                                             p->n_huff, p->d_coef, p->d_status));
+    else
+        MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
+                                       p->d_status, p->lut_slots));
     return MJ_OK;
 }
 
@@ -516,9 +549,7 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
         if (p->d_blob) {
             if ((rc = mj_plan_execute_stage1(p, s)) != MJ_OK) return rc;   // warm
             MJ_HIP(ctx, hipEventRecord(e0, s));
-            for (int i = 0; i < iters && rc == MJ_OK; ++i)
-                rc = mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
-                                        p->d_status, p->lut_slots) == hipSuccess ? MJ_OK : MJ_ERR_HIP;
+            for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = mj_plan_execute_stage1(p, s);
             MJ_HIP(ctx, hipEventRecord(e1, s));
             MJ_HIP(ctx, hipEventSynchronize(e1));
             MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));

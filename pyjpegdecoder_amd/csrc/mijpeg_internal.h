@@ -65,6 +65,13 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegm
                           const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
                           int lut_slots);
 
+// lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
+constexpr int kLaneLutBits = 11;
+constexpr int kMaxLaneTables = 8;
+hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+                                const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
+                                int16_t *coef, int32_t *status);
+
 struct ReconArgs {
     const DevImage *images;
     int32_t n_images;

@@ -289,3 +289,41 @@ def test_batch_of_1080p_roundtrip_properties(dec):
     assert np.array_equal(single, a[3])
     from oracle import oracle
     assert np.array_equal(oracle.decode(raws[5])["rgb"], a[5])
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_both_stage1_forms_every_fixture(dec, mode, monkeypatch):
+    """Stage 1 exists in two forms (one restart segment per wavefront / per lane); force each in turn and
+    require the reference's coefficients and pixels from both."""
+    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    names = golden_names()
+    raws = [load_golden(n)[0] for n in names]
+    imgs, seams = dec.decode(raws, return_seams=True)
+    for n, img, seam in zip(names, imgs, seams):
+        vec = load_golden(n)[1]
+        assert np.array_equal(seam["coef"], vec["coef"]), (mode, n)
+        assert np.array_equal(img, vec["rgb"]), (mode, n)
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_both_stage1_forms_1080p_and_errors(dec, mode, monkeypatch):
+    from pyjpegdecoder_amd import CorruptedJpeg, parse_jpeg
+    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    name = "c3_1920x1080_420_dri120"
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert sha(seam["coef"]) == meta["sha256"]["coef"] and sha(img) == meta["sha256"]["rgb"]
+    # ragged batch: files whose segments have different MCU counts and lengths share wavefronts
+    from tools import synth
+    from oracle import oracle
+    files = [synth.synth_jpeg(50 + i, 64 + 16 * i, 48 + 8 * (i % 5), 80 + i, "420", 1 + (i % 7), 30.0) for i in range(24)]
+    for f, img in zip(files, dec.decode(files)):
+        assert np.array_equal(img, oracle.decode(f)["rgb"])
+    raw, _ = load_golden("128x64_420_dri3")
+    s = parse_jpeg(raw).scans[0]
+    off = int(s.segment_offsets[2])
+    for bad in (raw[:off - 2] + b"\x12\x34" + raw[off - 2:],
+                raw[:int(s.entropy_start) + 3] + raw[int(s.segment_offsets[1]) - 2:]):
+        with pytest.raises(CorruptedJpeg):
+            dec.decode([bad])
