@@ -26,13 +26,6 @@ STAGE2_BYTES_PER_IMAGE = BLOCKS_PER_IMAGE * 128 + W * H * 3       # 12 487 680 (
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def shard(n_units: int, rank: int, world: int):
-    """Contiguous shard of `n_units` independent units for `rank` (sizes differ by at most one)."""
-    base, rem = divmod(n_units, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
 def cpu_baseline(raws, budget_s: float = 20.0):
     """The CPU oracle (bit-exact restatement of the reference path) timed on this host, one thread."""
     import ctypes
@@ -123,10 +116,8 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from pyjpegdecoder_amd.sharding import max_over_ranks
+    dt = max_over_ranks(dt, dev)
 
     # ---- parity spot check of what was just timed (first and last image of the batch vs the oracle) -------
     out = plan.read(rgb=False)

@@ -95,7 +95,8 @@ typedef struct {
 
     const uint8_t *blob;                  /* the file bytes of all images, back to back or not              */
     int64_t blob_len;
-    int32_t blob_mem;                     /* MJ_MEM_HOST or MJ_MEM_DEVICE (device: must stay valid for the plan) */
+    int32_t blob_mem;                     /* MJ_MEM_HOST or MJ_MEM_DEVICE (device: 4-byte aligned, must stay valid for the
+                                             plan, and be readable 256 bytes past every segment end: stage 1 prefetches) */
 
     int64_t n_segments;                   /* total entries of the two arrays below                          */
     const int64_t *seg_begin;             /* host: blob offset of the first entropy byte of each segment    */

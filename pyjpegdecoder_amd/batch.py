@@ -78,7 +78,8 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
     # keep every file 4-byte aligned inside the blob (stage 1 fetches aligned dwords)
     offs = np.zeros(n + 1, dtype=np.int64)
     offs[1:] = np.cumsum((sizes + 3) & ~3)
-    blob = np.zeros(int(offs[-1]) + 4, dtype=np.uint8)
+    # stage 1 prefetches up to 128 bytes ahead of a segment: keep that much readable slack behind the last file
+    blob = np.zeros(int(offs[-1]) + 1024, dtype=np.uint8)
     descs = (B.ImageDescC * n)()
     huff_ids: Dict[bytes, int] = {}
     huff_list: List[Tuple[np.ndarray, np.ndarray]] = []

@@ -19,6 +19,8 @@
 //   * coefficients: each lane owns a 128-byte block in LDS (row stride 132 B -> conflict-free scatter of
 //     "coefficient kk of every lane"); a finished round of 64 blocks leaves as 32 store instructions that each
 //     write two full 128-byte lines, in the natural [v][u] order stage 2 reads.
+#include <stdlib.h>
+
 #include "mijpeg_internal.h"
 
 namespace mj {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                                                        const DevHuff *__restrict__ huff,
                                                        const uint16_t *__restrict__ lut11,   // [n_huff][kLSize]
                                                        int n_huff, int16_t *__restrict__ coef,
-                                                       int32_t *__restrict__ status) {
+                                                       int32_t *__restrict__ status, int lpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     if (tid < 64) s_nat[tid] = c_nat_of_zz_l[tid];
     __syncthreads();
 
-    const int64_t seg_id = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
-    const bool have = seg_id < n_segs;
+    const int64_t seg_id = ((int64_t)blockIdx.x * 4 + wave) * lpw + lane;   // lpw segments per wave (tunable)
+    const bool have = lane < lpw && seg_id < n_segs;
     const DevSegment sg = segs[have ? seg_id : 0];
     const DevImage *im = images + sg.image;
     const int bpm = __builtin_amdgcn_readfirstlane(im->blocks_per_mcu);     // one sampling layout per plan
@@ -276,7 +278,9 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
                                 int16_t *coef, int32_t *status) {
     if (n_segs == 0) return hipSuccess;
-    const int64_t blocks = (n_segs + 255) / 256;
+    static int lpw = 0;
+    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : 64; if (lpw < 2 || lpw > 64 || (lpw & 1)) lpw = 64; }
+    const int64_t blocks = (n_segs + 4 * lpw - 1) / (4 * lpw);
     const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * 64 * kBlkStride * 4 + 64;
     static bool attr_set = false;
     if (!attr_set) {
@@ -284,7 +288,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
-                       lut11, n_huff, coef, status);
+                       lut11, n_huff, coef, status, lpw);
     return hipGetLastError();
 }
 
