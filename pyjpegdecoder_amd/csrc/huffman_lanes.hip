@@ -37,75 +37,71 @@ __constant__ uint8_t c_nat_of_zz_l[64] = {
    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// Per-lane bit reader state (kept in plain scalars so that the decode loop compiles to straight-line,
+// select-based code; divergent branches here made the compiler copy the whole state around every loop):
+//   bb/bc   bit buffer (next bit = bit 63) and its fill
+//   raw/rawn  fetched, not yet unstuffed bytes (little endian) and how many
+//   woff    dword index (from the blob start) of the next dword to append; nxtw = blob[woff], loaded one
+//           iteration before it can be needed
+//   left    segment bytes not yet appended to raw;  pad = zero bits fed past the end
+//   skipnext  the next raw byte follows an 0xFF and is dropped (jpeg_decoder.py:676-677)
 struct LaneBits {
-    uint64_t bb;          // bit buffer, next bit = bit 63
-    uint64_t raw;         // fetched, not yet unstuffed bytes (little endian, next byte = low byte)
-    const uint32_t *wp;   // next dword to append (the value is already in nxtw)
-    uint32_t nxtw;        // prefetched *wp
-    int bc;               // valid bits in bb
-    int rawn;             // bytes in raw
-    int left;             // segment bytes not yet appended to raw
-    int pad;              // zero bits fed past the end of the segment
-    bool skipnext;        // the next raw byte follows an 0xFF and is dropped
-
-    __device__ __forceinline__ void init(const uint8_t *blob, int64_t begin, int len) {
-        const int64_t abase = begin & ~(int64_t)3;
-        const int lead = (int)(begin - abase);
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(blob + abase);
-        raw = (uint64_t)(p[0] >> (8 * lead));
-        rawn = min(4 - lead, len);
-        left = len - rawn;
-        wp = p + 1;
-        nxtw = *wp;
-        bb = 0; bc = 0; pad = 0; skipnext = false;
-    }
-    __device__ __forceinline__ void append() {           // caller checked rawn <= 4 && left > 0
-        const int take = min(4, left);
-        raw |= (uint64_t)nxtw << (8 * rawn);
-        rawn += take;
-        left -= take;
-        ++wp;
-        nxtw = *wp;                                       // consumed at the next append, iterations from now
-    }
-    // one byte raw -> bb with the reference's stuffing rule, or a zero byte past the end
-    __device__ __forceinline__ void move_byte() {
-        if (rawn <= 4 && left > 0) append();
-        if (rawn > 0) {
-            const uint32_t b = (uint32_t)raw & 0xFFu;
-            raw >>= 8;
-            --rawn;
-            if (skipnext) skipnext = false;
-            else {
-                bb |= (uint64_t)b << (56 - bc);
-                bc += 8;
-                skipnext = b == 0xFFu;
-            }
-        } else {
-            bc += 8;
-            pad += 8;
-        }
-    }
-    // make >= 32 bits available in every lane of `need`
-    __device__ __forceinline__ void refill(bool need) {
-        if (need && rawn <= 4 && left > 0) append();
-        const uint32_t w = (uint32_t)raw, nw = ~w;
-        if (need && bc <= 32 && rawn >= 4 && !skipnext && (((nw - 0x01010101u) & ~nw & 0x80808080u) == 0)) {
-            bb |= (uint64_t)__builtin_bswap32(w) << (32 - bc);
-            bc += 32;
-            raw >>= 32;
-            rawn -= 4;
-        }
-        while (__any(need && bc < 32)) {
-            if (need && bc < 32) move_byte();
-        }
-    }
-    __device__ __forceinline__ uint32_t take(int n) {    // 0 <= n <= 16, branch-free for n == 0
-        const uint32_t v = (uint32_t)((bb >> 1) >> (63 - n));
-        bb <<= n;
-        bc -= n;
-        return v;
-    }
+    uint64_t bb, raw;
+    uint32_t woff, nxtw;
+    int bc, rawn, left, pad;
+    int skipnext;
 };
+
+// Rare, byte-wise path (a 0xFF among the next bytes, or the end of the segment): exact reference semantics.
+__device__ __noinline__ LaneBits refill_slow(LaneBits s, const uint32_t *blobw, bool need) {
+    while (__any(need && s.bc < 32)) {
+        if (need && s.bc < 32) {
+            if (s.rawn <= 4 && s.left > 0) {
+                const int take = min(4, s.left);
+                s.raw |= (uint64_t)blobw[s.woff] << (8 * s.rawn);
+                s.rawn += take; s.left -= take; s.woff += 1;
+            }
+            if (s.rawn > 0) {
+                const uint32_t b = (uint32_t)s.raw & 0xFFu;
+                s.raw >>= 8;
+                --s.rawn;
+                if (s.skipnext) s.skipnext = 0;
+                else {
+                    s.bb |= (uint64_t)b << (56 - s.bc);
+                    s.bc += 8;
+                    s.skipnext = b == 0xFFu;
+                }
+            } else {
+                s.bc += 8;
+                s.pad += 8;
+            }
+        }
+    }
+    s.nxtw = blobw[s.woff];
+    return s;
+}
+
+// Common path, branch-free: append the prefetched dword when raw runs low, then move four bytes at once
+// when none of them is 0xFF.  Lanes that still have < 32 bits afterwards take refill_slow().
+__device__ __forceinline__ void refill(LaneBits &s, const uint32_t *blobw, bool need) {
+    const bool c_app = need && s.rawn <= 4 && s.left > 0;
+    const int tk = min(4, s.left);
+    const uint64_t raw_app = s.raw | ((uint64_t)s.nxtw << (8 * s.rawn));
+    s.raw = c_app ? raw_app : s.raw;
+    s.rawn += c_app ? tk : 0;
+    s.left -= c_app ? tk : 0;
+    s.woff += c_app ? 1u : 0u;
+    s.nxtw = blobw[s.woff];                       // not needed before the next call
+    const uint32_t w = (uint32_t)s.raw;
+    const uint32_t ff = (~w - 0x01010101u) & w & 0x80808080u;      // non-zero iff some byte of w is 0xFF
+    const bool c_fast = need && s.bc <= 32 && s.rawn >= 4 && !s.skipnext && ff == 0;
+    const uint64_t bb_f = s.bb | ((uint64_t)__builtin_bswap32(w) << ((32 - s.bc) & 63));   // used only when bc <= 32
+    s.bb = c_fast ? bb_f : s.bb;
+    s.raw = c_fast ? s.raw >> 32 : s.raw;
+    s.rawn -= c_fast ? 4 : 0;
+    s.bc += c_fast ? 32 : 0;
+    if (__any(need && s.bc < 32)) s = refill_slow(s, blobw, need);
+}
 
 __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0
     const int half = (1 << n) >> 1;
@@ -164,8 +160,20 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     for (int o = 32; o > 0; o >>= 1) max_mcu = max(max_mcu, __shfl_xor(max_mcu, o));
     max_mcu = __builtin_amdgcn_readfirstlane(max_mcu);
 
+    // ---- per-lane bit reader (see LaneBits)
+    const uint32_t *blobw = reinterpret_cast<const uint32_t *>(blob);
     LaneBits br;
-    br.init(blob, sg.begin, have ? sg.len : 0);
+    {
+        const int64_t abase = sg.begin & ~(int64_t)3;
+        const int lead = (int)(sg.begin - abase), len = have ? sg.len : 0;
+        br.woff = (uint32_t)(abase >> 2);
+        br.raw = (uint64_t)(blobw[br.woff] >> (8 * lead));
+        br.rawn = min(4 - lead, len);
+        br.left = len - br.rawn;
+        br.woff += 1;
+        br.nxtw = blobw[br.woff];
+        br.bb = 0; br.bc = 0; br.pad = 0; br.skipnext = 0;
+    }
     // byte offset of this lane's first output block
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
     const uint32_t out_lo = (uint32_t)out_off, out_hi = (uint32_t)(out_off >> 32);
@@ -180,41 +188,47 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
             const int comp = (int)((comp_pk_u >> (8 * b)) & 0xFF);          // wave-uniform
             const int dct = comp == 0 ? dcT[0] : (comp == 1 ? dcT[1] : dcT[2]);
             const int act_ = comp == 0 ? acT[0] : (comp == 1 ? acT[1] : acT[2]);
-            bool act = in_mcu && err == 0;
+            const bool act = in_mcu && err == 0;
 
-            // ---- DC (:810-820)
-            br.refill(act);
+            // ---- DC (:810-820): one symbol per lane, straight-line
+            refill(br, blobw, act);
+            int k;
             {
                 const uint32_t p16 = (uint32_t)(br.bb >> 48);
-                int e = s_lut[dct * kLSize + (p16 >> (16 - kLBits))];
+                const int e = s_lut[dct * kLSize + (p16 >> (16 - kLBits))];
                 int len = e >> 8, s = e & 0xFF;
-                if (__any(act && len == 0)) {
+                if (__any(act && len == 0)) {                              // code longer than 11 bits: rare
                     if (act && len == 0) {
                         const DevHuff *t = huff + dct;
-                        s = -1;
+                        s = 255;
                         for (int l = kLBits + 1; l <= 16; ++l) {
                             const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
                             if (d >= 0 && d < t->count[l]) { s = t->vals[t->first_sym[l] + d]; len = l; break; }
                         }
                     }
                 }
-                if (act && (s < 0 || s > 16)) { err = MJ_ST_BAD_CODE; act = false; }
-                if (act) {
-                    br.bb <<= len; br.bc -= len;
-                    const int diff = extend(br.take(s), s);
-                    const int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
-                    const int dcv = (int)(int16_t)(diff + pred);
-                    if (comp == 0) pred0 = dcv; else if (comp == 1) pred1 = dcv; else pred2 = dcv;
-                    myblk16[0] = (int16_t)dcv;
-                }
+                const bool bad = act && s > 16;
+                err = bad ? MJ_ST_BAD_CODE : err;
+                const bool ok = act && !bad;
+                const int ln = ok ? len : 0, sz = ok ? s : 0;
+                br.bb <<= ln;
+                const uint32_t rawv = (uint32_t)((br.bb >> 1) >> (63 - sz));
+                br.bb <<= sz;
+                br.bc -= ln + sz;
+                const int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
+                const int dcv = (int)(int16_t)(extend(rawv, sz) + pred);
+                pred0 = (ok && comp == 0) ? dcv : pred0;
+                pred1 = (ok && comp == 1) ? dcv : pred1;
+                pred2 = (ok && comp == 2) ? dcv : pred2;
+                if (ok) myblk16[0] = (int16_t)dcv;
+                k = ok ? 1 : 64;
             }
-            // ---- AC (:833-866)
-            int k = act ? 1 : 64;
+            // ---- AC (:833-866): one symbol per lane and iteration until every lane is at its end of block
             while (__any(k < 64)) {
                 const bool on = k < 64;
-                br.refill(on);
+                refill(br, blobw, on);
                 const uint32_t p16 = (uint32_t)(br.bb >> 48);
-                int e = s_lut[act_ * kLSize + (p16 >> (16 - kLBits))];
+                const int e = s_lut[act_ * kLSize + (p16 >> (16 - kLBits))];
                 int len = e >> 8, hv = e & 0xFF;
                 if (__any(on && len == 0)) {
                     if (on && len == 0) {
@@ -226,25 +240,20 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                         }
                     }
                 }
-                if (on) {
-                    if (hv < 0) { err = MJ_ST_BAD_CODE; k = 64; }
-                    else {
-                        br.bb <<= len; br.bc -= len;
-                        if (hv == 0) k = 64;                             // EOB
-                        else {
-                            const int kk = k + (hv >> 4);
-                            const int n = hv & 15;
-                            if (kk >= 64) k = 64;                        // (:855-856) ends the block, bits of the value stay unread
-                            else {
-                                if (n > 0) {
-                                    const int val = extend(br.take(n), n);
-                                    myblk16[s_nat[kk]] = (int16_t)val;
-                                }
-                                k = kk + 1;
-                            }
-                        }
-                    }
-                }
+                const bool bad = on && hv < 0;
+                err = bad ? MJ_ST_BAD_CODE : err;
+                const bool ok = on && !bad;
+                const int kk = k + (hv >> 4);
+                const bool eob = hv == 0, over = kk >= 64;               // (:849), (:855-856): value bits stay unread
+                const bool val = ok && !eob && !over;
+                const int ln = ok ? len : 0, n = val ? (hv & 15) : 0;
+                br.bb <<= ln;
+                const uint32_t rawv = (uint32_t)((br.bb >> 1) >> (63 - n));
+                br.bb <<= n;
+                br.bc -= ln + n;
+                if (val && n > 0) myblk16[s_nat[kk]] = (int16_t)extend(rawv, n);
+                k = val ? kk + 1 : 64;
+                k = on ? k : 64;
             }
             // ---- round of 64 blocks done: LDS -> HBM, two full lines per instruction, and clear
             const uint64_t act_mask = __ballot(in_mcu);
@@ -279,8 +288,14 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
                                 int16_t *coef, int32_t *status) {
     if (n_segs == 0) return hipSuccess;
     static int lpw = 0;
-    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : 64; if (lpw < 2 || lpw > 64 || (lpw & 1)) lpw = 64; }
-    const int64_t blocks = (n_segs + 4 * lpw - 1) / (4 * lpw);
+    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64 || (lpw & 1))) lpw = -1; }
+    int use = lpw;
+    if (use < 0) {   // about two wavefronts per SIMD (measured best on MI355X): 64, 32, 16 or 8 segments per wave
+        use = 64;
+        while (use > 8 && n_segs / use < 2048) use >>= 1;
+    }
+    const int lpw_run = use;
+    const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * 64 * kBlkStride * 4 + 64;
     static bool attr_set = false;
     if (!attr_set) {
@@ -288,7 +303,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
-                       lut11, n_huff, coef, status, lpw);
+                       lut11, n_huff, coef, status, lpw_run);
     return hipGetLastError();
 }
 
