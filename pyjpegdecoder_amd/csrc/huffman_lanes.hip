@@ -31,6 +31,12 @@ constexpr int kLBits = 11;
 constexpr int kLSize = 1 << kLBits;
 constexpr int kBlkStride = 33;   // dwords per lane block in LDS (32 + 1 pad)
 
+// natural position (v*8+u) -> zig-zag index (the inverse of the table below)
+__constant__ uint8_t c_zz_of_nat_l[64] = {
+    0,  1,  5,  6, 14, 15, 27, 28,  2,  4,  7, 13, 16, 26, 29, 42,
+    3,  8, 12, 17, 25, 30, 41, 43,  9, 11, 18, 24, 31, 40, 44, 53,
+   10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+   21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 __constant__ uint8_t c_nat_of_zz_l[64] = {
     0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
@@ -51,6 +57,19 @@ struct LaneBits {
     int bc, rawn, left, pad;
     int skipnext;
 };
+
+// Codes longer than the 11-bit LUT (rare): canonical search (jpeg_decoder.py:366-377 semantics).  Out of line so
+// that its global loads do not put a vmcnt wait on the common path.  Returns (len << 8) | symbol, or -1.
+__device__ __noinline__ int long_code(const DevHuff *t, uint32_t p16, bool want) {
+    int r = -1;
+    if (want) {
+        for (int l = kLBits + 1; l <= 16; ++l) {
+            const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
+            if (d >= 0 && d < t->count[l]) { r = (l << 8) | t->vals[t->first_sym[l] + d]; break; }
+        }
+    }
+    return r;
+}
 
 // Rare, byte-wise path (a 0xFF among the next bytes, or the end of the segment): exact reference semantics.
 __device__ __noinline__ LaneBits refill_slow(LaneBits s, const uint32_t *blobw, bool need) {
@@ -179,6 +198,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     const uint32_t out_lo = (uint32_t)out_off, out_hi = (uint32_t)(out_off >> 32);
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int err = 0;
+    const int zz_a = c_zz_of_nat_l[2 * (lane & 31)], zz_b = c_zz_of_nat_l[2 * (lane & 31) + 1];
     uint32_t *myblk = s_blk + lane * kBlkStride;
     int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
 
@@ -198,14 +218,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 const int e = s_lut[dct * kLSize + (p16 >> (16 - kLBits))];
                 int len = e >> 8, s = e & 0xFF;
                 if (__any(act && len == 0)) {                              // code longer than 11 bits: rare
-                    if (act && len == 0) {
-                        const DevHuff *t = huff + dct;
-                        s = 255;
-                        for (int l = kLBits + 1; l <= 16; ++l) {
-                            const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
-                            if (d >= 0 && d < t->count[l]) { s = t->vals[t->first_sym[l] + d]; len = l; break; }
-                        }
-                    }
+                    const int r = long_code(huff + dct, p16, act && len == 0);
+                    if (act && len == 0) { len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF; }
                 }
                 const bool bad = act && s > 16;
                 err = bad ? MJ_ST_BAD_CODE : err;
@@ -231,14 +245,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 const int e = s_lut[act_ * kLSize + (p16 >> (16 - kLBits))];
                 int len = e >> 8, hv = e & 0xFF;
                 if (__any(on && len == 0)) {
-                    if (on && len == 0) {
-                        const DevHuff *t = huff + act_;
-                        hv = -1;
-                        for (int l = kLBits + 1; l <= 16; ++l) {
-                            const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
-                            if (d >= 0 && d < t->count[l]) { hv = t->vals[t->first_sym[l] + d]; len = l; break; }
-                        }
-                    }
+                    const int r = long_code(huff + act_, p16, on && len == 0);
+                    if (on && len == 0) { len = r < 0 ? 0 : r >> 8; hv = r < 0 ? -1 : r & 0xFF; }
                 }
                 const bool bad = on && hv < 0;
                 err = bad ? MJ_ST_BAD_CODE : err;
@@ -251,19 +259,23 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 const uint32_t rawv = (uint32_t)((br.bb >> 1) >> (63 - n));
                 br.bb <<= n;
                 br.bc -= ln + n;
-                if (val && n > 0) myblk16[s_nat[kk]] = (int16_t)extend(rawv, n);
+                if (val && n > 0) myblk16[kk] = (int16_t)extend(rawv, n);      // zig-zag order; the flush permutes
                 k = val ? kk + 1 : 64;
                 k = on ? k : 64;
             }
             // ---- round of 64 blocks done: LDS -> HBM, two full lines per instruction, and clear
+            // lane (o, dw) moves the two coefficients of natural positions 2dw, 2dw+1 of block o: they are read from
+            // their zig-zag slots, so the block lands in HBM in the natural [v][u] order stage 2 wants
             const uint64_t act_mask = __ballot(in_mcu);
             const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
 #pragma unroll 4
             for (int s2 = 0; s2 < 32; ++s2) {
                 if (((act_mask >> (2 * s2)) & 3) == 0) continue;         // uniform
                 const int o = 2 * s2 + (lane >> 5), dw = lane & 31;
-                const uint32_t v = s_blk[o * kBlkStride + dw];
-                s_blk[o * kBlkStride + dw] = 0;
+                int16_t *ob16 = reinterpret_cast<int16_t *>(s_blk + o * kBlkStride);
+                const uint32_t v = (uint32_t)(uint16_t)ob16[zz_a] | ((uint32_t)(uint16_t)ob16[zz_b] << 16);
+                ob16[zz_a] = 0;
+                ob16[zz_b] = 0;
                 const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)out_lo, 2 * s2), hi0 = (uint32_t)__builtin_amdgcn_readlane((int)out_hi, 2 * s2);
                 const uint32_t lo1 = (uint32_t)__builtin_amdgcn_readlane((int)out_lo, 2 * s2 + 1), hi1 = (uint32_t)__builtin_amdgcn_readlane((int)out_hi, 2 * s2 + 1);
                 const uint64_t base = (lane >> 5) ? (((uint64_t)hi1 << 32) | lo1) : (((uint64_t)hi0 << 32) | lo0);
