@@ -43,19 +43,18 @@ __constant__ uint8_t c_nat_of_zz_l[64] = {
    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// Per-lane bit reader state (kept in plain scalars so that the decode loop compiles to straight-line,
-// select-based code; divergent branches here made the compiler copy the whole state around every loop):
-//   bb/bc   bit buffer (next bit = bit 63) and its fill
-//   raw/rawn  fetched, not yet unstuffed bytes (little endian) and how many
-//   woff    dword index (from the blob start) of the next dword to append; nxtw = blob[woff], loaded one
-//           iteration before it can be needed
-//   left    segment bytes not yet appended to raw;  pad = zero bits fed past the end
-//   skipnext  the next raw byte follows an 0xFF and is dropped (jpeg_decoder.py:676-677)
+// Per-lane bit reader state (plain scalars: the decode loop is straight-line, select-based code):
+//   bb/bc     bit buffer (next bit = bit 63) and its fill
+//   woff      dword index (from the blob start) of the next stream dword; nxtw = blob[woff], loaded one
+//             iteration before it can be needed
+//   lead      bytes of nxtw that precede the segment (only the first dword of a segment has any)
+//   left      segment bytes from nxtw's position on (bytes of nxtw included);  pad = zero bits fed past the end
+//   skipnext  the next stream byte follows an 0xFF and is dropped (jpeg_decoder.py:676-677)
 struct LaneBits {
-    uint64_t bb, raw;
+    uint64_t bb;
     uint32_t woff, nxtw;
-    int bc, rawn, left, pad;
-    int skipnext;
+    int bc, left, pad;
+    int lead, skipnext;
 };
 
 // Codes longer than the 11-bit LUT (rare): canonical search (jpeg_decoder.py:366-377 semantics).  Out of line so
@@ -71,55 +70,52 @@ __device__ __noinline__ int long_code(const DevHuff *t, uint32_t p16, bool want)
     return r;
 }
 
-// Rare, byte-wise path (a 0xFF among the next bytes, or the end of the segment): exact reference semantics.
+// Rare path: the next dword holds an 0xFF, a dropped byte, the segment's first or last bytes, or nothing at all
+// (past the end: zero bits are fed and counted).  Byte by byte, exact reference semantics (:673-677).
 __device__ __noinline__ LaneBits refill_slow(LaneBits s, const uint32_t *blobw, bool need) {
-    while (__any(need && s.bc < 32)) {
-        if (need && s.bc < 32) {
-            if (s.rawn <= 4 && s.left > 0) {
-                const int take = min(4, s.left);
-                s.raw |= (uint64_t)blobw[s.woff] << (8 * s.rawn);
-                s.rawn += take; s.left -= take; s.woff += 1;
-            }
-            if (s.rawn > 0) {
-                const uint32_t b = (uint32_t)s.raw & 0xFFu;
-                s.raw >>= 8;
-                --s.rawn;
-                if (s.skipnext) s.skipnext = 0;
-                else {
-                    s.bb |= (uint64_t)b << (56 - s.bc);
-                    s.bc += 8;
-                    s.skipnext = b == 0xFFu;
-                }
+    while (__any(need && s.bc <= 32)) {
+        if (need && s.bc <= 32) {
+            if (s.left <= 0) {                       // nothing left: feed zeros, remember how many
+                s.bc += 32;
+                s.pad += 32;
             } else {
-                s.bc += 8;
-                s.pad += 8;
+                const int nb = min(4, s.left + s.lead);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t b = (s.nxtw >> (8 * i)) & 0xFFu;
+                    if (i >= s.lead && i < nb) {
+                        if (s.skipnext) s.skipnext = 0;
+                        else {
+                            s.bb |= (uint64_t)b << (56 - s.bc);
+                            s.bc += 8;
+                            s.skipnext = b == 0xFFu;
+                        }
+                    }
+                }
+                s.left -= nb - s.lead;
+                s.lead = 0;
+                s.woff += 1;
+                s.nxtw = blobw[s.woff];
             }
         }
     }
-    s.nxtw = blobw[s.woff];
     return s;
 }
 
-// Common path, branch-free: append the prefetched dword when raw runs low, then move four bytes at once
-// when none of them is 0xFF.  Lanes that still have < 32 bits afterwards take refill_slow().
+// Common path, branch-free: when the buffer is at most half full and the next dword is plain data (no 0xFF, no
+// pending drop, wholly inside the segment) it goes straight into the buffer.
 __device__ __forceinline__ void refill(LaneBits &s, const uint32_t *blobw, bool need) {
-    const bool c_app = need && s.rawn <= 4 && s.left > 0;
-    const int tk = min(4, s.left);
-    const uint64_t raw_app = s.raw | ((uint64_t)s.nxtw << (8 * s.rawn));
-    s.raw = c_app ? raw_app : s.raw;
-    s.rawn += c_app ? tk : 0;
-    s.left -= c_app ? tk : 0;
-    s.woff += c_app ? 1u : 0u;
-    s.nxtw = blobw[s.woff];                       // not needed before the next call
-    const uint32_t w = (uint32_t)s.raw;
+    const uint32_t w = s.nxtw;
     const uint32_t ff = (~w - 0x01010101u) & w & 0x80808080u;      // non-zero iff some byte of w is 0xFF
-    const bool c_fast = need && s.bc <= 32 && s.rawn >= 4 && !s.skipnext && ff == 0;
+    const bool want = need && s.bc <= 32;
+    const bool c_fast = want && ff == 0 && s.left >= 4 && (s.lead | s.skipnext) == 0;
     const uint64_t bb_f = s.bb | ((uint64_t)__builtin_bswap32(w) << ((32 - s.bc) & 63));   // used only when bc <= 32
     s.bb = c_fast ? bb_f : s.bb;
-    s.raw = c_fast ? s.raw >> 32 : s.raw;
-    s.rawn -= c_fast ? 4 : 0;
     s.bc += c_fast ? 32 : 0;
-    if (__any(need && s.bc < 32)) s = refill_slow(s, blobw, need);
+    s.left -= c_fast ? 4 : 0;
+    s.woff += c_fast ? 1u : 0u;
+    s.nxtw = blobw[s.woff];                       // not needed before the next call
+    if (__any(want && !c_fast)) s = refill_slow(s, blobw, need);
 }
 
 __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0
@@ -184,12 +180,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     LaneBits br;
     {
         const int64_t abase = sg.begin & ~(int64_t)3;
-        const int lead = (int)(sg.begin - abase), len = have ? sg.len : 0;
+        br.lead = (int)(sg.begin - abase);
+        br.left = have ? sg.len : 0;
         br.woff = (uint32_t)(abase >> 2);
-        br.raw = (uint64_t)(blobw[br.woff] >> (8 * lead));
-        br.rawn = min(4 - lead, len);
-        br.left = len - br.rawn;
-        br.woff += 1;
         br.nxtw = blobw[br.woff];
         br.bb = 0; br.bc = 0; br.pad = 0; br.skipnext = 0;
     }
@@ -225,9 +218,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 err = bad ? MJ_ST_BAD_CODE : err;
                 const bool ok = act && !bad;
                 const int ln = ok ? len : 0, sz = ok ? s : 0;
-                br.bb <<= ln;
-                const uint32_t rawv = (uint32_t)((br.bb >> 1) >> (63 - sz));
-                br.bb <<= sz;
+                const uint32_t hw = (uint32_t)(br.bb >> 32) << ln;             // ln + sz <= 32 <= bc
+                const uint32_t rawv = (hw >> 1) >> (31 - sz);
+                br.bb <<= ln + sz;
                 br.bc -= ln + sz;
                 const int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
                 const int dcv = (int)(int16_t)(extend(rawv, sz) + pred);
@@ -255,9 +248,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 const bool eob = hv == 0, over = kk >= 64;               // (:849), (:855-856): value bits stay unread
                 const bool val = ok && !eob && !over;
                 const int ln = ok ? len : 0, n = val ? (hv & 15) : 0;
-                br.bb <<= ln;
-                const uint32_t rawv = (uint32_t)((br.bb >> 1) >> (63 - n));
-                br.bb <<= n;
+                const uint32_t hw = (uint32_t)(br.bb >> 32) << ln;             // ln + n <= 27 <= bc
+                const uint32_t rawv = (hw >> 1) >> (31 - n);
+                br.bb <<= ln + n;
                 br.bc -= ln + n;
                 if (val && n > 0) myblk16[kk] = (int16_t)extend(rawv, n);      // zig-zag order; the flush permutes
                 k = val ? kk + 1 : 64;
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
 
     if (have) {
         if (!err) {
-            const int unconsumed = br.rawn + br.left - (br.skipnext ? 1 : 0);
+            const int unconsumed = br.left - (br.skipnext ? 1 : 0);
             if (br.pad > 0 && br.bc < br.pad) err = MJ_ST_OVERRUN;
             else if (!sg.last && (((br.bc - br.pad) >> 3) > 0 || unconsumed > 0)) err = MJ_ST_DESYNC;
         }
