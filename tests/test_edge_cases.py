@@ -1,0 +1,72 @@
+"""Edge cases of the host logic and the batch API that need no GPU: empty / ragged / oversized inputs,
+unsupported layouts, table de-duplication."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from pyjpegdecoder_amd import CorruptedJpeg, UnsupportedJpeg, parse_jpeg
+from pyjpegdecoder_amd.batch import check_supported, prepare_batch
+
+
+def test_ragged_batch_descriptors():
+    names = ["c1_64x64_444_pil", "70x50_420_pil_opt", "128x64_420_dri3", "100x36_420_dri7"]
+    raws = [load_golden(n)[0] for n in names]
+    prep = prepare_batch(raws[1:])           # three 4:2:0 files of different sizes / tables / restart intervals
+    assert [tuple(s) for s in prep.shapes] == [(70, 50, 3), (128, 64, 3), (100, 36, 3)]
+    segs = [prep.descs[i].n_segments for i in range(3)]
+    assert segs == [1, 11, 3]                 # ceil(mcus / restart_interval)
+    assert prep.seg_begin.size == sum(segs) and (prep.seg_end >= prep.seg_begin).all()
+    assert (prep.file_offsets % 4 == 0).all()
+    # optimised tables of the Pillow file and the Annex-K tables of the other two are distinct entries; the two
+    # Annex-K users share theirs
+    assert prep.n_huff == 8
+    assert prep.descs[1].dc_sel[0] == prep.descs[2].dc_sel[0] and prep.descs[0].dc_sel[0] != prep.descs[1].dc_sel[0]
+    for i in range(3):                        # every segment lies inside its file
+        d = prep.descs[i]
+        b = prep.seg_begin[d.first_segment:d.first_segment + d.n_segments]
+        e = prep.seg_end[d.first_segment:d.first_segment + d.n_segments]
+        assert (b >= prep.file_offsets[i]).all() and (e <= prep.file_offsets[i + 1]).all()
+
+
+def test_progressive_and_empty_are_rejected_on_the_host():
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(b, "JPEG", progressive=True)
+    p = parse_jpeg(b.getvalue())
+    assert p.scan_mode == "progressive_dct" and len(p.scans) > 1
+    with pytest.raises(UnsupportedJpeg):
+        check_supported(p)
+    # header only, no scan: the reference falls off the end of the file (:81-83); the batch API refuses
+    raw, _ = load_golden("c1_64x64_444_pil")
+    p = parse_jpeg(raw[:raw.index(b"\xFF\xDA")])
+    assert p.scans == [] and not p.reached_eoi
+    with pytest.raises(CorruptedJpeg):
+        check_supported(p)
+
+
+def test_restart_marker_count_is_checked():
+    raw, _ = load_golden("128x64_420_dri3")
+    p = parse_jpeg(raw)
+    off = int(p.scans[0].segment_offsets[3])
+    with pytest.raises(CorruptedJpeg):
+        prepare_batch([raw[:off - 2] + raw[off:]])      # one RSTn removed
+
+
+def test_missing_tables_are_corrupt():
+    raw, _ = load_golden("c1_64x64_444_pil")
+    i = raw.index(b"\xFF\xC4")
+    n = int.from_bytes(raw[i + 2:i + 4], "big")
+    with pytest.raises(CorruptedJpeg):
+        prepare_batch([raw[:i] + raw[i + 2 + n:]])      # first DHT segment dropped
+
+
+def test_max_dimension_geometry():
+    # SOF with 65535 x 65535: geometry arithmetic must not overflow (no decode attempted)
+    raw, _ = load_golden("64x64_grey_pil")
+    i = raw.index(b"\xFF\xC0")
+    big = bytearray(raw)
+    big[i + 5:i + 9] = b"\xFF\xFF\xFF\xFF"
+    p = parse_jpeg(bytes(big))
+    assert (p.image_width, p.image_height) == (65535, 65535)
+    assert p.scans[0].mcu_count_h == 8192 and p.scans[0].mcu_count == 8192 * 8192
