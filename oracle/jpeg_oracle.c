@@ -346,3 +346,194 @@ int orc_reconstruct_baseline(const OrcScan *sc, const int16_t *coef, const int16
     }
     return 0;
 }
+
+/* ================================================================================================
+ * Progressive scans  (progressive_dct_scan, :908-1304).
+ *
+ * Coefficient state between scans lives, in the reference, inside image_array at pixel coordinates
+ * (:1029, :1225); here it is the equivalent per-block store  coef[block][64]  in zig-zag order, blocks in
+ * the same interleaved order as the baseline seam (MCU raster, component, block_count), so that after the
+ * last scan orc_reconstruct_baseline() performs the reference's final pass (:1306-1362: in-place dequant,
+ * IDCT, per-block resize, store) unchanged.
+ *
+ * One call = one SOS.  Restatement notes:
+ *   - DC first (:1010-1029): value = (EXTEND(bits) + previous_dc) stored << Al (int16); DC refine (:1036-1038):
+ *     value |= bit << Al.
+ *   - AC first (:1122-1256): run/size symbols; size 0 with run 15 = 16 zeros; size 0 otherwise = EOB run
+ *     (1 << r) + bits(r) (r = 0: run of 1, no bits); value stored << Al; a band finished normally advances the
+ *     block counter by one, then the EOB run is added (:1240-1250).
+ *   - AC refine (:1176-1292): zero runs count only zero coefficients, non-zero ones passed on the way are
+ *     queued; a new value is placed at the next zero position; queued coefficients then receive one bit each,
+ *     applied as  value |= bit << Al  on the two's-complement int16 — NOT the spec's "subtract for negative
+ *     values"  — and the EOB-run walk queues every non-zero coefficient of the remaining bands.
+ *   - restarts are count driven (:1050-1053, :1297-1298); only DC-first scans reset the predictors.
+ * Scan geometry as prepared by start_of_scan (:591-621): interleaved DC scans walk MCUs; single-component scans
+ * walk the component's own 8x8 blocks, ceil(W_c/8) per row.
+ * Returns 0 ok, 1 bad Huffman code, 2 ran past the end of file, 4 coefficient index out of range (reference:
+ * IndexError), 5 scan form the reference mishandles and this oracle refuses (single-component DC scan of a
+ * subsampled-frame component with h or v > 1).
+ */
+typedef struct {
+    int32_t width, height, ncomp_frame;
+    int32_t hs[3], vs[3];            /* frame sampling */
+    int32_t n_scan_comp;             /* components in this scan */
+    int32_t scan_comp[3];            /* frame index (0..2) of each scan component */
+    int32_t dc_sel[3], ac_sel[3];    /* per scan component */
+    int32_t ss, se, ah, al;
+    int32_t restart_interval;
+    int32_t mcu_count_h, mcu_count_v;   /* of THIS scan (:609-621) */
+} OrcProgScan;
+
+typedef struct {
+    int hmax, vmax, bpm, mcus_x, mcus_y, first_blk[3];
+} OrcGrid;
+
+static void orc_grid(const OrcProgScan *s, OrcGrid *g) {
+    g->hmax = 1; g->vmax = 1;
+    if (s->ncomp_frame > 1)
+        for (int c = 0; c < s->ncomp_frame; c++) { if (s->hs[c] > g->hmax) g->hmax = s->hs[c]; if (s->vs[c] > g->vmax) g->vmax = s->vs[c]; }
+    g->bpm = 0;
+    for (int c = 0; c < s->ncomp_frame; c++) { g->first_blk[c] = g->bpm; g->bpm += s->ncomp_frame > 1 ? s->hs[c] * s->vs[c] : 1; }
+    int mw = 8 * g->hmax, mh = 8 * g->vmax;
+    g->mcus_x = (s->width + mw - 1) / mw; g->mcus_y = (s->height + mh - 1) / mh;
+}
+
+/* block (bx, by) of frame component c -> index into coef[] (interleaved order) */
+static inline int64_t orc_block_index(const OrcProgScan *s, const OrcGrid *g, int c, int bx, int by) {
+    int h = s->ncomp_frame > 1 ? s->hs[c] : 1, v = s->ncomp_frame > 1 ? s->vs[c] : 1;
+    int mx = bx / h, my = by / v;
+    return ((int64_t)my * g->mcus_x + mx) * g->bpm + g->first_blk[c] + (by % v) * h + (bx % h);
+}
+
+int orc_progressive_scan(const uint8_t *file, int64_t file_size, int64_t start, const OrcProgScan *s,
+                         const OrcHuff *dc_tabs, const OrcHuff *ac_tabs, int16_t *coef, int64_t *end_pos) {
+    OrcBits b = {file, file_size, start, 0, 0, 0};
+    OrcGrid g;
+    orc_grid(s, &g);
+    const int64_t mcu_count = (int64_t)s->mcu_count_h * s->mcu_count_v;
+    const int refining = s->ah != 0;
+    int status = 0;
+
+    if (s->ss == 0) { /* ------------------------------------------------ DC scan (:974-1057) */
+        int16_t prev[3] = {0, 0, 0};
+        for (int64_t mcu = 0; mcu < mcu_count;) {
+            for (int i = 0; i < s->n_scan_comp; i++) {
+                const int c = s->scan_comp[i];
+                const int h = s->ncomp_frame > 1 ? s->hs[c] : 1, v = s->ncomp_frame > 1 ? s->vs[c] : 1;
+                const int repeat = s->n_scan_comp > 1 ? h * v : 1;
+                if (s->n_scan_comp == 1 && (h > 1 || v > 1)) { *end_pos = b.pos; return 5; }
+                for (int r = 0; r < repeat; r++) {
+                    int bx, by;
+                    if (s->n_scan_comp > 1) { bx = (int)(mcu % s->mcu_count_h) * h + r % h; by = (int)(mcu / s->mcu_count_h) * v + r / h; }
+                    else { bx = (int)(mcu % s->mcu_count_h); by = (int)(mcu / s->mcu_count_h); }
+                    int16_t *blk = coef + orc_block_index(s, &g, c, bx, by) * 64;
+                    if (!refining) {
+                        int sz = orc_next_huffval(&b, &dc_tabs[s->dc_sel[i]]);
+                        if (sz < 0) { *end_pos = b.pos; return sz == -1 ? 1 : 2; }
+                        uint32_t raw = orc_get_bits(&b, sz);
+                        if (b.overrun) { *end_pos = b.pos; return 2; }
+                        int16_t dcv = (int16_t)(orc_extend(raw, sz) + prev[i]);
+                        prev[i] = dcv;
+                        blk[0] = (int16_t)((int32_t)dcv << s->al);
+                    } else {
+                        uint32_t bit = orc_get_bits(&b, 1);
+                        if (b.overrun) { *end_pos = b.pos; return 2; }
+                        blk[0] = (int16_t)(blk[0] | (int16_t)(bit << s->al));
+                    }
+                }
+            }
+            mcu++;
+            if (s->restart_interval > 0 && mcu % s->restart_interval == 0 && mcu != mcu_count) {
+                orc_restart(&b);
+                if (!refining) prev[0] = prev[1] = prev[2] = 0;
+            }
+        }
+        *end_pos = b.pos;
+        return 0;
+    }
+
+    /* ---------------------------------------------------------------- AC scan (:1060-1298) */
+    const int c = s->scan_comp[0];
+    const OrcHuff *ht = &ac_tabs[s->ac_sel[0]];
+    int64_t eob_run = 0;
+    int16_t *queue[64];        /* to_refine within one band: pointers to coefficients awaiting a correction bit */
+    int nq = 0;
+#define BLK(m) (coef + orc_block_index(s, &g, c, (int)((m) % s->mcu_count_h), (int)((m) / s->mcu_count_h)) * 64)
+#define REFINE_QUEUE()                                                          \
+    do {                                                                        \
+        for (int qi = 0; qi < nq; qi++) {                                       \
+            uint32_t bit = orc_get_bits(&b, 1);                                 \
+            if (b.overrun) { *end_pos = b.pos; return 2; }                      \
+            *queue[qi] = (int16_t)(*queue[qi] | (int16_t)(bit << s->al));       \
+        }                                                                       \
+        nq = 0;                                                                 \
+    } while (0)
+
+    for (int64_t mcu = 0; mcu < mcu_count;) {
+        int16_t *blk = BLK(mcu);
+        int index = s->ss;
+        while (index <= s->se) {
+            int hv = orc_next_huffval(&b, ht);
+            if (hv < 0) { *end_pos = b.pos; return hv == -1 ? 1 : 2; }
+            int run = hv >> 4, size = hv & 15, zero_run = 0;
+            if (hv == 0) { eob_run = 1; break; }
+            else if (hv == 0xF0) zero_run = 16;
+            else if (size == 0) {
+                uint32_t bits = orc_get_bits(&b, run);
+                if (b.overrun) { *end_pos = b.pos; return 2; }
+                eob_run = ((int64_t)1 << run) + bits;
+                break;
+            } else zero_run = run;
+
+            if (!refining) index += zero_run;                        /* :1177-1179 */
+            else {
+                while (zero_run > 0) {                               /* :1184-1193 */
+                    if (index > 63) { *end_pos = b.pos; return 4; }
+                    if (blk[index] == 0) zero_run--;
+                    else { if (nq < 64) queue[nq++] = &blk[index]; }
+                    index++;
+                }
+            }
+            if (size > 0) {                                          /* :1201-1228 */
+                uint32_t raw = orc_get_bits(&b, size);
+                if (b.overrun) { *end_pos = b.pos; return 2; }
+                int32_t val = orc_extend(raw, size);
+                if (index > 63) { *end_pos = b.pos; return 4; }
+                if (refining) {
+                    while (blk[index] != 0) {
+                        if (nq < 64) queue[nq++] = &blk[index];
+                        index++;
+                        if (index > 63) { *end_pos = b.pos; return 4; }
+                    }
+                }
+                blk[index] = (int16_t)(val << s->al);
+                index++;
+            }
+            if (refining) REFINE_QUEUE();                            /* :1231-1232 */
+        }
+        if (index > s->se) mcu++;                                    /* :1240-1245 */
+        if (!refining) { mcu += eob_run; eob_run = 0; }              /* :1248-1250 */
+        else {
+            while (eob_run > 0) {                                    /* :1259-1276 */
+                if (mcu >= mcu_count) { status = 4; break; }         /* reference: index error past the array */
+                blk = BLK(mcu);
+                if (blk[index] != 0) {
+                    /* the reference queues these and reads all their bits after the walk (:1286); nothing else
+                       reads the stream in between, so taking each bit right away is the same sequence */
+                    uint32_t bit = orc_get_bits(&b, 1);
+                    if (b.overrun) { *end_pos = b.pos; return 2; }
+                    blk[index] = (int16_t)(blk[index] | (int16_t)(bit << s->al));
+                }
+                index++;
+                if (index > s->se) { eob_run--; mcu++; index = s->ss; }
+            }
+            if (status) { *end_pos = b.pos; return status; }
+            REFINE_QUEUE();                                          /* :1285-1286 */
+        }
+        if (s->restart_interval > 0 && mcu % s->restart_interval == 0 && mcu != mcu_count) orc_restart(&b);
+    }
+#undef BLK
+#undef REFINE_QUEUE
+    *end_pos = b.pos;
+    return 0;
+}

@@ -22,7 +22,7 @@ def golden_index():
 
 def golden_names(small_only=True):
     idx = golden_index()
-    return sorted(n for n, m in idx.items() if not (small_only and "sampled" in m))
+    return sorted(n for n, m in idx.items() if not (small_only and "sampled" in m) and not n.startswith("prog_"))
 
 
 @pytest.fixture(scope="session")

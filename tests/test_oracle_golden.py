@@ -67,3 +67,24 @@ def test_file_fixture_every_seam(name):
     assert out["rgb"].dtype == np.uint8 and list(out["rgb"].shape) == meta["image_array_shape"]
     # file_header after the scan: the reference ends on EOI handling (+2 marker, +2 bogus length read)
     assert out["end_pos"] == scan.entropy_end
+
+
+def prog_names():
+    return [n for n in golden_index() if n.startswith("prog_")]
+
+
+@pytest.mark.parametrize("name", prog_names())
+def test_progressive_fixture_scan_by_scan(name):
+    """progressive_dct_scan (:908-1304) restated: the coefficient store after every scan, then the final pass."""
+    from pyjpegdecoder_amd import parse_jpeg
+    raw, vec = load_golden(name)
+    parsed = parse_jpeg(raw)
+    assert parsed.scan_mode == "progressive_dct" and len(parsed.scans) == vec["coef_before_scan"].shape[0]
+    for k in range(1, len(parsed.scans)):
+        coef, st, _ = oracle.progressive_entropy_decode(parsed, upto=k)
+        assert st == 0
+        assert np.array_equal(coef, vec["coef_before_scan"][k]), f"state before scan {k + 1}"
+    out = oracle.decode(raw)
+    assert np.array_equal(out["coef"], vec["coef"]), "coefficients before the IDCT pass (incl. F8 refinement semantics)"
+    assert np.array_equal(out["planes"], vec["planes"])
+    assert np.array_equal(out["rgb"], vec["rgb"])

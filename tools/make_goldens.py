@@ -83,6 +83,59 @@ def run_reference(path: Path):
     return dec, cap
 
 
+def run_reference_progressive(path: Path):
+    """Progressive file: snapshot the coefficient state (image_array) before every scan and before the final
+    IDCT pass (:1308-1317), plus the usual planes / rgb."""
+    cap = {"before_scan": [], "pre_idct": None, "planes": None}
+    holder = {}
+    o_scan, o_init, o_eoi = jd.JpegDecoder.progressive_dct_scan, jd.InverseDCT.__init__ if hasattr(jd.InverseDCT, "__init__") else None, jd.JpegDecoder.end_of_image
+
+    def w_scan(self, *a, **k):
+        holder["dec"] = self
+        cap["before_scan"].append(np.array(self.image_array, dtype=np.int16))
+        return o_scan(self, *a, **k)
+
+    class SnapIDCT(jd.InverseDCT):
+        def __init__(self):
+            if "dec" in holder and cap["pre_idct"] is None:
+                cap["pre_idct"] = np.array(holder["dec"].image_array, dtype=np.int16)
+
+    def w_eoi(self, data):
+        cap["planes"] = np.array(self.image_array[0:self.image_width, 0:self.image_height, :], dtype=np.int16)
+        return o_eoi(self, data)
+
+    o_cls = jd.InverseDCT
+    jd.JpegDecoder.progressive_dct_scan, jd.InverseDCT, jd.JpegDecoder.end_of_image = w_scan, SnapIDCT, w_eoi
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            dec = jd.JpegDecoder(path)
+    finally:
+        jd.JpegDecoder.progressive_dct_scan, jd.InverseDCT, jd.JpegDecoder.end_of_image = o_scan, o_cls, o_eoi
+    return dec, cap
+
+
+def pixel_layout_to_blocks(arr: np.ndarray, dec) -> np.ndarray:
+    """image_array holding coefficients at pixel coordinates (:1029, :1225) -> int16 [nblocks,64] zig-zag, blocks in
+    the interleaved order (MCU raster, component, block_count) of the baseline seam."""
+    comps = list(dec.color_components.values())
+    nc = len(comps)
+    hmax = max(c.horizontal_sampling for c in comps) if nc > 1 else 1
+    vmax = max(c.vertical_sampling for c in comps) if nc > 1 else 1
+    mw, mh = (8 * hmax, 8 * vmax) if nc > 1 else (8, 8)
+    mx, my = -(-dec.image_width // mw), -(-dec.image_height // mh)
+    zz = jd.zagzig
+    blocks = []
+    for m in range(mx * my):
+        my_, mx_ = divmod(m, mx)
+        for c in comps:
+            h, v = (c.horizontal_sampling, c.vertical_sampling) if nc > 1 else (1, 1)
+            for r in range(h * v):
+                by, bx = divmod(r, h)
+                X, Y = (mx_ * h + bx) * 8, (my_ * v + by) * 8
+                blocks.append([arr[X + zz[k][0], Y + zz[k][1], c.order] for k in range(64)])
+    return np.array(blocks, dtype=np.int16)
+
+
 def attrs_of(dec) -> dict:
     return {
         "file_size": dec.file_size, "file_header": dec.file_header, "scan_finished": dec.scan_finished,
@@ -138,6 +191,15 @@ def file_fixtures(big: bool):
     fx.append(("c2_512x512_420", synth.encode_rgb(S(16, 512, 512), 85, "420", 0)))
     if big:
         fx.append(("c3_1920x1080_420_dri120", synth.encode_rgb(S(0, 1920, 1080), 85, "420", 120)))
+    # progressive (SOF2): libjpeg's default 10-scan script with successive approximation, per-scan optimised tables
+    fx.append(("prog_64x64_420_pil", pil_jpeg(S(20, 64, 64), quality=85, subsampling=2, progressive=True)))
+    fx.append(("prog_64x64_444_pil", pil_jpeg(S(21, 64, 64), quality=90, subsampling=0, progressive=True)))
+    fx.append(("prog_70x50_420_pil", pil_jpeg(S(22, 70, 50), quality=75, subsampling=2, progressive=True)))
+    fx.append(("prog_64x48_422_pil", pil_jpeg(S(23, 64, 48), quality=85, subsampling=1, progressive=True)))
+    fx.append(("prog_64x64_grey_pil", pil_jpeg(S(24, 64, 64)[..., 1], quality=85, progressive=True)))
+    fx.append(("prog_96x80_420_noise_pil", pil_jpeg(synth.synth_rgb(25, 96, 80, 45.0), quality=95, subsampling=2, progressive=True)))
+    fx.append(("prog_128x64_420_rst_pil", pil_jpeg(S(26, 128, 64), quality=85, subsampling=2, progressive=True, restart_marker_rows=1)))
+    fx.append(("prog_48x32_420_flat_pil", pil_jpeg(flat, quality=50, subsampling=2, progressive=True)))
     return fx
 
 
@@ -247,6 +309,17 @@ def main():
             continue
         path = FILES / f"{name}.jpg"
         path.write_bytes(data)
+        if name.startswith("prog_"):
+            dec, cap = run_reference_progressive(path)
+            rgb = np.asarray(dec.image_array)
+            coef = pixel_layout_to_blocks(cap["pre_idct"], dec)
+            per_scan = np.stack([pixel_layout_to_blocks(a, dec) for a in cap["before_scan"]])
+            meta = attrs_of(dec)
+            meta["sha256"] = {"coef": sha(coef), "planes": sha(cap["planes"]), "rgb": sha(rgb)}
+            np.savez_compressed(FILES / f"{name}.npz", coef=coef, coef_before_scan=per_scan, planes=cap["planes"], rgb=rgb)
+            index[name] = meta
+            print(f"{name}: {len(data)} B, {coef.shape[0]} blocks, {per_scan.shape[0]} scans, rgb {rgb.shape}")
+            continue
         dec, cap = run_reference(path)
         coef, deq, idct_o = np.stack(cap["coef"]), np.stack(cap["deq"]), np.stack(cap["idct"])
         rgb = np.asarray(dec.image_array)
