@@ -10,6 +10,8 @@
  *                                       + InverseDCT.__call__               :1561-1573  dequantise, IDCT,
  *                                       + ResizeGrid.__call__               :1588-1626  upsample,
  *                                       + end_of_image crop / YCbCr_to_RGB  :1373-1386, :1683-1700  colour)
+ *   (progressive batches: stage 1 is JpegDecoder.progressive_dct_scan :908-1304, one launch per scan ordinal,
+ *    stage 2 is the final pass :1306-1362)
  *   mj_decode_baseline_batch            the same, one call (create + execute + sync + read back)
  *   mj_idct_batch                       the same minus the entropy decoder: caller supplies the zig-zag
  *                                       coefficients seen at :869 (BASELINE.json configs[1], "host Huffman")
@@ -89,6 +91,20 @@ typedef struct {
     int64_t first_segment;        /* index of this image's first entry in seg_begin / seg_end                 */
 } mj_image_desc;
 
+/* One SOS of a progressive (SOF2) image: what start_of_scan (:505-650) hands to progressive_dct_scan (:908).
+ * Scans must be listed image by image, in file order. */
+typedef struct {
+    int32_t image;                /* index into mj_batch.images                                               */
+    int32_t n_comp;               /* components in the scan (:530)                                            */
+    int32_t comp[3];              /* their positions in the frame (0 = Y, 1 = Cb, 2 = Cr)                     */
+    int32_t dc_sel[3], ac_sel[3]; /* per scan component: index into mj_batch.huff (:543-544)                  */
+    int32_t ss, se, ah, al;       /* spectral selection, successive approximation (:559-562)                  */
+    int32_t restart_interval;     /* value in force for this scan (:501-502)                                  */
+    int32_t mcu_count_h, mcu_count_v; /* of this scan (:609-621): interleaved MCUs or the component's 8x8 blocks */
+    int32_t n_segments;           /* restart segments of this scan                                            */
+    int64_t first_segment;        /* index of the scan's first entry in seg_begin / seg_end                   */
+} mj_scan_desc;
+
 typedef struct {
     int32_t n_images;
     const mj_image_desc *images;          /* host */
@@ -109,6 +125,10 @@ typedef struct {
 
     int32_t layout;                       /* MJ_LAYOUT_*                                                     */
     uint32_t flags;                       /* MJ_FLAG_*                                                       */
+
+    int32_t n_scans;                      /* 0 = baseline batch; > 0 = progressive batch: every image is SOF2  */
+    const mj_scan_desc *scans;            /* host; the images' own n_segments / first_segment / table selectors
+                                             are ignored in a progressive batch                               */
 } mj_batch;
 
 /* Sizes and per-image offsets of a plan's outputs (all outputs are packed image after image). */

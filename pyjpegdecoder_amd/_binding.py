@@ -42,13 +42,22 @@ class ImageDescC(ctypes.Structure):
                 ("n_segments", ctypes.c_int32), ("first_segment", ctypes.c_int64)]
 
 
+class ScanDescC(ctypes.Structure):
+    _fields_ = [("image", ctypes.c_int32), ("n_comp", ctypes.c_int32), ("comp", ctypes.c_int32 * 3),
+                ("dc_sel", ctypes.c_int32 * 3), ("ac_sel", ctypes.c_int32 * 3),
+                ("ss", ctypes.c_int32), ("se", ctypes.c_int32), ("ah", ctypes.c_int32), ("al", ctypes.c_int32),
+                ("restart_interval", ctypes.c_int32), ("mcu_count_h", ctypes.c_int32), ("mcu_count_v", ctypes.c_int32),
+                ("n_segments", ctypes.c_int32), ("first_segment", ctypes.c_int64)]
+
+
 class BatchC(ctypes.Structure):
     _fields_ = [("n_images", ctypes.c_int32), ("images", ctypes.POINTER(ImageDescC)),
                 ("blob", ctypes.c_void_p), ("blob_len", ctypes.c_int64), ("blob_mem", ctypes.c_int32),
                 ("n_segments", ctypes.c_int64), ("seg_begin", ctypes.c_void_p), ("seg_end", ctypes.c_void_p),
                 ("n_huff", ctypes.c_int32), ("huff", ctypes.POINTER(HuffSpecC)),
                 ("n_qt", ctypes.c_int32), ("qt", ctypes.c_void_p),
-                ("layout", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+                ("layout", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDescC))]
 
 
 class PlanInfoC(ctypes.Structure):

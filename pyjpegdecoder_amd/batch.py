@@ -23,14 +23,47 @@ _STATUS_TEXT = {
 
 
 def check_supported(p: ParsedJpeg) -> ScanInfo:
-    """What the MI355X path accepts: one interleaved baseline scan covering all frame components."""
-    if p.scan_mode != "baseline_dct":
-        raise UnsupportedJpeg("Encoding mode not supported by the MI355X path yet. Only 'Baseline DCT' is.")
+    """What the MI355X path accepts: one interleaved baseline scan covering all frame components, or a
+    progressive file whose DC scans are interleaved (libjpeg's scripts) and whose AC scans are single-component."""
     if not p.scans:
         raise CorruptedJpeg("No scan found in the file.")
+    if p.scan_mode == "progressive_dct":
+        for sc in p.scans:
+            # the reference's own checks (jpeg_decoder.py:917-934, :966-967)
+            if sc.spectral_start == 0 and sc.spectral_end != 0 or sc.spectral_start > sc.spectral_end:
+                raise CorruptedJpeg("Progressive JPEG images cannot contain both DC and AC values in the same scan.")
+            if sc.bit_high != 0 and sc.bit_high - sc.bit_low != 1:
+                raise CorruptedJpeg("Progressive JPEG images cannot contain more than 1 bit for each value on a refining scan.")
+            if sc.spectral_start > 0 and len(sc.component_ids) > 1:
+                raise CorruptedJpeg("An AC progressive scan can only have a single color component.")
+            if sc.spectral_start == 0 and 1 < len(sc.component_ids) < len(p.color_components):
+                raise UnsupportedJpeg("Interleaved scans of a subset of the components are not supported by the MI355X path.")
+            if sc.spectral_start == 0 and len(sc.component_ids) == 1 and len(p.color_components) > 1:
+                c = p.color_components[sc.component_ids[0]]
+                if c.horizontal_sampling > 1 or c.vertical_sampling > 1:
+                    raise UnsupportedJpeg("Single-component DC scan of a component with sampling > 1 "
+                                          "(the reference misplaces these blocks) is not supported.")
+        return p.scans[0]
+    if p.scan_mode != "baseline_dct":
+        raise UnsupportedJpeg("Encoding mode not supported. Only 'Baseline DCT' and 'Progressive DCT' are supported.")
     if len(p.scans) != 1 or len(p.scans[0].component_ids) != len(p.color_components):
         raise UnsupportedJpeg("Non-interleaved baseline scans are not supported by the MI355X path.")
     return p.scans[0]
+
+
+def _segments_of(scan: ScanInfo, off: int):
+    """(begin[], end[]) blob offsets of a scan's restart segments; checks the marker count (:898 is count driven)."""
+    so = scan.segment_offsets
+    if scan.restart_interval > 0:
+        want = -(-scan.mcu_count // scan.restart_interval)
+        if so.size - 1 != want:
+            raise CorruptedJpeg(f"Failed to decode image ({so.size - 2} restart markers found, {want - 1} expected).")
+        b = so[:-1].copy()
+        e = np.concatenate([so[1:-1] - 2, so[-1:]])
+    else:
+        b = np.array([scan.entropy_start], dtype=np.int64)
+        e = np.array([scan.entropy_end], dtype=np.int64)
+    return b + off, e + off
 
 
 @dataclass
@@ -48,6 +81,8 @@ class PreparedBatch:
     layout: int
     flags: int
     shapes: List[Tuple[int, int, int]] = field(default_factory=list)   # (W, H, ncomp)
+    scans: Optional[ctypes.Array] = None                               # progressive batches: mj_scan_desc[]
+    n_scans: int = 0
 
     def to_c(self, blob_device_ptr: int = 0) -> B.BatchC:
         b = B.BatchC()
@@ -65,6 +100,8 @@ class PreparedBatch:
         b.n_qt = self.qt.shape[0]
         b.qt = self.qt.ctypes.data
         b.layout, b.flags = self.layout, self.flags
+        b.n_scans = self.n_scans
+        b.scans = ctypes.cast(self.scans, ctypes.POINTER(B.ScanDescC)) if self.n_scans else None
         return b
 
 
@@ -104,10 +141,52 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
             qt_list.append(zz.astype(np.uint16))
         return qt_ids[key]
 
+    progressive = parsed[0].scan_mode == "progressive_dct" if parsed else False
+    scan_list: List[B.ScanDescC] = []
     for i, p in enumerate(parsed):
         scan = check_supported(p)
+        if (p.scan_mode == "progressive_dct") != progressive:
+            raise UnsupportedJpeg("A batch holds either baseline or progressive files; split it.")
         blob[offs[i]:offs[i] + sizes[i]] = np.frombuffer(p.raw, dtype=np.uint8)
         d = descs[i]
+        if progressive:
+            comp_ids = list(p.color_components)
+            d.width, d.height, d.ncomp = p.image_width, p.image_height, len(comp_ids)
+            for c, cid in enumerate(comp_ids):
+                comp = p.color_components[cid]
+                d.hs[c], d.vs[c] = comp.horizontal_sampling, comp.vertical_sampling
+                if comp.quantization_table_id not in p.quantization_zz:
+                    raise CorruptedJpeg("Scan uses a quantization table that the file does not define.")
+                d.qt_sel[c] = qt_id(p.quantization_zz[comp.quantization_table_id])
+            if d.ncomp == 1:
+                d.hs[0] = d.vs[0] = 1
+                mw = mh = 8
+            else:
+                mw, mh = 8 * max(d.hs[c] for c in range(3)), 8 * max(d.vs[c] for c in range(3))
+            d.mcu_count_h, d.mcu_count_v = -(-p.image_width // mw), -(-p.image_height // mh)
+            d.restart_interval, d.n_segments, d.first_segment = 0, 0, 0
+            for sc in p.scans:
+                sd = B.ScanDescC()
+                sd.image, sd.n_comp = i, len(sc.component_ids)
+                for k, cid in enumerate(sc.component_ids):
+                    sd.comp[k] = comp_ids.index(cid)
+                    tabs = sc.huffman_tables_id[cid]
+                    need_dc, need_ac = sc.spectral_start == 0 and sc.bit_high == 0, sc.spectral_start > 0
+                    if (need_dc and tabs.dc not in sc.huffman) or (need_ac and tabs.ac not in sc.huffman):
+                        raise CorruptedJpeg("Scan uses a Huffman table that the file does not define.")
+                    sd.dc_sel[k] = huff_id(sc.huffman[tabs.dc]) if need_dc else 0
+                    sd.ac_sel[k] = huff_id(sc.huffman[tabs.ac]) if need_ac else 0
+                sd.ss, sd.se, sd.ah, sd.al = sc.spectral_start, sc.spectral_end, sc.bit_high, sc.bit_low
+                sd.restart_interval = sc.restart_interval
+                sd.mcu_count_h, sd.mcu_count_v = sc.mcu_count_h, sc.mcu_count_v
+                b_, e_ = _segments_of(sc, int(offs[i]))
+                sd.n_segments, sd.first_segment = int(b_.size), n_seg_total
+                n_seg_total += int(b_.size)
+                seg_b.append(b_)
+                seg_e.append(e_)
+                scan_list.append(sd)
+            shapes.append((p.image_width, p.image_height, d.ncomp))
+            continue
         d.width, d.height, d.ncomp = p.image_width, p.image_height, len(scan.component_ids)
         for c, cid in enumerate(scan.component_ids):
             comp = p.color_components[cid]
@@ -124,22 +203,12 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
             d.hs[0] = d.vs[0] = 1     # a single-component scan is always 8x8 MCUs (jpeg_decoder.py:595-598)
         d.restart_interval = scan.restart_interval
         d.mcu_count_h, d.mcu_count_v = scan.mcu_count_h, scan.mcu_count_v
-        so = scan.segment_offsets
-        if scan.restart_interval > 0:
-            want = -(-scan.mcu_count // scan.restart_interval)
-            if so.size - 1 != want:
-                raise CorruptedJpeg(
-                    f"Failed to decode image ({so.size - 2} restart markers found, {want - 1} expected).")
-            b = so[:-1].copy()
-            e = np.concatenate([so[1:-1] - 2, so[-1:]])
-        else:
-            b = np.array([scan.entropy_start], dtype=np.int64)
-            e = np.array([scan.entropy_end], dtype=np.int64)
+        b, e = _segments_of(scan, int(offs[i]))
         d.n_segments = int(b.size)
         d.first_segment = n_seg_total
         n_seg_total += int(b.size)
-        seg_b.append(b + offs[i])
-        seg_e.append(e + offs[i])
+        seg_b.append(b)
+        seg_e.append(e)
         shapes.append((p.image_width, p.image_height, d.ncomp))
 
     huff = (B.HuffSpecC * max(1, len(huff_list)))()
@@ -149,7 +218,8 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
         v[:min(256, vals.size)] = vals[:256]
         huff[k].vals[:] = v.tolist()
     qt = np.ascontiguousarray(np.stack(qt_list), dtype=np.uint16)
-    return PreparedBatch(parsed=parsed, blob=blob, file_offsets=offs, descs=descs,
+    scans_c = (B.ScanDescC * len(scan_list))(*scan_list) if scan_list else None
+    return PreparedBatch(scans=scans_c, n_scans=len(scan_list), parsed=parsed, blob=blob, file_offsets=offs, descs=descs,
                          seg_begin=np.ascontiguousarray(np.concatenate(seg_b), dtype=np.int64),
                          seg_end=np.ascontiguousarray(np.concatenate(seg_e), dtype=np.int64),
                          huff=huff, n_huff=len(huff_list), qt=qt, layout=layout, flags=flags, shapes=shapes)
@@ -195,9 +265,9 @@ class BatchDecoder:
         parsed = [parse_jpeg(f) for f in files]
         groups: Dict[tuple, List[int]] = {}
         for i, p in enumerate(parsed):
-            scan = check_supported(p)
-            comps = [p.color_components[c] for c in scan.component_ids]
-            key = (len(comps),) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            check_supported(p)
+            comps = list(p.color_components.values())
+            key = (p.scan_mode, len(comps)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
             groups.setdefault(key, []).append(i)
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)

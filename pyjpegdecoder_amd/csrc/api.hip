@@ -42,6 +42,11 @@ struct mj_plan {
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     int n_huff = 0;
     bool use_lanes = false;
+    // progressive batches: scans grouped by ordinal (k-th scan of every image), one launch each
+    bool progressive = false;
+    mj::DevProgScan *d_pscans = nullptr;
+    mj::DevProgSeg *d_psegs = nullptr;
+    std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
     int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
@@ -210,7 +215,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -235,6 +240,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     struct Guard { mj_plan *p; ~Guard() { if (p) mj_plan_destroy(p); } } guard{p};
 
     const bool have_entropy = b->blob_mem != MJ_MEM_NONE && b->blob != nullptr;
+    const bool prog = have_entropy && b->n_scans > 0;
+    p->progressive = prog;
+    if (prog && !b->scans) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: n_scans > 0 without scans");
     if (have_entropy && (b->n_huff <= 0 || !b->huff || !b->seg_begin || !b->seg_end))
         return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: entropy data without Huffman tables / segment offsets");
 
@@ -275,7 +283,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if (d.qt_sel[c] < 0 || d.qt_sel[c] >= b->n_qt) return fail(ctx, MJ_ERR_INVALID, "image %d: qt_sel out of range", i);
             im.qt_index[c] = d.qt_sel[c];
             int dslot = 0, aslot = 0;
-            if (have_entropy) {
+            if (have_entropy && !prog) {
                 if (d.dc_sel[c] < 0 || d.dc_sel[c] >= b->n_huff || d.ac_sel[c] < 0 || d.ac_sel[c] >= b->n_huff)
                     return fail(ctx, MJ_ERR_INVALID, "image %d: Huffman table selector out of range", i);
                 auto slot_of = [&](int t) {
@@ -295,7 +303,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         im.block_off = blk; im.mcu_off = mcu; im.rgb_off = rgb; im.pix_off = pix;
         mcu_prefix[i] = mcu;
         if (i > 0 && (d.width != b->images[0].width || d.height != b->images[0].height)) p->uniform = false;
-        if (have_entropy) {
+        if (have_entropy && !prog) {
             const int64_t want = d.restart_interval > 0 ? (mcus + d.restart_interval - 1) / d.restart_interval : 1;
             if (d.n_segments != want)
                 return fail(ctx, MJ_ERR_INVALID, "image %d: %d restart segments given, %lld expected (restart interval %d, %lld MCUs)",
@@ -321,6 +329,81 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         pix += (int64_t)d.width * d.height;
     }
     mcu_prefix[b->n_images] = mcu;
+    std::vector<mj::DevProgScan> pscans;
+    std::vector<mj::DevProgSeg> psegs;
+    if (prog) {
+        std::vector<int> ordinal_of(b->n_scans, 0);
+        std::vector<int> seen(b->n_images, 0);
+        int n_ord = 0;
+        for (int k = 0; k < b->n_scans; ++k) {
+            const mj_scan_desc &sd = b->scans[k];
+            if (sd.image < 0 || sd.image >= b->n_images) return fail(ctx, MJ_ERR_INVALID, "scan %d: image index out of range", k);
+            if (k > 0 && sd.image < b->scans[k - 1].image) return fail(ctx, MJ_ERR_INVALID, "scans must be grouped by image, in file order");
+            ordinal_of[k] = seen[sd.image]++;
+            n_ord = std::max(n_ord, ordinal_of[k] + 1);
+            const mj_image_desc &d = b->images[sd.image];
+            const mj::DevImage &im = imgs[sd.image];
+            mj::DevProgScan ps{};
+            ps.image = sd.image; ps.n_comp = sd.n_comp;
+            if (sd.n_comp < 1 || sd.n_comp > d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: %d components", k, sd.n_comp);
+            if (sd.ss < 0 || sd.se > 63 || sd.se < sd.ss || sd.al < 0 || sd.al > 13 || (sd.ss == 0 && sd.se != 0))
+                return fail(ctx, MJ_ERR_INVALID, "scan %d: bad spectral selection / successive approximation", k);
+            if (sd.ss > 0 && sd.n_comp != 1) return fail(ctx, MJ_ERR_INVALID, "scan %d: an AC scan has one component", k);
+            for (int i = 0; i < sd.n_comp; ++i) {
+                if (sd.comp[i] < 0 || sd.comp[i] >= d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: component out of range", k);
+                ps.comp[i] = sd.comp[i];
+                const bool need_dc = sd.ss == 0 && sd.ah == 0, need_ac = sd.ss > 0;
+                if ((need_dc && (sd.dc_sel[i] < 0 || sd.dc_sel[i] >= b->n_huff)) || (need_ac && (sd.ac_sel[i] < 0 || sd.ac_sel[i] >= b->n_huff)))
+                    return fail(ctx, MJ_ERR_INVALID, "scan %d: Huffman table selector out of range", k);
+                ps.dc_tab[i] = need_dc ? sd.dc_sel[i] : 0;
+                ps.ac_tab[i] = need_ac ? sd.ac_sel[i] : 0;
+            }
+            // geometry the kernel relies on
+            int want_h, want_v;
+            if (sd.n_comp > 1) {
+                if (sd.n_comp != d.ncomp) return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: interleaved scans of a subset of the components are not supported", k);
+                want_h = im.mcu_count_h; want_v = im.mcu_count_v;
+            } else {
+                const int c = sd.comp[0];
+                const int h = (d.ncomp > 1 && c == 0) ? im.hmax : 1, v = (d.ncomp > 1 && c == 0) ? im.vmax : 1;
+                if (sd.ss == 0 && (h > 1 || v > 1))
+                    return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: single-component DC scan of a component with sampling > 1 (the reference misplaces these)", k);
+                const int cw = (d.width * h + im.hmax - 1) / im.hmax, ch = (d.height * v + im.vmax - 1) / im.vmax;   // ceil(W / ratio)
+                want_h = (cw + 7) / 8; want_v = (ch + 7) / 8;
+                if (d.ncomp == 1) { want_h = (d.width + 7) / 8; want_v = (d.height + 7) / 8; }
+            }
+            if (sd.mcu_count_h != want_h || sd.mcu_count_v != want_v)
+                return fail(ctx, MJ_ERR_INVALID, "scan %d: MCU counts %dx%d, expected %dx%d", k, sd.mcu_count_h, sd.mcu_count_v, want_h, want_v);
+            ps.ss = sd.ss; ps.se = sd.se; ps.ah = sd.ah; ps.al = sd.al;
+            ps.mcu_count_h = sd.mcu_count_h; ps.mcu_count_v = sd.mcu_count_v;
+            pscans.push_back(ps);
+        }
+        // segments grouped by ordinal
+        p->ordinal_seg_off.assign(n_ord + 1, 0);
+        for (int o = 0; o < n_ord; ++o) {
+            p->ordinal_seg_off[o] = (int64_t)psegs.size();
+            for (int k = 0; k < b->n_scans; ++k) {
+                if (ordinal_of[k] != o) continue;
+                const mj_scan_desc &sd = b->scans[k];
+                const int64_t mcus = (int64_t)sd.mcu_count_h * sd.mcu_count_v;
+                const int64_t want = sd.restart_interval > 0 ? (mcus + sd.restart_interval - 1) / sd.restart_interval : 1;
+                if (sd.n_segments != want || sd.first_segment < 0 || sd.first_segment + sd.n_segments > b->n_segments)
+                    return fail(ctx, MJ_ERR_INVALID, "scan %d: %d restart segments given, %lld expected", k, sd.n_segments, (long long)want);
+                for (int sgi = 0; sgi < sd.n_segments; ++sgi) {
+                    const int64_t sb = b->seg_begin[sd.first_segment + sgi], se = b->seg_end[sd.first_segment + sgi];
+                    if (sb < 0 || se < sb || se > b->blob_len) return fail(ctx, MJ_ERR_INVALID, "scan %d segment %d: bad byte range", k, sgi);
+                    mj::DevProgSeg g{};
+                    g.begin = sb; g.len = (int32_t)(se - sb); g.scan = k;
+                    g.mcu0 = sd.restart_interval > 0 ? sgi * sd.restart_interval : 0;
+                    g.n_mcu = (int32_t)(sd.restart_interval > 0 ? std::min<int64_t>(sd.restart_interval, mcus - g.mcu0) : mcus);
+                    g.last = sgi == sd.n_segments - 1;
+                    psegs.push_back(g);
+                    ent += se - sb;
+                }
+            }
+        }
+        p->ordinal_seg_off[n_ord] = (int64_t)psegs.size();
+    }
     p->mcus_per_image = (int32_t)(mcu / b->n_images);
     p->info.total_blocks = blk; p->info.total_mcus = mcu; p->info.total_pixels = pix;
     p->info.rgb_bytes = rgb; p->info.entropy_bytes = ent;
@@ -374,6 +457,10 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
         if (force && !strcmp(force, "lanes") && b->n_huff <= mj::kMaxLaneTables) p->use_lanes = true;
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
+        if (prog) {
+            if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
+            if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
+        }
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
             p->d_blob = p->d_blob_owned;
@@ -412,6 +499,16 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
     if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data (stage 1 unavailable)");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
+    if (p->progressive) {
+        // scans accumulate into the coefficient store (:1029, :1225): start from zeros, then one launch per scan ordinal
+        MJ_HIP(ctx, hipMemsetAsync(p->d_coef, 0, (size_t)p->info.total_blocks * 128, s));
+        for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
+            const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
+            MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images,
+                                                    p->d_huff, p->d_coef, p->d_status));
+        }
+        return MJ_OK;
+    }
     if (p->use_lanes)
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                              p->n_huff, p->d_coef, p->d_status));

@@ -57,7 +57,32 @@ struct DevSegment {
     int32_t pad;
 };
 
+// One SOS of a progressive image (device copy of mj_scan_desc with table indices resolved).
+struct DevProgScan {
+    int32_t image, n_comp;
+    int32_t comp[3];
+    int32_t dc_tab[3], ac_tab[3];   // indices into the batch's DevHuff array
+    int32_t ss, se, ah, al;
+    int32_t mcu_count_h, mcu_count_v;
+    int32_t pad;
+};
+
+// One restart segment of one progressive scan.
+struct DevProgSeg {
+    int64_t begin;
+    int32_t len;
+    int32_t scan;         // index into the DevProgScan array
+    int32_t mcu0, n_mcu;  // in units of the scan's own MCUs
+    int32_t last, pad;
+};
+
 }  // namespace mj
+
+namespace mj {
+hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
+                                   const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
+                                   int16_t *coef, int32_t *status);
+}
 
 // stage-1 / stage-2 launchers (defined in huffman.hip / reconstruct.hip)
 namespace mj {

@@ -1,0 +1,242 @@
+// Stage 1 for progressive files — one SOS (scan) of every image per launch, one wavefront per restart segment.
+//
+// Replaces JpegDecoder.progressive_dct_scan's entropy part (jpeg_decoder.py:908-1304).  The coefficient store
+// that the reference keeps inside image_array between scans (:1029, :1225) is the same HBM array the baseline
+// path uses — int16 blocks [v][u] in interleaved MCU order — so that after the last scan the ordinary stage-2
+// kernel performs the reference's final pass (:1306-1362).  Scans of one image depend on each other, hence one
+// launch per scan ordinal in stream order; within a scan restart segments are independent.
+//
+// The walk is wave-uniform (same bit reader as huffman.hip); the lanes hold the 64 zig-zag coefficients of the
+// block being refined, which turns the reference's element-by-element queues into mask arithmetic:
+//   * "skip r zero coefficients, queueing the non-zero ones passed" (:1184-1193) = clear r low bits of the
+//     zero mask above the cursor; the queue is the non-zero mask of the span;
+//   * "one correction bit per queued coefficient, in order" (:1107-1115) = lane l takes bit number
+//     popcount(queue below l) of the next popcount(queue) bits;
+//   * the correction is `value |= bit << Al` on the int16 two's complement exactly as the reference does it,
+//     i.e. NOT the spec's decrement for negative values.
+#include "mijpeg_internal.h"
+#include "wave_bits.h"
+
+namespace mj {
+
+namespace {
+
+using namespace wavebits;
+
+__constant__ uint8_t c_nat_of_zz_p[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__device__ __forceinline__ uint64_t bits_from(int k) { return k >= 64 ? 0 : ~(uint64_t)0 << k; }      // bits k..63
+__device__ __forceinline__ uint64_t bits_range(int a, int b) { return bits_from(a) & ~bits_from(b); } // bits a..b-1
+
+// take n <= 32 bits (0 allowed); the caller has refilled (>= 33 bits available)
+__device__ __forceinline__ uint32_t take32(BitReader &br, int n) {
+    if (n == 0) return 0;
+    uint32_t v = (uint32_t)(br.bb >> (64 - n));
+    br.bb <<= n;
+    br.bc -= n;
+    return v;
+}
+
+// one correction bit for every coefficient of `queue` (a mask over zig-zag positions), in ascending order
+__device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int al, int lane, int &coef, bool &dirty) {
+    while (queue) {
+        br.refill();
+        const int n = min(16, __builtin_popcountll(queue));
+        // the n lowest queued positions
+        uint64_t part = queue;
+        for (int i = 0; i < n; ++i) part &= part - 1;
+        part = queue & ~part;
+        queue &= ~part;
+        const uint32_t bits = take32(br, n);
+        if ((part >> lane) & 1) {
+            const int rank = __builtin_popcountll(part & (((uint64_t)1 << lane) - 1));
+            const int bit = (bits >> (n - 1 - rank)) & 1;
+            coef = (int)(int16_t)(coef | (int)(int16_t)(bit << al));
+        }
+        dirty = true;
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restrict__ blob,
+                                                          const DevProgSeg *__restrict__ segs, int n_segs,
+                                                          const DevProgScan *__restrict__ scans,
+                                                          const DevImage *__restrict__ images,
+                                                          const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
+                                                          int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][3 tables][kLutSize]
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int seg_id = blockIdx.x * 4 + wave;
+    if (seg_id >= n_segs) return;
+
+    const DevProgSeg *sg = segs + seg_id;
+    const DevProgScan *sc = scans + sg->scan;
+    const DevImage *im = images + sc->image;
+    uint16_t *my_lut = s_lut + (size_t)wave * 3 * kLutSize;
+    const int ss = sc->ss, se = sc->se, al = sc->al;
+    const bool refining = sc->ah != 0;
+    const bool is_dc = ss == 0;
+    const int nsc = sc->n_comp;
+
+    // tables of this scan: DC scans use one DC table per scan component, AC scans one AC table
+    const int n_tabs = is_dc ? (refining ? 0 : nsc) : 1;
+    for (int t = 0; t < n_tabs; ++t) {
+        const int gi = is_dc ? sc->dc_tab[t] : sc->ac_tab[0];
+        reinterpret_cast<uint4 *>(my_lut + t * kLutSize)[lane] = reinterpret_cast<const uint4 *>(huff[gi].lut)[lane];
+    }
+
+    BitReader br;
+    br.init(blob, sg->begin, sg->len, lane);
+
+    // frame geometry (interleaved block order of the coefficient store)
+    const int hmax = im->hmax, vmax = im->vmax, bpm = im->blocks_per_mcu, fmx = im->mcu_count_h;
+    const int ncf = im->ncomp;
+    int16_t *cbase = coef + im->block_off * 64;
+    auto block_ptr = [&](int c, int bx, int by) -> int16_t * {
+        const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
+        const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+        const int mx = bx / h, my = by / v;
+        return cbase + ((int64_t)(my * fmx + mx) * bpm + first + (by - my * v) * h + (bx - mx * h)) * 64;
+    };
+    const int smh = sc->mcu_count_h;
+    const int nat = c_nat_of_zz_p[lane];
+    int err = 0;
+
+    if (is_dc) {
+        // ------------------------------------------------------------ DC scans (:974-1057)
+        int pred0 = 0, pred1 = 0, pred2 = 0;
+        for (int m = sg->mcu0; m < sg->mcu0 + sg->n_mcu && !err; ++m) {
+            const int mcy = m / smh, mcx = m - mcy * smh;
+            for (int i = 0; i < nsc && !err; ++i) {
+                const int c = sc->comp[i];
+                const int h = (nsc > 1 && c == 0) ? hmax : 1, v = (nsc > 1 && c == 0) ? vmax : 1;
+                for (int r = 0; r < h * v; ++r) {
+                    const int bx = mcx * h + r % h, by = mcy * v + r / h;
+                    int16_t *p = block_ptr(c, bx, by);
+                    br.refill();
+                    if (!refining) {
+                        int s = decode_symbol(br, my_lut + i * kLutSize, huff + sc->dc_tab[i]);
+                        if (s < 0 || s > 16) { err = MJ_ST_BAD_CODE; break; }
+                        int diff = 0;
+                        if (s > 0) diff = extend(br.take(s), s);
+                        const int pred = i == 0 ? pred0 : (i == 1 ? pred1 : pred2);
+                        const int dcv = (int)(int16_t)(diff + pred);
+                        if (i == 0) pred0 = dcv; else if (i == 1) pred1 = dcv; else pred2 = dcv;
+                        if (lane == 0) p[0] = (int16_t)(dcv << al);                       // (:1029)
+                    } else {
+                        const int bit = (int)br.take(1);
+                        if (lane == 0) p[0] = (int16_t)(p[0] | (int16_t)(bit << al));     // (:1038)
+                    }
+                }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------ AC scans (:1060-1298)
+        const int c = sc->comp[0];
+        const uint16_t *lut = my_lut;
+        const DevHuff *tab = huff + sc->ac_tab[0];
+        const uint64_t band = bits_range(ss, se + 1);
+        int eobrun = 0;
+        const int m_end = sg->mcu0 + sg->n_mcu;
+        for (int m = sg->mcu0; m < m_end && !err; ++m) {
+            const int by = m / smh, bx = m - by * smh;
+            int16_t *p = block_ptr(c, bx, by);
+            if (!refining) {
+                // -------- first scan of the band: only writes (:1177-1179, :1225, :1248-1250)
+                if (eobrun > 0) { --eobrun; continue; }
+                int k = ss;
+                while (k <= se) {
+                    br.refill();
+                    const int hv = decode_symbol(br, lut, tab);
+                    if (hv < 0) { err = MJ_ST_BAD_CODE; break; }
+                    const int r = hv >> 4, s = hv & 15;
+                    if (hv == 0) { eobrun = 1; break; }
+                    if (s == 0 && r != 15) { eobrun = (1 << r) + (int)take32(br, r); break; }
+                    k += (hv == 0xF0) ? 16 : r;
+                    if (s > 0) {
+                        if (k > 63) { err = MJ_ST_OVERRUN; break; }
+                        const int val = extend(br.take(s), s);
+                        if (lane == 0) p[c_nat_of_zz_p[k]] = (int16_t)(val << al);
+                        ++k;
+                    }
+                }
+                if (eobrun > 0) --eobrun;          // the band that raised the run counts as its first one
+            } else {
+                // -------- refining scan: coefficients of the block in the lanes (lane = zig-zag index)
+                int cf = p[nat];
+                bool dirty = false;
+                if (eobrun > 0) {                   // inside an EOB run: every non-zero coefficient of the band gets a bit
+                    const uint64_t nz = __ballot(cf != 0);
+                    refine_queue(br, nz & band, al, lane, cf, dirty);
+                    --eobrun;
+                } else {
+                    int k = ss;
+                    while (k <= se) {
+                        br.refill();
+                        const int hv = decode_symbol(br, lut, tab);
+                        if (hv < 0) { err = MJ_ST_BAD_CODE; break; }
+                        const int r = hv >> 4, s = hv & 15;
+                        if (hv == 0) { eobrun = 1; break; }
+                        if (s == 0 && r != 15) { eobrun = (1 << r) + (int)take32(br, r); break; }
+                        int zr = (hv == 0xF0) ? 16 : r;
+                        uint64_t nz = __ballot(cf != 0);
+                        // pass zr zero coefficients from k on (:1184-1193)
+                        uint64_t zeros = ~nz & bits_from(k);
+                        int pnext = k;
+                        if (zr > 0) {
+                            for (int i = 1; i < zr; ++i) zeros &= zeros - 1;
+                            if (zeros == 0) { err = MJ_ST_OVERRUN; break; }
+                            pnext = __builtin_ctzll(zeros) + 1;
+                        }
+                        uint64_t queue = nz & bits_range(k, pnext);
+                        k = pnext;
+                        if (s > 0) {
+                            br.refill();
+                            const int val = extend(br.take(s), s);              // value bits precede the corrections (:1202)
+                            const uint64_t z2 = ~nz & bits_from(k);             // next zero position (:1212-1215)
+                            if (z2 == 0) { err = MJ_ST_OVERRUN; break; }
+                            const int pz = __builtin_ctzll(z2);
+                            queue |= nz & bits_range(k, pz);
+                            k = pz;
+                            if (lane == k) cf = (int)(int16_t)(val << al);      // (:1225)
+                            dirty = true;
+                            ++k;
+                        }
+                        refine_queue(br, queue, al, lane, cf, dirty);           // (:1231-1232)
+                    }
+                    if (!err && eobrun > 0) {       // rest of this band, then the run continues in the next blocks
+                        const uint64_t nz = __ballot(cf != 0);
+                        refine_queue(br, nz & bits_range(k, se + 1), al, lane, cf, dirty);
+                        --eobrun;
+                    }
+                }
+                if (dirty) p[nat] = (int16_t)cf;
+            }
+        }
+    }
+
+    if (!err) {
+        if (br.pad > 0 && br.bc < br.pad) err = MJ_ST_OVERRUN;
+        else if (!sg->last && (((br.bc - br.pad) >> 3) > 0 || br.pos < br.end)) err = MJ_ST_DESYNC;
+    }
+    if (err && lane == 0) atomicMax(status + sc->image, err);
+}
+
+hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
+                                   const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
+                                   int16_t *coef, int32_t *status) {
+    if (n_segs == 0) return hipSuccess;
+    const int blocks = (n_segs + 3) / 4;
+    const size_t lds = (size_t)4 * 3 * kLutSize * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_progressive_scan, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, scans,
+                       images, huff, coef, status);
+    return hipGetLastError();
+}
+
+}  // namespace mj

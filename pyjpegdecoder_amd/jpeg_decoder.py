@@ -83,15 +83,17 @@ class JpegDecoder():
             return
         scan = check_supported(parsed)
         self.scan_amount = parsed.scan_amount
+        scan = parsed.scans[-1]          # the geometry attributes are those of the last scan decoded (:591-621)
         self.mcu_width, self.mcu_height = scan.mcu_width, scan.mcu_height
         self.mcu_shape = (scan.mcu_width, scan.mcu_height)
         self.mcu_count_h, self.mcu_count_v, self.mcu_count = scan.mcu_count_h, scan.mcu_count_v, scan.mcu_count
         self.array_width, self.array_height, self.array_depth = parsed.array_width, parsed.array_height, parsed.array_depth
 
         # Device side: Huffman decode -> dequantise -> IDCT -> upsample -> crop -> colour  (the hot path)
-        self._say(f"\nScan 1 of {self.scan_amount}")
-        self._say(f"Color components: {', '.join(parsed.color_components[c].name for c in scan.component_ids)}")
-        self._say(f"MCU count: {self.mcu_count}")
+        for k, sc in enumerate(parsed.scans, start=1):
+            self._say(f"\nScan {k} of {self.scan_amount}")
+            self._say(f"Color components: {', '.join(parsed.color_components[c].name for c in sc.component_ids)}")
+            self._say(f"MCU count: {sc.mcu_count}")
         self._say("Decoding MCUs and performing IDCT on the GPU...")
         ctx = _context(device)
         prep = prepare_batch([self.raw_file], B.MJ_LAYOUT_XMAJOR, 0, [parsed])
@@ -103,7 +105,7 @@ class JpegDecoder():
         finally:
             plan.close()
         raise_for_status(out["status"])
-        self.scan_count = 1
+        self.scan_count = len(parsed.scans)
         self.file_header = parsed.file_header
 
         if not parsed.reached_eoi:

@@ -28,15 +28,18 @@ def test_ragged_batch_descriptors():
         assert (b >= prep.file_offsets[i]).all() and (e <= prep.file_offsets[i + 1]).all()
 
 
-def test_progressive_and_empty_are_rejected_on_the_host():
-    import io
-    from PIL import Image
-    b = io.BytesIO()
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(b, "JPEG", progressive=True)
-    p = parse_jpeg(b.getvalue())
-    assert p.scan_mode == "progressive_dct" and len(p.scans) > 1
-    with pytest.raises(UnsupportedJpeg):
-        check_supported(p)
+def test_progressive_descriptors_and_empty_file():
+    raw, _ = load_golden("prog_70x50_420_pil")
+    p = parse_jpeg(raw)
+    assert p.scan_mode == "progressive_dct" and len(p.scans) == 10
+    check_supported(p)
+    prep = prepare_batch([raw, load_golden("prog_64x64_420_pil")[0]])
+    assert prep.n_scans == 20 and [prep.scans[k].image for k in (0, 9, 10, 19)] == [0, 0, 1, 1]
+    s0, s1 = prep.scans[0], prep.scans[1]
+    assert (s0.ss, s0.se, s0.n_comp) == (0, 0, 3) and (s0.mcu_count_h, s0.mcu_count_v) == (5, 4)      # interleaved DC scan
+    assert s1.n_comp == 1 and s1.ss > 0 and (s1.mcu_count_h, s1.mcu_count_v) == (9, 7)                # luma AC scan: ceil(70/8) x ceil(50/8)
+    with pytest.raises(UnsupportedJpeg):                                                              # no mixing of modes in one plan
+        prepare_batch([raw, load_golden("64x64_420_pil")[0]])
     # header only, no scan: the reference falls off the end of the file (:81-83); the batch API refuses
     raw, _ = load_golden("c1_64x64_444_pil")
     p = parse_jpeg(raw[:raw.index(b"\xFF\xDA")])

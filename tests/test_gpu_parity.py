@@ -327,3 +327,52 @@ def test_both_stage1_forms_1080p_and_errors(dec, mode, monkeypatch):
                 raw[:int(s.entropy_start) + 3] + raw[int(s.segment_offsets[1]) - 2:]):
         with pytest.raises(CorruptedJpeg):
             dec.decode([bad])
+
+
+def prog_names():
+    return sorted(n for n in golden_index() if n.startswith("prog_"))
+
+
+@pytest.mark.parametrize("name", prog_names())
+def test_progressive_fixture_bit_exact(dec, name):
+    """BASELINE configs[4] path: progressive scans (DC/AC, first/refining, EOB runs, the reference's `|=`
+    refinement semantics F8) on the GPU, then the ordinary stage 2 — coefficients, planes and RGB as the reference."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], vec["coef"]), "coefficient store before the final pass"
+    assert np.array_equal(seam["planes"], vec["planes"])
+    assert np.array_equal(img, vec["rgb"])
+    assert np.array_equal(dec.decode([raw])[0], vec["rgb"])
+
+
+def test_progressive_batch_and_class_surface(dec, tmp_path):
+    from pyjpegdecoder_amd import JpegDecoder
+    names = prog_names()
+    raws = [load_golden(n)[0] for n in names]
+    for n, img in zip(names, dec.decode(raws + [load_golden("64x64_420_pil")[0]])):     # mixed modes: grouped per plan
+        assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
+    name = "prog_70x50_420_pil"
+    f = tmp_path / "p.jpg"
+    f.write_bytes(load_golden(name)[0])
+    d = JpegDecoder(f)
+    meta = golden_index()[name]
+    assert np.array_equal(d.image_array, load_golden(name)[1]["rgb"])
+    for k in ("scan_mode", "scan_count", "scan_amount", "image_width", "image_height", "file_header", "scan_finished",
+              "mcu_count_h", "mcu_count_v", "mcu_count", "mcu_width", "mcu_height", "restart_interval"):
+        assert getattr(d, k) == meta[k], k
+
+
+def test_progressive_larger_random_against_oracle(dec):
+    import io
+    from PIL import Image
+    from oracle import oracle
+    from tools import synth
+    for i, (w, h, ss, q) in enumerate([(333, 211, 2, 85), (256, 192, 0, 92), (200, 120, 1, 70)]):
+        rgb = synth.synth_rgb(900 + i, w, h, 25.0)
+        b = io.BytesIO()
+        Image.fromarray(rgb).save(b, "JPEG", quality=q, subsampling=ss, progressive=True)
+        raw = b.getvalue()
+        ref = oracle.decode(raw)
+        (img,), (seam,) = dec.decode([raw], return_seams=True)
+        assert np.array_equal(seam["coef"], ref["coef"])
+        assert np.array_equal(img, ref["rgb"])
