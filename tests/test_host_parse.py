@@ -69,3 +69,21 @@ def test_undo_zigzag_is_the_reference_layout():
     xy = _parse.undo_zigzag(zz)
     # [x, y]: x = horizontal; zig-zag 1 is the first horizontal frequency, 2 the first vertical one
     assert xy[1, 0] == 1 and xy[0, 1] == 2 and xy[7, 7] == 63 and xy[2, 0] == 5
+
+
+@pytest.mark.parametrize("name", sorted(n for n in golden_index() if n.startswith("prog_")))
+def test_progressive_attribute_surface(name):
+    """Progressive files: same attribute surface; the MCU geometry left on the object is the LAST scan's (:591-621)."""
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    p = _parse.parse_jpeg(raw)
+    last = p.scans[-1]
+    assert p.scan_mode == meta["scan_mode"] == "progressive_dct"
+    assert len(p.scans) == meta["scan_count"] == meta["scan_amount"] == p.scan_amount
+    assert (last.mcu_width, last.mcu_height) == (meta["mcu_width"], meta["mcu_height"])
+    assert (last.mcu_count_h, last.mcu_count_v, last.mcu_count) == (meta["mcu_count_h"], meta["mcu_count_v"], meta["mcu_count"])
+    assert (p.array_width, p.array_height, p.array_depth) == (meta["array_width"], meta["array_height"], meta["array_depth"])
+    assert {str(k): dict(v.tree) for k, v in p.huffman.items()} == meta["huffman_tables"]       # tables of the last DHTs
+    assert p.restart_interval == meta["restart_interval"] and p.file_header == meta["file_header"]
+    for sc in p.scans:                                                                          # every scan ends on a marker
+        assert raw[sc.entropy_end] == 0xFF and raw[sc.entropy_end + 1] not in (0x00,) + tuple(range(0xD0, 0xD8))
