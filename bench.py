@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to --batch)")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / MAX of timings (gloo: self-test on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,10 +69,15 @@ def main():
     import numpy as np
     import torch                                # before libmijpeg: one HIP runtime per process
     import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
@@ -117,7 +125,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     from pyjpegdecoder_amd.sharding import max_over_ranks
-    dt = max_over_ranks(dt, dev)
+    dt = max_over_ranks(dt, dev if args.backend == "nccl" else None)
 
     # ---- parity spot check of what was just timed (first and last image of the batch vs the oracle) -------
     out = plan.read(rgb=False)

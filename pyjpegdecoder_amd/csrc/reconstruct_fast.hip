@@ -62,6 +62,7 @@ __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int deq(int c, uint32_t q) { return (int)(int16_t)__mul24(c, (int)q); }   // int16 wrap (:869)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two coefficients at once: the low 16 bits of a 16x16 product are exactly numpy's int16 * int16 wrap (:869)
 __device__ __forceinline__ uint32_t deq2(uint32_t c2, uint32_t q2) {
     const u16x2 p = __builtin_bit_cast(u16x2, c2) * __builtin_bit_cast(u16x2, q2);   // v_pk_mul_lo_u16
@@ -377,17 +378,22 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
                     // chroma source rows sx0, sx0+1 of this lane's column, as floats
                     const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
                     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
-                    float cA[2][8], cB[2][8];
+                    // (Cb, Cr) pairs: the two chroma planes ride in the two halves of packed-fp32 registers, so one
+                    // v_pk_* instruction serves both components
+                    f32x2 cA[8], cB[8];
+                    {
+                        const int16_t *cbp = mt + G::NBY * 64, *crp = cbp + 64;
+                        const uint4 ba = *reinterpret_cast<const uint4 *>(cbp + sx0 * 8), ra = *reinterpret_cast<const uint4 *>(crp + sx0 * 8);
+                        const uint32_t bw[4] = {ba.x, ba.y, ba.z, ba.w}, rw[4] = {ra.x, ra.y, ra.z, ra.w};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int16_t *cp = mt + (G::NBY + c) * 64;
-                        const uint4 wa = *reinterpret_cast<const uint4 *>(cp + sx0 * 8);
-                        cA[c][0] = (float)lo16(wa.x); cA[c][1] = (float)hi16(wa.x); cA[c][2] = (float)lo16(wa.y); cA[c][3] = (float)hi16(wa.y);
-                        cA[c][4] = (float)lo16(wa.z); cA[c][5] = (float)hi16(wa.z); cA[c][6] = (float)lo16(wa.w); cA[c][7] = (float)hi16(wa.w);
+                        for (int i = 0; i < 8; ++i)
+                            cA[i] = f32x2{(float)((i & 1) ? hi16(bw[i >> 1]) : lo16(bw[i >> 1])), (float)((i & 1) ? hi16(rw[i >> 1]) : lo16(rw[i >> 1]))};
                         if constexpr (HS == 2) {
-                            const uint4 wb = *reinterpret_cast<const uint4 *>(cp + sx1 * 8);
-                            cB[c][0] = (float)lo16(wb.x); cB[c][1] = (float)hi16(wb.x); cB[c][2] = (float)lo16(wb.y); cB[c][3] = (float)hi16(wb.y);
-                            cB[c][4] = (float)lo16(wb.z); cB[c][5] = (float)hi16(wb.z); cB[c][6] = (float)lo16(wb.w); cB[c][7] = (float)hi16(wb.w);
+                            const uint4 bb = *reinterpret_cast<const uint4 *>(cbp + sx1 * 8), rb = *reinterpret_cast<const uint4 *>(crp + sx1 * 8);
+                            const uint32_t bw2[4] = {bb.x, bb.y, bb.z, bb.w}, rw2[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                cB[i] = f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))};
                         }
                     }
 #pragma unroll
@@ -399,43 +405,42 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
                         for (int i = 0; i < 8; ++i) {
                             const int y = by * 8 + i;
                             const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
-                            float Cbf, Crf;
+                            f32x2 C;
                             if constexpr (G::SUB) {
                                 // sum(n_i v_i)/15 is never within 1/30 of a half-integer and the fp32 evaluation is
                                 // within 0.012 of it for any int16 inputs, so rintf() returns the reference's value
                                 const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
                                 const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
                                 const float4 wq = s_wts[px * G::WTS_ROW + y];
-                                float sb = wq.x * cA[0][sy0], sr = wq.x * cA[1][sy0];
-                                sb = __builtin_fmaf(wq.y, cA[0][sy1], sb); sr = __builtin_fmaf(wq.y, cA[1][sy1], sr);
+                                f32x2 sv = cA[sy0] * wq.x;
+                                sv = __builtin_elementwise_fma(cA[sy1], f32x2{wq.y, wq.y}, sv);
                                 if constexpr (HS == 2) {
-                                    sb = __builtin_fmaf(wq.z, cB[0][sy0], sb); sr = __builtin_fmaf(wq.z, cB[1][sy0], sr);
-                                    sb = __builtin_fmaf(wq.w, cB[0][sy1], sb); sr = __builtin_fmaf(wq.w, cB[1][sy1], sr);
+                                    sv = __builtin_elementwise_fma(cB[sy0], f32x2{wq.z, wq.z}, sv);
+                                    sv = __builtin_elementwise_fma(cB[sy1], f32x2{wq.w, wq.w}, sv);
                                 }
-                                Cbf = __builtin_rintf(sb);
-                                Crf = __builtin_rintf(sr);
+                                C = f32x2{__builtin_rintf(sv.x), __builtin_rintf(sv.y)};
                             } else {
-                                Cbf = cA[0][y];
-                                Crf = cA[1][y];
+                                C = cA[y];
                             }
                             // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact: 1.402c = 701c/500 and
                             // 1.772c = 443c/250 have their first exact .5 at |c| = 250 resp. 125 and are otherwise >= 0.002
                             // away from one; N = 17207cb + 35707cr is an exact fp32 integer for |c| <= 255 and its
                             // remainder against 50000 is obtained exactly with one fma.
-                            const float cb = Cbf - 128.0f, cr = Crf - 128.0f;
-                            const float Rf = Yf + __builtin_rintf(cr * 1.402f);
-                            const float Bf = Yf + __builtin_rintf(cb * 1.772f);
-                            const float N = __builtin_fmaf(35707.0f, cr, 17207.0f * cb);
+                            const f32x2 c2 = C - 128.0f;                                   // (cb, cr)
+                            const f32x2 p2 = c2 * f32x2{1.772f, 1.402f};
+                            const f32x2 br2 = f32x2{__builtin_rintf(p2.x), __builtin_rintf(p2.y)} + Yf;   // (B, R)
+                            const f32x2 n2 = c2 * f32x2{17207.0f, 35707.0f};               // both products exact
+                            const float N = n2.x + n2.y;                                  // exact: |N| < 2^24
                             float q = __builtin_rintf(N * 2e-5f);
                             const float rem = __builtin_fmaf(-50000.0f, q, N);
                             q += (rem > 25000.0f ? 1.0f : 0.0f) - (rem < -25000.0f ? 1.0f : 0.0f);
                             const float Gf = Yf - q;
-                            slow |= (__builtin_fabsf(cb) > 255.0f) | (__builtin_fabsf(cr) >= 250.0f) |
-                                    (__builtin_fabsf(cb) == 125.0f) | (__builtin_fabsf(rem) == 25000.0f);
+                            slow |= (__builtin_fabsf(c2.x) > 255.0f) | (__builtin_fabsf(c2.y) >= 250.0f) |
+                                    (__builtin_fabsf(c2.x) == 125.0f) | (__builtin_fabsf(rem) == 25000.0f);
                             const int o0 = 3 * y, o1 = 3 * y + 1, o2 = 3 * y + 2;
-                            ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Rf, o0 & 3, ob[o0 >> 2]);
+                            ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.y, o0 & 3, ob[o0 >> 2]);
                             ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
-                            ob[o2 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Bf, o2 & 3, ob[o2 >> 2]);
+                            ob[o2 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.x, o2 & 3, ob[o2 >> 2]);
                         }
                     }
                 } else {
