@@ -136,12 +136,14 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * (64 * kBlkStride);
-    uint8_t *s_nat = smem + (size_t)n_huff * kLSize * 2 + 4 * 64 * kBlkStride * 4;
+    // block buffers: lpw lanes per wave are active (rounded up to even: the flush moves blocks in pairs)
+    const int lpw2 = (lpw + 1) & ~1;
+    uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * (lpw2 * kBlkStride);
+    uint8_t *s_nat = smem + (size_t)n_huff * kLSize * 2 + 4 * lpw2 * kBlkStride * 4;
 
     for (int i = tid; i < n_huff * kLSize / 8; i += 256)
         reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
-    for (int i = tid; i < 4 * 64 * kBlkStride; i += 256)
+    for (int i = tid; i < 4 * lpw2 * kBlkStride; i += 256)
         (reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2))[i] = 0;
     if (tid < 64) s_nat[tid] = c_nat_of_zz_l[tid];
     __syncthreads();
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int err = 0;
     const int zz_a = c_zz_of_nat_l[2 * (lane & 31)], zz_b = c_zz_of_nat_l[2 * (lane & 31) + 1];
-    uint32_t *myblk = s_blk + lane * kBlkStride;
+    uint32_t *myblk = s_blk + (lane < lpw2 ? lane : 0) * kBlkStride;
     int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
 
     for (int m = 0; m < max_mcu; ++m) {
@@ -293,15 +295,17 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
                                 int16_t *coef, int32_t *status) {
     if (n_segs == 0) return hipSuccess;
     static int lpw = 0;
-    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64 || (lpw & 1))) lpw = -1; }
+    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
     int use = lpw;
-    if (use < 0) {   // about two wavefronts per SIMD (measured best on MI355X): 64, 32, 16 or 8 segments per wave
-        use = 64;
-        while (use > 8 && n_segs / use < 2048) use >>= 1;
+    if (use < 0) {
+        // measured on MI355X: the kernel is VALU-issue bound with every instruction costing the same
+        // whatever the number of active lanes, and latency-bound below ~2 waves per SIMD; ~2.7 waves per SIMD is best
+        const int64_t want = (n_segs + 2815) / 2816;
+        use = (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
     }
     const int lpw_run = use;
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
-    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * 64 * kBlkStride * 4 + 64;
+    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * ((lpw_run + 1) & ~1) * kBlkStride * 4 + 64;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
