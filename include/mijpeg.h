@@ -68,6 +68,8 @@ extern "C" {
 #define MJ_FLAG_KEEP_PLANES  2u   /* also produce the cropped int16 YCbCr planes (:1373 seam)               */
 #define MJ_FLAG_KEEP_IDCT    4u   /* also produce the per-block IDCT output (:872 return value)             */
 #define MJ_FLAG_EXACT_ONLY   8u   /* stage 2: use only the exact-order fp64 summation (no fast path)        */
+#define MJ_FLAG_SPEC_REFINE 16u   /* progressive AC refinement per ITU-T T.81 G.1.2.3 (move negative values away
+                                     from zero) instead of the reference's `|=` on two's complement (:1114)  */
 
 typedef struct mj_context mj_context;
 typedef struct mj_plan mj_plan;

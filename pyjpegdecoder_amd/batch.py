@@ -239,11 +239,12 @@ class BatchDecoder:
     >>> images = dec.decode([open(p, 'rb').read() for p in paths])      # list of uint8 (W,H,3) arrays
     """
 
-    def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False):
+    def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False):
         self.ctx = B.Context(device)
         self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
         # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
-        self.base_flags = B.MJ_FLAG_EXACT_ONLY if exact_only else 0
+        # spec_refine: progressive AC refinement as ITU-T T.81 defines it instead of the reference's behaviour (SURVEY F8)
+        self.base_flags = (B.MJ_FLAG_EXACT_ONLY if exact_only else 0) | (B.MJ_FLAG_SPEC_REFINE if spec_refine else 0)
 
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
         prep = prepare_batch(files, self.layout, flags | self.base_flags)

@@ -505,7 +505,7 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
             const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
             MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images,
-                                                    p->d_huff, p->d_coef, p->d_status));
+                                                    p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0));
         }
         return MJ_OK;
     }

@@ -81,7 +81,7 @@ struct DevProgSeg {
 namespace mj {
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status);
+                                   int16_t *coef, int32_t *status, int spec_refine);
 }
 
 // stage-1 / stage-2 launchers (defined in huffman.hip / reconstruct.hip)

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t take32(BitReader &br, int n) {
 }
 
 // one correction bit for every coefficient of `queue` (a mask over zig-zag positions), in ascending order
-__device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int al, int lane, int &coef, bool &dirty) {
+__device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int al, int lane, int &coef, bool &dirty, bool spec) {
     while (queue) {
         br.refill();
         const int n = min(16, __builtin_popcountll(queue));
@@ -55,7 +55,8 @@ __device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int 
         if ((part >> lane) & 1) {
             const int rank = __builtin_popcountll(part & (((uint64_t)1 << lane) - 1));
             const int bit = (bits >> (n - 1 - rank)) & 1;
-            coef = (int)(int16_t)(coef | (int)(int16_t)(bit << al));
+            if (spec) coef = (int)(int16_t)(coef + (coef < 0 ? -(bit << al) : (bit << al)));   // T.81 G.1.2.3
+            else coef = (int)(int16_t)(coef | (int)(int16_t)(bit << al));                      // the reference (:1114)
         }
         dirty = true;
     }
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                                                           const DevProgScan *__restrict__ scans,
                                                           const DevImage *__restrict__ images,
                                                           const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
-                                                          int32_t *__restrict__ status) {
+                                                          int32_t *__restrict__ status, int spec_refine) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][3 tables][kLutSize]
+    const bool spec = spec_refine != 0;
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int seg_id = blockIdx.x * 4 + wave;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 bool dirty = false;
                 if (eobrun > 0) {                   // inside an EOB run: every non-zero coefficient of the band gets a bit
                     const uint64_t nz = __ballot(cf != 0);
-                    refine_queue(br, nz & band, al, lane, cf, dirty);
+                    refine_queue(br, nz & band, al, lane, cf, dirty, spec);
                     --eobrun;
                 } else {
                     int k = ss;
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                             dirty = true;
                             ++k;
                         }
-                        refine_queue(br, queue, al, lane, cf, dirty);           // (:1231-1232)
+                        refine_queue(br, queue, al, lane, cf, dirty, spec);     // (:1231-1232)
                     }
                     if (!err && eobrun > 0) {       // rest of this band, then the run continues in the next blocks
                         const uint64_t nz = __ballot(cf != 0);
-                        refine_queue(br, nz & bits_range(k, se + 1), al, lane, cf, dirty);
+                        refine_queue(br, nz & bits_range(k, se + 1), al, lane, cf, dirty, spec);
                         --eobrun;
                     }
                 }
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
 
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status) {
+                                   int16_t *coef, int32_t *status, int spec_refine) {
     if (n_segs == 0) return hipSuccess;
     const int blocks = (n_segs + 3) / 4;
     const size_t lds = (size_t)4 * 3 * kLutSize * sizeof(uint16_t);
     hipLaunchKernelGGL(k_progressive_scan, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, scans,
-                       images, huff, coef, status);
+                       images, huff, coef, status, spec_refine);
     return hipGetLastError();
 }
 

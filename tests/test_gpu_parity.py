@@ -376,3 +376,31 @@ def test_progressive_larger_random_against_oracle(dec):
         (img,), (seam,) = dec.decode([raw], return_seams=True)
         assert np.array_equal(seam["coef"], ref["coef"])
         assert np.array_equal(img, ref["rgb"])
+
+
+def test_progressive_spec_refinement_switch(dec):
+    """the reference refines negative AC coefficients with `|=` on the two's complement, which is not what
+    T.81 says.  Default = the reference's behaviour (pinned above); with spec_refine=True the progressive decode of a
+    file must give exactly the coefficients of the same pixels coded baseline (libjpeg quantises both identically)."""
+    import io
+    from PIL import Image
+    from pyjpegdecoder_amd import BatchDecoder
+    from tools import synth
+    rgb = synth.synth_rgb(77, 96, 80, 30.0)
+    files = {}
+    for prog in (False, True):
+        b = io.BytesIO()
+        Image.fromarray(rgb).save(b, "JPEG", quality=88, subsampling=2, progressive=prog)
+        files[prog] = b.getvalue()
+    (_,), (base,) = dec.decode([files[False]], return_seams=True)
+    (_,), (ref_like,) = dec.decode([files[True]], return_seams=True)
+    d2 = BatchDecoder(device=0, spec_refine=True)
+    try:
+        (img_spec,), (spec,) = d2.decode([files[True]], return_seams=True)
+        (img_base,) = d2.decode([files[False]])
+    finally:
+        d2.close()
+    assert np.array_equal(spec["coef"], base["coef"]), "spec-correct refinement reproduces the baseline coefficients"
+    assert np.array_equal(img_spec, img_base)
+    diff = ref_like["coef"] != base["coef"]
+    assert diff.any() and (base["coef"][diff] < 0).all(), "the reference's behaviour differs only on negative coefficients"
