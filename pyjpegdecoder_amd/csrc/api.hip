@@ -42,7 +42,7 @@ struct mj_plan {
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     int n_huff = 0;
     bool use_lanes = false;
-    // progressive batches: scans grouped by ordinal (k-th scan of every image), one launch each
+    // progressive batches: scans grouped by dependency level, one launch per level
     bool progressive = false;
     mj::DevProgScan *d_pscans = nullptr;
     mj::DevProgSeg *d_psegs = nullptr;
@@ -53,6 +53,9 @@ struct mj_plan {
     int64_t total_tiles = 0;
     int32_t tiles_per_image = 0;
     int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
+    uint8_t *d_xmajor_tmp = nullptr;    // row-major plans: the fast kernel's x-major image before the transpose pass
+    int64_t *d_tr_prefix = nullptr;     // 32x32-pixel transpose tiles per image (prefix sums)
+    int64_t tr_tiles = 0;
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
     int16_t *d_planes = nullptr;
@@ -164,6 +167,90 @@ __global__ void k_permute_blocks(const int16_t *__restrict__ src, int16_t *__res
         else dst[b * 64 + lane] = src[b * 64 + nat[lane]];
     }
 }
+// x-major (W,H,C) -> row-major (H,W,C) per image, TT x TT pixel tiles through LDS (both sides move 3*TT-byte
+// runs: whole 128-byte lines).  Used for MJ_LAYOUT_ROWMAJOR: the fast stage-2 kernel produces the reference's x-major
+// image, this pass turns it (one extra read + write of the output; a native row-major fast kernel is future work).
+constexpr int kTT = 128;
+template <int NC>
+__global__ __launch_bounds__(256) void k_transpose_pixels(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                          const DevImage *__restrict__ images, const int64_t *__restrict__ tprefix,
+                                                          int n_images) {
+    constexpr int RB = kTT * NC;                                  // bytes of one tile row
+    constexpr int RS = RB + 4;                                    // LDS row stride (dword aligned, odd number of dwords)
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [x][y*NC + c]
+    const int64_t g = blockIdx.x;
+    int lo = 0, hi = n_images;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tprefix[mid] <= g) lo = mid; else hi = mid; }
+    const DevImage *im = images + lo;
+    const int W = im->width, H = im->height;
+    const int tiles_y = (H + kTT - 1) / kTT;
+    const int t = (int)(g - tprefix[lo]);
+    const int x0 = (t / tiles_y) * kTT, y0 = (t % tiles_y) * kTT;
+    const int nx = min(kTT, W - x0), ny = min(kTT, H - y0);
+    const uint8_t *s = src + im->rgb_off;
+    uint8_t *d = dst + im->rgb_off;
+    const bool aligned = ((((int64_t)H * NC) | ((int64_t)W * NC) | im->rgb_off | ((int64_t)y0 * NC) | ((int64_t)x0 * NC)) & 3) == 0 &&
+                         (((uintptr_t)src | (uintptr_t)dst) & 3) == 0;
+    const bool a16 = ((((int64_t)H * NC) | ((int64_t)W * NC) | im->rgb_off) & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (aligned && a16 && nx == kTT && ny == kTT) {                      // whole tile: compile-time strides, 16-byte global accesses
+        constexpr int RQ = RB / 16;                               // 16-byte pieces per row
+        for (int i = threadIdx.x; i < kTT * RQ; i += 256) {       // read: contiguous along y
+            const int x = i / RQ, q = i - x * RQ;
+            const uint4 v = *reinterpret_cast<const uint4 *>(s + ((int64_t)(x0 + x) * H + y0) * NC + 16 * q);
+            uint32_t *tp = reinterpret_cast<uint32_t *>(tile + x * RS + 16 * q);
+            tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kTT * RQ; i += 256) {       // write: contiguous along x
+            const int y = i / RQ, q = i - y * RQ;
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 16 * q + 4 * j + k, x = r / NC, c = r - x * NC;
+                    v |= (uint32_t)tile[x * RS + y * NC + c] << (8 * k);
+                }
+                o[j] = v;
+            }
+            *reinterpret_cast<uint4 *>(d + ((int64_t)(y0 + y) * W + x0) * NC + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
+    if (aligned && ((ny * NC) & 3) == 0 && ((nx * NC) & 3) == 0) {
+        const int rw = ny * NC / 4;                               // dwords per source row of the tile
+        for (int i = threadIdx.x; i < nx * rw; i += 256) {        // read: contiguous along y
+            const int x = i / rw, w = i - x * rw;
+            *reinterpret_cast<uint32_t *>(tile + x * RS + 4 * w) =
+                *reinterpret_cast<const uint32_t *>(s + ((int64_t)(x0 + x) * H + y0) * NC + 4 * w);
+        }
+        __syncthreads();
+        const int ww = nx * NC / 4;                               // dwords per destination row of the tile
+        for (int i = threadIdx.x; i < ny * ww; i += 256) {        // write: contiguous along x
+            const int y = i / ww, w = i - y * ww;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * w + k, x = r / NC, c = r - x * NC;
+                v |= (uint32_t)tile[x * RS + y * NC + c] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(d + ((int64_t)(y0 + y) * W + x0) * NC + 4 * w) = v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < nx * ny * NC; i += 256) {       // byte-wise fallback
+        const int x = i / (ny * NC), r = i - x * (ny * NC);
+        tile[x * RS + r] = s[((int64_t)(x0 + x) * H + y0) * NC + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nx * ny * NC; i += 256) {
+        const int y = i / (nx * NC), r = i - y * (nx * NC);
+        const int x = r / NC, c = r - x * NC;
+        d[((int64_t)(y0 + y) * W + x0) * NC + r] = tile[x * RS + y * NC + c];
+    }
+}
+
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural) {
     if (n_blocks == 0) return hipSuccess;
     int64_t want = (n_blocks + 3) / 4;
@@ -215,7 +302,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_xmajor_tmp, p->d_tr_prefix, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -339,7 +426,21 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             const mj_scan_desc &sd = b->scans[k];
             if (sd.image < 0 || sd.image >= b->n_images) return fail(ctx, MJ_ERR_INVALID, "scan %d: image index out of range", k);
             if (k > 0 && sd.image < b->scans[k - 1].image) return fail(ctx, MJ_ERR_INVALID, "scans must be grouped by image, in file order");
-            ordinal_of[k] = seen[sd.image]++;
+            // Dependency level instead of file ordinal: a scan must wait only for earlier scans of the same image that
+            // touch the same coefficients (same component, overlapping spectral band).  libjpeg's 10-scan script has
+            // 4 levels: DC | the four first AC scans | the refinements of what is complete | the last luma refinement.
+            {
+                int lvl = 0;
+                for (int j = k - 1; j >= 0 && b->scans[j].image == sd.image; --j) {
+                    const mj_scan_desc &pj = b->scans[j];
+                    bool comp_overlap = false;
+                    for (int a1 = 0; a1 < sd.n_comp && a1 < 3; ++a1)
+                        for (int a2 = 0; a2 < pj.n_comp && a2 < 3; ++a2) comp_overlap |= sd.comp[a1] == pj.comp[a2];
+                    if (comp_overlap && sd.ss <= pj.se && pj.ss <= sd.se) lvl = std::max(lvl, ordinal_of[j] + 1);
+                }
+                ordinal_of[k] = lvl;
+            }
+            (void)seen;
             n_ord = std::max(n_ord, ordinal_of[k] + 1);
             const mj_image_desc &d = b->images[sd.image];
             const mj::DevImage &im = imgs[sd.image];
@@ -425,6 +526,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         p->total_tiles = tp[b->n_images];
         p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
         if ((rc = upload(ctx, &p->d_tile_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
+        std::vector<int64_t> tr(b->n_images + 1, 0);
+        for (int i = 0; i < b->n_images; ++i)
+            tr[i + 1] = tr[i] + (int64_t)((imgs[i].width + mj::kTT - 1) / mj::kTT) * ((imgs[i].height + mj::kTT - 1) / mj::kTT);
+        p->tr_tiles = tr[b->n_images];
+        if ((rc = upload(ctx, &p->d_tr_prefix, tr.data(), tr.size())) != MJ_OK) return rc;
     }
     if (have_entropy) {
         std::vector<mj::DevHuff> hh(b->n_huff);
@@ -534,11 +640,26 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
     a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
-    if (p->layout == MJ_LAYOUT_XMAJOR && !a.exact_only)
+    if (a.exact_only) {
+        MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
+    } else if (p->layout == MJ_LAYOUT_XMAJOR) {
         MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,
                                                p->tiles_per_image));
-    else
-        MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
+    } else {
+        // row-major: fast kernel into an x-major scratch image, then a tiled transpose into the caller's buffer
+        if (!p->d_xmajor_tmp) MJ_HIP(ctx, hipMalloc((void **)&p->d_xmajor_tmp, (size_t)p->info.rgb_bytes + 16));
+        a.rgb = p->d_xmajor_tmp;
+        a.layout = MJ_LAYOUT_XMAJOR;
+        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,
+                                               p->tiles_per_image));
+        if (p->ncomp == 3)
+            hipLaunchKernelGGL((mj::k_transpose_pixels<3>), dim3((unsigned)p->tr_tiles), dim3(256), mj::kTT * (mj::kTT * 3 + 4), s, p->d_xmajor_tmp,
+                               rgb_device, p->d_images, p->d_tr_prefix, p->n_images);
+        else
+            hipLaunchKernelGGL((mj::k_transpose_pixels<1>), dim3((unsigned)p->tr_tiles), dim3(256), mj::kTT * (mj::kTT * 1 + 4), s, p->d_xmajor_tmp,
+                               rgb_device, p->d_images, p->d_tr_prefix, p->n_images);
+        MJ_HIP(ctx, hipGetLastError());
+    }
     return MJ_OK;
 }
 

@@ -4,7 +4,8 @@
 // that the reference keeps inside image_array between scans (:1029, :1225) is the same HBM array the baseline
 // path uses — int16 blocks [v][u] in interleaved MCU order — so that after the last scan the ordinary stage-2
 // kernel performs the reference's final pass (:1306-1362).  Scans of one image depend on each other, hence one
-// launch per scan ordinal in stream order; within a scan restart segments are independent.
+// launch per dependency level (scans that touch disjoint coefficients share a launch) in stream order; within a
+// scan restart segments are independent.
 //
 // The walk is wave-uniform (same bit reader as huffman.hip); the lanes hold the 64 zig-zag coefficients of the
 // block being refined, which turns the reference's element-by-element queues into mask arithmetic:
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                         --eobrun;
                     }
                 }
-                if (dirty) p[nat] = (int16_t)cf;
+                // only this scan's band is written back: other scans of the same dependency level may be updating
+                // other coefficients of the block at the same time
+                if (dirty && lane >= ss && lane <= se) p[nat] = (int16_t)cf;
             }
         }
     }
