@@ -111,7 +111,8 @@ struct ReconArgs {
     int16_t *idct_out;           // optional
     int32_t layout;
     int32_t exact_only;
-    int32_t debug;               // profiling ablations (MJ_DEBUG_STAGE2 env): 1 = no phase A, 2 = no phase B, 3 = no stores
+    int32_t debug;               // diagnostic builds only (make DIAG=1, MJ_DEBUG_STAGE2 env): 1 = no IDCT rounds, 2 = no
+                                 // pixel phase, 3 = no stores, 4 = in-kernel clock probe
     // homogeneous-batch shortcut: all images share one geometry
     int32_t uniform_geometry;
     int32_t mcus_per_image;

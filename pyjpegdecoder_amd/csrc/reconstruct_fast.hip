@@ -179,7 +179,7 @@ __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qb
 }  // namespace
 
 template <int HS, int VS, int NC, bool SEAMS>
-__global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
+__global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
                                                           int64_t total_tiles, int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -253,22 +253,17 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
         }
     };
 
+#ifdef MJ_DIAGNOSTIC   // clock probe / phase ablations: separate diagnostic build only (make DIAG=1), never in the product
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t n_tiles = (uint32_t)total_tiles, stride_tiles = (uint32_t)n_waves;
     uint32_t tg = blockIdx.x * 4 + wave;
     if (tg >= n_tiles) return;
     Strip cur = strip_of(tg);
     const DevImage *qt_owner = nullptr;
-    uint4 cw[G::ROUNDS], cwn[G::ROUNDS];
+    uint4 cw[G::ROUNDS];
     fetch(cur, cw);
     for (; tg < n_tiles; tg += stride_tiles) {
-        // the next strip's coefficients are requested now and consumed one iteration later (HBM latency hidden)
-        const bool has_next = tg + stride_tiles < n_tiles;
-        Strip nxt = cur;
-        if (has_next) {
-            nxt = strip_of(tg + stride_tiles);
-            fetch(nxt, cwn);
-        }
         const DevImage *im = cur.im;
         const int W = im->width, H = im->height;
         const int mch = im->mcu_count_h;
@@ -289,7 +284,9 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
         uint32_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
+#ifdef MJ_DIAGNOSTIC
             if (a.debug == 1) break;
+#endif
             const int bt = r * 8 + grp;
             const int k = bt / G::NB, b = bt - k * G::NB;
             const int qc = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
@@ -357,8 +354,21 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
                         (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr);
         }
 
+        // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
+        // they are consumed one iteration later, so HBM latency hides behind the pixel phase
+        const bool has_next = tg + stride_tiles < n_tiles;
+        Strip nxt = cur;
+        if (has_next) {
+            nxt = strip_of(tg + stride_tiles);
+            fetch(nxt, cw);
+        }
+
         // ================= phase B: pixels ==================
+#ifdef MJ_DIAGNOSTIC
         if (pk < n_valid && a.debug != 2) {
+#else
+        if (pk < n_valid) {
+#endif
             const int gx = mcu_x * G::MW + px, gy0 = (y_first + pk) * G::MH;
             const int16_t *mt = s_strip + pk * G::MCU_STRIDE;
             const int nrows = min(G::MH, H - gy0);
@@ -380,27 +390,37 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
                     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
                     // (Cb, Cr) pairs: the two chroma planes ride in the two halves of packed-fp32 registers, so one
                     // v_pk_* instruction serves both components
-                    f32x2 cA[8], cB[8];
-                    {
-                        const int16_t *cbp = mt + G::NBY * 64, *crp = cbp + 64;
-                        const uint4 ba = *reinterpret_cast<const uint4 *>(cbp + sx0 * 8), ra = *reinterpret_cast<const uint4 *>(crp + sx0 * 8);
-                        const uint32_t bw[4] = {ba.x, ba.y, ba.z, ba.w}, rw[4] = {ra.x, ra.y, ra.z, ra.w};
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            cA[i] = f32x2{(float)((i & 1) ? hi16(bw[i >> 1]) : lo16(bw[i >> 1])), (float)((i & 1) ? hi16(rw[i >> 1]) : lo16(rw[i >> 1]))};
-                        if constexpr (HS == 2) {
-                            const uint4 bb = *reinterpret_cast<const uint4 *>(cbp + sx1 * 8), rb = *reinterpret_cast<const uint4 *>(crp + sx1 * 8);
-                            const uint32_t bw2[4] = {bb.x, bb.y, bb.z, bb.w}, rw2[4] = {rb.x, rb.y, rb.z, rb.w};
-#pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                cB[i] = f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))};
-                        }
+                    // the packed int16 rows stay in 8 (16 with a second source row) registers; each half of the column
+                    // converts only the source samples it touches, which keeps the live set under the 128-VGPR budget
+                    const int16_t *cbp = mt + G::NBY * 64, *crp = cbp + 64;
+                    const uint4 ba = *reinterpret_cast<const uint4 *>(cbp + sx0 * 8), ra = *reinterpret_cast<const uint4 *>(crp + sx0 * 8);
+                    const uint32_t bw[4] = {ba.x, ba.y, ba.z, ba.w}, rw[4] = {ra.x, ra.y, ra.z, ra.w};
+                    uint32_t bw2[4] = {0, 0, 0, 0}, rw2[4] = {0, 0, 0, 0};
+                    if constexpr (HS == 2) {
+                        const uint4 bb = *reinterpret_cast<const uint4 *>(cbp + sx1 * 8), rb = *reinterpret_cast<const uint4 *>(crp + sx1 * 8);
+                        bw2[0] = bb.x; bw2[1] = bb.y; bw2[2] = bb.z; bw2[3] = bb.w;
+                        rw2[0] = rb.x; rw2[1] = rb.y; rw2[2] = rb.z; rw2[3] = rb.w;
                     }
+                    auto pairA = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw[i >> 1]) : lo16(bw[i >> 1])), (float)((i & 1) ? hi16(rw[i >> 1]) : lo16(rw[i >> 1]))}; };
+                    auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
                         const int yb = by * HS + (px >> 3);
                         const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
                         const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
+                        // source samples this half of the column interpolates between
+                        constexpr int S_LO = (G::SUB && VS == 2) ? (7 * (8 * 0)) / 15 : 0;   // by = 0 starts at 0
+                        const int s_lo = (G::SUB && VS == 2) ? (7 * (by * 8)) / 15 : (G::SUB ? 0 : 0);
+                        (void)S_LO;
+                        f32x2 cA[8], cB[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const bool used = !G::SUB || VS == 1 || (i >= s_lo && i <= ((7 * (by * 8 + 7)) / 15) + 1);
+                            if (used) {
+                                cA[i] = pairA(i);
+                                if constexpr (HS == 2) cB[i] = pairB(i);
+                            }
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int y = by * 8 + i;
@@ -452,11 +472,14 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
                         ob[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Yf, i & 3, ob[i >> 2]);
                     }
                 }
+#ifdef MJ_DIAGNOSTIC
                 if (a.debug == 3) { uint32_t acc = 0;
 #pragma unroll
                     for (int i = 0; i < (NBYTES + 3) / 4; ++i) acc ^= ob[i];
                     if (acc == 0x12345678u && slow) dst[0] = 1; }
-                else if (gx < W) {
+                else
+#endif
+                if (gx < W) {
                     if (slow || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
                         pixel_run_exact<HS, VS, NC>(mt, px, dst, nrows, nullptr);
                     } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
@@ -476,14 +499,14 @@ __global__ __launch_bounds__(256) void k_reconstruct_fast(ReconArgs a, const int
         }
         // the strip is private to this wave and LDS operations of one wave complete in order: no barrier
         cur = nxt;
-#pragma unroll
-        for (int r = 0; r < G::ROUNDS; ++r) cw[r] = cwn[r];
     }
+#ifdef MJ_DIAGNOSTIC
     if (a.debug == 4 && blockIdx.x == 7 && tid == 0) {   // diagnostic only: shader clock vs 100 MHz wall clock
         uint64_t *o = reinterpret_cast<uint64_t *>(a.rgb);
         o[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
         o[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
     }
+#endif
 }
 
 template <int HS, int VS, int NC>
