@@ -29,6 +29,8 @@ struct mj_plan {
     int hmax = 1, vmax = 1, ncomp = 3;
     int lut_slots = 1;
     bool uniform = false;
+    // row-major plans run the fast stage 2 on the transposed problem: blocks and tables are then stored [u][v]
+    bool transposed = false;
     int32_t mcus_per_image = 0;
     mj_plan_info info{};
     std::vector<mj::DevImage> h_images;
@@ -53,9 +55,6 @@ struct mj_plan {
     int64_t total_tiles = 0;
     int32_t tiles_per_image = 0;
     int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
-    uint8_t *d_xmajor_tmp = nullptr;    // row-major plans: the fast kernel's x-major image before the transpose pass
-    int64_t *d_tr_prefix = nullptr;     // 32x32-pixel transpose tiles per image (prefix sums)
-    int64_t tr_tiles = 0;
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
     int16_t *d_planes = nullptr;
@@ -158,104 +157,21 @@ __constant__ uint8_t c_nat[64] = {
    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 __global__ void k_permute_blocks(const int16_t *__restrict__ src, int16_t *__restrict__ dst, int64_t n_blocks,
-                                 int to_natural) {
-    const uint8_t *nat = c_nat;
+                                 int to_natural, int tr) {
     const int lane = threadIdx.x & 63;
+    const int n0 = c_nat[lane], pos = tr ? ((n0 & 7) << 3 | n0 >> 3) : n0;   // store position of zig-zag index `lane`
     for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < n_blocks;
          b += (int64_t)gridDim.x * (blockDim.x >> 6)) {
-        if (to_natural) dst[b * 64 + nat[lane]] = src[b * 64 + lane];   // lane = zig-zag index
-        else dst[b * 64 + lane] = src[b * 64 + nat[lane]];
+        if (to_natural) dst[b * 64 + pos] = src[b * 64 + lane];
+        else dst[b * 64 + lane] = src[b * 64 + pos];
     }
 }
-// x-major (W,H,C) -> row-major (H,W,C) per image, TT x TT pixel tiles through LDS (both sides move 3*TT-byte
-// runs: whole 128-byte lines).  Used for MJ_LAYOUT_ROWMAJOR: the fast stage-2 kernel produces the reference's x-major
-// image, this pass turns it (one extra read + write of the output; a native row-major fast kernel is future work).
-constexpr int kTT = 128;
-template <int NC>
-__global__ __launch_bounds__(256) void k_transpose_pixels(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                          const DevImage *__restrict__ images, const int64_t *__restrict__ tprefix,
-                                                          int n_images) {
-    constexpr int RB = kTT * NC;                                  // bytes of one tile row
-    constexpr int RS = RB + 4;                                    // LDS row stride (dword aligned, odd number of dwords)
-    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [x][y*NC + c]
-    const int64_t g = blockIdx.x;
-    int lo = 0, hi = n_images;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (tprefix[mid] <= g) lo = mid; else hi = mid; }
-    const DevImage *im = images + lo;
-    const int W = im->width, H = im->height;
-    const int tiles_y = (H + kTT - 1) / kTT;
-    const int t = (int)(g - tprefix[lo]);
-    const int x0 = (t / tiles_y) * kTT, y0 = (t % tiles_y) * kTT;
-    const int nx = min(kTT, W - x0), ny = min(kTT, H - y0);
-    const uint8_t *s = src + im->rgb_off;
-    uint8_t *d = dst + im->rgb_off;
-    const bool aligned = ((((int64_t)H * NC) | ((int64_t)W * NC) | im->rgb_off | ((int64_t)y0 * NC) | ((int64_t)x0 * NC)) & 3) == 0 &&
-                         (((uintptr_t)src | (uintptr_t)dst) & 3) == 0;
-    const bool a16 = ((((int64_t)H * NC) | ((int64_t)W * NC) | im->rgb_off) & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
-    if (aligned && a16 && nx == kTT && ny == kTT) {                      // whole tile: compile-time strides, 16-byte global accesses
-        constexpr int RQ = RB / 16;                               // 16-byte pieces per row
-        for (int i = threadIdx.x; i < kTT * RQ; i += 256) {       // read: contiguous along y
-            const int x = i / RQ, q = i - x * RQ;
-            const uint4 v = *reinterpret_cast<const uint4 *>(s + ((int64_t)(x0 + x) * H + y0) * NC + 16 * q);
-            uint32_t *tp = reinterpret_cast<uint32_t *>(tile + x * RS + 16 * q);
-            tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < kTT * RQ; i += 256) {       // write: contiguous along x
-            const int y = i / RQ, q = i - y * RQ;
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t v = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = 16 * q + 4 * j + k, x = r / NC, c = r - x * NC;
-                    v |= (uint32_t)tile[x * RS + y * NC + c] << (8 * k);
-                }
-                o[j] = v;
-            }
-            *reinterpret_cast<uint4 *>(d + ((int64_t)(y0 + y) * W + x0) * NC + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        return;
-    }
-    if (aligned && ((ny * NC) & 3) == 0 && ((nx * NC) & 3) == 0) {
-        const int rw = ny * NC / 4;                               // dwords per source row of the tile
-        for (int i = threadIdx.x; i < nx * rw; i += 256) {        // read: contiguous along y
-            const int x = i / rw, w = i - x * rw;
-            *reinterpret_cast<uint32_t *>(tile + x * RS + 4 * w) =
-                *reinterpret_cast<const uint32_t *>(s + ((int64_t)(x0 + x) * H + y0) * NC + 4 * w);
-        }
-        __syncthreads();
-        const int ww = nx * NC / 4;                               // dwords per destination row of the tile
-        for (int i = threadIdx.x; i < ny * ww; i += 256) {        // write: contiguous along x
-            const int y = i / ww, w = i - y * ww;
-            uint32_t v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = 4 * w + k, x = r / NC, c = r - x * NC;
-                v |= (uint32_t)tile[x * RS + y * NC + c] << (8 * k);
-            }
-            *reinterpret_cast<uint32_t *>(d + ((int64_t)(y0 + y) * W + x0) * NC + 4 * w) = v;
-        }
-        return;
-    }
-    for (int i = threadIdx.x; i < nx * ny * NC; i += 256) {       // byte-wise fallback
-        const int x = i / (ny * NC), r = i - x * (ny * NC);
-        tile[x * RS + r] = s[((int64_t)(x0 + x) * H + y0) * NC + r];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nx * ny * NC; i += 256) {
-        const int y = i / (nx * NC), r = i - y * (nx * NC);
-        const int x = r / NC, c = r - x * NC;
-        d[((int64_t)(y0 + y) * W + x0) * NC + r] = tile[x * RS + y * NC + c];
-    }
-}
-
-hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural) {
+hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
+                                 int transposed) {
     if (n_blocks == 0) return hipSuccess;
     int64_t want = (n_blocks + 3) / 4;
     unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(k_permute_blocks, dim3(blocks), dim3(256), 0, stream, src, dst, n_blocks, to_natural);
+    hipLaunchKernelGGL(k_permute_blocks, dim3(blocks), dim3(256), 0, stream, src, dst, n_blocks, to_natural, transposed);
     return hipGetLastError();
 }
 }  // namespace mj
@@ -302,7 +218,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_xmajor_tmp, p->d_tr_prefix, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -324,6 +240,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->n_images = b->n_images;
     p->layout = b->layout;
     p->flags = b->flags;
+    p->transposed = b->layout == MJ_LAYOUT_ROWMAJOR && !(b->flags & MJ_FLAG_EXACT_ONLY);
     struct Guard { mj_plan *p; ~Guard() { if (p) mj_plan_destroy(p); } } guard{p};
 
     const bool have_entropy = b->blob_mem != MJ_MEM_NONE && b->blob != nullptr;
@@ -516,21 +433,22 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     {
         std::vector<uint16_t> qn((size_t)b->n_qt * 64);
         for (int t = 0; t < b->n_qt; ++t)
-            for (int z = 0; z < 64; ++z) qn[(size_t)t * 64 + kNatOfZz[z]] = b->qt[(size_t)t * 64 + z];
+            for (int z = 0; z < 64; ++z) {
+                const int n = kNatOfZz[z];
+                qn[(size_t)t * 64 + (p->transposed ? ((n & 7) << 3 | n >> 3) : n)] = b->qt[(size_t)t * 64 + z];
+            }
         if ((rc = upload(ctx, &p->d_qt, qn.data(), qn.size())) != MJ_OK) return rc;
-        const int tm = mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp);
+        const int tm = mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp, p->transposed);
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
-            tp[i + 1] = tp[i] + (int64_t)imgs[i].mcu_count_h * ((imgs[i].mcu_count_v + tm - 1) / tm);   // column strips
+            // strips run down the MCU columns of the image the kernel sees (the transposed one for row-major plans)
+            const int cols = p->transposed ? imgs[i].mcu_count_v : imgs[i].mcu_count_h;
+            const int rows = p->transposed ? imgs[i].mcu_count_h : imgs[i].mcu_count_v;
+            tp[i + 1] = tp[i] + (int64_t)cols * ((rows + tm - 1) / tm);
         }
         p->total_tiles = tp[b->n_images];
         p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
         if ((rc = upload(ctx, &p->d_tile_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
-        std::vector<int64_t> tr(b->n_images + 1, 0);
-        for (int i = 0; i < b->n_images; ++i)
-            tr[i + 1] = tr[i] + (int64_t)((imgs[i].width + mj::kTT - 1) / mj::kTT) * ((imgs[i].height + mj::kTT - 1) / mj::kTT);
-        p->tr_tiles = tr[b->n_images];
-        if ((rc = upload(ctx, &p->d_tr_prefix, tr.data(), tr.size())) != MJ_OK) return rc;
     }
     if (have_entropy) {
         std::vector<mj::DevHuff> hh(b->n_huff);
@@ -611,16 +529,17 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
             const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
             MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images,
-                                                    p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0));
+                                                    p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0,
+                                                    p->transposed ? 1 : 0));
         }
         return MJ_OK;
     }
     if (p->use_lanes)
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
-                                             p->n_huff, p->d_coef, p->d_status));
+                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0));
     else
         MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
-                                       p->d_status, p->lut_slots));
+                                       p->d_status, p->lut_slots, p->transposed ? 1 : 0));
     return MJ_OK;
 }
 
@@ -642,23 +561,10 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
     if (a.exact_only) {
         MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
-    } else if (p->layout == MJ_LAYOUT_XMAJOR) {
-        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,
-                                               p->tiles_per_image));
     } else {
-        // row-major: fast kernel into an x-major scratch image, then a tiled transpose into the caller's buffer
-        if (!p->d_xmajor_tmp) MJ_HIP(ctx, hipMalloc((void **)&p->d_xmajor_tmp, (size_t)p->info.rgb_bytes + 16));
-        a.rgb = p->d_xmajor_tmp;
-        a.layout = MJ_LAYOUT_XMAJOR;
-        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->d_tile_prefix, p->total_tiles,
-                                               p->tiles_per_image));
-        if (p->ncomp == 3)
-            hipLaunchKernelGGL((mj::k_transpose_pixels<3>), dim3((unsigned)p->tr_tiles), dim3(256), mj::kTT * (mj::kTT * 3 + 4), s, p->d_xmajor_tmp,
-                               rgb_device, p->d_images, p->d_tr_prefix, p->n_images);
-        else
-            hipLaunchKernelGGL((mj::k_transpose_pixels<1>), dim3((unsigned)p->tr_tiles), dim3(256), mj::kTT * (mj::kTT * 1 + 4), s, p->d_xmajor_tmp,
-                               rgb_device, p->d_images, p->d_tr_prefix, p->n_images);
-        MJ_HIP(ctx, hipGetLastError());
+        // row-major plans: the same kernel on the transposed problem, whose x-major output IS the row-major image
+        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->transposed, p->d_tile_prefix,
+                                               p->total_tiles, p->tiles_per_image));
     }
     return MJ_OK;
 }
@@ -695,7 +601,7 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
     }
     if (coef_host) {   // the :869 seam is in zig-zag order; the device keeps blocks in natural order
         if (!p->d_tmp_coef) MJ_HIP(ctx, hipMalloc((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
-        MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, p->d_coef, p->d_tmp_coef, p->info.total_blocks, 0));
+        MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, p->d_coef, p->d_tmp_coef, p->info.total_blocks, 0, p->transposed ? 1 : 0));
         MJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         MJ_HIP(ctx, hipMemcpy(coef_host, p->d_tmp_coef, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
     }
@@ -721,7 +627,7 @@ int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
         src = p->d_tmp_coef;
     }
     MJ_HIP(ctx, hipDeviceSynchronize());
-    MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, src, p->d_coef, p->info.total_blocks, 1));   // zig-zag -> natural
+    MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, src, p->d_coef, p->info.total_blocks, 1, p->transposed ? 1 : 0));   // zig-zag -> store order
     MJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MJ_OK;
 }

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
                                                  const DevSegment *__restrict__ segs, int64_t n_segs,
                                                  const DevImage *__restrict__ images,
                                                  const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
-                                                 int32_t *__restrict__ status, int lut_slots) {
+                                                 int32_t *__restrict__ status, int lut_slots, int tr) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][lut_slots][kLutSize]
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
     const uint64_t dc_pk = *reinterpret_cast<const uint64_t *>(im->blk_dc_slot);
     const uint64_t ac_pk = *reinterpret_cast<const uint64_t *>(im->blk_ac_slot);
 
-    int16_t *out = coef + (im->block_off + (int64_t)sg->mcu0 * bpm) * 64 + c_nat_of_zz[lane];
+    // tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
+    const int nat0 = c_nat_of_zz[lane], nat = tr ? ((nat0 & 7) << 3 | nat0 >> 3) : nat0;
+    int16_t *out = coef + (im->block_off + (int64_t)sg->mcu0 * bpm) * 64 + nat;
     int pred0 = 0, pred1 = 0, pred2 = 0;   // previous_dc (:735), int16 arithmetic
     int err = 0;
 
@@ -133,12 +135,12 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
 
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                           const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
-                          int lut_slots) {
+                          int lut_slots, int transposed) {
     if (n_segs == 0) return hipSuccess;
     const int64_t blocks = (n_segs + 3) / 4;
     const size_t lds = (size_t)4 * lut_slots * kLutSize * sizeof(uint16_t);
     hipLaunchKernelGGL(k_huffman, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
-                       coef, status, lut_slots);
+                       coef, status, lut_slots, transposed);
     return hipGetLastError();
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                                                        const DevHuff *__restrict__ huff,
                                                        const uint16_t *__restrict__ lut11,   // [n_huff][kLSize]
                                                        int n_huff, int16_t *__restrict__ coef,
-                                                       int32_t *__restrict__ status, int lpw) {
+                                                       int32_t *__restrict__ status, int lpw, int tr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     const uint32_t out_lo = (uint32_t)out_off, out_hi = (uint32_t)(out_off >> 32);
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int err = 0;
-    const int zz_a = c_zz_of_nat_l[2 * (lane & 31)], zz_b = c_zz_of_nat_l[2 * (lane & 31) + 1];
+    // store positions 2dw, 2dw+1 of a block; tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
+    const int na = 2 * (lane & 31), nb = na + 1;
+    const int zz_a = c_zz_of_nat_l[tr ? ((na & 7) << 3 | na >> 3) : na], zz_b = c_zz_of_nat_l[tr ? ((nb & 7) << 3 | nb >> 3) : nb];
     uint32_t *myblk = s_blk + (lane < lpw2 ? lane : 0) * kBlkStride;
     int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
 
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
 
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status) {
+                                int16_t *coef, int32_t *status, int transposed) {
     if (n_segs == 0) return hipSuccess;
     static int lpw = 0;
     if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
@@ -312,7 +314,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
-                       lut11, n_huff, coef, status, lpw_run);
+                       lut11, n_huff, coef, status, lpw_run, transposed);
     return hipGetLastError();
 }
 

@@ -81,21 +81,21 @@ struct DevProgSeg {
 namespace mj {
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status, int spec_refine);
+                                   int16_t *coef, int32_t *status, int spec_refine, int transposed);
 }
 
 // stage-1 / stage-2 launchers (defined in huffman.hip / reconstruct.hip)
 namespace mj {
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                           const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
-                          int lut_slots);
+                          int lut_slots, int transposed);
 
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
 constexpr int kLaneLutBits = 11;
 constexpr int kMaxLaneTables = 8;
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status);
+                                int16_t *coef, int32_t *status, int transposed);
 
 struct ReconArgs {
     const DevImage *images;
@@ -103,7 +103,8 @@ struct ReconArgs {
     const int64_t *mcu_prefix;   // [n_images + 1]
     int64_t total_mcus;
     const int16_t *coef;
-    const uint16_t *qt;          // [n_qt][64] natural order [v][u] (same layout as the coefficient blocks)
+    const uint16_t *qt;          // [n_qt][64] natural order [v][u] (same layout as the coefficient blocks;
+                                 // [u][v] like them when the plan is transposed)
     const double *idct_tt;       // [64 (u*8+v)][64 (x*8+y)] transposed reference table
     const uint32_t *up_taps;     // packed upsample taps, see reconstruct.hip
     uint8_t *rgb;
@@ -118,10 +119,12 @@ struct ReconArgs {
     int32_t mcus_per_image;
 };
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);
-// fast form (x-major output): tiles of fast_tile_mcus() MCUs in column-major MCU order
-int fast_tile_mcus(int hmax, int vmax, int ncomp);
-hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp,
+// fast form: strips of fast_tile_mcus() MCUs in column-major MCU order.  transposed = the kernel runs on the transposed
+// image (blocks and tables stored [u][v]), so its x-major output is the row-major image (MJ_LAYOUT_ROWMAJOR)
+int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
+hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image);
 // 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]
-hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural);
+hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
+                                 int transposed);
 }  // namespace mj

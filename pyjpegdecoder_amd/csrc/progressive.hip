@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                                                           const DevProgScan *__restrict__ scans,
                                                           const DevImage *__restrict__ images,
                                                           const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
-                                                          int32_t *__restrict__ status, int spec_refine) {
+                                                          int32_t *__restrict__ status, int spec_refine, int tr) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][3 tables][kLutSize]
     const bool spec = spec_refine != 0;
     const int lane = threadIdx.x & 63;
@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
         return cbase + ((int64_t)(my * fmx + mx) * bpm + first + (by - my * v) * h + (bx - mx * h)) * 64;
     };
     const int smh = sc->mcu_count_h;
-    const int nat = c_nat_of_zz_p[lane];
+    // tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
+    auto store_pos = [&](int z) { const int n = c_nat_of_zz_p[z]; return tr ? ((n & 7) << 3 | n >> 3) : n; };
+    const int nat = store_pos(lane);
     int err = 0;
 
     if (is_dc) {
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                     if (s > 0) {
                         if (k > 63) { err = MJ_ST_OVERRUN; break; }
                         const int val = extend(br.take(s), s);
-                        if (lane == 0) p[c_nat_of_zz_p[k]] = (int16_t)(val << al);
+                        if (lane == 0) p[store_pos(k)] = (int16_t)(val << al);
                         ++k;
                     }
                 }
@@ -235,12 +237,12 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
 
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status, int spec_refine) {
+                                   int16_t *coef, int32_t *status, int spec_refine, int transposed) {
     if (n_segs == 0) return hipSuccess;
     const int blocks = (n_segs + 3) / 4;
     const size_t lds = (size_t)4 * 3 * kLutSize * sizeof(uint16_t);
     hipLaunchKernelGGL(k_progressive_scan, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, scans,
-                       images, huff, coef, status, spec_refine);
+                       images, huff, coef, status, spec_refine, transposed);
     return hipGetLastError();
 }
 

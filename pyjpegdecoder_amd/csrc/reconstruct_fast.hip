@@ -102,6 +102,13 @@ struct FGeo {
     static_assert(WAVE_BYTES % 16 == 0, "16-byte LDS accesses");
 };
 
+// Corner-weight table of a kernel geometry; T = the kernel runs on the transposed image (row-major output)
+template <int HS, int VS, bool T>
+__device__ __forceinline__ const uint16_t *w4_table() {
+    if constexpr (T) return (HS == 2 && VS == 2) ? UP_W4T_16x16 : (HS == 2 ? UP_W4T_16x8 : UP_W4T_8x16);
+    else return (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
+}
+
 // Upsampled chroma of pixel (column px, row y) from the two source rows, integer form (exact):
 // round(sum(n_i*v_i)/15) — jpeg_decoder.py:1624-1626 through the captured operator.
 template <int HS, int VS>
@@ -115,16 +122,17 @@ __device__ __forceinline__ int upsample_int(const int16_t *cp, int sx0, int sx1,
 
 // Slow, always-exact version of one lane's pixel run (rare): integer upsample + float64 colour, straight from
 // the LDS strip to global memory.  Also serves the seam outputs (planes) of the parity tests.
-template <int HS, int VS, int NC>
+template <int HS, int VS, int NC, bool T>
 __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned char *dst, int nrows,
-                                             int16_t *planes /* or null */) {
+                                             int16_t *planes /* or null */, int planes_step /* int16 elements per row */) {
     using G = FGeo<HS, VS, NC>;
-    const uint16_t *w4 = (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
+    const uint16_t *w4 = w4_table<HS, VS, T>();
     const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
 #pragma unroll 1
     for (int y = 0; y < nrows; ++y) {
-        const int yb = NC == 1 ? 0 : (y >> 3) * HS + (px >> 3);
+        // block order inside an MCU is the original image's (block_count = by*h + bx, jpeg_decoder.py:875)
+        const int yb = NC == 1 ? 0 : (T ? (px >> 3) * VS + (y >> 3) : (y >> 3) * HS + (px >> 3));
         const int Yv = mt[yb * 64 + (px & 7) * 8 + (y & 7)];
         if constexpr (NC == 3) {
             int Cbv, Crv;
@@ -136,11 +144,11 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
                 Cbv = mt[G::NBY * 64 + px * 8 + y];
                 Crv = mt[(G::NBY + 1) * 64 + px * 8 + y];
             }
-            if (planes) { planes[3 * y] = (int16_t)Yv; planes[3 * y + 1] = (int16_t)Cbv; planes[3 * y + 2] = (int16_t)Crv; }
+            if (planes) { int16_t *pl = planes + (int64_t)y * planes_step; pl[0] = (int16_t)Yv; pl[1] = (int16_t)Cbv; pl[2] = (int16_t)Crv; }
             const uint32_t p = ycc_to_rgb_f64(Yv, Cbv, Crv);
             dst[3 * y] = (unsigned char)p; dst[3 * y + 1] = (unsigned char)(p >> 8); dst[3 * y + 2] = (unsigned char)(p >> 16);
         } else {
-            if (planes) planes[y] = (int16_t)Yv;
+            if (planes) planes[(int64_t)y * planes_step] = (int16_t)Yv;
             dst[y] = (unsigned char)clamp255(Yv);
         }
     }
@@ -148,10 +156,11 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
 
 // Exact-order IDCT of one block by a whole wave (lane = x*8+y), result into the LDS strip.
 __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qblk, const double *tt, int16_t *out_lds,
-                                         int16_t *idct_out /* or null */) {
+                                         int16_t *idct_out /* or null */, bool transposed) {
     const int lane = threadIdx.x & 63;
     const int u = lane >> 3, v = lane & 7;
-    const int dn = deq(cblk[v * 8 + u], qblk[v * 8 + u]);
+    const int src = transposed ? u * 8 + v : v * 8 + u;       // blocks (and tables) are stored [u][v] for row-major plans
+    const int dn = deq(cblk[src], qblk[src]);
     const uint64_t mask = __ballot(dn != 0);
     // r[v] accumulates u = 0..7 in order (NumPy pairwise sum); zero terms are skipped (x + 0.0 == x)
     double rsum[8];
@@ -172,13 +181,15 @@ __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qb
     }
     const double s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
     const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);
-    out_lds[lane] = (int16_t)val;
+    out_lds[transposed ? (lane & 7) * 8 + (lane >> 3) : lane] = (int16_t)val;   // strip holds [x'][y'] = [y][x] when transposed
     if (idct_out) idct_out[lane] = (int16_t)val;
 }
 
 }  // namespace
 
-template <int HS, int VS, int NC, bool SEAMS>
+// T: the kernel works on the transposed image (x' = y, y' = x) — its x-major output is the row-major image of the
+// original; HS/VS are then the transposed sampling factors, coefficient blocks and tables are stored [u][v].
+template <int HS, int VS, int NC, bool SEAMS, bool T>
 __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
                                                           int64_t total_tiles, int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     const double T0 = a.idct_tt[0];     // T[x,y,0,0], identical for every (x,y)
 
     if constexpr (G::SUB) {             // four corner weights / 15 as floats, [x][y]
-        const uint16_t *w4 = (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
+        const uint16_t *w4 = w4_table<HS, VS, T>();
         float4 *wt = reinterpret_cast<float4 *>(smem + 4 * G::WAVE_BYTES);
         for (int i = tid; i < G::MW * G::MH; i += 256) {
             const uint32_t w = w4[i];
@@ -233,13 +244,21 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         Strip st;
         st.im = a.images + img;
-        const int mch = st.im->mcu_count_h, mcv = st.im->mcu_count_v;
+        // MCU grid of the (possibly transposed) image: mch columns, mcv rows
+        const int mch = T ? st.im->mcu_count_v : st.im->mcu_count_h, mcv = T ? st.im->mcu_count_h : st.im->mcu_count_v;
         const uint32_t spc = (uint32_t)(mcv + G::TMW - 1) / G::TMW;     // strips per MCU column
         st.mcu_x = __builtin_amdgcn_readfirstlane((int)(tile / spc));
         st.y_first = (int)(tile - (uint32_t)st.mcu_x * spc) * G::TMW;
         st.n_valid = min(G::TMW, mcv - st.y_first);
-        st.cbase = a.coef + (st.im->block_off + (int64_t)st.mcu_x * G::NB) * 64;
-        st.row_elems = mch * G::NB * 64;
+        // coefficient blocks are in the ORIGINAL image's MCU raster: stepping down the strip moves one MCU row of the
+        // original (or, transposed, one MCU to the right)
+        if constexpr (T) {
+            st.cbase = a.coef + (st.im->block_off + (int64_t)st.mcu_x * mcv * G::NB) * 64;
+            st.row_elems = G::NB * 64;
+        } else {
+            st.cbase = a.coef + (st.im->block_off + (int64_t)st.mcu_x * G::NB) * 64;
+            st.row_elems = mch * G::NB * 64;
+        }
         return st;
     };
     // all rounds' coefficient rows of a strip: ROUNDS x 16 B per lane
@@ -265,10 +284,14 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     fetch(cur, cw);
     for (; tg < n_tiles; tg += stride_tiles) {
         const DevImage *im = cur.im;
-        const int W = im->width, H = im->height;
-        const int mch = im->mcu_count_h;
+        const int W = T ? im->height : im->width, H = T ? im->width : im->height;
+        const int mch_o = im->mcu_count_h;              // MCUs per row of the ORIGINAL image (coefficient raster)
         const int mcu_x = cur.mcu_x, y_first = cur.y_first, n_valid = cur.n_valid;
         const int64_t block_off = im->block_off;
+        // first block of strip MCU k in the coefficient store
+        auto mcu_block = [&](int k) -> int64_t {
+            return block_off + (T ? (int64_t)(mcu_x * mch_o + y_first + k) : (int64_t)((y_first + k) * mch_o + mcu_x)) * G::NB;
+        };
         const uint16_t *qbase = a.qt;
         const int q0i = im->qt_index[0] * 64, q1i = im->qt_index[NC == 3 ? 1 : 0] * 64, q2i = im->qt_index[NC == 3 ? 2 : 0] * 64;
         if (im != qt_owner) {           // wave-uniform, rare: stage this image's tables (3 x 128 B) into the wave's LDS
@@ -336,8 +359,15 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             ow.w = (uint32_t)(o[6] & 0xFFFF) | ((uint32_t)o[7] << 16);
             *reinterpret_cast<uint4 *>(s_strip + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
             if constexpr (SEAMS) {
-                if (a.idct_out && k < n_valid)
-                    *reinterpret_cast<uint4 *>(a.idct_out + (block_off + (int64_t)((y_first + k) * mch + mcu_x) * G::NB + b) * 64 + j * 8) = ow;
+                if (a.idct_out && k < n_valid) {
+                    int16_t *io = a.idct_out + (mcu_block(k) + b) * 64;     // seam order is the original [x][y]
+                    if constexpr (T) {
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) io[y * 8 + j] = (int16_t)o[y];   // lane x' = original y
+                    } else {
+                        *reinterpret_cast<uint4 *>(io + j * 8) = ow;
+                    }
+                }
             }
         }
 
@@ -348,10 +378,10 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             susp_bits &= susp_bits - 1;
             const int k = bt / G::NB, b = bt - k * G::NB;
             if (k >= n_valid) continue;
-            const int64_t blk = block_off + (int64_t)((y_first + k) * mch + mcu_x) * G::NB + b;
+            const int64_t blk = mcu_block(k) + b;
             const int qi = (NC == 1 || b < G::NBY) ? q0i : (b == G::NBY ? q1i : q2i);
             block_exact(a.coef + blk * 64, qbase + qi, a.idct_tt, s_strip + k * G::MCU_STRIDE + b * 64,
-                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr);
+                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr, T);
         }
 
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
@@ -377,8 +407,10 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 
             if constexpr (SEAMS) {
                 if (gx < W)
-                    pixel_run_exact<HS, VS, NC>(mt, px, dst, nrows,
-                                                a.planes ? a.planes + (im->pix_off + (int64_t)gx * H + gy0) * NC : nullptr);
+                    // planes are always the original x-major (W,H,C): transposed, this lane walks along the original x
+                    pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows,
+                                                   a.planes ? a.planes + (im->pix_off + (T ? (int64_t)gy0 * W + gx : (int64_t)gx * H + gy0)) * NC : nullptr,
+                                                   T ? W * NC : NC);
             } else {
                 uint32_t ob[(NBYTES + 3) / 4];
 #pragma unroll
@@ -405,7 +437,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
-                        const int yb = by * HS + (px >> 3);
+                        const int yb = T ? (px >> 3) * VS + by : by * HS + (px >> 3);   // original block order (:875)
                         const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
                         const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
                         // source samples this half of the column interpolates between
@@ -481,7 +513,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 #endif
                 if (gx < W) {
                     if (slow || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
-                        pixel_run_exact<HS, VS, NC>(mt, px, dst, nrows, nullptr);
+                        pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows, nullptr, 0);
                     } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
 #pragma unroll
                         for (int i = 0; i < NBYTES / 16; ++i)
@@ -509,7 +541,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 #endif
 }
 
-template <int HS, int VS, int NC>
+template <int HS, int VS, int NC, bool T>
 static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const int64_t *tile_prefix, int64_t total_tiles,
                                 int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
@@ -528,20 +560,27 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, tile_prefix, total_tiles, tiles_per_image);
     };
-    if (a.planes || a.idct_out) launch(k_reconstruct_fast<HS, VS, NC, true>);
-    else launch(k_reconstruct_fast<HS, VS, NC, false>);
+    if (a.planes || a.idct_out) launch(k_reconstruct_fast<HS, VS, NC, true, T>);
+    else launch(k_reconstruct_fast<HS, VS, NC, false, T>);
     return hipGetLastError();
 }
 
-int fast_tile_mcus(int hmax, int vmax, int ncomp) { return 64 / (ncomp == 1 ? 8 : 8 * hmax); }
+// hmax/vmax are the ORIGINAL image's sampling factors; a transposed plan runs the kernel with them swapped
+int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed) {
+    return 64 / (ncomp == 1 ? 8 : 8 * (transposed ? vmax : hmax));
+}
 
-hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp,
+hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image) {
-    if (ncomp == 1) return launch_fast_t<1, 1, 1>(stream, a, tile_prefix, total_tiles, tiles_per_image);
-    if (hmax == 1 && vmax == 1) return launch_fast_t<1, 1, 3>(stream, a, tile_prefix, total_tiles, tiles_per_image);
-    if (hmax == 2 && vmax == 1) return launch_fast_t<2, 1, 3>(stream, a, tile_prefix, total_tiles, tiles_per_image);
-    if (hmax == 1 && vmax == 2) return launch_fast_t<1, 2, 3>(stream, a, tile_prefix, total_tiles, tiles_per_image);
-    if (hmax == 2 && vmax == 2) return launch_fast_t<2, 2, 3>(stream, a, tile_prefix, total_tiles, tiles_per_image);
+#define MJ_FAST(H, V, C) \
+    (transposed ? launch_fast_t<V, H, C, true>(stream, a, tile_prefix, total_tiles, tiles_per_image) \
+                : launch_fast_t<H, V, C, false>(stream, a, tile_prefix, total_tiles, tiles_per_image))
+    if (ncomp == 1) return MJ_FAST(1, 1, 1);
+    if (hmax == 1 && vmax == 1) return MJ_FAST(1, 1, 3);
+    if (hmax == 2 && vmax == 1) return MJ_FAST(2, 1, 3);
+    if (hmax == 1 && vmax == 2) return MJ_FAST(1, 2, 3);
+    if (hmax == 2 && vmax == 2) return MJ_FAST(2, 2, 3);
+#undef MJ_FAST
     return hipErrorInvalidValue;
 }
 

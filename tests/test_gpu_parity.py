@@ -27,6 +27,14 @@ def dec_exact():
     d.close()
 
 
+@pytest.fixture(scope="module")
+def dec_rm():
+    from pyjpegdecoder_amd import BatchDecoder
+    d = BatchDecoder(device=0, layout="rowmajor")
+    yield d
+    d.close()
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -81,23 +89,56 @@ def test_full_size_1080p_dri_against_reference_hashes(dec):
     assert np.array_equal(img[::st["x_stride"], ::st["y_stride"]], vec["rgb"])
 
 
-def test_rowmajor_layout_is_the_transpose(dec):
-    from pyjpegdecoder_amd import BatchDecoder
-    d2 = BatchDecoder(device=0, layout="rowmajor")
-    try:
-        for name in ("70x50_420_pil_opt", "64x48_422_pil", "48x80_440", "50x70_grey_dri4", "40x40_444_dri5"):
-            raw, vec = load_golden(name)
-            (img,) = d2.decode([raw])
-            assert np.array_equal(np.swapaxes(img, 0, 1), vec["rgb"]), name
-    finally:
-        d2.close()
+@pytest.mark.parametrize("name", golden_names())
+def test_rowmajor_fixture_every_seam(dec_rm, name):
+    """MJ_LAYOUT_ROWMAJOR runs stage 2 on the transposed problem (blocks stored [u][v], transposed tables): the
+    seams still come back in the reference's order and the image is the transpose of the reference's [x, y, c]."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec_rm.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], vec["coef"])
+    assert np.array_equal(seam["idct"], vec["idct"])
+    assert np.array_equal(seam["planes"], vec["planes"])
+    assert np.array_equal(np.swapaxes(img, 0, 1), vec["rgb"])
+    assert np.array_equal(np.swapaxes(dec_rm.decode([raw])[0], 0, 1), vec["rgb"]), "production launch"
 
 
-@pytest.mark.parametrize("ss,w,h,ri,q", [
+def test_rowmajor_mixed_batch_and_1080p(dec_rm):
+    names = golden_names()
+    imgs = dec_rm.decode([load_golden(n)[0] for n in names])
+    for n, img in zip(names, imgs):
+        assert np.array_equal(np.swapaxes(img, 0, 1), load_golden(n)[1]["rgb"]), n
+    name = "c3_1920x1080_420_dri120"
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    (img,), (seam,) = dec_rm.decode([raw], return_seams=True)
+    assert img.shape == (1080, 1920, 3)
+    assert sha(seam["coef"]) == meta["sha256"]["coef"] and sha(seam["idct"]) == meta["sha256"]["idct"]
+    assert sha(seam["planes"]) == meta["sha256"]["planes"]
+    assert sha(np.swapaxes(img, 0, 1)) == meta["sha256"]["rgb"]
+    assert sha(np.swapaxes(dec_rm.decode([raw])[0], 0, 1)) == meta["sha256"]["rgb"]
+
+
+RANDOM_CASES = [
     ("420", 333, 211, 5, 85), ("420", 16, 16, 0, 50), ("420", 17, 9, 1, 95), ("422", 250, 130, 9, 90),
     ("440", 130, 250, 4, 75), ("444", 99, 101, 13, 92), ("grey", 123, 77, 6, 88), ("420", 640, 480, 40, 85),
     ("420", 1, 1, 0, 85), ("444", 8, 8, 1, 30), ("420", 1024, 64, 64, 100),
-])
+]
+
+
+@pytest.mark.parametrize("ss,w,h,ri,q", RANDOM_CASES)
+def test_rowmajor_random_sizes_against_oracle(dec_rm, ss, w, h, ri, q):
+    from oracle import oracle
+    from tools import synth
+    sigma = 40.0 if q >= 95 else 12.0
+    raw = synth.encode_rgb(synth.synth_rgb(w * 1000 + h + 7, w, h, sigma), q, ss, ri)
+    ref = oracle.decode(raw)
+    (img,), (seam,) = dec_rm.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"]) and np.array_equal(seam["planes"], ref["planes"])
+    assert np.array_equal(np.swapaxes(img, 0, 1), ref["rgb"])
+    assert np.array_equal(np.swapaxes(dec_rm.decode([raw])[0], 0, 1), ref["rgb"])
+
+
+@pytest.mark.parametrize("ss,w,h,ri,q", RANDOM_CASES)
 def test_random_sizes_against_oracle(dec, ss, w, h, ri, q):
     """Seeded synthetic files at sizes the oracle finishes in well under a second; bit-exact on G1 and G6."""
     from oracle import oracle
@@ -138,7 +179,8 @@ def test_config2_idct_only_on_host_decoded_coefficients(dec):
     assert np.array_equal(got[0], load_golden("c2_512x512_420")[1]["rgb"])
 
 
-def test_idct_tie_blocks_through_the_kernel(dec):
+@pytest.mark.parametrize("layout", ["xmajor", "rowmajor"])
+def test_idct_tie_blocks_through_the_kernel(dec, layout):
     """The F6/F7 exact-tie blocks: feed the golden dequantised blocks as coefficients with an all-ones
     quantisation table through stage 2 and compare the IDCT seam."""
     from pyjpegdecoder_amd import _binding as B
@@ -164,7 +206,8 @@ def test_idct_tie_blocks_through_the_kernel(dec):
     bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
     bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
     bc.n_qt = 1; bc.qt = qt.ctypes.data
-    bc.layout = B.MJ_LAYOUT_XMAJOR; bc.flags = B.MJ_FLAG_KEEP_IDCT | B.MJ_FLAG_KEEP_PLANES
+    bc.layout = B.MJ_LAYOUT_ROWMAJOR if layout == "rowmajor" else B.MJ_LAYOUT_XMAJOR
+    bc.flags = B.MJ_FLAG_KEEP_IDCT | B.MJ_FLAG_KEEP_PLANES
     plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
     try:
         plan.write_coef(zz)
@@ -176,7 +219,8 @@ def test_idct_tie_blocks_through_the_kernel(dec):
     assert np.array_equal(out["idct"].reshape(n, 8, 8), want)
 
 
-def test_colour_conversion_ties_through_the_kernel(dec):
+@pytest.mark.parametrize("layout", ["xmajor", "rowmajor"])
+def test_colour_conversion_ties_through_the_kernel(dec, layout):
     """YCbCr_to_RGB golden triples (incl. exact .5 ties): build 4:4:4 DC-only blocks whose IDCT gives the
     wanted Y/Cb/Cr (DC*q = 8*(v-128) -> every sample = v), then compare the RGB."""
     from pyjpegdecoder_amd import _binding as B
@@ -201,7 +245,8 @@ def test_colour_conversion_ties_through_the_kernel(dec):
     bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
     bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
     bc.n_qt = 1; bc.qt = qt.ctypes.data
-    bc.layout = B.MJ_LAYOUT_XMAJOR; bc.flags = B.MJ_FLAG_KEEP_PLANES
+    bc.layout = B.MJ_LAYOUT_ROWMAJOR if layout == "rowmajor" else B.MJ_LAYOUT_XMAJOR
+    bc.flags = B.MJ_FLAG_KEEP_PLANES
     plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
     try:
         plan.write_coef(coef.reshape(-1, 64))
@@ -210,8 +255,10 @@ def test_colour_conversion_ties_through_the_kernel(dec):
         out = plan.read(rgb=True, planes=True)
     finally:
         plan.close()
-    planes = out["planes"].reshape(8 * cols, 8 * rows, 3)
-    rgb = out["rgb"].reshape(8 * cols, 8 * rows, 3)
+    planes = out["planes"].reshape(8 * cols, 8 * rows, 3)          # seams keep the reference's [x, y, c] order
+    as_xy = (lambda a: a.reshape(8 * rows, 8 * cols, 3).swapaxes(0, 1)) if layout == "rowmajor" else \
+            (lambda a: a.reshape(8 * cols, 8 * rows, 3))
+    rgb = as_xy(out["rgb"])
     # and once more through the production launch (fp32 fast colour path with its tie detection)
     bc.flags = 0
     plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
@@ -219,7 +266,7 @@ def test_colour_conversion_ties_through_the_kernel(dec):
         plan.write_coef(coef.reshape(-1, 64))
         plan.execute_stage2()
         plan.sync()
-        rgb2 = plan.read(rgb=True)["rgb"].reshape(8 * cols, 8 * rows, 3)
+        rgb2 = as_xy(plan.read(rgb=True)["rgb"])
     finally:
         plan.close()
     assert np.array_equal(rgb2, rgb)
@@ -343,6 +390,27 @@ def test_progressive_fixture_bit_exact(dec, name):
     assert np.array_equal(seam["planes"], vec["planes"])
     assert np.array_equal(img, vec["rgb"])
     assert np.array_equal(dec.decode([raw])[0], vec["rgb"])
+
+
+@pytest.mark.parametrize("name", prog_names())
+def test_progressive_rowmajor(dec_rm, name):
+    """Progressive scans write the transposed ([u][v]) coefficient store of a row-major plan."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec_rm.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], vec["coef"]) and np.array_equal(seam["planes"], vec["planes"])
+    assert np.array_equal(np.swapaxes(img, 0, 1), vec["rgb"])
+    assert np.array_equal(np.swapaxes(dec_rm.decode([raw])[0], 0, 1), vec["rgb"])
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_rowmajor_both_stage1_forms(dec_rm, mode, monkeypatch):
+    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    names = golden_names()
+    imgs, seams = dec_rm.decode([load_golden(n)[0] for n in names], return_seams=True)
+    for n, img, seam in zip(names, imgs, seams):
+        vec = load_golden(n)[1]
+        assert np.array_equal(seam["coef"], vec["coef"]), (mode, n)
+        assert np.array_equal(np.swapaxes(img, 0, 1), vec["rgb"]), (mode, n)
 
 
 def test_progressive_batch_and_class_surface(dec, tmp_path):
