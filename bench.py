@@ -153,16 +153,18 @@ def main():
     # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench);
     # only quoted when the workload is the one that was profiled, else null
     traffic = {}
-    tfile = ROOT / "profiles" / "r01b_hbm_traffic_batch1024.json"
-    if args.batch == 1024 and args.layout == "xmajor" and tfile.exists():
+    tfiles = sorted((ROOT / "profiles").glob("r*_hbm_traffic_batch1024.json"))      # newest round's passes
+    tfile = tfiles[-1] if tfiles else None
+    if args.batch == 1024 and args.layout == "xmajor" and tfile is not None:
         for k, d in json.loads(tfile.read_text())["kernels"].items():
-            traffic["stage1" if "huffman" in k else "stage2"] = int(d["traffic_bytes_per_launch"])
+            if "traffic_bytes_per_launch" in d:
+                traffic["stage1" if "huffman" in k else "stage2"] = int(d["traffic_bytes_per_launch"])
 
     def roof(name, nbytes, ms, note, tkey):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey),
-                "traffic_source": "profiles/r01b_hbm_traffic_batch1024.json (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else None,
+                "traffic_source": f"profiles/{tfile.name} (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else None,
                 "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4), "note": note}
 
     r1 = roof("k_huffman_lanes / k_huffman (stage 1: Huffman decode)", s1_bytes, s1_ms,

@@ -42,6 +42,8 @@ struct mj_plan {
     mj::DevImage *d_images = nullptr;
     mj::DevHuff *d_huff = nullptr;
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
+    uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
+    int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     int n_huff = 0;
     bool use_lanes = false;
     // progressive batches: scans grouped by dependency level, one launch per level
@@ -218,7 +220,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -455,19 +457,31 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         for (int t = 0; t < b->n_huff; ++t) build_dev_huff(b->huff[t], hh[t]);
         if ((rc = upload(ctx, &p->d_huff, hh.data(), hh.size())) != MJ_OK) return rc;
         p->n_huff = b->n_huff;
+        std::vector<int> role(b->n_huff, 0);
+        bool both_roles = false;
         {   // 11-bit LUTs for the lane-parallel kernel
             const int LB = mj::kLaneLutBits, LS = 1 << LB;
             std::vector<uint16_t> l11((size_t)b->n_huff * LS, 0);
+            // how each table is used: bit 0 = as a DC table, bit 1 = as an AC table (the two LUT formats differ)
+            for (const mj::DevImage &im : imgs)
+                for (int k2 = 0; k2 < im.blocks_per_mcu && k2 < 8; ++k2) {
+                    role[im.tab_index[im.blk_dc_slot[k2]]] |= 1;
+                    role[im.tab_index[im.blk_ac_slot[k2]]] |= 2;
+                }
+            for (int t = 0; t < b->n_huff; ++t) both_roles = both_roles || role[t] == 3;
             for (int t = 0; t < b->n_huff; ++t) {
                 int code = 0, k = 0;
                 for (int l = 1; l <= 16; ++l) {
                     code <<= 1;
                     for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
                         if (l <= LB && code < (1 << l)) {
-                            const int shift = LB - l;
+                            const int shift = LB - l, hv = b->huff[t].vals[k];
+                            // AC tables: length, zero run and size ready for use; end of block = a run of 64 (huffman_lanes.hip)
+                            const uint16_t entry = (role[t] & 2) ? (uint16_t)((l << 11) | ((hv == 0 ? 64 : hv >> 4) << 4) | (hv & 15))
+                                                                 : (uint16_t)((l << 8) | hv);
                             for (int f = 0; f < (1 << shift); ++f) {
                                 uint16_t &e = l11[(size_t)t * LS + ((code << shift) | f)];
-                                if (e == 0) e = (uint16_t)((l << 8) | b->huff[t].vals[k]);
+                                if (e == 0) e = entry;
                             }
                         }
                     }
@@ -477,9 +491,19 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         // one segment per lane pays off once there are enough segments to fill the chip that way
         const char *force = getenv("MJ_HUFFMAN");
-        p->use_lanes = b->n_huff <= mj::kMaxLaneTables && (int64_t)segs.size() >= 8192;
+        // (a table serving as DC and as AC table at once, or a stream beyond 32-bit offsets, stays with the wave form)
+        const bool lanes_ok = b->n_huff <= mj::kMaxLaneTables && !both_roles && !prog &&
+                              (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
+        p->use_lanes = lanes_ok && (int64_t)segs.size() >= 8192;
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
-        if (force && !strcmp(force, "lanes") && b->n_huff <= mj::kMaxLaneTables) p->use_lanes = true;
+        if (force && !strcmp(force, "lanes") && lanes_ok) p->use_lanes = true;
+        if (p->use_lanes) {
+            // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
+            const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
+            MJ_HIP(ctx, hipMalloc((void **)&p->d_stream, sbytes));
+            MJ_HIP(ctx, hipMemset(p->d_stream, 0, sbytes));
+            MJ_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
+        }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
         if (prog) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
@@ -534,10 +558,11 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         }
         return MJ_OK;
     }
-    if (p->use_lanes)
-        MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
+    if (p->use_lanes) {
+        MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
+        MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                              p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0));
-    else
+    } else
         MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
                                        p->d_status, p->lut_slots, p->transposed ? 1 : 0));
     return MJ_OK;

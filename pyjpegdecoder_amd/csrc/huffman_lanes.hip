@@ -10,12 +10,14 @@
 //   * lock-step at block granularity: all lanes decode block b of MCU m together (the component, hence
 //     which table, is wave-uniform; all images of a plan share one sampling layout).  One DC symbol, then
 //     AC symbols until every lane has reached its end of block; lanes that finish early idle.
-//   * per-lane bit reader: bytes are fetched as aligned dwords one dword ahead of need (the load is not
-//     consumed until a later iteration), unstuffed exactly like the reference's get_bits — whatever
-//     follows a 0xFF is dropped (jpeg_decoder.py:676-677) — four at a time when none is 0xFF, else byte-wise.
+//   * per-lane bit reader: the input is the stream stage 0 (destuff.hip) prepared — the segment's bytes with the
+//     ones the reference's get_bits drops after a 0xFF (jpeg_decoder.py:676-677) already removed, as aligned
+//     big-endian dwords — so a refill is one dword load (issued an iteration before it can be needed), a shift
+//     and an or; reading past the segment's end is detected by bit count.
 //   * Huffman tables: an 11-bit primary LUT per table, ALL tables of the batch resident in LDS (this form
 //     is chosen when the batch has at most kMaxLaneTables distinct tables, e.g. everybody uses the Annex-K
-//     tables); codes longer than 11 bits take a per-lane canonical search (rare).
+//     tables); AC tables are stored as (length, zero run, size) with the end-of-block symbol as a run of 64;
+//     codes longer than 11 bits take a per-lane canonical search (rare).
 //   * coefficients: each lane owns a 128-byte block in LDS (row stride 132 B -> conflict-free scatter of
 //     "coefficient kk of every lane"); a finished round of 64 blocks leaves as 32 store instructions that each
 //     write two full 128-byte lines, in the natural [v][u] order stage 2 reads.
@@ -37,85 +39,38 @@ __constant__ uint8_t c_zz_of_nat_l[64] = {
     3,  8, 12, 17, 25, 30, 41, 43,  9, 11, 18, 24, 31, 40, 44, 53,
    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
    21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
-__constant__ uint8_t c_nat_of_zz_l[64] = {
-    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
-   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
-   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
-   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
 // Per-lane bit reader state (plain scalars: the decode loop is straight-line, select-based code):
-//   bb/bc     bit buffer (next bit = bit 63) and its fill
-//   woff      dword index (from the blob start) of the next stream dword; nxtw = blob[woff], loaded one
-//             iteration before it can be needed
-//   lead      bytes of nxtw that precede the segment (only the first dword of a segment has any)
-//   left      segment bytes from nxtw's position on (bytes of nxtw included);  pad = zero bits fed past the end
-//   skipnext  the next stream byte follows an 0xFF and is dropped (jpeg_decoder.py:676-677)
+//   bb/bc   bit buffer (next bit = bit 63) and its fill
+//   voff    byte offset (from the stream buffer's start) of the next dword; nxtw = that dword, loaded one
+//           iteration before it can be needed
 struct LaneBits {
     uint64_t bb;
-    uint32_t woff, nxtw;
-    int bc, left, pad;
-    int lead, skipnext;
+    uint32_t voff, nxtw;
+    int bc;
 };
 
-// Codes longer than the 11-bit LUT (rare): canonical search (jpeg_decoder.py:366-377 semantics).  Out of line so
-// that its global loads do not put a vmcnt wait on the common path.  Returns (len << 8) | symbol, or -1.
-__device__ __noinline__ int long_code(const DevHuff *t, uint32_t p16, bool want) {
+// Codes longer than the 11-bit LUT (rare): canonical search (jpeg_decoder.py:366-377 semantics).
+// Returns (len << 8) | symbol, or -1.
+__device__ __forceinline__ int long_code(const DevHuff *t, uint32_t p16) {
     int r = -1;
-    if (want) {
-        for (int l = kLBits + 1; l <= 16; ++l) {
-            const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
-            if (d >= 0 && d < t->count[l]) { r = (l << 8) | t->vals[t->first_sym[l] + d]; break; }
-        }
+#pragma unroll 1
+    for (int l = kLBits + 1; l <= 16; ++l) {
+        const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
+        if (r < 0 && d >= 0 && d < t->count[l]) r = (l << 8) | t->vals[t->first_sym[l] + d];
     }
     return r;
 }
 
-// Rare path: the next dword holds an 0xFF, a dropped byte, the segment's first or last bytes, or nothing at all
-// (past the end: zero bits are fed and counted).  Byte by byte, exact reference semantics (:673-677).
-__device__ __noinline__ LaneBits refill_slow(LaneBits s, const uint32_t *blobw, bool need) {
-    while (__any(need && s.bc <= 32)) {
-        if (need && s.bc <= 32) {
-            if (s.left <= 0) {                       // nothing left: feed zeros, remember how many
-                s.bc += 32;
-                s.pad += 32;
-            } else {
-                const int nb = min(4, s.left + s.lead);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t b = (s.nxtw >> (8 * i)) & 0xFFu;
-                    if (i >= s.lead && i < nb) {
-                        if (s.skipnext) s.skipnext = 0;
-                        else {
-                            s.bb |= (uint64_t)b << (56 - s.bc);
-                            s.bc += 8;
-                            s.skipnext = b == 0xFFu;
-                        }
-                    }
-                }
-                s.left -= nb - s.lead;
-                s.lead = 0;
-                s.woff += 1;
-                s.nxtw = blobw[s.woff];
-            }
-        }
-    }
-    return s;
-}
-
-// Common path, branch-free: when the buffer is at most half full and the next dword is plain data (no 0xFF, no
-// pending drop, wholly inside the segment) it goes straight into the buffer.
-__device__ __forceinline__ void refill(LaneBits &s, const uint32_t *blobw, bool need) {
-    const uint32_t w = s.nxtw;
-    const uint32_t ff = (~w - 0x01010101u) & w & 0x80808080u;      // non-zero iff some byte of w is 0xFF
-    const bool want = need && s.bc <= 32;
-    const bool c_fast = want && ff == 0 && s.left >= 4 && (s.lead | s.skipnext) == 0;
-    const uint64_t bb_f = s.bb | ((uint64_t)__builtin_bswap32(w) << ((32 - s.bc) & 63));   // used only when bc <= 32
-    s.bb = c_fast ? bb_f : s.bb;
-    s.bc += c_fast ? 32 : 0;
-    s.left -= c_fast ? 4 : 0;
-    s.woff += c_fast ? 1u : 0u;
-    s.nxtw = blobw[s.woff];                       // not needed before the next call
-    if (__any(want && !c_fast)) s = refill_slow(s, blobw, need);
+// Branch-free: when the buffer is at most half full the next dword goes in.  The load of the dword after it is
+// issued right away and not needed before the next call.
+__device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb, bool on) {
+    const bool want = on && s.bc <= 32;
+    const uint32_t t = want ? s.nxtw : 0u;
+    s.bb |= (uint64_t)t << ((32 - s.bc) & 63);
+    const uint32_t inc = want ? 4u : 0u;
+    s.voff += inc;
+    s.bc += (int)(inc * 8u);
+    s.nxtw = *reinterpret_cast<const uint32_t *>(streamb + s.voff);
 }
 
 __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0
@@ -125,7 +80,8 @@ __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_compl
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict__ blob,
+__global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restrict__ stream,   // stage 0's output
+                                                       const int32_t *__restrict__ seg_bits,  // bits per segment
                                                        const DevSegment *__restrict__ segs, int64_t n_segs,
                                                        const DevImage *__restrict__ images,
                                                        const DevHuff *__restrict__ huff,
@@ -139,13 +95,11 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     // block buffers: lpw lanes per wave are active (rounded up to even: the flush moves blocks in pairs)
     const int lpw2 = (lpw + 1) & ~1;
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * (lpw2 * kBlkStride);
-    uint8_t *s_nat = smem + (size_t)n_huff * kLSize * 2 + 4 * lpw2 * kBlkStride * 4;
 
     for (int i = tid; i < n_huff * kLSize / 8; i += 256)
         reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
     for (int i = tid; i < 4 * lpw2 * kBlkStride; i += 256)
         (reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2))[i] = 0;
-    if (tid < 64) s_nat[tid] = c_nat_of_zz_l[tid];
     __syncthreads();
 
     const int64_t seg_id = ((int64_t)blockIdx.x * 4 + wave) * lpw + lane;   // lpw segments per wave (tunable)
@@ -177,17 +131,14 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     for (int o = 32; o > 0; o >>= 1) max_mcu = max(max_mcu, __shfl_xor(max_mcu, o));
     max_mcu = __builtin_amdgcn_readfirstlane(max_mcu);
 
-    // ---- per-lane bit reader (see LaneBits)
-    const uint32_t *blobw = reinterpret_cast<const uint32_t *>(blob);
+    // ---- per-lane bit reader (see LaneBits); lanes without a segment read dword 0 and never decode
+    const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
     LaneBits br;
-    {
-        const int64_t abase = sg.begin & ~(int64_t)3;
-        br.lead = (int)(sg.begin - abase);
-        br.left = have ? sg.len : 0;
-        br.woff = (uint32_t)(abase >> 2);
-        br.nxtw = blobw[br.woff];
-        br.bb = 0; br.bc = 0; br.pad = 0; br.skipnext = 0;
-    }
+    const uint32_t voff0 = have ? (uint32_t)(((sg.begin >> 2) + seg_id) * 4) : 0u;
+    const int nbits = have ? seg_bits[seg_id] : 0;
+    br.voff = voff0;
+    br.nxtw = *reinterpret_cast<const uint32_t *>(streamb + br.voff);
+    br.bb = 0; br.bc = 0;
     // byte offset of this lane's first output block
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
     const uint32_t out_lo = (uint32_t)out_off, out_hi = (uint32_t)(out_off >> 32);
@@ -208,15 +159,17 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
             const bool act = in_mcu && err == 0;
 
             // ---- DC (:810-820): one symbol per lane, straight-line
-            refill(br, blobw, act);
+            refill(br, streamb, act);
             int k;
             {
                 const uint32_t p16 = (uint32_t)(br.bb >> 48);
                 const int e = s_lut[dct * kLSize + (p16 >> (16 - kLBits))];
                 int len = e >> 8, s = e & 0xFF;
-                if (__any(act && len == 0)) {                              // code longer than 11 bits: rare
-                    const int r = long_code(huff + dct, p16, act && len == 0);
-                    if (act && len == 0) { len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF; }
+                if (__builtin_amdgcn_ballot_w64(act && len == 0) != 0) {                              // code longer than 11 bits: rare
+                    if (act && len == 0) {
+                        const int r = long_code(huff + dct, p16);
+                        len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF;
+                    }
                 }
                 const bool bad = act && s > 16;
                 err = bad ? MJ_ST_BAD_CODE : err;
@@ -234,32 +187,40 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
                 if (ok) myblk16[0] = (int16_t)dcv;
                 k = ok ? 1 : 64;
             }
-            // ---- AC (:833-866): one symbol per lane and iteration until every lane is at its end of block
-            while (__any(k < 64)) {
+            // ---- AC (:833-866): one symbol per lane and iteration until every lane is at its end of block.
+            // LUT entry = len << 11 | run << 4 | size; the end-of-block symbol carries run = 64, so "kk >= 64" covers
+            // both :849 and :855-856 (the value bits stay unread in both cases).
+            const uint16_t *alut = s_lut + act_ * kLSize;
+            while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
                 const bool on = k < 64;
-                refill(br, blobw, on);
-                const uint32_t p16 = (uint32_t)(br.bb >> 48);
-                const int e = s_lut[act_ * kLSize + (p16 >> (16 - kLBits))];
-                int len = e >> 8, hv = e & 0xFF;
-                if (__any(on && len == 0)) {
-                    const int r = long_code(huff + act_, p16, on && len == 0);
-                    if (on && len == 0) { len = r < 0 ? 0 : r >> 8; hv = r < 0 ? -1 : r & 0xFF; }
+                refill(br, streamb, on);
+                const uint32_t hi = (uint32_t)(br.bb >> 32);
+                int e = alut[hi >> (32 - kLBits)];
+                if (__builtin_amdgcn_ballot_w64(on && e < 2048) != 0) {                                  // code longer than 11 bits: rare
+                    if (on && e < 2048) {
+                        const int r = long_code(huff + act_, hi >> 16);
+                        err = r < 0 ? MJ_ST_BAD_CODE : err;
+                        const int hv = r & 0xFF;
+                        e = r < 0 ? (64 << 4) : ((r >> 8) << 11) | ((hv == 0 ? 64 : hv >> 4) << 4) | (hv & 15);
+                    }
                 }
-                const bool bad = on && hv < 0;
-                err = bad ? MJ_ST_BAD_CODE : err;
-                const bool ok = on && !bad;
-                const int kk = k + (hv >> 4);
-                const bool eob = hv == 0, over = kk >= 64;               // (:849), (:855-856): value bits stay unread
-                const bool val = ok && !eob && !over;
-                const int ln = ok ? len : 0, n = val ? (hv & 15) : 0;
-                const uint32_t hw = (uint32_t)(br.bb >> 32) << ln;             // ln + n <= 27 <= bc
-                const uint32_t rawv = (hw >> 1) >> (31 - n);
+                const int kk = k + ((e >> 4) & 127);
+                const bool val = on && kk < 64;
+                const int ln = on ? e >> 11 : 0, n = val ? (e & 15) : 0;
+                const uint32_t hw = hi << ln;                                  // ln + n <= 27 <= bc
+                if (n > 0) {
+                    // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
+                    // itself, a leading 0 is value - (2^n - 1) = -(~value)
+                    const uint32_t neg = ~(uint32_t)((int32_t)hw >> 31);      // all ones for a leading 0
+                    const uint32_t mag = (hw ^ neg) >> ((32 - n) & 31);
+                    myblk16[kk] = (int16_t)((mag ^ neg) - neg);               // zig-zag order; the flush permutes
+                }
                 br.bb <<= ln + n;
                 br.bc -= ln + n;
-                if (val && n > 0) myblk16[kk] = (int16_t)extend(rawv, n);      // zig-zag order; the flush permutes
                 k = val ? kk + 1 : 64;
-                k = on ? k : 64;
             }
+            // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
+            err = (act && err == 0 && (int)((br.voff - voff0) * 8u) - br.bc > nbits) ? MJ_ST_OVERRUN : err;
             // ---- round of 64 blocks done: LDS -> HBM, two full lines per instruction, and clear
             // lane (o, dw) moves the two coefficients of natural positions 2dw, 2dw+1 of block o: they are read from
             // their zig-zag slots, so the block lands in HBM in the natural [v][u] order stage 2 wants
@@ -283,16 +244,14 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint8_t *__restrict
     }
 
     if (have) {
-        if (!err) {
-            const int unconsumed = br.left - (br.skipnext ? 1 : 0);
-            if (br.pad > 0 && br.bc < br.pad) err = MJ_ST_OVERRUN;
-            else if (!sg.last && (((br.bc - br.pad) >> 3) > 0 || unconsumed > 0)) err = MJ_ST_DESYNC;
-        }
+        // bits left over: a whole unread byte before the next restart marker means the count-driven reference and the
+        // marker-driven segmentation disagree (:898-900)
+        if (!err && !sg.last && nbits - ((int)((br.voff - voff0) * 8u) - br.bc) >= 8) err = MJ_ST_DESYNC;
         if (err) atomicMax(status + sg.image, err);
     }
 }
 
-hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
                                 int16_t *coef, int32_t *status, int transposed) {
     if (n_segs == 0) return hipSuccess;
@@ -313,7 +272,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const D
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, images, huff,
+    hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
                        lut11, n_huff, coef, status, lpw_run, transposed);
     return hipGetLastError();
 }

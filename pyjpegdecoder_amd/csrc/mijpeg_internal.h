@@ -93,7 +93,13 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegm
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
 constexpr int kLaneLutBits = 11;
 constexpr int kMaxLaneTables = 8;
-hipError_t launch_huffman_lanes(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+// stage 0 (destuff.hip): per restart segment, the bytes the bit reader keeps, as big-endian dwords at dword
+// (begin >> 2) + segment index of `out_stream`; seg_bits[i] = 8 x kept bytes
+hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
+                          uint32_t *out_stream, int32_t *seg_bits);
+// lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
+hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits,
+                                const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
                                 int16_t *coef, int32_t *status, int transposed);
 
