@@ -63,8 +63,8 @@ __device__ __forceinline__ int long_code(const DevHuff *t, uint32_t p16) {
 
 // Branch-free: when the buffer is at most half full the next dword goes in.  The load of the dword after it is
 // issued right away and not needed before the next call.
-__device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb, bool on) {
-    const bool want = on && s.bc <= 32;
+__device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb) {
+    const bool want = s.bc <= 32;       // idle lanes top up as well: harmless, their stream is theirs
     const uint32_t t = want ? s.nxtw : 0u;
     s.bb |= (uint64_t)t << ((32 - s.bc) & 63);
     const uint32_t inc = want ? 4u : 0u;
@@ -94,11 +94,14 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // block buffers: lpw lanes per wave are active (rounded up to even: the flush moves blocks in pairs)
     const int lpw2 = (lpw + 1) & ~1;
-    uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * (lpw2 * kBlkStride);
+    const int wstride = (lpw2 * kBlkStride + 3) & ~3;                             // dwords per wave, 16-byte multiple
+    uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * wstride;
+    // output byte offset of every lane's segment, for the flush (lane (o, dw) needs block o's, not its own)
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4) + wave * lpw2;
 
     for (int i = tid; i < n_huff * kLSize / 8; i += 256)
         reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
-    for (int i = tid; i < 4 * lpw2 * kBlkStride; i += 256)
+    for (int i = tid; i < 4 * wstride; i += 256)
         (reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2))[i] = 0;
     __syncthreads();
 
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     br.bb = 0; br.bc = 0;
     // byte offset of this lane's first output block
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
-    const uint32_t out_lo = (uint32_t)out_off, out_hi = (uint32_t)(out_off >> 32);
+    if (lane < lpw2) s_base[lane] = (uint64_t)out_off;
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int err = 0;
     // store positions 2dw, 2dw+1 of a block; tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     uint32_t *myblk = s_blk + (lane < lpw2 ? lane : 0) * kBlkStride;
     int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
 
+    const uint64_t full_mask = lpw >= 64 ? ~0ull : (1ull << lpw) - 1;
     for (int m = 0; m < max_mcu; ++m) {
         const bool in_mcu = m < n_mcu;
         for (int b = 0; b < bpm; ++b) {
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             const bool act = in_mcu && err == 0;
 
             // ---- DC (:810-820): one symbol per lane, straight-line
-            refill(br, streamb, act);
+            refill(br, streamb);
             int k;
             {
                 const uint32_t p16 = (uint32_t)(br.bb >> 48);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 pred0 = (ok && comp == 0) ? dcv : pred0;
                 pred1 = (ok && comp == 1) ? dcv : pred1;
                 pred2 = (ok && comp == 2) ? dcv : pred2;
-                if (ok) myblk16[0] = (int16_t)dcv;
+                myblk16[ok ? 0 : 64] = (int16_t)dcv;                           // 64 = the row's pad slot, never flushed
                 k = ok ? 1 : 64;
             }
             // ---- AC (:833-866): one symbol per lane and iteration until every lane is at its end of block.
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             const uint16_t *alut = s_lut + act_ * kLSize;
             while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
                 const bool on = k < 64;
-                refill(br, streamb, on);
+                refill(br, streamb);
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
                 int e = alut[hi >> (32 - kLBits)];
                 if (__builtin_amdgcn_ballot_w64(on && e < 2048) != 0) {                                  // code longer than 11 bits: rare
@@ -208,13 +212,12 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 const bool val = on && kk < 64;
                 const int ln = on ? e >> 11 : 0, n = val ? (e & 15) : 0;
                 const uint32_t hw = hi << ln;                                  // ln + n <= 27 <= bc
-                if (n > 0) {
-                    // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
-                    // itself, a leading 0 is value - (2^n - 1) = -(~value)
-                    const uint32_t neg = ~(uint32_t)((int32_t)hw >> 31);      // all ones for a leading 0
-                    const uint32_t mag = (hw ^ neg) >> ((32 - n) & 31);
-                    myblk16[kk] = (int16_t)((mag ^ neg) - neg);               // zig-zag order; the flush permutes
-                }
+                // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
+                // itself, a leading 0 is value - (2^n - 1) = -(~value).  Lanes with nothing to store (n = 0) write
+                // garbage to the row's pad slot instead of branching around the store.
+                const uint32_t neg = ~(uint32_t)((int32_t)hw >> 31);          // all ones for a leading 0
+                const uint32_t mag = (hw ^ neg) >> ((32 - n) & 31);
+                myblk16[n > 0 ? kk : 64] = (int16_t)((mag ^ neg) - neg);       // zig-zag order; the flush permutes
                 br.bb <<= ln + n;
                 br.bc -= ln + n;
                 k = val ? kk + 1 : 64;
@@ -226,20 +229,35 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             // their zig-zag slots, so the block lands in HBM in the natural [v][u] order stage 2 wants
             const uint64_t act_mask = __ballot(in_mcu);
             const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
+            const int half = lane >> 5, dw = lane & 31;
+            unsigned char *dst0 = reinterpret_cast<unsigned char *>(coef) + blk_byte + dw * 4;
+            if (act_mask == full_mask) {
+                // every lane of the wave has a block: no per-pair tests, offsets fold into the instructions
+                const int16_t *hb = reinterpret_cast<const int16_t *>(s_blk + half * kBlkStride);
+                const uint64_t *bp = s_base + half;
 #pragma unroll 4
-            for (int s2 = 0; s2 < 32; ++s2) {
-                if (((act_mask >> (2 * s2)) & 3) == 0) continue;         // uniform
-                const int o = 2 * s2 + (lane >> 5), dw = lane & 31;
-                int16_t *ob16 = reinterpret_cast<int16_t *>(s_blk + o * kBlkStride);
-                const uint32_t v = (uint32_t)(uint16_t)ob16[zz_a] | ((uint32_t)(uint16_t)ob16[zz_b] << 16);
-                ob16[zz_a] = 0;
-                ob16[zz_b] = 0;
-                const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)out_lo, 2 * s2), hi0 = (uint32_t)__builtin_amdgcn_readlane((int)out_hi, 2 * s2);
-                const uint32_t lo1 = (uint32_t)__builtin_amdgcn_readlane((int)out_lo, 2 * s2 + 1), hi1 = (uint32_t)__builtin_amdgcn_readlane((int)out_hi, 2 * s2 + 1);
-                const uint64_t base = (lane >> 5) ? (((uint64_t)hi1 << 32) | lo1) : (((uint64_t)hi0 << 32) | lo0);
-                if ((act_mask >> o) & 1)
-                    *reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(coef) + base + blk_byte + dw * 4) = v;
+                for (int s2 = 0; s2 < (lpw >> 1); ++s2) {
+                    const int16_t *ob16 = hb + s2 * (4 * kBlkStride);
+                    const uint32_t v = (uint32_t)(uint16_t)ob16[zz_a] | ((uint32_t)(uint16_t)ob16[zz_b] << 16);
+                    *reinterpret_cast<uint32_t *>(dst0 + bp[2 * s2]) = v;
+                }
+                if ((lpw & 1) && half == 0) {
+                    const int16_t *ob16 = hb + (lpw >> 1) * (4 * kBlkStride);
+                    const uint32_t v = (uint32_t)(uint16_t)ob16[zz_a] | ((uint32_t)(uint16_t)ob16[zz_b] << 16);
+                    *reinterpret_cast<uint32_t *>(dst0 + bp[lpw - 1]) = v;
+                }
+            } else {
+#pragma unroll 2
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    if (((act_mask >> (2 * s2)) & 3) == 0) continue;         // uniform
+                    const int o = 2 * s2 + half;
+                    const int16_t *ob16 = reinterpret_cast<const int16_t *>(s_blk + o * kBlkStride);
+                    const uint32_t v = (uint32_t)(uint16_t)ob16[zz_a] | ((uint32_t)(uint16_t)ob16[zz_b] << 16);
+                    if ((act_mask >> o) & 1) *reinterpret_cast<uint32_t *>(dst0 + s_base[o]) = v;
+                }
             }
+            // clear the wave's block rows for the next round, 16 bytes per lane and instruction
+            for (int i = lane; i < wstride / 4; i += 64) reinterpret_cast<uint4 *>(s_blk)[i] = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -266,7 +284,8 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     }
     const int lpw_run = use;
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
-    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * ((lpw_run + 1) & ~1) * kBlkStride * 4 + 64;
+    const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
+    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
