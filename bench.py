@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to --batch)")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
+    ap.add_argument("--segment", default="host", choices=["host", "gpu"],
+                    help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / MAX of timings (gloo: self-test on a box with fewer GPUs than ranks)")
@@ -94,7 +96,11 @@ def main():
     # ---- host side of the path: header parse + restart segmentation (Python, not timed as "step") ---------
     t0 = time.perf_counter()
     layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
-    prep = prepare_batch(files, layout, 0)
+    if args.segment == "gpu":       # headers only; parse each distinct file once, as a caller with real files would each file
+        from pyjpegdecoder_amd import parse_jpeg
+        prep = prepare_batch(files, layout, 0, [parse_jpeg(f, headers_only=True) for f in files])
+    else:
+        prep = prepare_batch(files, layout, 0)
     host_prep_s = time.perf_counter() - t0
 
     # ---- device residency: torch owns the HBM buffers, libmijpeg gets raw pointers -----------------------
@@ -185,7 +191,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, DRI=120 (one MCU row, 68 segments/image), "
                                    "on-GPU Huffman + dequant/IDCT/upsample/RGB (BASELINE configs[2])",
-                       "images_per_gpu": args.batch, "distinct_images_per_gpu": distinct, "layout": args.layout,
+                       "images_per_gpu": args.batch, "distinct_images_per_gpu": distinct, "layout": args.layout, "restart_segmentation": args.segment,
                        "entropy_bytes_per_image": int(ent_bytes // args.batch), "parallelism": f"image-sharded x{world}, no collective"},
             "roofline": dominant, "roofline_other_stage": other,
             "parity": parity,

@@ -54,6 +54,9 @@ extern "C" {
 #define MJ_ST_DESYNC      3   /* a segment's MCUs end before its next RSTn: the reference's count-driven restart
                                  (:667-669, :898-900) would lose synchronisation here                           */
 
+#define MJ_ST_TAIL        4   /* MJ_FLAG_GPU_SEGMENT only: the scan is not followed by EOI (more scans, DNL, ...): the
+                                 host-side marker loop (:78-110) has to segment this file                          */
+
 /* memory spaces */
 #define MJ_MEM_NONE   0
 #define MJ_MEM_HOST   1
@@ -70,6 +73,12 @@ extern "C" {
 #define MJ_FLAG_EXACT_ONLY   8u   /* stage 2: use only the exact-order fp64 summation (no fast path)        */
 #define MJ_FLAG_SPEC_REFINE 16u   /* progressive AC refinement per ITU-T T.81 G.1.2.3 (move negative values away
                                      from zero) instead of the reference's `|=` on two's complement (:1114)  */
+
+#define MJ_FLAG_GPU_SEGMENT 32u  /* baseline batches: find the RSTn markers and the end of the scan on the GPU (what
+                                     _parse.py's find_entropy_end / find_restart_segments do on the host).  Every
+                                     image then has n_segments = 1 and seg_begin/seg_end = first entropy-coded byte /
+                                     any bound at or behind the end of the scan (e.g. the end of the file); the blob
+                                     must be 16-byte aligned with 16 readable bytes behind blob_len                */
 
 typedef struct mj_context mj_context;
 typedef struct mj_plan mj_plan;

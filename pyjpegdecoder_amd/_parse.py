@@ -188,12 +188,18 @@ class ParsedJpeg:
     array_depth: int = 0
     file_header: int = 2
     reached_eoi: bool = False
+    headers_only: bool = False       # parse stopped at the SOS (see parse_jpeg)
     log: List[str] = field(default_factory=list)
 
 
-def parse_jpeg(raw: bytes) -> ParsedJpeg:
+def parse_jpeg(raw: bytes, headers_only: bool = False) -> ParsedJpeg:
     """Walk the file like the reference's constructor does (jpeg_decoder.py:29-110), but instead of
-    decoding each scan in place, record a :class:`ScanInfo` and jump to the marker that ends it."""
+    decoding each scan in place, record a :class:`ScanInfo` and jump to the marker that ends it.
+
+    ``headers_only``: stop at the SOS of a baseline frame whose scan holds every component, without
+    looking at the entropy-coded bytes at all — the GPU finds the restart markers and the end of the
+    scan (MJ_FLAG_GPU_SEGMENT).  The scan then carries ``entropy_end = len(raw)`` as a bound and no
+    ``segment_offsets``; progressive and multi-scan files are parsed in full regardless."""
     if not raw.startswith(SOI + b"\xFF"):
         raise NotJpeg("File is not a JPEG image.")
     p = ParsedJpeg(raw=raw, file_size=len(raw))
@@ -239,8 +245,12 @@ def parse_jpeg(raw: bytes) -> ParsedJpeg:
             say(f"Restart interval: {p.restart_interval}")
             pos += 2
         elif marker == SOS:                # start_of_scan (:505-650)
-            scan = _start_of_scan(p, data, pos, arr, say)
+            scan = _start_of_scan(p, data, pos, arr, say, headers_only)
             p.scans.append(scan)
+            if scan.segment_offsets is None:       # headers_only: the rest of the file is the GPU's to look at
+                p.headers_only = True
+                pos = scan.entropy_start
+                break
             pos = scan.entropy_end
         else:
             pos += size                    # unknown segment: skipped (:104-106)
@@ -296,7 +306,7 @@ def _start_of_frame(p: ParsedJpeg, marker: bytes, data: bytes, say) -> None:
     say("Vertical sampling  : " + " x ".join(str(c.vertical_sampling) for c in p.color_components.values()))
 
 
-def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, say) -> ScanInfo:
+def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, say, headers_only: bool = False) -> ScanInfo:
     if p.scan_mode is None:
         raise CorruptedJpeg("Start of scan before start of frame.")
     h = 0
@@ -344,11 +354,20 @@ def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, s
         count_h = (p.image_width // sw) + (0 if p.image_width % sw == 0 else 1)
         count_v = (p.image_height // sh) + (0 if p.image_height % sh == 0 else 1)
         p.array_width, p.array_height, p.array_depth = sw * count_h, sh * count_v, len(comps)
-        p.scan_amount = p.raw[scan.entropy_start:].count(SOS) + 1
-        say(f"Number of scans: {p.scan_amount}")
+        gpu_scan = headers_only and p.scan_mode == "baseline_dct" and components_amount == len(comps) and p.image_height > 0
+        if not gpu_scan:
+            p.scan_amount = p.raw[scan.entropy_start:].count(SOS) + 1
+            say(f"Number of scans: {p.scan_amount}")
+    else:
+        gpu_scan = False
 
     scan.restart_interval = p.restart_interval
     scan.huffman = dict(p.huffman)
+    if gpu_scan:
+        p.scan_amount = 1
+        scan.entropy_end = len(p.raw)
+        scan.segment_offsets = None
+        return scan
     scan.entropy_end = find_entropy_end(arr, scan.entropy_start)
     scan.segment_offsets = find_restart_segments(arr, scan.entropy_start, scan.entropy_end)
     return scan

@@ -54,6 +54,8 @@ def check_supported(p: ParsedJpeg) -> ScanInfo:
 def _segments_of(scan: ScanInfo, off: int):
     """(begin[], end[]) blob offsets of a scan's restart segments; checks the marker count (:898 is count driven)."""
     so = scan.segment_offsets
+    if so is None:          # headers-only parse: one byte range, the GPU segments it (MJ_FLAG_GPU_SEGMENT)
+        return (np.array([scan.entropy_start + off], dtype=np.int64), np.array([scan.entropy_end + off], dtype=np.int64))
     if scan.restart_interval > 0:
         want = -(-scan.mcu_count // scan.restart_interval)
         if so.size - 1 != want:
@@ -117,6 +119,10 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
     offs[1:] = np.cumsum((sizes + 3) & ~3)
     # stage 1 prefetches up to 128 bytes ahead of a segment: keep that much readable slack behind the last file
     blob = np.zeros(int(offs[-1]) + 1024, dtype=np.uint8)
+    if parsed and any(p.headers_only for p in parsed):
+        if not all(p.headers_only for p in parsed):
+            raise UnsupportedJpeg("A batch is segmented either on the GPU (headers-only parse) or on the host; split it.")
+        flags |= B.MJ_FLAG_GPU_SEGMENT
     descs = (B.ImageDescC * n)()
     huff_ids: Dict[bytes, int] = {}
     huff_list: List[Tuple[np.ndarray, np.ndarray]] = []
@@ -239,15 +245,25 @@ class BatchDecoder:
     >>> images = dec.decode([open(p, 'rb').read() for p in paths])      # list of uint8 (W,H,3) arrays
     """
 
-    def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False):
+    def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False,
+                 segment: str = "host"):
         self.ctx = B.Context(device)
         self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
         # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
         # spec_refine: progressive AC refinement as ITU-T T.81 defines it instead of the reference's behaviour (SURVEY F8)
         self.base_flags = (B.MJ_FLAG_EXACT_ONLY if exact_only else 0) | (B.MJ_FLAG_SPEC_REFINE if spec_refine else 0)
+        # segment="gpu": the host parses headers only; restart markers and the end of each baseline scan are found on
+        # the GPU (SURVEY.md §8 f-2).  Files the GPU scan hands back (MJ_ST_TAIL: something other than EOI follows the
+        # scan) and progressive files take the host path.
+        if segment not in ("host", "gpu"):
+            raise ValueError("segment must be 'host' or 'gpu'")
+        self.gpu_segment = segment == "gpu"
 
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
-        prep = prepare_batch(files, self.layout, flags | self.base_flags)
+        parsed = [parse_jpeg(f, headers_only=True) for f in files] if self.gpu_segment else None
+        if parsed is not None and not all(p.headers_only for p in parsed):
+            parsed = None                       # progressive / multi-scan files: host segmentation for the whole batch
+        prep = prepare_batch(files, self.layout, flags | self.base_flags, parsed)
         plan = B.Plan(self.ctx, prep.to_c(blob_device_ptr), {"prep": prep, "n_images": len(prep.parsed)})
         return prep, plan
 
@@ -263,23 +279,32 @@ class BatchDecoder:
 
     def decode(self, files: Sequence[bytes], return_seams: bool = False):
         """Decode files that may mix sampling layouts (one plan per layout)."""
-        parsed = [parse_jpeg(f) for f in files]
+        parsed = [parse_jpeg(f, headers_only=self.gpu_segment) for f in files]
         groups: Dict[tuple, List[int]] = {}
         for i, p in enumerate(parsed):
             check_supported(p)
             comps = list(p.color_components.values())
-            key = (p.scan_mode, len(comps)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            key = (p.scan_mode, len(comps), p.headers_only) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
             groups.setdefault(key, []).append(i)
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)
         flags = ((B.MJ_FLAG_KEEP_PLANES | B.MJ_FLAG_KEEP_IDCT) if return_seams else 0) | self.base_flags
-        for idxs in groups.values():
+        work = list(groups.values())
+        while work:
+            idxs = work.pop(0)
             prep = prepare_batch([files[i] for i in idxs], self.layout, flags, [parsed[i] for i in idxs])
             plan = B.Plan(self.ctx, prep.to_c(), {"prep": prep, "n_images": len(idxs)})
             try:
                 plan.execute()
                 plan.sync()
                 out = plan.read(rgb=True, coef=return_seams, planes=return_seams, idct=return_seams)
+                redo = [i for k, i in enumerate(idxs) if out["status"][k] == B.MJ_ST_TAIL]
+                if redo:                        # the GPU scan met something other than EOI after the scan: host parse
+                    for i in redo:
+                        parsed[i] = parse_jpeg(files[i])
+                        check_supported(parsed[i])
+                    work.append(redo)
+                    out["status"][[k for k, i in enumerate(idxs) if i in redo]] = 0
                 raise_for_status(out["status"])
                 imgs = self.split_outputs(prep, out["rgb"])
                 for k, i in enumerate(idxs):

@@ -44,6 +44,8 @@ struct mj_plan {
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
+    mj::DevScanJob *d_jobs = nullptr;   // MJ_FLAG_GPU_SEGMENT: per-image byte ranges for the marker scan
+    int n_jobs = 0;
     int n_huff = 0;
     bool use_lanes = false;
     // progressive batches: scans grouped by dependency level, one launch per level
@@ -220,7 +222,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -254,6 +256,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
 
     std::vector<mj::DevImage> &imgs = p->h_images;
     std::vector<mj::DevSegment> segs;
+    std::vector<mj::DevScanJob> jobs;      // MJ_FLAG_GPU_SEGMENT: one marker-scan job per image
     std::vector<int64_t> mcu_prefix(b->n_images + 1, 0);
     imgs.resize(b->n_images);
     int64_t blk = 0, mcu = 0, rgb = 0, pix = 0, ent = 0;
@@ -311,22 +314,37 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (i > 0 && (d.width != b->images[0].width || d.height != b->images[0].height)) p->uniform = false;
         if (have_entropy && !prog) {
             const int64_t want = d.restart_interval > 0 ? (mcus + d.restart_interval - 1) / d.restart_interval : 1;
-            if (d.n_segments != want)
+            const bool gpu_seg = (b->flags & MJ_FLAG_GPU_SEGMENT) != 0;
+            if (d.n_segments != (gpu_seg ? 1 : want))
                 return fail(ctx, MJ_ERR_INVALID, "image %d: %d restart segments given, %lld expected (restart interval %d, %lld MCUs)",
-                            i, d.n_segments, (long long)want, d.restart_interval, (long long)mcus);
+                            i, d.n_segments, (long long)(gpu_seg ? 1 : want), d.restart_interval, (long long)mcus);
             if (d.first_segment < 0 || d.first_segment + d.n_segments > b->n_segments)
                 return fail(ctx, MJ_ERR_INVALID, "image %d: segment range outside seg_begin/seg_end", i);
-            for (int s = 0; s < d.n_segments; ++s) {
-                const int64_t sb = b->seg_begin[d.first_segment + s], se = b->seg_end[d.first_segment + s];
+            if (gpu_seg) {      // one byte range per image; stage 0 finds the markers and fills begin/len (destuff.hip)
+                const int64_t sb = b->seg_begin[d.first_segment], se = b->seg_end[d.first_segment];
                 if (sb < 0 || se < sb || se > b->blob_len || se - sb > 0x7fff0000)
-                    return fail(ctx, MJ_ERR_INVALID, "image %d segment %d: bad byte range [%lld, %lld)", i, s, (long long)sb, (long long)se);
+                    return fail(ctx, MJ_ERR_INVALID, "image %d: bad byte range [%lld, %lld)", i, (long long)sb, (long long)se);
+                mj::DevScanJob jb{};
+                jb.begin = sb; jb.end = se; jb.first_seg = (int64_t)segs.size(); jb.n_seg = (int32_t)want; jb.image = i;
+                jobs.push_back(jb);
+                ent += se - sb;
+            }
+            for (int s = 0; s < (int)want; ++s) {
                 mj::DevSegment g{};
-                g.begin = sb; g.len = (int32_t)(se - sb); g.image = i;
+                if (gpu_seg) {
+                    g.begin = b->seg_begin[d.first_segment]; g.len = 0;
+                } else {
+                    const int64_t sb = b->seg_begin[d.first_segment + s], se = b->seg_end[d.first_segment + s];
+                    if (sb < 0 || se < sb || se > b->blob_len || se - sb > 0x7fff0000)
+                        return fail(ctx, MJ_ERR_INVALID, "image %d segment %d: bad byte range [%lld, %lld)", i, s, (long long)sb, (long long)se);
+                    g.begin = sb; g.len = (int32_t)(se - sb);
+                    ent += se - sb;
+                }
+                g.image = i;
                 g.mcu0 = d.restart_interval > 0 ? s * d.restart_interval : 0;
                 g.n_mcu = (int32_t)(d.restart_interval > 0 ? std::min<int64_t>(d.restart_interval, mcus - g.mcu0) : mcus);
-                g.last = s == d.n_segments - 1;
+                g.last = s == (int)want - 1;
                 segs.push_back(g);
-                ent += se - sb;
             }
         }
         blk += mcus * im.blocks_per_mcu;
@@ -505,6 +523,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             MJ_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
         }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
+        if (!jobs.empty()) {
+            if (prog) return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT is for baseline batches");
+            if ((rc = upload(ctx, &p->d_jobs, jobs.data(), jobs.size())) != MJ_OK) return rc;
+            p->n_jobs = (int)jobs.size();
+        }
         if (prog) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
             if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
@@ -514,6 +537,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->d_blob = p->d_blob_owned;
         } else {
             if (((uintptr_t)b->blob & 3) != 0) return fail(ctx, MJ_ERR_INVALID, "device blob must be 4-byte aligned");
+            if (!jobs.empty() && ((uintptr_t)b->blob & 15) != 0)
+                return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT: device blob must be 16-byte aligned");
             p->d_blob = b->blob;
         }
     }
@@ -558,6 +583,8 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         }
         return MJ_OK;
     }
+    if (p->n_jobs)      // restart markers and the end of each scan, found on the GPU
+        MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     if (p->use_lanes) {
         MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,

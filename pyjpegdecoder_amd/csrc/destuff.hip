@@ -104,6 +104,104 @@ __global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blo
     if (lane == 0) seg_bits[seg] = total * 8;
 }
 
+// Restart-marker scan: with MJ_FLAG_GPU_SEGMENT the caller hands over ONE byte range per image —
+// first entropy-coded byte up to any bound at or behind the end of the scan (normally the end of the file) — and
+// this kernel does what pyjpegdecoder_amd/_parse.py does on the host otherwise (find_entropy_end,
+// find_restart_segments): the entropy-coded data ends at the first 0xFF followed by anything but 0x00, 0xFF or
+// RSTn; every "FF D0..D7" before that ends a restart segment, the next one starts two bytes later.  The reference
+// itself never looks at those bytes (it skips two bytes after every restart_interval MCUs, jpeg_decoder.py:667-669,
+// :898-900); a file whose marker count differs from ceil(mcu_count / restart_interval) - 1 is reported as
+// MJ_ST_DESYNC, and one whose scan is not followed by EOI as MJ_ST_TAIL (the host parser has to look at it).
+// One wavefront per image, 4 KiB per iteration; markers are rare, so they are emitted by scalar code in file order.
+__global__ __launch_bounds__(64) void k_scan_markers(const uint8_t *__restrict__ blob, const DevScanJob *__restrict__ jobs,
+                                                    int n_jobs, DevSegment *__restrict__ segs, int32_t *__restrict__ status) {
+    const int lane = threadIdx.x;
+    const DevScanJob *jb = jobs + blockIdx.x;
+    const int64_t begin = jb->begin, end = jb->end, first = jb->first_seg;
+    const int n_seg = jb->n_seg;
+    const int64_t abase = begin & ~(int64_t)15;
+    const int len32 = (int)(end - begin);
+    int r = 0;                           // markers seen
+    int64_t cur_begin = begin, T = end;
+    bool stop = false;
+    for (int64_t c0 = abase; c0 < end && !stop; c0 += 4096) {
+        uint4 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t pos = c0 + q * 1024 + lane * 16;
+            w[q] = pos < end ? *reinterpret_cast<const uint4 *>(blob + pos) : make_uint4(0, 0, 0, 0);
+        }
+        const uint32_t tail = c0 + 4096 < end ? blob[c0 + 4096] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4 && !stop; ++q) {
+            const uint32_t d[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+            // the byte after this lane's sixteen: the next lane's first, the next row's, or the next iteration's
+            uint32_t nb = __shfl_down(d[0], 1) & 0xFFu;
+            const uint32_t wrap = q < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)w[q < 3 ? q + 1 : 3].x) & 0xFFu : tail;
+            nb = lane == 63 ? wrap : nb;
+            uint32_t rstm = 0, termm = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t b = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t n = j < 15 ? (d[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : nb;
+                const bool isr = (n & 0xF8u) == 0xD0u;
+                const bool ist = n != 0u && n != 0xFFu && !isr;
+                rstm |= (b == 0xFFu && isr) ? 1u << j : 0u;
+                termm |= (b == 0xFFu && ist) ? 1u << j : 0u;
+            }
+            // bytes of the range whose successor is in the range too: begin <= p, p + 1 < end
+            const int rel = (int)(c0 + q * 1024 + lane * 16 - begin);
+            const int lo = rel < 0 ? -rel : 0, hi = len32 - 1 - rel;          // valid j: lo <= j < hi
+            const uint32_t vmask = hi <= 0 || lo >= 16 ? 0u : ((hi >= 16 ? 0xFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u));
+            rstm &= vmask;
+            termm &= vmask;
+            const uint64_t tb = __ballot(termm != 0);
+            int64_t tpos = end;
+            if (tb) {
+                const int L = __builtin_ctzll(tb);
+                tpos = c0 + q * 1024 + L * 16 + __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)termm, L));
+                T = tpos;
+                stop = true;
+            }
+            uint64_t rb = __ballot(rstm != 0);
+            while (rb) {
+                const int L = __builtin_ctzll(rb);
+                rb &= rb - 1;
+                uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)rstm, L);
+                while (bits) {
+                    const int j = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int64_t p = c0 + q * 1024 + L * 16 + j;
+                    if (p > tpos) { rb = 0; break; }
+                    if (r + 1 < n_seg && lane == 0) {
+                        segs[first + r].begin = cur_begin;
+                        segs[first + r].len = (int32_t)(p - cur_begin);
+                    }
+                    cur_begin = p + 2;
+                    ++r;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        const int last = r < n_seg - 1 ? r : n_seg - 1;
+        if (r <= n_seg - 1) {
+            segs[first + last].begin = cur_begin;
+            segs[first + last].len = (int32_t)(T > cur_begin ? T - cur_begin : 0);
+        }
+        for (int k = last + 1; k < n_seg; ++k) { segs[first + k].begin = T; segs[first + k].len = 0; }
+        if (r != n_seg - 1) atomicMax(status + jb->image, MJ_ST_DESYNC);
+        else if (T + 1 < end && blob[T + 1] != 0xD9u) atomicMax(status + jb->image, MJ_ST_TAIL);
+    }
+}
+
+hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
+                               int32_t *status) {
+    if (n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_markers, dim3((unsigned)n_jobs), dim3(64), 0, stream, blob, jobs, n_jobs, segs, status);
+    return hipGetLastError();
+}
+
 hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                           uint32_t *out_stream, int32_t *seg_bits) {
     if (n_segs == 0) return hipSuccess;

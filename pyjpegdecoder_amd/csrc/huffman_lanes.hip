@@ -200,13 +200,11 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 refill(br, streamb);
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
                 int e = alut[hi >> (32 - kLBits)];
-                if (__builtin_amdgcn_ballot_w64(on && e < 2048) != 0) {                                  // code longer than 11 bits: rare
-                    if (on && e < 2048) {
-                        const int r = long_code(huff + act_, hi >> 16);
-                        err = r < 0 ? MJ_ST_BAD_CODE : err;
-                        const int hv = r & 0xFF;
-                        e = r < 0 ? (64 << 4) : ((r >> 8) << 11) | ((hv == 0 ? 64 : hv >> 4) << 4) | (hv & 15);
-                    }
+                if (on && e < 2048) {                                         // code longer than 11 bits: rare (the branch
+                    const int r = long_code(huff + act_, hi >> 16);           // is skipped when no lane has one)
+                    err = r < 0 ? MJ_ST_BAD_CODE : err;
+                    const int hv = r & 0xFF;
+                    e = r < 0 ? (64 << 4) : ((r >> 8) << 11) | ((hv == 0 ? 64 : hv >> 4) << 4) | (hv & 15);
                 }
                 const int kk = k + ((e >> 4) & 127);
                 const bool val = on && kk < 64;

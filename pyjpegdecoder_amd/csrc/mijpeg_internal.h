@@ -57,6 +57,14 @@ struct DevSegment {
     int32_t pad;
 };
 
+// One image's byte range for the on-GPU restart-marker scan (MJ_FLAG_GPU_SEGMENT, destuff.hip)
+struct DevScanJob {
+    int64_t begin, end;   // blob offsets: first entropy-coded byte, a bound at or behind the end of the scan
+    int64_t first_seg;    // index of the image's first DevSegment
+    int32_t n_seg;        // ceil(mcu_count / restart_interval), 1 without restart interval
+    int32_t image;
+};
+
 // One SOS of a progressive image (device copy of mj_scan_desc with table indices resolved).
 struct DevProgScan {
     int32_t image, n_comp;
@@ -97,6 +105,8 @@ constexpr int kMaxLaneTables = 8;
 // (begin >> 2) + segment index of `out_stream`; seg_bits[i] = 8 x kept bytes
 hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
                           uint32_t *out_stream, int32_t *seg_bits);
+hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
+                               int32_t *status);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits,
                                 const DevSegment *segs, int64_t n_segs,

@@ -472,3 +472,63 @@ def test_progressive_spec_refinement_switch(dec):
     assert np.array_equal(img_spec, img_base)
     diff = ref_like["coef"] != base["coef"]
     assert diff.any() and (base["coef"][diff] < 0).all(), "the reference's behaviour differs only on negative coefficients"
+
+
+# ---- restart-marker scan on the GPU -------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dec_gs():
+    from pyjpegdecoder_amd import BatchDecoder
+    d = BatchDecoder(device=0, segment="gpu")
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_gpu_segmentation_fixture_every_seam(dec_gs, name):
+    """Headers parsed on the host, restart markers and the end of the scan found by k_scan_markers: same seams."""
+    raw, vec = load_golden(name)
+    (img,), (seam,) = dec_gs.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], vec["coef"]) and np.array_equal(seam["planes"], vec["planes"])
+    assert np.array_equal(img, vec["rgb"])
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_gpu_segmentation_batches_and_1080p(dec_gs, mode, monkeypatch):
+    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    names = golden_names()
+    for n, img in zip(names, dec_gs.decode([load_golden(n)[0] for n in names])):
+        assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
+    name = "c3_1920x1080_420_dri120"
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    (img,), (seam,) = dec_gs.decode([raw], return_seams=True)
+    assert sha(seam["coef"]) == meta["sha256"]["coef"] and sha(img) == meta["sha256"]["rgb"]
+    from tools import synth
+    from oracle import oracle
+    files = [synth.synth_jpeg(90 + i, 40 + 24 * i, 200 - 8 * i, 70 + i, ("420", "444", "422", "440", "grey")[i % 5], (i * 3) % 11, 25.0)
+             for i in range(20)]
+    for f, img in zip(files, dec_gs.decode(files)):
+        assert np.array_equal(img, oracle.decode(f)["rgb"])
+
+
+def test_gpu_segmentation_hands_back_what_it_cannot_segment(dec_gs):
+    """A segment between the scan and EOI (here a COM) is MJ_ST_TAIL: the file is re-parsed on the host.  Progressive
+    files never take the GPU scan.  A missing restart marker is a corrupt file either way."""
+    from pyjpegdecoder_amd import CorruptedJpeg, parse_jpeg
+    raw, vec = load_golden("128x64_420_dri3")
+    assert raw[-2:] == b"\xff\xd9"
+    with_com = raw[:-2] + b"\xff\xfe\x00\x06abcd" + b"\xff\xd9"
+    plain = load_golden("64x64_420_pil")
+    imgs = dec_gs.decode([with_com, plain[0], raw])
+    assert np.array_equal(imgs[0], vec["rgb"]) and np.array_equal(imgs[2], vec["rgb"])
+    assert np.array_equal(imgs[1], plain[1]["rgb"])
+    name = prog_names()[0]
+    praw, pvec = load_golden(name)
+    assert np.array_equal(dec_gs.decode([praw])[0], pvec["rgb"])
+    s = parse_jpeg(raw).scans[0]
+    off = int(s.segment_offsets[2])
+    no_marker = raw[:off - 2] + raw[off:]                        # one RSTn removed
+    with pytest.raises(CorruptedJpeg):
+        dec_gs.decode([no_marker])
+    trailing = raw + b"\x00" * 37                                # bytes after EOI are nobody's business
+    assert np.array_equal(dec_gs.decode([trailing])[0], vec["rgb"])

@@ -87,3 +87,27 @@ def test_progressive_attribute_surface(name):
     assert p.restart_interval == meta["restart_interval"] and p.file_header == meta["file_header"]
     for sc in p.scans:                                                                          # every scan ends on a marker
         assert raw[sc.entropy_end] == 0xFF and raw[sc.entropy_end + 1] not in (0x00,) + tuple(range(0xD0, 0xD8))
+
+
+def test_headers_only_parse_matches_full_parse():
+    """segment="gpu": the host stops at the SOS of a single-scan baseline file; everything before it is parsed as
+    usual and the scan carries the end of the file as its bound."""
+    from pyjpegdecoder_amd import parse_jpeg
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    for name in golden_names():
+        raw, _ = load_golden(name)
+        full, head = parse_jpeg(raw), parse_jpeg(raw, headers_only=True)
+        if full.scan_mode != "baseline_dct" or len(full.scans) != 1:
+            assert not head.headers_only
+            continue
+        assert head.headers_only and not full.headers_only
+        assert (head.image_width, head.image_height, head.restart_interval) == (full.image_width, full.image_height, full.restart_interval)
+        a, b = head.scans[0], full.scans[0]
+        assert a.entropy_start == b.entropy_start and a.entropy_end == len(raw) and a.segment_offsets is None
+        assert (a.mcu_count_h, a.mcu_count_v, a.component_ids) == (b.mcu_count_h, b.mcu_count_v, b.component_ids)
+        prep = prepare_batch([raw], parsed=[head])
+        assert prep.flags & B.MJ_FLAG_GPU_SEGMENT and prep.seg_begin.size == 1
+        assert prep.seg_begin[0] == a.entropy_start and prep.seg_end[0] == len(raw)
+    for name in (n for n in golden_index() if n.startswith("prog_")):
+        assert not parse_jpeg(load_golden(name)[0], headers_only=True).headers_only
