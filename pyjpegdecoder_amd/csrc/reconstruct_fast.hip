@@ -24,6 +24,9 @@
 //            for the two chroma source rows it needs; upsample (four cell-corner weights) and colour run in
 //            fp32 where fp32 is provably exact, bytes are packed with v_cvt_pk_u8_f32, and the lane writes
 //            3*MH contiguous bytes; lanes k+1.. continue the same image column.
+//   Chroma blocks sit in the strip WITHOUT the +128 level shift (:872 adds it, :1697-1699 take it off again):
+//   phase B works on Cb-128 / Cr-128 directly; the seam outputs and the exact routines put the 128 back
+//   (with the reference's int16 wrap).
 //   The colour conversion is the reference's float64 expression whenever a pixel sits on (or outside the
 //   range where we can rule out) an exact rounding tie — see the comments in phase B and DESIGN.md.
 #include "mijpeg_internal.h"
@@ -63,6 +66,12 @@ __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 2
 __device__ __forceinline__ int deq(int c, uint32_t q) { return (int)(int16_t)__mul24(c, (int)q); }   // int16 wrap (:869)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Image descriptors are read-only for the whole launch and every wave reads them at wave-uniform addresses: through the
+// constant address space they are scalar loads, which (unlike vector loads) do not queue behind the wave's outstanding
+// pixel stores — a vector load at the top of the strip loop made every strip wait for the previous strip's stores.
+typedef const DevImage __attribute__((address_space(4))) *ConstImage;
+__device__ __forceinline__ ConstImage cimg(const DevImage *p) { return (ConstImage)(uintptr_t)p; }
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte store at a dword-aligned address
 // two coefficients at once: the low 16 bits of a 16x16 product are exactly numpy's int16 * int16 wrap (:869)
 __device__ __forceinline__ uint32_t deq2(uint32_t c2, uint32_t q2) {
     const u16x2 p = __builtin_bit_cast(u16x2, c2) * __builtin_bit_cast(u16x2, q2);   // v_pk_mul_lo_u16
@@ -116,7 +125,8 @@ __device__ __forceinline__ int upsample_int(const int16_t *cp, int sx0, int sx1,
     const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
     const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
     const int w00 = w & 15, w01 = (w >> 4) & 15, w10 = (w >> 8) & 15, w11 = w >> 12;
-    const int s = w00 * cp[sx0 * 8 + sy0] + w01 * cp[sx0 * 8 + sy1] + w10 * cp[sx1 * 8 + sy0] + w11 * cp[sx1 * 8 + sy1];
+    auto v = [&](int i) { return (int)(int16_t)(cp[i] + 128); };        // strip holds chroma without the level shift
+    const int s = w00 * v(sx0 * 8 + sy0) + w01 * v(sx0 * 8 + sy1) + w10 * v(sx1 * 8 + sy0) + w11 * v(sx1 * 8 + sy1);
     return (int)(int16_t)((int)((unsigned)(2 * s + 15 + 30 * 65536) / 30u) - 65536);
 }
 
@@ -141,8 +151,8 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
                 Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
                 Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
             } else {
-                Cbv = mt[G::NBY * 64 + px * 8 + y];
-                Crv = mt[(G::NBY + 1) * 64 + px * 8 + y];
+                Cbv = (int)(int16_t)(mt[G::NBY * 64 + px * 8 + y] + 128);
+                Crv = (int)(int16_t)(mt[(G::NBY + 1) * 64 + px * 8 + y] + 128);
             }
             if (planes) { int16_t *pl = planes + (int64_t)y * planes_step; pl[0] = (int16_t)Yv; pl[1] = (int16_t)Cbv; pl[2] = (int16_t)Crv; }
             const uint32_t p = ycc_to_rgb_f64(Yv, Cbv, Crv);
@@ -154,9 +164,39 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
     }
 }
 
+// Green of one lane's pixel run, again, where the fp32 quotient of the fast path may be one off or sits on a tie
+// (|17207 cb + 35707 cr  mod 50000| within 1 of 25000): the reference's float64 expression for exactly those pixels,
+// patched into the bytes the fast path has already stored.  Integer upsample, so nothing here depends on fp32.
+template <int HS, int VS, bool T>
+__device__ __noinline__ void green_again(const int16_t *mt, int px, unsigned char *dst) {
+    using G = FGeo<HS, VS, 3>;
+    const uint16_t *w4 = w4_table<HS, VS, T>();
+    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+    const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
+#pragma unroll 1
+    for (int y = 0; y < G::MH; ++y) {
+        int Cbv, Crv;
+        if constexpr (G::SUB) {
+            const uint32_t w = w4[px * G::MH + y];
+            Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
+            Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
+        } else {
+            Cbv = (int)(int16_t)(mt[G::NBY * 64 + px * 8 + y] + 128);
+            Crv = (int)(int16_t)(mt[(G::NBY + 1) * 64 + px * 8 + y] + 128);
+        }
+        int r = (17207 * (Cbv - 128) + 35707 * (Crv - 128)) % 50000;
+        r = r < 0 ? -r : r;
+        if (r >= 24999 && r <= 25001) {
+            const int yb = T ? (px >> 3) * VS + (y >> 3) : (y >> 3) * HS + (px >> 3);
+            const uint32_t p = ycc_to_rgb_f64(mt[yb * 64 + (px & 7) * 8 + (y & 7)], Cbv, Crv);
+            dst[3 * y + 1] = (unsigned char)(p >> 8);
+        }
+    }
+}
+
 // Exact-order IDCT of one block by a whole wave (lane = x*8+y), result into the LDS strip.
 __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qblk, const double *tt, int16_t *out_lds,
-                                         int16_t *idct_out /* or null */, bool transposed) {
+                                         int16_t *idct_out /* or null */, bool transposed, bool chroma) {
     const int lane = threadIdx.x & 63;
     const int u = lane >> 3, v = lane & 7;
     const int src = transposed ? u * 8 + v : v * 8 + u;       // blocks (and tables) are stored [u][v] for row-major plans
@@ -180,8 +220,8 @@ __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qb
         }
     }
     const double s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
-    const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);
-    out_lds[transposed ? (lane & 7) * 8 + (lane >> 3) : lane] = (int16_t)val;   // strip holds [x'][y'] = [y][x] when transposed
+    const int raw = (int)(int16_t)(int)__builtin_rint(s), val = (int)(int16_t)(raw + 128);
+    out_lds[transposed ? (lane & 7) * 8 + (lane >> 3) : lane] = (int16_t)(chroma ? raw : val);   // [x'][y'] = [y][x] when transposed
     if (idct_out) idct_out[lane] = (int16_t)val;
 }
 
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         Strip st;
         st.im = a.images + img;
         // MCU grid of the (possibly transposed) image: mch columns, mcv rows
-        const int mch = T ? st.im->mcu_count_v : st.im->mcu_count_h, mcv = T ? st.im->mcu_count_h : st.im->mcu_count_v;
+        const int mch = T ? cimg(st.im)->mcu_count_v : cimg(st.im)->mcu_count_h, mcv = T ? cimg(st.im)->mcu_count_h : cimg(st.im)->mcu_count_v;
         const uint32_t spc = (uint32_t)(mcv + G::TMW - 1) / G::TMW;     // strips per MCU column
         st.mcu_x = __builtin_amdgcn_readfirstlane((int)(tile / spc));
         st.y_first = (int)(tile - (uint32_t)st.mcu_x * spc) * G::TMW;
@@ -253,10 +293,10 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         // coefficient blocks are in the ORIGINAL image's MCU raster: stepping down the strip moves one MCU row of the
         // original (or, transposed, one MCU to the right)
         if constexpr (T) {
-            st.cbase = a.coef + (st.im->block_off + (int64_t)st.mcu_x * mcv * G::NB) * 64;
+            st.cbase = a.coef + (cimg(st.im)->block_off + (int64_t)st.mcu_x * mcv * G::NB) * 64;
             st.row_elems = G::NB * 64;
         } else {
-            st.cbase = a.coef + (st.im->block_off + (int64_t)st.mcu_x * G::NB) * 64;
+            st.cbase = a.coef + (cimg(st.im)->block_off + (int64_t)st.mcu_x * G::NB) * 64;
             st.row_elems = mch * G::NB * 64;
         }
         return st;
@@ -283,7 +323,8 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     uint4 cw[G::ROUNDS];
     fetch(cur, cw);
     for (; tg < n_tiles; tg += stride_tiles) {
-        const DevImage *im = cur.im;
+        const DevImage *im_g = cur.im;
+        const ConstImage im = cimg(im_g);
         const int W = T ? im->height : im->width, H = T ? im->width : im->height;
         const int mch_o = im->mcu_count_h;              // MCUs per row of the ORIGINAL image (coefficient raster)
         const int mcu_x = cur.mcu_x, y_first = cur.y_first, n_valid = cur.n_valid;
@@ -294,8 +335,8 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         };
         const uint16_t *qbase = a.qt;
         const int q0i = im->qt_index[0] * 64, q1i = im->qt_index[NC == 3 ? 1 : 0] * 64, q2i = im->qt_index[NC == 3 ? 2 : 0] * 64;
-        if (im != qt_owner) {           // wave-uniform, rare: stage this image's tables (3 x 128 B) into the wave's LDS
-            qt_owner = im;
+        if (im_g != qt_owner) {           // wave-uniform, rare: stage this image's tables (3 x 128 B) into the wave's LDS
+            qt_owner = im_g;
             const int c = lane >> 4, part = lane & 15;     // lanes 0..47: 3 tables x 16 pieces of 8 bytes
             if (c < 3) {
                 const int qi = c == 0 ? q0i : (c == 1 ? q1i : q2i);
@@ -313,6 +354,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             const int bt = r * 8 + grp;
             const int k = bt / G::NB, b = bt - k * G::NB;
             const int qc = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
+            const int shift = qc == 0 ? 128 : 0;          // chroma stays centred in the strip
             const uint4 qw = *reinterpret_cast<const uint4 *>(s_qt + qc * 64 + j * 8);
             const uint32_t p0 = deq2(cw[r].x, qw.x), p1 = deq2(cw[r].y, qw.y), p2 = deq2(cw[r].z, qw.z), p3 = deq2(cw[r].w, qw.w);
             int d[8];
@@ -339,10 +381,10 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             for (int y = 0; y < 8; ++y) {
                 const double rr = __builtin_rint(t[y]);
                 err = fmax(err, __builtin_fabs(t[y] - rr));
-                o[y] = (int)(int16_t)((int)(int16_t)(int)rr + 128);
+                o[y] = (int)(int16_t)((int)(int16_t)(int)rr + shift);
             }
             if (dconly) {
-                const int vdc = (int)(int16_t)((int)(int16_t)(int)__builtin_rint((double)dc * T0) + 128);
+                const int vdc = (int)(int16_t)((int)(int16_t)(int)__builtin_rint((double)dc * T0) + shift);
 #pragma unroll
                 for (int y = 0; y < 8; ++y) o[y] = vdc;
             }
@@ -361,12 +403,9 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             if constexpr (SEAMS) {
                 if (a.idct_out && k < n_valid) {
                     int16_t *io = a.idct_out + (mcu_block(k) + b) * 64;     // seam order is the original [x][y]
-                    if constexpr (T) {
+                    const int back = 128 - shift;          // the :872 seam carries the level shift on every component
 #pragma unroll
-                        for (int y = 0; y < 8; ++y) io[y * 8 + j] = (int16_t)o[y];   // lane x' = original y
-                    } else {
-                        *reinterpret_cast<uint4 *>(io + j * 8) = ow;
-                    }
+                    for (int y = 0; y < 8; ++y) io[T ? y * 8 + j : j * 8 + y] = (int16_t)(o[y] + back);   // T: lane x' = original y
                 }
             }
         }
@@ -381,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             const int64_t blk = mcu_block(k) + b;
             const int qi = (NC == 1 || b < G::NBY) ? q0i : (b == G::NBY ? q1i : q2i);
             block_exact(a.coef + blk * 64, qbase + qi, a.idct_tt, s_strip + k * G::MCU_STRIDE + b * 64,
-                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr, T);
+                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr, T, NC == 3 && b >= G::NBY);
         }
 
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
@@ -394,10 +433,11 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         }
 
         // ================= phase B: pixels ==================
+        {
 #ifdef MJ_DIAGNOSTIC
-        if (pk < n_valid && a.debug != 2) {
+            const bool have = pk < n_valid && a.debug != 2;
 #else
-        if (pk < n_valid) {
+            const bool have = pk < n_valid;
 #endif
             const int gx = mcu_x * G::MW + px, gy0 = (y_first + pk) * G::MH;
             const int16_t *mt = s_strip + pk * G::MCU_STRIDE;
@@ -406,7 +446,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             constexpr int NBYTES = G::MH * NC;
 
             if constexpr (SEAMS) {
-                if (gx < W)
+                if (have && gx < W)
                     // planes are always the original x-major (W,H,C): transposed, this lane walks along the original x
                     pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows,
                                                    a.planes ? a.planes + (im->pix_off + (T ? (int64_t)gy0 * W + gx : (int64_t)gx * H + gy0)) * NC : nullptr,
@@ -415,14 +455,15 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 uint32_t ob[(NBYTES + 3) / 4];
 #pragma unroll
                 for (int i = 0; i < (NBYTES + 3) / 4; ++i) ob[i] = 0;
-                bool slow = false;
+                bool slow = false, regreen = false;
+                if (have) {
                 if constexpr (NC == 3) {
                     // chroma source rows sx0, sx0+1 of this lane's column, as floats
                     const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
                     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
-                    // (Cb, Cr) pairs: the two chroma planes ride in the two halves of packed-fp32 registers, so one
-                    // v_pk_* instruction serves both components
-                    // the packed int16 rows stay in 8 (16 with a second source row) registers; each half of the column
+                    // (Cb-128, Cr-128) pairs: the two chroma planes ride in the two halves of packed-fp32 registers, so
+                    // one v_pk_* instruction serves both components.
+                    // The packed int16 rows stay in 8 (16 with a second source row) registers; each half of the column
                     // converts only the source samples it touches, which keeps the live set under the 128-VGPR budget
                     const int16_t *cbp = mt + G::NBY * 64, *crp = cbp + 64;
                     const uint4 ba = *reinterpret_cast<const uint4 *>(cbp + sx0 * 8), ra = *reinterpret_cast<const uint4 *>(crp + sx0 * 8);
@@ -435,29 +476,35 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     }
                     auto pairA = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw[i >> 1]) : lo16(bw[i >> 1])), (float)((i & 1) ? hi16(rw[i >> 1]) : lo16(rw[i >> 1]))}; };
                     auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
+                    // largest |Cb-128|, |Cr-128| among the source samples (an upsampled value lies between its sources)
+                    // and largest |remainder| of the green term: both decide, once per lane, whether fp32 was exact
+                    float crange = 0.0f, remmax = 0.0f;
+                    constexpr float MAGIC = 12582912.0f;                       // 1.5 * 2^23: x + MAGIC rounds x to an integer
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
                         const int yb = T ? (px >> 3) * VS + by : by * HS + (px >> 3);   // original block order (:875)
                         const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
                         const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
                         // source samples this half of the column interpolates between
-                        constexpr int S_LO = (G::SUB && VS == 2) ? (7 * (8 * 0)) / 15 : 0;   // by = 0 starts at 0
-                        const int s_lo = (G::SUB && VS == 2) ? (7 * (by * 8)) / 15 : (G::SUB ? 0 : 0);
-                        (void)S_LO;
+                        const int s_lo = (G::SUB && VS == 2) ? (7 * (by * 8)) / 15 : 0;
                         f32x2 cA[8], cB[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const bool used = !G::SUB || VS == 1 || (i >= s_lo && i <= ((7 * (by * 8 + 7)) / 15) + 1);
                             if (used) {
                                 cA[i] = pairA(i);
-                                if constexpr (HS == 2) cB[i] = pairB(i);
+                                crange = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cA[i].x), __builtin_fabsf(cA[i].y)), crange);
+                                if constexpr (HS == 2) {
+                                    cB[i] = pairB(i);
+                                    crange = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cB[i].x), __builtin_fabsf(cB[i].y)), crange);
+                                }
                             }
                         }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int y = by * 8 + i;
                             const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
-                            f32x2 C;
+                            f32x2 C;                                               // (cb, cr) = (Cb - 128, Cr - 128)
                             if constexpr (G::SUB) {
                                 // sum(n_i v_i)/15 is never within 1/30 of a half-integer and the fp32 evaluation is
                                 // within 0.012 of it for any int16 inputs, so rintf() returns the reference's value
@@ -472,29 +519,31 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                                 }
                                 C = f32x2{__builtin_rintf(sv.x), __builtin_rintf(sv.y)};
                             } else {
-                                C = cA[y];
+                                C = cA[i];
                             }
-                            // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact: 1.402c = 701c/500 and
-                            // 1.772c = 443c/250 have their first exact .5 at |c| = 250 resp. 125 and are otherwise >= 0.002
-                            // away from one; N = 17207cb + 35707cr is an exact fp32 integer for |c| <= 255 and its
-                            // remainder against 50000 is obtained exactly with one fma.
-                            const f32x2 c2 = C - 128.0f;                                   // (cb, cr)
-                            const f32x2 p2 = c2 * f32x2{1.772f, 1.402f};
-                            const f32x2 br2 = f32x2{__builtin_rintf(p2.x), __builtin_rintf(p2.y)} + Yf;   // (B, R)
-                            const f32x2 n2 = c2 * f32x2{17207.0f, 35707.0f};               // both products exact
+                            // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact.
+                            // B, R: 1.772 cb = 443 cb / 250 and 1.402 cr = 701 cr / 500 hit an exact .5 first at |cb| = 125,
+                            // |cr| = 250 and are otherwise >= 0.002 away from one, far more than the fp32 constants are off;
+                            // one fma rounds  cb * 1.772 + (Y + MAGIC)  straight to  MAGIC + Y + round(1.772 cb).
+                            const float Ym = Yf + MAGIC;
+                            const f32x2 br2 = __builtin_elementwise_fma(C, f32x2{1.772f, 1.402f}, f32x2{Ym, Ym}) - MAGIC;   // (B, R)
+                            // G: N = 17207 cb + 35707 cr is an exact fp32 integer for |c| < 250; q = round(N / 50000) may
+                            // be off by one only when the remainder is within 1.6 of +-25000, which also covers the ties
+                            const f32x2 n2 = C * f32x2{17207.0f, 35707.0f};               // both products exact
                             const float N = n2.x + n2.y;                                  // exact: |N| < 2^24
-                            float q = __builtin_rintf(N * 2e-5f);
+                            const float q = __builtin_rintf(N * 2e-5f);
                             const float rem = __builtin_fmaf(-50000.0f, q, N);
-                            q += (rem > 25000.0f ? 1.0f : 0.0f) - (rem < -25000.0f ? 1.0f : 0.0f);
+                            remmax = __builtin_fmaxf(__builtin_fabsf(rem), remmax);
                             const float Gf = Yf - q;
-                            slow |= (__builtin_fabsf(c2.x) > 255.0f) | (__builtin_fabsf(c2.y) >= 250.0f) |
-                                    (__builtin_fabsf(c2.x) == 125.0f) | (__builtin_fabsf(rem) == 25000.0f);
+                            slow |= __builtin_fabsf(C.x) == 125.0f;
                             const int o0 = 3 * y, o1 = 3 * y + 1, o2 = 3 * y + 2;
                             ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.y, o0 & 3, ob[o0 >> 2]);
                             ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
                             ob[o2 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.x, o2 & 3, ob[o2 >> 2]);
                         }
                     }
+                    slow |= crange >= 250.0f;
+                    regreen = remmax >= 24998.5f;
                 } else {
                     const uint4 yw = *reinterpret_cast<const uint4 *>(mt + (px & 7) * 8);
                     const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
@@ -504,6 +553,9 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                         ob[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Yf, i & 3, ob[i >> 2]);
                     }
                 }
+                }   // have
+                const bool active = have && gx < W;
+                const bool fast = active && !slow && nrows == G::MH;
 #ifdef MJ_DIAGNOSTIC
                 if (a.debug == 3) { uint32_t acc = 0;
 #pragma unroll
@@ -511,7 +563,39 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     if (acc == 0x12345678u && slow) dst[0] = 1; }
                 else
 #endif
-                if (gx < W) {
+                // ---- stores.  A lane holds NBYTES consecutive bytes of one image column and the TMW lanes of a column
+                // hold one contiguous run; written lane by lane, one store instruction would touch 64 separate
+                // 16-byte pieces.  So the wave's bytes go through LDS (the transpose scratch is free now) and come back
+                // as 16-byte pieces in run order: consecutive lanes write consecutive addresses.
+                if (n_valid == G::TMW && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0) {
+                    constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
+                    static_assert(RUN % 16 == 0 && NBYTES % 8 == 0, "column runs are whole 16-byte pieces");
+                    unsigned char *s_out = smem + wave * G::WAVE_BYTES + G::STRIP_BYTES;
+                    unsigned char *mine = s_out + lane * NBYTES;
+                    if constexpr (NBYTES % 16 == 0) {
+#pragma unroll
+                        for (int i = 0; i < NBYTES / 16; ++i)
+                            reinterpret_cast<uint4 *>(mine)[i] = make_uint4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NBYTES / 8; ++i) reinterpret_cast<uint2 *>(mine)[i] = make_uint2(ob[2 * i], ob[2 * i + 1]);
+                    }
+                    const uint64_t am = __ballot(active);
+                    unsigned char *sbase = a.rgb + im->rgb_off + ((int64_t)(mcu_x * G::MW) * H + (int64_t)y_first * G::MH) * NC;
+#pragma unroll
+                    for (int t = 0; t * 64 < NPIECE; ++t) {
+                        const int pce = t * 64 + lane;                       // 16-byte piece of the wave's 64 runs
+                        const int c = (16 * pce) / RUN, o = (16 * pce) % RUN;
+                        const int src_lane = c * G::TMW + o / NBYTES;        // columns are active or inactive as a whole
+                        if (pce < NPIECE && ((am >> src_lane) & 1)) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(s_out + 16 * pce);
+                            *reinterpret_cast<u32x4_a4 *>(sbase + (int64_t)c * (H * NC) + o) = u32x4_a4{v.x, v.y, v.z, v.w};
+                        }
+                    }
+                    if constexpr (NC == 3) {
+                        if (regreen && fast) green_again<HS, VS, T>(mt, px, dst);
+                    }
+                } else if (active) {
                     if (slow || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
                         pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows, nullptr, 0);
                     } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
@@ -525,6 +609,9 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     } else {
 #pragma unroll
                         for (int i = 0; i < NBYTES / 4; ++i) reinterpret_cast<uint32_t *>(dst)[i] = ob[i];
+                    }
+                    if constexpr (NC == 3) {
+                        if (regreen && !slow && nrows == G::MH && ((uintptr_t)dst & 3) == 0) green_again<HS, VS, T>(mt, px, dst);
                     }
                 }
             }
