@@ -164,7 +164,10 @@ def main():
     if args.batch == 1024 and args.layout == "xmajor" and tfile is not None:
         for k, d in json.loads(tfile.read_text())["kernels"].items():
             if "traffic_bytes_per_launch" in d:
-                traffic["stage1" if "huffman" in k else "stage2"] = int(d["traffic_bytes_per_launch"])
+                if "huffman" in k or "destuff" in k or "scan_markers" in k:      # stage 0 + stage 1 launches of one step
+                    traffic["stage1"] = traffic.get("stage1", 0) + int(d["traffic_bytes_per_launch"])
+                elif "reconstruct" in k:
+                    traffic["stage2"] = int(d["traffic_bytes_per_launch"])
 
     def roof(name, nbytes, ms, note, tkey):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -173,8 +176,8 @@ def main():
                 "traffic_source": f"profiles/{tfile.name} (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else None,
                 "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4), "note": note}
 
-    r1 = roof("k_huffman_lanes / k_huffman (stage 1: Huffman decode)", s1_bytes, s1_ms,
-              "entropy bytes read + 128 B/block coefficients written; serial-decode (VALU issue) bound, quoted against HBM as SURVEY §8d asks",
+    r1 = roof("k_destuff + k_huffman_lanes (stage 0+1: byte-drop pass + Huffman decode; k_scan_markers too with --segment gpu)", s1_bytes, s1_ms,
+              "entropy bytes read + 128 B/block coefficients written; serial-decode (instruction issue) bound, quoted against HBM as SURVEY §8d asks",
               "stage1")
     r2 = roof("k_reconstruct_fast (stage 2: dequant+IDCT+upsample+colour)", s2_bytes, s2_ms,
               "128 B/block read + 3 B/pixel written = 12 487 680 B per 1080p image", "stage2")
