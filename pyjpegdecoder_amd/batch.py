@@ -320,5 +320,49 @@ class BatchDecoder:
                 plan.close()
         return (results, seams) if return_seams else results
 
+    def decode_device(self, files: Sequence[bytes]):
+        """Like :meth:`decode`, but the pixels stay in HBM: a list of ``torch.uint8`` tensors on this decoder's GPU,
+        views into one packed buffer per plan (zero-copy for any DLPack consumer via ``tensor.__dlpack__()``).
+        torch is only the allocator here; import it before this package."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        parsed = [parse_jpeg(f, headers_only=self.gpu_segment) for f in files]
+        groups: Dict[tuple, List[int]] = {}
+        for i, p in enumerate(parsed):
+            check_supported(p)
+            comps = list(p.color_components.values())
+            key = (p.scan_mode, len(comps), p.headers_only) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            groups.setdefault(key, []).append(i)
+        results: List[Optional["torch.Tensor"]] = [None] * len(files)
+        work = list(groups.values())
+        while work:
+            idxs = work.pop(0)
+            prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
+            d_blob = torch.from_numpy(prep.blob).to(dev)
+            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(idxs)})
+            try:
+                d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+                plan.execute(0, d_rgb.data_ptr())
+                plan.sync()
+                status = plan.read(rgb=False)["status"]
+                redo = [i for k, i in enumerate(idxs) if status[k] == B.MJ_ST_TAIL]
+                if redo:
+                    for i in redo:
+                        parsed[i] = parse_jpeg(files[i])
+                        check_supported(parsed[i])
+                    work.append(redo)
+                    status[[k for k, i in enumerate(idxs) if i in redo]] = 0
+                raise_for_status(status)
+                off = 0
+                for k, i in enumerate(idxs):
+                    w, h, nc = prep.shapes[k]
+                    n = w * h * nc
+                    shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
+                    results[i] = d_rgb[off:off + n].view(shape)
+                    off += n
+            finally:
+                plan.close()
+        return results
+
     def close(self):
         self.ctx.close()

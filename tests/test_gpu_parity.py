@@ -532,3 +532,53 @@ def test_gpu_segmentation_hands_back_what_it_cannot_segment(dec_gs):
         dec_gs.decode([no_marker])
     trailing = raw + b"\x00" * 37                                # bytes after EOI are nobody's business
     assert np.array_equal(dec_gs.decode([trailing])[0], vec["rgb"])
+
+
+def test_device_resident_output_and_dlpack(dec, dec_rm):
+    """§8 f-4: pixels stay in HBM as torch tensors (views of one packed buffer); any DLPack consumer can take them."""
+    import torch
+    names = ["70x50_420_pil_opt", "64x48_422_pil", "50x70_grey_dri4", "40x40_444_dri5", "128x64_420_dri3"]
+    raws = [load_golden(n)[0] for n in names]
+    outs = dec.decode_device(raws)
+    for n, t in zip(names, outs):
+        assert t.is_cuda and t.dtype == torch.uint8
+        assert np.array_equal(t.cpu().numpy(), load_golden(n)[1]["rgb"]), n
+        again = torch.from_dlpack(t)                       # zero-copy round trip
+        assert again.data_ptr() == t.data_ptr()
+    for n, t in zip(names, dec_rm.decode_device(raws)):
+        want = load_golden(n)[1]["rgb"]
+        assert np.array_equal(t.cpu().numpy(), np.swapaxes(want, 0, 1)), n
+
+
+def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
+    """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
+    reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""
+    import os
+    from pyjpegdecoder_amd import CorruptedJpeg, JpegError, parse_jpeg
+    rng = np.random.default_rng(1234)
+    for name in ("128x64_420_dri3", "64x64_420_pil", "40x40_444_dri5", "50x70_grey_dri4"):
+        raw, vec = load_golden(name)
+        sc = parse_jpeg(raw).scans[0]
+        lo, hi = int(sc.entropy_start), int(sc.entropy_end)
+        damaged = []
+        for _ in range(24):
+            b = bytearray(raw)
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(lo, hi))
+                b[pos] = int(rng.integers(0, 256))
+            damaged.append(bytes(b))
+        damaged.append(raw[:lo + (hi - lo) // 2] + raw[hi:])          # half the entropy data missing
+        damaged.append(raw[:hi] + b"\xff\xd9")
+        for mode in ("wave", "lanes"):
+            os.environ["MJ_HUFFMAN"] = mode
+            try:
+                for d in (dec, dec_gs):
+                    for f in damaged:
+                        try:
+                            img = d.decode([f])[0]
+                            assert img.shape == vec["rgb"].shape
+                        except JpegError:
+                            pass
+                    assert np.array_equal(d.decode([raw])[0], vec["rgb"])       # the decoder is still healthy
+            finally:
+                os.environ.pop("MJ_HUFFMAN", None)
