@@ -275,9 +275,18 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
     int use = lpw;
     if (use < 0) {
-        // measured on MI355X: the kernel is VALU-issue bound with every instruction costing the same
-        // whatever the number of active lanes, and latency-bound below ~2 waves per SIMD; ~2.7 waves per SIMD is best
-        const int64_t want = (n_segs + 2815) / 2816;
+        // measured on MI355X: the kernel is instruction-issue bound, every instruction costing the same
+        // whatever the number of active lanes, and latency bound below ~2 waves per SIMD.  All workgroups are resident
+        // at once and run equally long, so what matters besides ~3-4 waves per SIMD is that every CU gets the SAME
+        // number of workgroups: lanes per wave = segments / (4 workgroups x 4 waves x CUs), rounded up.
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        }
+        const int64_t per = (int64_t)16 * cus;
+        const int64_t want = (n_segs + per - 1) / per;
         use = (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
     }
     const int lpw_run = use;
