@@ -57,7 +57,24 @@ class HuffSpec:
     ``{codeword-string: value}`` dict (jpeg_decoder.py:366-377)."""
     bits: np.ndarray          # uint8[16]
     vals: np.ndarray          # uint8[n]
-    tree: Dict[str, int]
+    _tree: Optional[Dict[str, int]] = None
+
+    @property
+    def tree(self) -> Dict[str, int]:
+        """The reference's ``{zero-padded binary codeword: value}`` dict, built on first use (only the
+        ``JpegDecoder`` class surface shows it; batch decoding never needs the strings)."""
+        if self._tree is None:
+            tree: Dict[str, int] = {}
+            code, k = 0, 0
+            for bit_length, count in enumerate(self.bits.tolist(), start=1):
+                code <<= 1
+                for _ in range(count):
+                    if k < self.vals.size:
+                        tree[bin(code)[2:].rjust(bit_length, "0")] = int(self.vals[k])
+                    k += 1
+                    code += 1
+            self._tree = tree
+        return self._tree
 
 
 @dataclass
@@ -96,20 +113,13 @@ def parse_huffman_segment(data: bytes) -> Dict[int, HuffSpec]:
         bits[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
         pos += 16
         vals_by_len = []
-        for count in bits:
-            vals_by_len.append(data[pos:pos + int(count)])
-            pos += int(count)
+        for count in bits.tolist():
+            vals_by_len.append(data[pos:pos + count])
+            pos += count
         if pos > size:
             raise CorruptedJpeg("Failed to parse Huffman tables.")
-        tree: Dict[str, int] = {}
-        code = 0
-        for bit_length, values in enumerate(vals_by_len, start=1):
-            code <<= 1
-            for huffval in values:
-                tree[bin(code)[2:].rjust(bit_length, "0")] = huffval
-                code += 1
         vals = np.frombuffer(b"".join(vals_by_len), dtype=np.uint8).copy()
-        out[dest] = HuffSpec(bits=bits, vals=vals, tree=tree)
+        out[dest] = HuffSpec(bits=bits, vals=vals)
     return out
 
 
