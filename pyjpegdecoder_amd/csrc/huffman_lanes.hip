@@ -195,9 +195,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             // LUT entry = len << 11 | run << 4 | size; the end-of-block symbol carries run = 64, so "kk >= 64" covers
             // both :849 and :855-856 (the value bits stay unread in both cases).
             const uint16_t *alut = s_lut + act_ * kLSize;
-            while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
-                const bool on = k < 64;
-                refill(br, streamb);
+            // one symbol of this lane, if `on`: look up, EXTEND, store, consume
+            auto symbol = [&](bool on) {
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
                 int e = alut[hi >> (32 - kLBits)];
                 if (on && e < 2048) {                                         // code longer than 11 bits: rare (the branch
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 const int kk = k + ((e >> 4) & 127);
                 const bool val = on && kk < 64;
                 const int ln = on ? e >> 11 : 0, n = val ? (e & 15) : 0;
-                const uint32_t hw = hi << ln;                                  // ln + n <= 27 <= bc
+                const uint32_t hw = hi << ln;                                  // ln + n <= 31 <= bc
                 // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
                 // itself, a leading 0 is value - (2^n - 1) = -(~value).  Lanes with nothing to store (n = 0) write
                 // garbage to the row's pad slot instead of branching around the store.
@@ -218,7 +217,15 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 myblk16[n > 0 ? kk : 64] = (int16_t)((mag ^ neg) - neg);       // zig-zag order; the flush permutes
                 br.bb <<= ln + n;
                 br.bc -= ln + n;
-                k = val ? kk + 1 : 64;
+                k = on ? (val ? kk + 1 : 64) : k;
+            };
+            // Two symbols per iteration: the refill, the loop test and the register shuffling at the loop head are paid
+            // once.  After a refill the buffer holds >= 33 bits; the second symbol goes ahead when >= 31 are left
+            // (16 code bits + 15 value bits is the longest symbol), else it simply waits for the next iteration.
+            while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
+                refill(br, streamb);
+                symbol(k < 64);
+                symbol(k < 64 && br.bc >= 31);
             }
             // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
             err = (act && err == 0 && (int)((br.voff - voff0) * 8u) - br.bc > nbits) ? MJ_ST_OVERRUN : err;
