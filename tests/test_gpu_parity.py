@@ -582,3 +582,16 @@ def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
                     assert np.array_equal(d.decode([raw])[0], vec["rgb"])       # the decoder is still healthy
             finally:
                 os.environ.pop("MJ_HUFFMAN", None)
+
+
+def test_reference_repository_example_progressive_file(dec):
+    """4160x2340 4:2:0 progressive with DRI redefined between scans: the two truncations whose
+    decoded images the reference repository ships as PNGs, and the whole file against the oracle."""
+    from test_oracle_golden import _example, example_cut
+    from oracle import oracle
+    raw, meta, samples = _example()
+    cuts = [example_cut(raw, meta, 1), example_cut(raw, meta, 2)]
+    imgs = dec.decode(cuts + [raw])
+    for k in (1, 2):
+        assert sha(imgs[k - 1]) == meta["after_scan"][str(k)]["sha256_rgb_xmajor"], f"after scan {k}"
+    assert np.array_equal(imgs[2], oracle.decode(raw)["rgb"])

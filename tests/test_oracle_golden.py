@@ -88,3 +88,31 @@ def test_progressive_fixture_scan_by_scan(name):
     assert np.array_equal(out["coef"], vec["coef"]), "coefficients before the IDCT pass (incl. F8 refinement semantics)"
     assert np.array_equal(out["planes"], vec["planes"])
     assert np.array_equal(out["rgb"], vec["rgb"])
+
+
+def _example():
+    import json
+    d = GOLDEN / "example"
+    meta = json.loads((d / "known_answers.json").read_text())
+    raw = (d / "base_image.jpg").read_bytes()
+    return raw, meta, np.load(d / "samples.npz")
+
+
+def example_cut(raw, meta, k):
+    """The file as it stood after scan k: everything up to that scan's terminating marker, then EOI."""
+    return raw[:meta["scans"][k - 1]["entropy_end"]] + b"\xff\xd9"
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_reference_repository_known_answers_after_scan(k):
+    """The reference repository's own example (progressive, 4160x2340, restart interval redefined between scans):
+    its PNGs of the image after scan 1 and after scan 2 are known answers nobody here generated; the oracle's decode
+    of the file truncated after that scan must reproduce them exactly."""
+    import hashlib
+    from oracle import oracle
+    raw, meta, samples = _example()
+    out = oracle.decode(example_cut(raw, meta, k))["rgb"]
+    assert out.shape == (meta["width"], meta["height"], 3)
+    sx, sy = meta["sample_strides"]
+    assert np.array_equal(out[::sx, ::sy], samples[f"after_scan_{k}"])
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == meta["after_scan"][str(k)]["sha256_rgb_xmajor"]

@@ -38,6 +38,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 from tools import synth  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
+REF = Path("/root/reference")
 FILES = GOLD / "files"
 
 jd.JpegDecoder.show = lambda self: None  # never open a viewer
@@ -223,11 +224,45 @@ def capture_W(src, dst) -> np.ndarray:
     return Wi
 
 
+def example_known_answers():
+    """The reference repository's own known answers: `progressive scan example/` holds a 4160x2340 4:2:0 progressive
+    file whose restart interval is redefined between scans (4160 / 8320 MCUs, :474-503) and two PNGs of the padded
+    image array as it stood after scan 1 and after scan 2.  The JPEG is copied as a data fixture; of each PNG the
+    SHA-256 of the cropped image in the reference's [x, y, c] order and a strided sample are kept."""
+    from PIL import Image
+    src = REF / "progressive scan example"
+    out = GOLD / "example"
+    out.mkdir(parents=True, exist_ok=True)
+    raw = (src / "base image.jpg").read_bytes()
+    (out / "base_image.jpg").write_bytes(raw)
+    sys.path.insert(0, str(ROOT))
+    from pyjpegdecoder_amd import parse_jpeg
+    p = parse_jpeg(raw)
+    meta = {"source": "progressive scan example/base image.jpg", "width": p.image_width, "height": p.image_height,
+            "scans": [{"components": s.component_ids, "ss": s.spectral_start, "se": s.spectral_end, "ah": s.bit_high,
+                       "al": s.bit_low, "restart_interval": s.restart_interval, "entropy_end": int(s.entropy_end)} for s in p.scans],
+            "after_scan": {}}
+    samples = {}
+    for k, name in ((1, "after scan 01.png"), (2, "after scan 02.png")):
+        png = np.asarray(Image.open(src / name).convert("RGB"))             # (padded H, W, 3)
+        xy = np.ascontiguousarray(np.swapaxes(png[:p.image_height, :p.image_width], 0, 1))
+        meta["after_scan"][str(k)] = {"png": name, "png_shape": list(png.shape), "sha256_rgb_xmajor": sha(xy)}
+        samples[f"after_scan_{k}"] = xy[::41, ::37]
+    meta["sample_strides"] = [41, 37]
+    np.savez_compressed(out / "samples.npz", **samples)
+    (out / "known_answers.json").write_text(json.dumps(meta, indent=1))
+    print("example known answers:", {k: v["sha256_rgb_xmajor"][:16] for k, v in meta["after_scan"].items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--example", action="store_true", help="only (re)generate tests/golden/example from the reference's example directory")
     args = ap.parse_args()
+    if args.example:
+        example_known_answers()
+        return
     FILES.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(20261002)
 
