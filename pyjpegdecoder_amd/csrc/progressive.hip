@@ -46,11 +46,10 @@ __device__ __forceinline__ uint32_t take32(BitReader &br, int n) {
 __device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int al, int lane, int &coef, bool &dirty, bool spec) {
     while (queue) {
         br.refill();
-        const int n = min(16, __builtin_popcountll(queue));
-        // the n lowest queued positions
-        uint64_t part = queue;
-        for (int i = 0; i < n; ++i) part &= part - 1;
-        part = queue & ~part;
+        // the queued positions of the lowest non-empty 16-position window (at most 16 bits per refill)
+        const int w = __builtin_ctzll(queue) & ~15;
+        const uint64_t part = queue & ((uint64_t)0xFFFF << w);
+        const int n = __builtin_popcountll(part);
         queue &= ~part;
         const uint32_t bits = take32(br, n);
         if ((part >> lane) & 1) {
@@ -116,6 +115,37 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     if (is_dc) {
         // ------------------------------------------------------------ DC scans (:974-1057)
         int pred0 = 0, pred1 = 0, pred2 = 0;
+        if (refining) {
+            // One bit per block (:1038), blocks in scan order: lane i takes the i-th block of a group of 64, so the
+            // read-modify-write of 64 DC values is one load and one store instead of 64 dependent round trips.
+            int bps = 0;                                   // blocks per MCU of this scan
+            for (int i = 0; i < nsc; ++i) { const int c = sc->comp[i]; bps += (nsc > 1 && c == 0) ? hmax * vmax : 1; }
+            const int total = sg->n_mcu * bps;
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                const int n = min(64, total - t0);
+                br.refill();
+                const uint32_t w0 = take32(br, min(32, n));
+                br.refill();
+                const uint32_t w1 = take32(br, max(0, n - 32));
+                const int t = t0 + lane;
+                if (lane < n) {
+                    const int m = sg->mcu0 + t / bps;
+                    int j = t % bps, c = 0, r = 0;
+                    for (int i = 0; i < nsc; ++i) {               // which scan component / block of the MCU
+                        const int ci = sc->comp[i];
+                        const int cnt = (nsc > 1 && ci == 0) ? hmax * vmax : 1;
+                        if (j < cnt) { c = ci; r = j; break; }
+                        j -= cnt;
+                    }
+                    const int mcy = m / smh, mcx = m - mcy * smh;
+                    const int h = (nsc > 1 && c == 0) ? hmax : 1, v = (nsc > 1 && c == 0) ? vmax : 1;
+                    int16_t *p = block_ptr(c, mcx * h + r % h, mcy * v + r / h);
+                    const int nlo = min(32, n);
+                    const int bit = lane < 32 ? (w0 >> (nlo - 1 - lane)) & 1 : (w1 >> (n - 32 - 1 - (lane - 32))) & 1;
+                    p[0] = (int16_t)(p[0] | (int16_t)(bit << al));
+                }
+            }
+        } else
         for (int m = sg->mcu0; m < sg->mcu0 + sg->n_mcu && !err; ++m) {
             const int mcy = m / smh, mcx = m - mcy * smh;
             for (int i = 0; i < nsc && !err; ++i) {
@@ -149,9 +179,21 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
         const uint64_t band = bits_range(ss, se + 1);
         int eobrun = 0;
         const int m_end = sg->mcu0 + sg->n_mcu;
+        // refining scans read every block before they touch it: the next block's coefficients are requested while
+        // this one is being worked on (a dependent load per block was most of a refining scan's time)
+        int cf_next = 0;
+        if (refining && sg->n_mcu > 0) {
+            const int by0 = sg->mcu0 / smh, bx0 = sg->mcu0 - by0 * smh;
+            cf_next = block_ptr(c, bx0, by0)[nat];
+        }
         for (int m = sg->mcu0; m < m_end && !err; ++m) {
             const int by = m / smh, bx = m - by * smh;
             int16_t *p = block_ptr(c, bx, by);
+            const int cf_cur = cf_next;
+            if (refining && m + 1 < m_end) {
+                const int by1 = (m + 1) / smh, bx1 = (m + 1) - by1 * smh;
+                cf_next = block_ptr(c, bx1, by1)[nat];
+            }
             if (!refining) {
                 // -------- first scan of the band: only writes (:1177-1179, :1225, :1248-1250)
                 if (eobrun > 0) { --eobrun; continue; }
@@ -174,7 +216,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 if (eobrun > 0) --eobrun;          // the band that raised the run counts as its first one
             } else {
                 // -------- refining scan: coefficients of the block in the lanes (lane = zig-zag index)
-                int cf = p[nat];
+                int cf = cf_cur;
                 bool dirty = false;
                 if (eobrun > 0) {                   // inside an EOB run: every non-zero coefficient of the band gets a bit
                     const uint64_t nz = __ballot(cf != 0);
