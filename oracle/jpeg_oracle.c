@@ -414,6 +414,45 @@ int orc_progressive_scan(const uint8_t *file, int64_t file_size, int64_t start, 
     const int refining = s->ah != 0;
     int status = 0;
 
+    if (s->ss == 0 && s->se == 63) { /* --------------------------------- one component of a non-interleaved BASELINE file:
+        baseline_dct_scan (:734-866, :894-900) with a single scan component; the scan's MCU is one 8x8 block (:612-619) */
+        if (s->n_scan_comp != 1) { *end_pos = b.pos; return 5; }
+        const int c = s->scan_comp[0];
+        if (s->ncomp_frame > 1 && (s->hs[c] > 1 || s->vs[c] > 1)) { *end_pos = b.pos; return 5; }   /* the reference breaks here (:882-891) */
+        int16_t prev = 0;
+        for (int64_t mcu = 0; mcu < mcu_count;) {
+            int16_t *blk = coef + orc_block_index(s, &g, c, (int)(mcu % s->mcu_count_h), (int)(mcu / s->mcu_count_h)) * 64;
+            int sz = orc_next_huffval(&b, &dc_tabs[s->dc_sel[0]]);
+            if (sz < 0) { *end_pos = b.pos; return sz == -1 ? 1 : 2; }
+            uint32_t raw = orc_get_bits(&b, sz);
+            if (b.overrun) { *end_pos = b.pos; return 2; }
+            prev = (int16_t)(orc_extend(raw, sz) + prev);                                /* :818-820 */
+            blk[0] = prev;
+            int index = 1;
+            while (index < 64) {                                                         /* :834-866 */
+                int hv = orc_next_huffval(&b, &ac_tabs[s->ac_sel[0]]);
+                if (hv < 0) { *end_pos = b.pos; return hv == -1 ? 1 : 2; }
+                if (hv == 0x00) break;                                                   /* :849 */
+                index += hv >> 4;
+                if (index >= 64) break;                                                  /* :855-856 */
+                int n = hv & 0x0F;
+                if (n > 0) {
+                    uint32_t vb = orc_get_bits(&b, n);
+                    if (b.overrun) { *end_pos = b.pos; return 2; }
+                    blk[index] = (int16_t)orc_extend(vb, n);
+                }
+                index += 1;
+            }
+            mcu++;
+            if (s->restart_interval > 0 && mcu % s->restart_interval == 0 && mcu != mcu_count) {   /* :898-900 */
+                orc_restart(&b);
+                prev = 0;
+            }
+        }
+        *end_pos = b.pos;
+        return 0;
+    }
+
     if (s->ss == 0) { /* ------------------------------------------------ DC scan (:974-1057) */
         int16_t prev[3] = {0, 0, 0};
         for (int64_t mcu = 0; mcu < mcu_count;) {

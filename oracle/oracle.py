@@ -266,7 +266,7 @@ def decode(raw: bytes, want_idct: bool = False) -> Dict[str, Optional[np.ndarray
     container (host logic, checked separately against the reference's attribute surface)."""
     from pyjpegdecoder_amd._parse import parse_jpeg
     parsed = parse_jpeg(raw)
-    if parsed.scan_mode == "progressive_dct":
+    if parsed.scan_mode == "progressive_dct" or len(parsed.scans) > 1:     # scan by scan (non-interleaved baseline too)
         coef, st, frame = progressive_entropy_decode(parsed)
         if st:
             raise RuntimeError(f"oracle: progressive scan status {st}")

@@ -46,9 +46,24 @@ def check_supported(p: ParsedJpeg) -> ScanInfo:
         return p.scans[0]
     if p.scan_mode != "baseline_dct":
         raise UnsupportedJpeg("Encoding mode not supported. Only 'Baseline DCT' and 'Progressive DCT' are supported.")
-    if len(p.scans) != 1 or len(p.scans[0].component_ids) != len(p.color_components):
-        raise UnsupportedJpeg("Non-interleaved baseline scans are not supported by the MI355X path.")
+    if len(p.scans) == 1 and len(p.scans[0].component_ids) == len(p.color_components):
+        return p.scans[0]
+    # Non-interleaved baseline: one scan per component.  The reference only gets these right when no component is
+    # subsampled (it assigns the resized MCU into an 8x8 slot otherwise, jpeg_decoder.py:882-891), so that is the scope.
+    comps = p.color_components
+    single = all(len(sc.component_ids) == 1 for sc in p.scans)
+    once = sorted(sc.component_ids[0] for sc in p.scans) == sorted(comps) if single else False
+    flat = all(c.horizontal_sampling == 1 and c.vertical_sampling == 1 for c in comps.values())
+    if not (single and once and flat):
+        raise UnsupportedJpeg("Baseline files with several scans are supported when every scan holds one component, "
+                              "every component has one scan and no component is subsampled.")
     return p.scans[0]
+
+
+def is_scan_list(p: ParsedJpeg) -> bool:
+    """Files decoded scan by scan into the coefficient store (mj_batch.scans): progressive ones and baseline files
+    with one scan per component."""
+    return p.scan_mode == "progressive_dct" or len(p.scans) > 1
 
 
 def _segments_of(scan: ScanInfo, off: int):
@@ -147,12 +162,13 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
             qt_list.append(zz.astype(np.uint16))
         return qt_ids[key]
 
-    progressive = parsed[0].scan_mode == "progressive_dct" if parsed else False
+    progressive = is_scan_list(parsed[0]) if parsed else False       # "progressive" = scan-list batch from here on
     scan_list: List[B.ScanDescC] = []
     for i, p in enumerate(parsed):
         scan = check_supported(p)
-        if (p.scan_mode == "progressive_dct") != progressive:
-            raise UnsupportedJpeg("A batch holds either baseline or progressive files; split it.")
+        if is_scan_list(p) != progressive:
+            raise UnsupportedJpeg("A batch holds either single-scan baseline files or scan-by-scan (progressive / "
+                                  "non-interleaved) files; split it.")
         blob[offs[i]:offs[i] + sizes[i]] = np.frombuffer(p.raw, dtype=np.uint8)
         d = descs[i]
         if progressive:
@@ -177,7 +193,7 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
                 for k, cid in enumerate(sc.component_ids):
                     sd.comp[k] = comp_ids.index(cid)
                     tabs = sc.huffman_tables_id[cid]
-                    need_dc, need_ac = sc.spectral_start == 0 and sc.bit_high == 0, sc.spectral_start > 0
+                    need_dc, need_ac = sc.spectral_start == 0 and sc.bit_high == 0, sc.spectral_end > 0
                     if (need_dc and tabs.dc not in sc.huffman) or (need_ac and tabs.ac not in sc.huffman):
                         raise CorruptedJpeg("Scan uses a Huffman table that the file does not define.")
                     sd.dc_sel[k] = huff_id(sc.huffman[tabs.dc]) if need_dc else 0
@@ -284,7 +300,7 @@ class BatchDecoder:
         for i, p in enumerate(parsed):
             check_supported(p)
             comps = list(p.color_components.values())
-            key = (p.scan_mode, len(comps), p.headers_only) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
             groups.setdefault(key, []).append(i)
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)
@@ -331,7 +347,7 @@ class BatchDecoder:
         for i, p in enumerate(parsed):
             check_supported(p)
             comps = list(p.color_components.values())
-            key = (p.scan_mode, len(comps), p.headers_only) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
             groups.setdefault(key, []).append(i)
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
         work = list(groups.values())

@@ -384,13 +384,16 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             mj::DevProgScan ps{};
             ps.image = sd.image; ps.n_comp = sd.n_comp;
             if (sd.n_comp < 1 || sd.n_comp > d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: %d components", k, sd.n_comp);
-            if (sd.ss < 0 || sd.se > 63 || sd.se < sd.ss || sd.al < 0 || sd.al > 13 || (sd.ss == 0 && sd.se != 0))
+            // ss = 0, se = 63, ah = al = 0: a sequential (baseline) scan of one component — non-interleaved baseline files
+            const bool sequential = sd.ss == 0 && sd.se == 63 && sd.ah == 0 && sd.al == 0;
+            if (sd.ss < 0 || sd.se > 63 || sd.se < sd.ss || sd.al < 0 || sd.al > 13 || (sd.ss == 0 && sd.se != 0 && !sequential))
                 return fail(ctx, MJ_ERR_INVALID, "scan %d: bad spectral selection / successive approximation", k);
-            if (sd.ss > 0 && sd.n_comp != 1) return fail(ctx, MJ_ERR_INVALID, "scan %d: an AC scan has one component", k);
+            if ((sd.ss > 0 || sequential) && sd.n_comp != 1)
+                return fail(ctx, sequential ? MJ_ERR_UNSUPPORTED : MJ_ERR_INVALID, "scan %d: an AC or sequential scan has one component here", k);
             for (int i = 0; i < sd.n_comp; ++i) {
                 if (sd.comp[i] < 0 || sd.comp[i] >= d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: component out of range", k);
                 ps.comp[i] = sd.comp[i];
-                const bool need_dc = sd.ss == 0 && sd.ah == 0, need_ac = sd.ss > 0;
+                const bool need_dc = sd.ss == 0 && sd.ah == 0, need_ac = sd.se > 0;
                 if ((need_dc && (sd.dc_sel[i] < 0 || sd.dc_sel[i] >= b->n_huff)) || (need_ac && (sd.ac_sel[i] < 0 || sd.ac_sel[i] >= b->n_huff)))
                     return fail(ctx, MJ_ERR_INVALID, "scan %d: Huffman table selector out of range", k);
                 ps.dc_tab[i] = need_dc ? sd.dc_sel[i] : 0;

@@ -83,13 +83,14 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     uint16_t *my_lut = s_lut + (size_t)wave * 3 * kLutSize;
     const int ss = sc->ss, se = sc->se, al = sc->al;
     const bool refining = sc->ah != 0;
-    const bool is_dc = ss == 0;
+    const bool sequential = ss == 0 && se == 63;          // one component, DC + AC per block (baseline_dct_scan, :734-866)
+    const bool is_dc = ss == 0 && !sequential;
     const int nsc = sc->n_comp;
 
-    // tables of this scan: DC scans use one DC table per scan component, AC scans one AC table
-    const int n_tabs = is_dc ? (refining ? 0 : nsc) : 1;
+    // tables of this scan: DC scans use one DC table per scan component, AC scans one AC table, sequential scans both
+    const int n_tabs = sequential ? 2 : (is_dc ? (refining ? 0 : nsc) : 1);
     for (int t = 0; t < n_tabs; ++t) {
-        const int gi = is_dc ? sc->dc_tab[t] : sc->ac_tab[0];
+        const int gi = sequential ? (t == 0 ? sc->dc_tab[0] : sc->ac_tab[0]) : (is_dc ? sc->dc_tab[t] : sc->ac_tab[0]);
         reinterpret_cast<uint4 *>(my_lut + t * kLutSize)[lane] = reinterpret_cast<const uint4 *>(huff[gi].lut)[lane];
     }
 
@@ -112,7 +113,38 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     const int nat = store_pos(lane);
     int err = 0;
 
-    if (is_dc) {
+    if (sequential) {
+        // ------------------------------------------------------------ one component of a non-interleaved baseline file:
+        // the scan's MCU is one 8x8 block, blocks in raster order of the component (:612-619, :771-866)
+        const int c = sc->comp[0];
+        int pred = 0;
+        for (int m = sg->mcu0; m < sg->mcu0 + sg->n_mcu && !err; ++m) {
+            const int by = m / smh, bx = m - by * smh;
+            int16_t *p = block_ptr(c, bx, by);
+            br.refill();
+            const int s = decode_symbol(br, my_lut, huff + sc->dc_tab[0]);
+            if (s < 0 || s > 16) { err = MJ_ST_BAD_CODE; break; }
+            int diff = 0;
+            if (s > 0) diff = extend(br.take(s), s);
+            pred = (int)(int16_t)(diff + pred);                                          // (:818-820)
+            if (lane == 0) p[0] = (int16_t)pred;
+            int k = 1;
+            while (k < 64) {                                                             // (:834-866)
+                br.refill();
+                const int hv = decode_symbol(br, my_lut + kLutSize, huff + sc->ac_tab[0]);
+                if (hv < 0) { err = MJ_ST_BAD_CODE; break; }
+                if (hv == 0) break;                                                      // end of block (:849)
+                k += hv >> 4;
+                if (k >= 64) break;                                                      // (:855-856): value bits stay unread
+                const int n = hv & 15;
+                if (n > 0) {
+                    const int val = extend(br.take(n), n);
+                    if (lane == 0) p[store_pos(k)] = (int16_t)val;
+                }
+                ++k;
+            }
+        }
+    } else if (is_dc) {
         // ------------------------------------------------------------ DC scans (:974-1057)
         int pred0 = 0, pred1 = 0, pred2 = 0;
         if (refining) {

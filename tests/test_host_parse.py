@@ -42,7 +42,9 @@ def test_restart_segmentation(name):
         assert so.size - 1 == -(-scan.mcu_count // scan.restart_interval)
         for k, off in enumerate(so[1:-1]):
             assert raw[off - 2] == 0xFF and raw[off - 1] == 0xD0 + (k % 8)
-    assert raw[scan.entropy_end:scan.entropy_end + 2] == b"\xFF\xD9"
+    # what ends a scan: EOI after the last one, the next SOS in non-interleaved files
+    assert raw[scan.entropy_end:scan.entropy_end + 2] == (b"\xFF\xD9" if len(p.scans) == 1 else b"\xFF\xDA")
+    assert raw[p.scans[-1].entropy_end:p.scans[-1].entropy_end + 2] == b"\xFF\xD9"
 
 
 def test_not_jpeg():

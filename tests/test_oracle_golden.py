@@ -52,8 +52,8 @@ def test_file_fixture_every_seam(name):
     # G2: dequantised blocks
     deq = []
     bpm_comp = []
-    scan = parsed.scans[0]
-    comps = [parsed.color_components[c] for c in scan.component_ids]
+    scan = parsed.scans[-1]                      # non-interleaved files (ni_*): one scan per component
+    comps = [parsed.color_components[c] for c in (scan.component_ids if len(parsed.scans) == 1 else parsed.color_components)]
     for c in comps:
         bpm_comp += [c.quantization_table_id] * (c.repeat if len(comps) > 1 else 1)
     for i in range(out["coef"].shape[0]):

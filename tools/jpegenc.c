@@ -199,7 +199,9 @@ static void put_marker_seg(BitW *w, uint8_t m, const uint8_t *data, int len) {
 long mjenc_encode_rgb(const uint8_t *rgb, int W, int H, int quality, int subsamp,
                       int restart_interval, uint8_t *out, size_t cap) {
     if (!fd_ready) fd_init();
-    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || subsamp < 0 || subsamp > 4) return -1;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || subsamp < 0 || subsamp > 5) return -1;
+    const int non_interleaved = subsamp == 5;     /* 4:4:4 with one scan per component */
+    if (non_interleaved) subsamp = 0;
     int ncomp = subsamp == 4 ? 1 : 3;
     int hs = (subsamp == 1 || subsamp == 2) ? 2 : 1;
     int vs = (subsamp == 2 || subsamp == 3) ? 2 : 1;
@@ -284,6 +286,33 @@ long mjenc_encode_rgb(const uint8_t *rgb, int W, int H, int quality, int subsamp
     if (restart_interval > 0) {
         uint8_t seg[2] = {(uint8_t)(restart_interval >> 8), (uint8_t)restart_interval};
         put_marker_seg(&w, 0xDD, seg, 2);
+    }
+    if (non_interleaved) {
+        /* three scans, one component each: the scan's MCU is one 8x8 block, blocks in raster order */
+        float *P[3] = {Y, Cb, Cr};
+        float blk[64]; int16_t zz[64];
+        for (int c = 0; c < 3; c++) {
+            uint8_t seg[6]; int n = 0;
+            seg[n++] = 1; seg[n++] = (uint8_t)(c + 1); seg[n++] = c == 0 ? 0x00 : 0x11;
+            seg[n++] = 0; seg[n++] = 63; seg[n++] = 0;
+            put_marker_seg(&w, 0xDA, seg, n);
+            int pred1 = 0, total = mcus_x * mcus_y, rst = 0;
+            for (int m = 0; m < total; m++) {
+                int x0 = (m % mcus_x) * 8, y0 = (m / mcus_x) * 8;
+                for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) blk[y*8+x] = P[c][(size_t)(y0 + y) * PW + x0 + x];
+                fdct_quant(blk, qt[c == 0 ? 0 : 1], zz);
+                encode_block(&w, zz, &pred1, &hdc[c == 0 ? 0 : 1], &hac[c == 0 ? 0 : 1]);
+                if (restart_interval > 0 && (m + 1) % restart_interval == 0 && m + 1 != total) {
+                    flush_bits(&w);
+                    put_byte(&w, 0xFF); put_byte(&w, (uint8_t)(0xD0 + (rst & 7))); rst++;
+                    pred1 = 0;
+                }
+            }
+            flush_bits(&w);
+        }
+        put_byte(&w, 0xFF); put_byte(&w, 0xD9);
+        free(Y); free(Cb); free(Cr);
+        return w.overflow ? -1 : (long)(w.p - out);
     }
     {
         uint8_t seg[1 + 6 + 3]; int n = 0;

@@ -188,6 +188,10 @@ def file_fixtures(big: bool):
     flat = np.full((32, 48, 3), 77, dtype=np.uint8)
     flat[:, 24:] = (200, 30, 120)
     fx.append(("48x32_420_flat", synth.encode_rgb(flat, 50, "420", 0)))
+    # non-interleaved baseline (one scan per component): plain, with DRI, non-multiple-of-8 size
+    fx.append(("ni_40x24_444", synth.encode_rgb(S(30, 40, 24), 85, "444ni", 0)))
+    fx.append(("ni_64x48_444_dri5", synth.encode_rgb(S(31, 64, 48), 90, "444ni", 5)))
+    fx.append(("ni_37x29_444_dri4", synth.encode_rgb(synth.synth_rgb(32, 37, 29, 30.0), 95, "444ni", 4)))
     # config 2 shape (512x512 4:2:0, no DRI)
     fx.append(("c2_512x512_420", synth.encode_rgb(S(16, 512, 512), 85, "420", 0)))
     if big:
@@ -357,6 +361,12 @@ def main():
             continue
         dec, cap = run_reference(path)
         coef, deq, idct_o = np.stack(cap["coef"]), np.stack(cap["deq"]), np.stack(cap["idct"])
+        if name.startswith("ni_"):
+            # captured scan by scan (all Y blocks, all Cb, all Cr); the seam arrays are kept in the interleaved block
+            # order of the coefficient store, like every other fixture: block of MCU m, component c at m * 3 + c
+            nb = coef.shape[0] // 3
+            order = np.arange(3 * nb).reshape(3, nb).T.reshape(-1)
+            coef, deq, idct_o = coef[order], deq[order], idct_o[order]
         rgb = np.asarray(dec.image_array)
         meta = attrs_of(dec)
         meta["sha256"] = {"coef": sha(coef), "deq": sha(deq), "idct": sha(idct_o), "planes": sha(cap["planes"]), "rgb": sha(rgb)}
