@@ -102,7 +102,9 @@ typedef struct {
     int64_t first_segment;        /* index of this image's first entry in seg_begin / seg_end                 */
 } mj_image_desc;
 
-/* One SOS of a progressive (SOF2) image: what start_of_scan (:505-650) hands to progressive_dct_scan (:908).
+/* One SOS of an image that is decoded scan by scan: what start_of_scan (:505-650) hands to progressive_dct_scan
+ * (:908) for a progressive (SOF2) image, or to baseline_dct_scan (:697) for a baseline image with one scan per
+ * component (then ss = 0, se = 63, ah = al = 0, n_comp = 1, no component subsampled).
  * Scans must be listed image by image, in file order. */
 typedef struct {
     int32_t image;                /* index into mj_batch.images                                               */
@@ -137,9 +139,10 @@ typedef struct {
     int32_t layout;                       /* MJ_LAYOUT_*                                                     */
     uint32_t flags;                       /* MJ_FLAG_*                                                       */
 
-    int32_t n_scans;                      /* 0 = baseline batch; > 0 = progressive batch: every image is SOF2  */
+    int32_t n_scans;                      /* 0 = single-scan baseline batch; > 0 = scan-by-scan batch: every image is
+                                             progressive (SOF2) or non-interleaved baseline                    */
     const mj_scan_desc *scans;            /* host; the images' own n_segments / first_segment / table selectors
-                                             are ignored in a progressive batch                               */
+                                             are ignored in a scan-by-scan batch                              */
 } mj_batch;
 
 /* Sizes and per-image offsets of a plan's outputs (all outputs are packed image after image). */
