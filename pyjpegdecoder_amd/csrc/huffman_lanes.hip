@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2) + wave * wstride;
     // output byte offset of every lane's segment, for the flush (lane (o, dw) needs block o's, not its own)
     uint64_t *s_base = reinterpret_cast<uint64_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4) + wave * lpw2;
+    // what a lane that sits a symbol out reads instead of its LUT: length 0, run 64, size 0 (bit 15 keeps it apart from
+    // the all-zero "longer than 11 bits" entries; real lengths are 1..11 and use bits 11..14)
+    uint16_t *s_null = reinterpret_cast<uint16_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4 + (size_t)4 * lpw2 * 8);
+    if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));
 
     for (int i = tid; i < n_huff * kLSize / 8; i += 256)
         reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
@@ -195,37 +199,46 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             // LUT entry = len << 11 | run << 4 | size; the end-of-block symbol carries run = 64, so "kk >= 64" covers
             // both :849 and :855-856 (the value bits stay unread in both cases).
             const uint16_t *alut = s_lut + act_ * kLSize;
-            // one symbol of this lane, if `on`: look up, EXTEND, store, consume
-            auto symbol = [&](bool on) {
+            // One symbol of this lane: look up, EXTEND, store, consume.  Lanes that sit this one out (`on` false) read the
+            // null entry instead of their LUT — length 0, run 64, size 0 — and fall through the same straight-line code
+            // without consuming or storing anything; `parked` says whether k may be set to 64 for them (true when they
+            // are at their end of block anyway, false when they only wait for more bits).
+            auto symbol = [&](bool on, bool parked) {
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
-                int e = alut[hi >> (32 - kLBits)];
-                if (on && e < 2048) {                                         // code longer than 11 bits: rare (the branch
+                const uint16_t *ep = alut + (hi >> (32 - kLBits));
+                const int e = *(on ? ep : s_null);
+                int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
+                if (e < 2048) {                                               // code longer than 11 bits: rare (the branch
                     const int r = long_code(huff + act_, hi >> 16);           // is skipped when no lane has one)
                     err = r < 0 ? MJ_ST_BAD_CODE : err;
                     const int hv = r & 0xFF;
-                    e = r < 0 ? (64 << 4) : ((r >> 8) << 11) | ((hv == 0 ? 64 : hv >> 4) << 4) | (hv & 15);
+                    ln = r < 0 ? 0 : r >> 8;
+                    run = (r < 0 || hv == 0) ? 64 : hv >> 4;
+                    size = r < 0 ? 0 : hv & 15;
                 }
-                const int kk = k + ((e >> 4) & 127);
-                const bool val = on && kk < 64;
-                const int ln = on ? e >> 11 : 0, n = val ? (e & 15) : 0;
+                const int kk = k + run;
+                const bool val = kk < 64;                                      // not end of block (:849), not past it (:855-856)
+                const int n = val ? size : 0;                                  // else the value bits stay unread
                 const uint32_t hw = hi << ln;                                  // ln + n <= 31 <= bc
                 // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
-                // itself, a leading 0 is value - (2^n - 1) = -(~value).  Lanes with nothing to store (n = 0) write
-                // garbage to the row's pad slot instead of branching around the store.
-                const uint32_t neg = ~(uint32_t)((int32_t)hw >> 31);          // all ones for a leading 0
-                const uint32_t mag = (hw ^ neg) >> ((32 - n) & 31);
-                myblk16[n > 0 ? kk : 64] = (int16_t)((mag ^ neg) - neg);       // zig-zag order; the flush permutes
+                // itself, a leading 0 is value - (2^n - 1).  n = 0 (a run of 16, or nothing to do) gives 0, stored over a
+                // coefficient that is still 0, or into the row's pad slot (index 64) when the block is over.
+                const uint32_t lead = (uint32_t)((int32_t)hw >> 31);           // all ones for a leading 1
+                const uint32_t raw = __builtin_amdgcn_ubfe(hw, (uint32_t)(32 - n) & 31u, (uint32_t)n);
+                const uint32_t ones = ((1u << n) - 1u) & ~lead;
+                myblk16[min(kk, 64)] = (int16_t)(raw - ones);                  // zig-zag order; the flush permutes
                 br.bb <<= ln + n;
                 br.bc -= ln + n;
-                k = on ? (val ? kk + 1 : 64) : k;
+                const int knew = val ? kk + 1 : 64;
+                k = parked ? knew : (on ? knew : k);
             };
             // Two symbols per iteration: the refill, the loop test and the register shuffling at the loop head are paid
             // once.  After a refill the buffer holds >= 33 bits; the second symbol goes ahead when >= 31 are left
             // (16 code bits + 15 value bits is the longest symbol), else it simply waits for the next iteration.
             while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
                 refill(br, streamb);
-                symbol(k < 64);
-                symbol(k < 64 && br.bc >= 31);
+                symbol(k < 64, true);
+                symbol(k < 64 && br.bc >= 31, false);
             }
             // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
             err = (act && err == 0 && (int)((br.voff - voff0) * 8u) - br.bc > nbits) ? MJ_ST_OVERRUN : err;
@@ -299,7 +312,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     const int lpw_run = use;
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
-    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8;
+    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
