@@ -595,3 +595,32 @@ def test_reference_repository_example_progressive_file(dec):
     for k in (1, 2):
         assert sha(imgs[k - 1]) == meta["after_scan"][str(k)]["sha256_rgb_xmajor"], f"after scan {k}"
     assert np.array_equal(imgs[2], oracle.decode(raw)["rgb"])
+
+
+def test_caller_stream_and_device_blob(dec):
+    """The C ABI takes a caller's HIP stream and device pointers (blob in, pixels out): work queued on a non-default
+    torch stream is ordered with that stream's other work and nothing else is synchronised."""
+    import torch
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    names = ["128x64_420_dri3", "100x36_420_dri7", "96x64_420_q100_noise"]
+    raws = [load_golden(n)[0] for n in names]
+    prep = prepare_batch(raws)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        d_blob = torch.from_numpy(prep.blob).to(dev, non_blocking=True)
+        plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(raws)})
+        try:
+            d_rgb = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            for _ in range(3):                                   # re-execution of one plan is idempotent
+                plan.execute(st.cuda_stream, d_rgb.data_ptr())
+            flipped = 255 - d_rgb                                # consumer on the same stream, no explicit sync in between
+            st.synchronize()
+            out = dec.split_outputs(prep, d_rgb.cpu().numpy())
+            for n, img in zip(names, out):
+                assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
+            assert torch.equal(flipped, 255 - d_rgb)
+            assert not plan.read(rgb=False)["status"].any()
+        finally:
+            plan.close()
