@@ -128,7 +128,9 @@ typedef struct {
                                              plan, and be readable 256 bytes past every segment end: stage 1 prefetches) */
 
     int64_t n_segments;                   /* total entries of the two arrays below                          */
-    const int64_t *seg_begin;             /* host: blob offset of the first entropy byte of each segment    */
+    const int64_t *seg_begin;             /* host: blob offset of the first entropy byte of each segment; list them in
+                                             ascending blob order (any order works, but only ordered batches take the
+                                             lane-parallel stage 1)                                          */
     const int64_t *seg_end;               /* host: blob offset one past its last entropy byte (= position of
                                              the RSTn / next marker)                                         */
     int32_t n_huff;

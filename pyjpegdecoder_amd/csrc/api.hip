@@ -513,7 +513,15 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // one segment per lane pays off once there are enough segments to fill the chip that way
         const char *force = getenv("MJ_HUFFMAN");
         // (a table serving as DC and as AC table at once, or a stream beyond 32-bit offsets, stays with the wave form)
-        const bool lanes_ok = b->n_huff <= mj::kMaxLaneTables && !both_roles && !prog &&
+        // stage 0 places segment i's stream at dword (begin_i >> 2) + i: that needs the segments (or, with the GPU
+        // marker scan, the images' byte ranges) in ascending, non-overlapping blob order — what any packer produces
+        bool ordered = true;
+        if (jobs.empty()) {
+            for (size_t i = 1; i < segs.size() && ordered; ++i) ordered = segs[i].begin >= segs[i - 1].begin + segs[i - 1].len;
+        } else {
+            for (size_t i = 1; i < jobs.size() && ordered; ++i) ordered = jobs[i].begin >= jobs[i - 1].end;
+        }
+        const bool lanes_ok = ordered && b->n_huff <= mj::kMaxLaneTables && !both_roles && !prog &&
                               (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
         p->use_lanes = lanes_ok && (int64_t)segs.size() >= 8192;
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
