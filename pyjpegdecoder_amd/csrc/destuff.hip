@@ -112,19 +112,27 @@ __global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blo
 // itself never looks at those bytes (it skips two bytes after every restart_interval MCUs, jpeg_decoder.py:667-669,
 // :898-900); a file whose marker count differs from ceil(mcu_count / restart_interval) - 1 is reported as
 // MJ_ST_DESYNC, and one whose scan is not followed by EOI as MJ_ST_TAIL (the host parser has to look at it).
-// One wavefront per image, 4 KiB per iteration; markers are rare, so they are emitted by scalar code in file order.
-__global__ __launch_bounds__(64) void k_scan_markers(const uint8_t *__restrict__ blob, const DevScanJob *__restrict__ jobs,
-                                                    int n_jobs, DevSegment *__restrict__ segs, int32_t *__restrict__ status) {
-    const int lane = threadIdx.x;
+// One workgroup per image: its four waves take 4 KiB pieces of the range in turn, append the (rare) marker positions
+// to a list in LDS in whatever order they find them and keep the lowest terminator position; the list is then
+// rank-sorted and thread r writes segment r.  More markers than the list holds: MJ_ST_TAIL, the host segments it.
+namespace {
+constexpr int kScanCap = 2048;
+}
+__global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict__ blob, const DevScanJob *__restrict__ jobs,
+                                                     int n_jobs, DevSegment *__restrict__ segs, int32_t *__restrict__ status) {
+    __shared__ uint32_t s_pos[kScanCap], s_sorted[kScanCap];
+    __shared__ uint32_t s_count, s_term;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const DevScanJob *jb = jobs + blockIdx.x;
     const int64_t begin = jb->begin, end = jb->end, first = jb->first_seg;
     const int n_seg = jb->n_seg;
     const int64_t abase = begin & ~(int64_t)15;
-    const int len32 = (int)(end - begin);
-    int r = 0;                           // markers seen
-    int64_t cur_begin = begin, T = end;
-    bool stop = false;
-    for (int64_t c0 = abase; c0 < end && !stop; c0 += 4096) {
+    const uint32_t len32 = (uint32_t)(end - begin);
+    if (tid == 0) { s_count = 0; s_term = len32; }
+    __syncthreads();
+    for (int64_t c0 = abase + (int64_t)wave * 4096; c0 < end; c0 += 4 * 4096) {
+        // everything behind the terminator is somebody else's data (wave-uniform test; the value only ever drops)
+        if (c0 > begin && (uint32_t)(c0 - begin) > *(volatile uint32_t *)&s_term) break;
         uint4 w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -133,9 +141,9 @@ __global__ __launch_bounds__(64) void k_scan_markers(const uint8_t *__restrict__
         }
         const uint32_t tail = c0 + 4096 < end ? blob[c0 + 4096] : 0u;
 #pragma unroll
-        for (int q = 0; q < 4 && !stop; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const uint32_t d[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
-            // the byte after this lane's sixteen: the next lane's first, the next row's, or the next iteration's
+            // the byte after this lane's sixteen: the next lane's first, the next row's, or the next piece's
             uint32_t nb = __shfl_down(d[0], 1) & 0xFFu;
             const uint32_t wrap = q < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)w[q < 3 ? q + 1 : 3].x) & 0xFFu : tail;
             nb = lane == 63 ? wrap : nb;
@@ -151,54 +159,69 @@ __global__ __launch_bounds__(64) void k_scan_markers(const uint8_t *__restrict__
             }
             // bytes of the range whose successor is in the range too: begin <= p, p + 1 < end
             const int rel = (int)(c0 + q * 1024 + lane * 16 - begin);
-            const int lo = rel < 0 ? -rel : 0, hi = len32 - 1 - rel;          // valid j: lo <= j < hi
+            const int lo = rel < 0 ? -rel : 0, hi = (int)len32 - 1 - rel;           // valid j: lo <= j < hi
             const uint32_t vmask = hi <= 0 || lo >= 16 ? 0u : ((hi >= 16 ? 0xFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u));
             rstm &= vmask;
             termm &= vmask;
-            const uint64_t tb = __ballot(termm != 0);
-            int64_t tpos = end;
-            if (tb) {
-                const int L = __builtin_ctzll(tb);
-                tpos = c0 + q * 1024 + L * 16 + __builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)termm, L));
-                T = tpos;
-                stop = true;
-            }
-            uint64_t rb = __ballot(rstm != 0);
-            while (rb) {
-                const int L = __builtin_ctzll(rb);
-                rb &= rb - 1;
-                uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)rstm, L);
-                while (bits) {
-                    const int j = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const int64_t p = c0 + q * 1024 + L * 16 + j;
-                    if (p > tpos) { rb = 0; break; }
-                    if (r + 1 < n_seg && lane == 0) {
-                        segs[first + r].begin = cur_begin;
-                        segs[first + r].len = (int32_t)(p - cur_begin);
-                    }
-                    cur_begin = p + 2;
-                    ++r;
-                }
+            if (termm) atomicMin(&s_term, (uint32_t)(rel + __builtin_ctz(termm)));
+            while (rstm) {
+                const int j = __builtin_ctz(rstm);
+                rstm &= rstm - 1;
+                const uint32_t slot = atomicAdd(&s_count, 1u);
+                if (slot < (uint32_t)kScanCap) s_pos[slot] = (uint32_t)(rel + j);
             }
         }
     }
-    if (lane == 0) {
-        const int last = r < n_seg - 1 ? r : n_seg - 1;
-        if (r <= n_seg - 1) {
-            segs[first + last].begin = cur_begin;
-            segs[first + last].len = (int32_t)(T > cur_begin ? T - cur_begin : 0);
+    __syncthreads();
+    const uint32_t T = s_term;                       // range-relative end of the entropy-coded data
+    const uint32_t n_found = s_count;
+    if (n_found > (uint32_t)kScanCap) {              // pathological restart interval: let the host do it
+        if (tid == 0) atomicMax(status + jb->image, MJ_ST_TAIL);
+        return;
+    }
+    // rank sort of the markers in front of the terminator (positions are distinct)
+    for (uint32_t i = tid; i < n_found; i += 256) {
+        const uint32_t p = s_pos[i];
+        if (p >= T) continue;
+        uint32_t r = 0;
+        for (uint32_t k2 = 0; k2 < n_found; ++k2) r += s_pos[k2] < p ? 1u : 0u;
+        s_sorted[r] = p;
+    }
+    __shared__ uint32_t s_m;
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    {
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < n_found; i += 256) mine += s_pos[i] < T ? 1u : 0u;
+        if (mine) atomicAdd(&s_m, mine);
+    }
+    __syncthreads();
+    const int m = (int)s_m;                          // markers = segments that end at one
+    for (int r = tid; r < n_seg; r += 256) {
+        DevSegment *g = segs + first + r;
+        if (r < m && r < n_seg - 1) {
+            const uint32_t b0 = r == 0 ? 0u : s_sorted[r - 1] + 2u;
+            g->begin = begin + b0;
+            g->len = (int32_t)(s_sorted[r] - b0);
+        } else if (r == (m < n_seg - 1 ? m : n_seg - 1) && m <= n_seg - 1) {
+            const uint32_t b0 = m == 0 ? 0u : s_sorted[m - 1] + 2u;              // the segment the terminator ends
+            g->begin = begin + b0;
+            g->len = (int32_t)(T > b0 ? T - b0 : 0u);
+        } else {
+            g->begin = begin + T;
+            g->len = 0;
         }
-        for (int k = last + 1; k < n_seg; ++k) { segs[first + k].begin = T; segs[first + k].len = 0; }
-        if (r != n_seg - 1) atomicMax(status + jb->image, MJ_ST_DESYNC);
-        else if (T + 1 < end && blob[T + 1] != 0xD9u) atomicMax(status + jb->image, MJ_ST_TAIL);
+    }
+    if (tid == 0) {
+        if (m != n_seg - 1) atomicMax(status + jb->image, MJ_ST_DESYNC);
+        else if ((int64_t)T + 1 < (int64_t)len32 && blob[begin + T + 1] != 0xD9u) atomicMax(status + jb->image, MJ_ST_TAIL);
     }
 }
 
 hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
                                int32_t *status) {
     if (n_jobs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_markers, dim3((unsigned)n_jobs), dim3(64), 0, stream, blob, jobs, n_jobs, segs, status);
+    hipLaunchKernelGGL(k_scan_markers, dim3((unsigned)n_jobs), dim3(256), 0, stream, blob, jobs, n_jobs, segs, status);
     return hipGetLastError();
 }
 

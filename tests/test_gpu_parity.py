@@ -530,6 +530,13 @@ def test_gpu_segmentation_hands_back_what_it_cannot_segment(dec_gs):
     no_marker = raw[:off - 2] + raw[off:]                        # one RSTn removed
     with pytest.raises(CorruptedJpeg):
         dec_gs.decode([no_marker])
+    # more restart markers than the scan kernel's list holds (restart interval 1 on 4096 MCUs): handed back as well
+    from tools import synth
+    from oracle import oracle
+    many = synth.synth_jpeg(77, 512, 512, 85, "444", 1, 10.0)
+    assert np.array_equal(dec_gs.decode([many])[0], oracle.decode(many)["rgb"])
+    mid = synth.synth_jpeg(78, 256, 128, 85, "420", 1, 10.0)     # 128 segments of one MCU: fits, scanned on the GPU
+    assert np.array_equal(dec_gs.decode([mid])[0], oracle.decode(mid)["rgb"])
     trailing = raw + b"\x00" * 37                                # bytes after EOI are nobody's business
     assert np.array_equal(dec_gs.decode([trailing])[0], vec["rgb"])
 
