@@ -631,3 +631,25 @@ def test_caller_stream_and_device_blob(dec):
             assert not plan.read(rgb=False)["status"].any()
         finally:
             plan.close()
+
+
+def test_one_large_image_and_ragged_batch(dec, dec_rm):
+    """A 24-megapixel 4:2:0 image (6016x4000, no DRI: one 4 MB segment through the wave form; with DRI through the
+    lane form) and a batch whose images differ in size (per-image tile prefix, binary search in stage 2)."""
+    from tools import synth
+    from oracle import oracle
+    big = synth.synth_jpeg(5, 6016, 4000, 85, "420", 0, 12.0)
+    ref = oracle.decode(big)["rgb"]
+    assert np.array_equal(dec.decode([big])[0], ref)
+    assert np.array_equal(np.swapaxes(dec_rm.decode([big])[0], 0, 1), ref)
+    big_dri = synth.synth_jpeg(5, 6016, 4000, 85, "420", 47, 12.0)          # 47 MCUs per segment: 2000 segments
+    ragged = [big_dri] + [synth.synth_jpeg(100 + i, 333 + 160 * i, 1200 - 97 * i, 85, "420", 11, 12.0) for i in range(9)]
+    import os
+    os.environ["MJ_HUFFMAN"] = "lanes"
+    try:
+        outs = dec.decode(ragged)
+    finally:
+        os.environ.pop("MJ_HUFFMAN", None)
+    assert np.array_equal(outs[0], ref)
+    for f, img in zip(ragged[1:], outs[1:]):
+        assert np.array_equal(img, oracle.decode(f)["rgb"])
