@@ -166,6 +166,22 @@ def main():
 
     # ---- per-kernel device times, HIP events on the launch stream ------------------------------------------
     s1_ms, s2_ms = plan.time_stages(5, d_rgb.data_ptr())
+    # second denominator SURVEY 8d asks for: what a plain device-to-device copy of the output buffer achieves here
+    copy_gbs = None
+    try:
+        d_tmp = torch.empty_like(d_rgb)
+        d_tmp.copy_(d_rgb)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            d_tmp.copy_(d_rgb)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(2 * d_rgb.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del d_tmp
+    except Exception:
+        pass
     ent_bytes = plan.info.entropy_bytes
     s1_bytes = ent_bytes + args.batch * BLOCKS_PER_IMAGE * 128
     s2_bytes = args.batch * STAGE2_BYTES_PER_IMAGE
@@ -188,7 +204,9 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey),
                 "traffic_source": f"profiles/{tfile.name} (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else None,
-                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4), "note": note}
+                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4),
+                "device_copy_gbs": copy_gbs, "frac_of_device_copy": round(gbs / copy_gbs, 4) if copy_gbs else None,
+                "note": note}
 
     r1 = roof("k_destuff + k_huffman_lanes (stage 0+1: byte-drop pass + Huffman decode; k_scan_markers too with --segment gpu)", s1_bytes, s1_ms,
               "entropy bytes read + 128 B/block coefficients written; serial-decode (instruction issue) bound, quoted against HBM as SURVEY §8d asks",
