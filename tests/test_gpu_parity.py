@@ -653,3 +653,57 @@ def test_one_large_image_and_ragged_batch(dec, dec_rm):
     assert np.array_equal(outs[0], ref)
     for f, img in zip(ragged[1:], outs[1:]):
         assert np.array_equal(img, oracle.decode(f)["rgb"])
+
+
+def test_full_config3_batch_properties(dec):
+    """BASELINE configs[2] at full size: 1024 x 1920x1080 4:2:0 with DRI = one MCU row, 64 distinct images tiled.
+    Size-independent properties: every copy of an image decodes to the same bytes wherever it sits in the batch
+    (checksums of all 1024 outputs), no image reports a status, and a sample of the distinct images equals the oracle."""
+    from tools import synth
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, n, distinct = 1920, 1080, 1024, 64
+    blob, offs = synth.synth_batch(distinct, 4242, W, H, 85, "420", 120)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
+    files = [raws[(7 * i + i // distinct) % distinct] for i in range(n)]          # copies land in different waves / lanes
+    prep = prepare_batch(files)
+    plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": n})
+    try:
+        plan.execute()
+        plan.sync()
+        out = plan.read(rgb=True)
+    finally:
+        plan.close()
+    assert not out["status"].any()
+    per = W * H * 3
+    rgb = out["rgb"].reshape(n, per)
+    sums = rgb.view(np.uint64).sum(axis=1, dtype=np.uint64) ^ rgb.view(np.uint64)[:, ::977].sum(axis=1, dtype=np.uint64) * np.uint64(2654435761)
+    by_image = {}
+    for i in range(n):
+        by_image.setdefault((7 * i + i // distinct) % distinct, set()).add(int(sums[i]))
+    assert all(len(v) == 1 for v in by_image.values()), "copies of one image differ"
+    assert len({next(iter(v)) for v in by_image.values()}) == distinct
+    for d in (0, 17, 63):
+        i = next(k for k in range(n) if (7 * k + k // distinct) % distinct == d)
+        assert np.array_equal(rgb[i].reshape(W, H, 3), oracle.decode(raws[d])["rgb"]), d
+
+
+def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
+    """80 seeded files over size x sampling x quality x restart interval x noise, decoded in mixed batches by the
+    x-major, the row-major and the GPU-segmenting decoder; every pixel against the oracle."""
+    from tools import synth
+    from oracle import oracle
+    rng = np.random.default_rng(20261003)
+    files = []
+    for i in range(80):
+        ss = ("420", "444", "422", "440", "grey", "444ni")[int(rng.integers(0, 6))]
+        w, h = int(rng.integers(1, 260)), int(rng.integers(1, 200))
+        q = int(rng.choice([20, 50, 75, 85, 92, 98, 100]))
+        ri = int(rng.choice([0, 0, 1, 2, 3, 7, 16, 50]))
+        sigma = float(rng.choice([0.0, 5.0, 12.0, 40.0]))
+        files.append(synth.synth_jpeg(1000 + i, w, h, q, ss, ri, sigma))
+    refs = [oracle.decode(f)["rgb"] for f in files]
+    for d, fix in ((dec, lambda a: a), (dec_rm, lambda a: np.swapaxes(a, 0, 1)), (dec_gs, lambda a: a)):
+        for i, (img, ref) in enumerate(zip(d.decode(files), refs)):
+            assert np.array_equal(fix(img), ref), i
