@@ -44,6 +44,11 @@ struct mj_plan {
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
+    uint16_t *d_lut11u = nullptr;       // MJ_SYNC_PROBE
+    mj::DevChunk *d_chunks = nullptr;
+    int64_t n_chunks = 0;
+    uint64_t *d_stateA = nullptr, *d_stateB = nullptr;
+    int32_t *d_cblocks = nullptr;
     mj::DevScanJob *d_jobs = nullptr;   // MJ_FLAG_GPU_SEGMENT: per-image byte ranges for the marker scan
     int n_jobs = 0;
     int n_huff = 0;
@@ -222,7 +227,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_cblocks, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -509,6 +514,27 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 }
             }
             if ((rc = upload(ctx, &p->d_lut11, l11.data(), l11.size())) != MJ_OK) return rc;
+            if (getenv("MJ_SYNC_PROBE")) {     // experimental (huffman_sync.hip): every table in the unified format
+                std::vector<uint16_t> lu = l11;
+                for (int t = 0; t < b->n_huff; ++t) {
+                    if (role[t] & 2) continue;
+                    std::fill(lu.begin() + (size_t)t * LS, lu.begin() + (size_t)(t + 1) * LS, (uint16_t)0);
+                    int code = 0, k = 0;
+                    for (int l = 1; l <= 16; ++l) {
+                        code <<= 1;
+                        for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                            if (l <= LB && code < (1 << l)) {
+                                const int shift = LB - l, hv = b->huff[t].vals[k];
+                                for (int f = 0; f < (1 << shift); ++f) {
+                                    uint16_t &e = lu[(size_t)t * LS + ((code << shift) | f)];
+                                    if (e == 0) e = (uint16_t)((l << 11) | (hv & 15));
+                                }
+                            }
+                        }
+                    }
+                }
+                if ((rc = upload(ctx, &p->d_lut11u, lu.data(), lu.size())) != MJ_OK) return rc;
+            }
         }
         // one segment per lane pays off once there are enough segments to fill the chip that way
         const char *force = getenv("MJ_HUFFMAN");
@@ -532,6 +558,17 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             MJ_HIP(ctx, hipMalloc((void **)&p->d_stream, sbytes));
             MJ_HIP(ctx, hipMemset(p->d_stream, 0, sbytes));
             MJ_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
+            if (getenv("MJ_SYNC_PROBE") && jobs.empty()) {
+                const int cb = atoi(getenv("MJ_SYNC_PROBE")) > 0 ? atoi(getenv("MJ_SYNC_PROBE")) : 2048;   // chunk bytes
+                std::vector<mj::DevChunk> ck;
+                for (size_t i = 0; i < segs.size(); ++i)
+                    for (int j = 0; j < std::max(1, (segs[i].len + cb - 1) / cb); ++j) ck.push_back(mj::DevChunk{(int32_t)i, j});
+                p->n_chunks = (int64_t)ck.size();
+                if ((rc = upload(ctx, &p->d_chunks, ck.data(), ck.size())) != MJ_OK) return rc;
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_stateA, ck.size() * 8 + 16));
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_stateB, ck.size() * 8 + 16));
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_cblocks, ck.size() * 4 + 16));
+            }
         }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
         if (!jobs.empty()) {
@@ -598,6 +635,33 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     if (p->use_lanes) {
         MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
+        if (p->d_chunks) {   // experimental probe: how fast are the synchronisation passes, how many chunks re-synchronise?
+            const int cb = atoi(getenv("MJ_SYNC_PROBE")) > 0 ? atoi(getenv("MJ_SYNC_PROBE")) : 2048;
+            hipEvent_t e[6];
+            for (auto &x : e) MJ_HIP(ctx, hipEventCreate(&x));
+            std::vector<uint64_t> A(p->n_chunks), Bv(p->n_chunks);
+            std::vector<int32_t> blk(p->n_chunks);
+            uint64_t *in = nullptr, *out = p->d_stateA;
+            for (int round = 0; round < 4; ++round) {
+                MJ_HIP(ctx, hipEventRecord(e[0], s));
+                MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cb * 8, in, out, p->d_cblocks));
+                MJ_HIP(ctx, hipEventRecord(e[1], s));
+                MJ_HIP(ctx, hipStreamSynchronize(s));
+                float ms = 0;
+                MJ_HIP(ctx, hipEventElapsedTime(&ms, e[0], e[1]));
+                MJ_HIP(ctx, hipMemcpy(Bv.data(), out, p->n_chunks * 8, hipMemcpyDeviceToHost));
+                MJ_HIP(ctx, hipMemcpy(blk.data(), p->d_cblocks, p->n_chunks * 4, hipMemcpyDeviceToHost));
+                int64_t changed = 0, total_blocks = 0;
+                for (int64_t i = 0; i < p->n_chunks; ++i) { changed += (round == 0 || A[i] != Bv[i]) ? 1 : 0; total_blocks += blk[i]; }
+                fprintf(stderr, "[sync probe] round %d: %.3f ms, %lld chunks of %d B, %lld exit states changed, %lld blocks counted (plan has %lld)\n",
+                        round, ms, (long long)p->n_chunks, cb, (long long)changed, (long long)total_blocks, (long long)p->info.total_blocks);
+                A = Bv;
+                in = out;
+                out = out == p->d_stateA ? p->d_stateB : p->d_stateA;
+            }
+            for (auto &x : e) (void)hipEventDestroy(x);
+        }
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                              p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0));
     } else

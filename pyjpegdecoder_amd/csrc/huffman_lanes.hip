@@ -70,7 +70,7 @@ __device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb
     const uint32_t inc = want ? 4u : 0u;
     s.voff += inc;
     s.bc += (int)(inc * 8u);
-    s.nxtw = *reinterpret_cast<const uint32_t *>(streamb + s.voff);
+    if (want) s.nxtw = *reinterpret_cast<const uint32_t *>(streamb + s.voff);     // every lane reads its own cache line: only who needs it
 }
 
 __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0

@@ -65,6 +65,12 @@ struct DevScanJob {
     int32_t image;
 };
 
+// One chunk of a restart segment's stage-0 stream (huffman_sync.hip, experimental)
+struct DevChunk {
+    int32_t seg;          // index of the DevSegment
+    int32_t j;            // chunk number within the segment: bits [j * cbits, (j + 1) * cbits)
+};
+
 // One SOS of a progressive image (device copy of mj_scan_desc with table indices resolved).
 struct DevProgScan {
     int32_t image, n_comp;
@@ -107,6 +113,10 @@ hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegm
                           uint32_t *out_stream, int32_t *seg_bits);
 hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
                                int32_t *status);
+hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
+                             const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
+                             const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
+                             int32_t *blocks_out);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits,
                                 const DevSegment *segs, int64_t n_segs,
