@@ -44,11 +44,16 @@ struct mj_plan {
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
-    uint16_t *d_lut11u = nullptr;       // MJ_SYNC_PROBE
+    // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
+    bool use_sync = false;
+    int sync_chunk_bytes = 2048;
+    uint16_t *d_lut11u = nullptr;       // every table as len << 11 | run << 4 | size
     mj::DevChunk *d_chunks = nullptr;
     int64_t n_chunks = 0;
     uint64_t *d_stateA = nullptr, *d_stateB = nullptr;
-    int32_t *d_cblocks = nullptr;
+    mj::DevChunkOut *d_couts = nullptr;
+    mj::DevVSeg *d_vsegs = nullptr;
+    int32_t *d_changed = nullptr;
     mj::DevScanJob *d_jobs = nullptr;   // MJ_FLAG_GPU_SEGMENT: per-image byte ranges for the marker scan
     int n_jobs = 0;
     int n_huff = 0;
@@ -227,7 +232,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_cblocks, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -484,7 +489,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if ((rc = upload(ctx, &p->d_huff, hh.data(), hh.size())) != MJ_OK) return rc;
         p->n_huff = b->n_huff;
         std::vector<int> role(b->n_huff, 0);
-        bool both_roles = false;
+        bool both_roles = false, dc_fits = true;
         {   // 11-bit LUTs for the lane-parallel kernel
             const int LB = mj::kLaneLutBits, LS = 1 << LB;
             std::vector<uint16_t> l11((size_t)b->n_huff * LS, 0);
@@ -514,7 +519,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 }
             }
             if ((rc = upload(ctx, &p->d_lut11, l11.data(), l11.size())) != MJ_OK) return rc;
-            if (getenv("MJ_SYNC_PROBE")) {     // experimental (huffman_sync.hip): every table in the unified format
+            {   // huffman_sync.hip wants every table in the unified format (DC tables: run 0, size = the symbol)
                 std::vector<uint16_t> lu = l11;
                 for (int t = 0; t < b->n_huff; ++t) {
                     if (role[t] & 2) continue;
@@ -525,6 +530,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                         for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
                             if (l <= LB && code < (1 << l)) {
                                 const int shift = LB - l, hv = b->huff[t].vals[k];
+                                if (hv > 15) dc_fits = false;          // a DC size above 15 has no place in the format
                                 for (int f = 0; f < (1 << shift); ++f) {
                                     uint16_t &e = lu[(size_t)t * LS + ((code << shift) | f)];
                                     if (e == 0) e = (uint16_t)((l << 11) | (hv & 15));
@@ -552,14 +558,24 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         p->use_lanes = lanes_ok && (int64_t)segs.size() >= 8192;
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
         if (force && !strcmp(force, "lanes") && lanes_ok) p->use_lanes = true;
+        // Long segments (no DRI, or a very large restart interval) leave the chip empty at one lane each: they are cut
+        // into chunks, the decoder state at the chunk boundaries is found by synchronisation rounds (huffman_sync.hip)
+        // and the pieces are decoded by the lane-parallel kernel.  Chosen when segments average >= 32 KiB and the
+        // batch yields >= 4096 chunks; MJ_HUFFMAN=sync forces it, wave / lanes exclude it.
+        int64_t total_len = 0, est_chunks = 0;
+        for (const auto &g : segs) { total_len += g.len; est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes); }
+        const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 4096;
+        const bool sync_ok = lanes_ok && jobs.empty() && dc_fits;
+        const bool want_sync = sync_ok && ((force && !strcmp(force, "sync")) || (!force && long_segs));
+        if (want_sync) p->use_lanes = true;
         if (p->use_lanes) {
             // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
             const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
             MJ_HIP(ctx, hipMalloc((void **)&p->d_stream, sbytes));
             MJ_HIP(ctx, hipMemset(p->d_stream, 0, sbytes));
             MJ_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
-            if (getenv("MJ_SYNC_PROBE") && jobs.empty()) {
-                const int cb = atoi(getenv("MJ_SYNC_PROBE")) > 0 ? atoi(getenv("MJ_SYNC_PROBE")) : 2048;   // chunk bytes
+            if (want_sync) {
+                const int cb = p->sync_chunk_bytes;
                 std::vector<mj::DevChunk> ck;
                 for (size_t i = 0; i < segs.size(); ++i)
                     for (int j = 0; j < std::max(1, (segs[i].len + cb - 1) / cb); ++j) ck.push_back(mj::DevChunk{(int32_t)i, j});
@@ -567,7 +583,10 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 if ((rc = upload(ctx, &p->d_chunks, ck.data(), ck.size())) != MJ_OK) return rc;
                 MJ_HIP(ctx, hipMalloc((void **)&p->d_stateA, ck.size() * 8 + 16));
                 MJ_HIP(ctx, hipMalloc((void **)&p->d_stateB, ck.size() * 8 + 16));
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_cblocks, ck.size() * 4 + 16));
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_changed, 16));
+                p->use_sync = true;
             }
         }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
@@ -635,32 +654,28 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
         MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     if (p->use_lanes) {
         MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
-        if (p->d_chunks) {   // experimental probe: how fast are the synchronisation passes, how many chunks re-synchronise?
-            const int cb = atoi(getenv("MJ_SYNC_PROBE")) > 0 ? atoi(getenv("MJ_SYNC_PROBE")) : 2048;
-            hipEvent_t e[6];
-            for (auto &x : e) MJ_HIP(ctx, hipEventCreate(&x));
-            std::vector<uint64_t> A(p->n_chunks), Bv(p->n_chunks);
-            std::vector<int32_t> blk(p->n_chunks);
-            uint64_t *in = nullptr, *out = p->d_stateA;
-            for (int round = 0; round < 4; ++round) {
-                MJ_HIP(ctx, hipEventRecord(e[0], s));
+        if (p->use_sync) {
+            // round 0 guesses, round 1.. start every chunk from its predecessor's exit state until no exit state changes
+            // (typically the second true-state round changes nothing), then the pieces are decoded like restart segments
+            const int cbits = p->sync_chunk_bytes * 8;
+            MJ_HIP(ctx, hipMemsetAsync(p->d_couts, 0xFF, (size_t)p->n_chunks * sizeof(mj::DevChunkOut), s));
+            MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
+                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed));
+            uint64_t *in = p->d_stateA, *out = p->d_stateB;
+            for (int round = 1;; ++round) {
+                MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, sizeof(int32_t), s));
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cb * 8, in, out, p->d_cblocks));
-                MJ_HIP(ctx, hipEventRecord(e[1], s));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed));
+                int32_t changed = 0;
+                MJ_HIP(ctx, hipMemcpyAsync(&changed, p->d_changed, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 MJ_HIP(ctx, hipStreamSynchronize(s));
-                float ms = 0;
-                MJ_HIP(ctx, hipEventElapsedTime(&ms, e[0], e[1]));
-                MJ_HIP(ctx, hipMemcpy(Bv.data(), out, p->n_chunks * 8, hipMemcpyDeviceToHost));
-                MJ_HIP(ctx, hipMemcpy(blk.data(), p->d_cblocks, p->n_chunks * 4, hipMemcpyDeviceToHost));
-                int64_t changed = 0, total_blocks = 0;
-                for (int64_t i = 0; i < p->n_chunks; ++i) { changed += (round == 0 || A[i] != Bv[i]) ? 1 : 0; total_blocks += blk[i]; }
-                fprintf(stderr, "[sync probe] round %d: %.3f ms, %lld chunks of %d B, %lld exit states changed, %lld blocks counted (plan has %lld)\n",
-                        round, ms, (long long)p->n_chunks, cb, (long long)changed, (long long)total_blocks, (long long)p->info.total_blocks);
-                A = Bv;
-                in = out;
-                out = out == p->d_stateA ? p->d_stateB : p->d_stateA;
+                std::swap(in, out);
+                if (changed == 0 || round > 4096) break;
             }
-            for (auto &x : e) (void)hipEventDestroy(x);
+            MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
+            MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
+                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs));
+            return MJ_OK;
         }
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                              p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0));

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                                                        const DevHuff *__restrict__ huff,
                                                        const uint16_t *__restrict__ lut11,   // [n_huff][kLSize]
                                                        int n_huff, int16_t *__restrict__ coef,
-                                                       int32_t *__restrict__ status, int lpw, int tr) {
+                                                       int32_t *__restrict__ status, int lpw, int tr,
+                                                       const DevVSeg *__restrict__ vsegs /* or null */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,7 +112,14 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
 
     const int64_t seg_id = ((int64_t)blockIdx.x * 4 + wave) * lpw + lane;   // lpw segments per wave (tunable)
     const bool have = lane < lpw && seg_id < n_segs;
-    const DevSegment sg = segs[have ? seg_id : 0];
+    // The unit of work is a restart segment, or — for long segments cut up by the synchronisation passes
+    // (huffman_sync.hip) — a virtual segment: a run of whole MCUs inside one, with its start bit and DC predictors.
+    DevSegment sg = segs[(have && !vsegs) ? seg_id : 0];
+    DevVSeg vs{};
+    if (vsegs) {
+        vs = vsegs[have ? seg_id : 0];
+        sg.image = vs.image; sg.mcu0 = vs.mcu0; sg.n_mcu = vs.n_mcu; sg.last = vs.last == 1;
+    }
     const DevImage *im = images + sg.image;
     const int bpm = __builtin_amdgcn_readfirstlane(im->blocks_per_mcu);     // one sampling layout per plan
     const uint64_t comp_pk = *reinterpret_cast<const uint64_t *>(im->blk_comp);
@@ -141,15 +149,22 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     // ---- per-lane bit reader (see LaneBits); lanes without a segment read dword 0 and never decode
     const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
     LaneBits br;
-    const uint32_t voff0 = have ? (uint32_t)(((sg.begin >> 2) + seg_id) * 4) : 0u;
-    const int nbits = have ? seg_bits[seg_id] : 0;
-    br.voff = voff0;
-    br.nxtw = *reinterpret_cast<const uint32_t *>(streamb + br.voff);
-    br.bb = 0; br.bc = 0;
+    const uint32_t bit_sh = vsegs ? (uint32_t)vs.bit0 & 31u : 0u;           // a virtual segment starts at any bit
+    const uint32_t voff0 = !have ? 0u : (vsegs ? vs.voff0 + ((uint32_t)vs.bit0 >> 5) * 4u : (uint32_t)(((sg.begin >> 2) + seg_id) * 4));
+    const int nbits = !have ? 0 : (vsegs ? vs.bit_end - vs.bit0 : seg_bits[seg_id]);
+    {
+        const uint32_t d0 = *reinterpret_cast<const uint32_t *>(streamb + voff0), d1 = *reinterpret_cast<const uint32_t *>(streamb + voff0 + 4);
+        br.bb = (((uint64_t)d0 << 32) | d1) << bit_sh;
+        br.bc = 64 - (int)bit_sh;
+        br.voff = voff0 + 8;
+        br.nxtw = *reinterpret_cast<const uint32_t *>(streamb + br.voff);
+    }
+    // bits consumed since the (virtual) segment's first bit: everything fetched minus what is still buffered
+    auto consumed = [&]() { return (int)((br.voff - voff0) * 8u) - br.bc - (int)bit_sh; };
     // byte offset of this lane's first output block
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
     if (lane < lpw2) s_base[lane] = (uint64_t)out_off;
-    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int pred0 = vs.pred[0], pred1 = vs.pred[1], pred2 = vs.pred[2];        // zero for a restart segment (:900)
     int err = 0;
     // store positions 2dw, 2dw+1 of a block; tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
     const int na = 2 * (lane & 31), nb = na + 1;
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 symbol(k < 64 && br.bc >= 31, false);
             }
             // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
-            err = (act && err == 0 && (int)((br.voff - voff0) * 8u) - br.bc > nbits) ? MJ_ST_OVERRUN : err;
+            err = (act && err == 0 && consumed() > nbits) ? MJ_ST_OVERRUN : err;
             // ---- round of 64 blocks done: LDS -> HBM, two full lines per instruction, and clear
             // lane (o, dw) moves the two coefficients of natural positions 2dw, 2dw+1 of block o: they are read from
             // their zig-zag slots, so the block lands in HBM in the natural [v][u] order stage 2 wants
@@ -282,14 +297,16 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     if (have) {
         // bits left over: a whole unread byte before the next restart marker means the count-driven reference and the
         // marker-driven segmentation disagree (:898-900)
-        if (!err && !sg.last && nbits - ((int)((br.voff - voff0) * 8u) - br.bc) >= 8) err = MJ_ST_DESYNC;
+        const int left = nbits - consumed();
+        if (!err && vsegs && vs.last == 0 && left != 0) err = MJ_ST_DESYNC;     // a virtual segment ends exactly where the next starts
+        if (!err && (vsegs ? vs.last == 2 : !sg.last) && left >= 8) err = MJ_ST_DESYNC;
         if (err) atomicMax(status + sg.image, err);
     }
 }
 
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status, int transposed) {
+                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs) {
     if (n_segs == 0) return hipSuccess;
     static int lpw = 0;
     if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
@@ -319,7 +336,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
-                       lut11, n_huff, coef, status, lpw_run, transposed);
+                       lut11, n_huff, coef, status, lpw_run, transposed, vsegs);
     return hipGetLastError();
 }
 

@@ -65,11 +65,31 @@ struct DevScanJob {
     int32_t image;
 };
 
-// One chunk of a restart segment's stage-0 stream (huffman_sync.hip, experimental)
+// One chunk of a restart segment's stage-0 stream (huffman_sync.hip): the unit of the synchronisation passes that
+// find, inside long segments (files without restart markers), places where an independent decoder can start.
 struct DevChunk {
     int32_t seg;          // index of the DevSegment
     int32_t j;            // chunk number within the segment: bits [j * cbits, (j + 1) * cbits)
 };
+// What a counting pass learns about a chunk, decoded from the entry state its predecessor handed over.
+struct DevChunkOut {
+    uint64_t entry;       // the entry state this record was computed from (a later round skips the chunk if unchanged)
+    int32_t blocks;       // blocks completed in the chunk
+    int32_t bnd_pos;      // bit position of the first MCU boundary inside the chunk, -1 if none
+    int32_t bnd_blocks;   // blocks completed before that boundary
+    int16_t dc_bnd[3];    // DC differences per component summed up to the boundary (int16 wrap, :818-820)
+    int16_t dc_sum[3];    // ... over the whole chunk
+};
+static_assert(sizeof(DevChunkOut) == 32, "DevChunkOut layout");
+// A virtual segment: a run of whole MCUs inside a restart segment with everything a decoder needs to start there.
+struct DevVSeg {
+    uint32_t voff0;       // byte offset of the parent segment's stream in the stage-0 buffer
+    int32_t bit0, bit_end;    // first bit, one past the last bit (relative to the parent segment's stream)
+    int32_t image, mcu0, n_mcu;
+    int16_t pred[3];      // DC predictors at the first MCU
+    int16_t last;         // 1 = runs to the end of its restart segment (padding bits may follow)
+};
+static_assert(sizeof(DevVSeg) == 32, "DevVSeg layout");
 
 // One SOS of a progressive image (device copy of mj_scan_desc with table indices resolved).
 struct DevProgScan {
@@ -113,15 +133,19 @@ hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegm
                           uint32_t *out_stream, int32_t *seg_bits);
 hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
                                int32_t *status);
+// one counting round: entry == nullptr -> speculative round (every chunk assumes a block starts at its first bit);
+// otherwise chunk c starts from entry[c - 1].  *changed counts the chunks whose exit state differs from prev_exit[c].
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             int32_t *blocks_out);
+                             DevChunkOut *outs, int32_t *changed);
+hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
+                              const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits,
                                 const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status, int transposed);
+                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs = nullptr);
 
 struct ReconArgs {
     const DevImage *images;

@@ -707,3 +707,56 @@ def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
     for d, fix in ((dec, lambda a: a), (dec_rm, lambda a: np.swapaxes(a, 0, 1)), (dec_gs, lambda a: a)):
         for i, (img, ref) in enumerate(zip(d.decode(files), refs)):
             assert np.array_equal(fix(img), ref), i
+
+
+# ---- long segments: synchronisation passes + virtual segments (huffman_sync.hip) ---------------------------------------
+def test_sync_form_every_fixture(dec, monkeypatch):
+    """MJ_HUFFMAN=sync forces the third stage-1 form on everything: segments shorter than a chunk are one virtual
+    segment each, longer ones are cut up; coefficients and pixels as the reference's."""
+    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    names = golden_names()
+    imgs, seams = dec.decode([load_golden(n)[0] for n in names], return_seams=True)
+    for n, img, seam in zip(names, imgs, seams):
+        vec = load_golden(n)[1]
+        assert np.array_equal(seam["coef"], vec["coef"]), n
+        assert np.array_equal(img, vec["rgb"]), n
+
+
+@pytest.mark.parametrize("ss,w,h,ri,q,sigma", [
+    ("420", 640, 480, 0, 85, 12.0), ("444", 500, 375, 0, 92, 25.0), ("422", 777, 333, 0, 75, 12.0), ("grey", 900, 700, 0, 85, 20.0),
+    ("420", 1920, 1080, 0, 85, 12.0), ("420", 1024, 768, 1500, 90, 30.0), ("440", 333, 999, 0, 85, 5.0), ("420", 800, 600, 0, 100, 60.0),
+    ("420", 1200, 900, 0, 40, 0.0),
+])
+def test_sync_form_files_without_restart_markers(dec, dec_rm, ss, w, h, ri, q, sigma, monkeypatch):
+    from oracle import oracle
+    from tools import synth
+    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    raw = synth.synth_jpeg(w * 7 + h, w, h, q, ss, ri, sigma)
+    ref = oracle.decode(raw)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"])
+    assert np.array_equal(img, ref["rgb"])
+    assert np.array_equal(np.swapaxes(dec_rm.decode([raw])[0], 0, 1), ref["rgb"])
+
+
+def test_sync_form_batch_and_damage(dec, monkeypatch):
+    """A batch of DRI-less files picks the form by itself (no env); damaged streams still end in CorruptedJpeg or an image."""
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import JpegError, parse_jpeg
+    files = [synth.synth_jpeg(300 + i, 640 + 64 * (i % 5), 512 - 32 * (i % 3), 85, ("420", "444", "422")[i % 3], 0, 15.0) for i in range(48)]
+    for f, img in zip(files, dec.decode(files)):
+        assert np.array_equal(img, oracle.decode(f)["rgb"])
+    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    rng = np.random.default_rng(99)
+    raw = files[0]
+    sc = parse_jpeg(raw).scans[0]
+    for _ in range(20):
+        b = bytearray(raw)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(sc.entropy_start, sc.entropy_end))] = int(rng.integers(0, 256))
+        try:
+            assert dec.decode([bytes(b)])[0].shape == oracle.decode(raw)["rgb"].shape
+        except JpegError:
+            pass
+    assert np.array_equal(dec.decode([raw])[0], oracle.decode(raw)["rgb"])

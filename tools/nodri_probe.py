@@ -10,7 +10,7 @@ blob, offs = synth.synth_batch(16, 0, 1920, 1080, 85, "420", 0)
 raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(16)]
 files = [raws[i % 16] for i in range(n)]
 dec = BatchDecoder(0)
-for mode in ("wave", "lanes"):
+for mode in ("wave", "lanes", "sync"):
     os.environ["MJ_HUFFMAN"] = mode
     prep = prepare_batch(files)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": n})
