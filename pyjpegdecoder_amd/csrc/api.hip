@@ -560,12 +560,18 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (force && !strcmp(force, "lanes") && lanes_ok) p->use_lanes = true;
         // Long segments (no DRI, or a very large restart interval) leave the chip empty at one lane each: they are cut
         // into chunks, the decoder state at the chunk boundaries is found by synchronisation rounds (huffman_sync.hip)
-        // and the pieces are decoded by the lane-parallel kernel.  Chosen when segments average >= 32 KiB and the
-        // batch yields >= 4096 chunks; MJ_HUFFMAN=sync forces it, wave / lanes exclude it.
+        // and the pieces are decoded by the lane-parallel kernel.  Chosen when segments average >= 32 KiB (a single such
+        // image already wins: the alternative is one serial walk per segment); MJ_HUFFMAN=sync forces it, wave / lanes
+        // exclude it.  With the GPU marker scan the segment lengths are not known here: possible when every image is one
+        // segment (no DRI), whose byte range bounds its length.
+        bool one_seg_each = true;
+        for (const auto &jb : jobs) one_seg_each = one_seg_each && jb.n_seg == 1;
+        if (!jobs.empty() && one_seg_each)
+            for (size_t i = 0; i < jobs.size(); ++i) segs[(size_t)jobs[i].first_seg].len = (int32_t)(jobs[i].end - jobs[i].begin);   // upper bound; the scan writes the real one
         int64_t total_len = 0, est_chunks = 0;
         for (const auto &g : segs) { total_len += g.len; est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes); }
-        const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 4096;
-        const bool sync_ok = lanes_ok && jobs.empty() && dc_fits;
+        const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 64;
+        const bool sync_ok = lanes_ok && (jobs.empty() || one_seg_each) && dc_fits;
         const bool want_sync = sync_ok && ((force && !strcmp(force, "sync")) || (!force && long_segs));
         if (want_sync) p->use_lanes = true;
         if (p->use_lanes) {
@@ -615,6 +621,10 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     MJ_HIP(ctx, hipMemset(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t)));
     if (b->flags & MJ_FLAG_KEEP_PLANES) MJ_HIP(ctx, hipMalloc((void **)&p->d_planes, (size_t)rgb * sizeof(int16_t) + 16));
     if (b->flags & MJ_FLAG_KEEP_IDCT) MJ_HIP(ctx, hipMalloc((void **)&p->d_idct, (size_t)blk * 64 * sizeof(int16_t) + 16));
+    // hipMemset on device memory returns before it is done and runs on the null stream, which the (non-blocking)
+    // context stream and a caller's stream do not wait for: without this the tail of the 6 GB clear above could land
+    // after the first blocks the first execute writes.
+    MJ_HIP(ctx, hipDeviceSynchronize());
     guard.p = nullptr;
     *out = p;
     return MJ_OK;

@@ -747,6 +747,14 @@ def test_sync_form_batch_and_damage(dec, monkeypatch):
     files = [synth.synth_jpeg(300 + i, 640 + 64 * (i % 5), 512 - 32 * (i % 3), 85, ("420", "444", "422")[i % 3], 0, 15.0) for i in range(48)]
     for f, img in zip(files, dec.decode(files)):
         assert np.array_equal(img, oracle.decode(f)["rgb"])
+    # the same files with headers-only parsing: the GPU finds the end of each scan, then the chunks
+    from pyjpegdecoder_amd import BatchDecoder
+    d2 = BatchDecoder(device=0, segment="gpu", layout="rowmajor")
+    try:
+        for f, img in zip(files[:12], d2.decode(files[:12])):
+            assert np.array_equal(np.swapaxes(img, 0, 1), oracle.decode(f)["rgb"])
+    finally:
+        d2.close()
     monkeypatch.setenv("MJ_HUFFMAN", "sync")
     rng = np.random.default_rng(99)
     raw = files[0]
