@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--segment", default="host", choices=["host", "gpu"],
                     help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
+    ap.add_argument("--restart-interval", type=int, default=120,
+                    help="MCUs per restart segment of the synthetic files (120 = one MCU row = BASELINE configs[2]; 0 = no DRI: "
+                         "one segment per image, decoded through the synchronisation passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / MAX of timings (gloo: self-test on a box with fewer GPUs than ranks)")
@@ -102,7 +105,7 @@ def main():
     # ---- synthetic inputs (host): the SURVEY §8d family, q85, 4:2:0, DRI = one MCU row --------------------
     distinct = min(args.distinct, args.batch)
     t0 = time.perf_counter()
-    blob, offs = synth.synth_batch(distinct, 100000 * rank, W, H, 85, "420", 120)
+    blob, offs = synth.synth_batch(distinct, 100000 * rank, W, H, 85, "420", args.restart_interval)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
     gen_s = time.perf_counter() - t0
     files = [raws[i % distinct] for i in range(args.batch)]
@@ -224,8 +227,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, DRI=120 (one MCU row, 68 segments/image), "
-                                   "on-GPU Huffman + dequant/IDCT/upsample/RGB (BASELINE configs[2])",
+            "config": {"workload": (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, DRI=120 (one MCU row, 68 segments/image), "
+                                    "on-GPU Huffman + dequant/IDCT/upsample/RGB (BASELINE configs[2])") if args.restart_interval == 120 else
+                                   (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, restart interval {args.restart_interval} "
+                                    "(NOT the BASELINE configuration)"),
                        "images_per_gpu": args.batch, "distinct_images_per_gpu": distinct, "layout": args.layout, "restart_segmentation": args.segment,
                        "entropy_bytes_per_image": int(ent_bytes // args.batch), "parallelism": f"image-sharded x{world}, no collective"},
             "roofline": dominant, "roofline_other_stage": other,
