@@ -240,9 +240,35 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(raws[:64])
+        if world == 1 and not args.no_cpu_baseline and args.restart_interval == 120:
+            # beside the headline: the same images written WITHOUT restart markers (one serial bitstream per image, the
+            # usual case in the wild), decoded through the synchronisation passes; not BASELINE's configuration
+            try:
+                plan.close()
+                nb, nd = 256, 32
+                blob2, offs2 = synth.synth_batch(nd, 700000, W, H, 85, "420", 0)
+                raws2 = [blob2[int(offs2[i]):int(offs2[i + 1])].tobytes() for i in range(nd)]
+                prep2 = prepare_batch([raws2[i % nd] for i in range(nb)], layout, 0)
+                d_blob2 = torch.from_numpy(prep2.blob).to(dev)
+                plan2 = B.Plan(ctx, prep2.to_c(d_blob2.data_ptr()), {"prep": prep2, "n_images": nb})
+                d_rgb2 = d_rgb[:plan2.info.rgb_bytes]
+                plan2.execute(stream, d_rgb2.data_ptr()); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    plan2.execute(stream, d_rgb2.data_ptr())
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / 5
+                ok2 = np.array_equal(d_rgb2[:W * H * 3].cpu().numpy().reshape((W, H, 3) if args.layout == "xmajor" else (H, W, 3)),
+                                     oracle.decode(raws2[0])["rgb"] if args.layout == "xmajor" else np.swapaxes(oracle.decode(raws2[0])["rgb"], 0, 1))
+                line["without_restart_markers"] = {"value": round(nb * W * H / 1e6 / dt2, 1), "unit": "MP/s", "ms_per_step": round(dt2 * 1e3, 3),
+                                                   "workload": f"{nb} x 1920x1080 4:2:0 baseline JPEG, q85, no DRI (one segment per image)",
+                                                   "parity": "bit-exact vs oracle (image 0)" if ok2 else "MISMATCH"}
+                plan2.close()
+            except Exception as exc:
+                line["without_restart_markers"] = {"error": str(exc)}
         print(json.dumps(line), flush=True)
 
-    plan.close()
+    plan.close()          # (idempotent)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
