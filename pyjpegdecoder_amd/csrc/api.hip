@@ -564,6 +564,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // image already wins: the alternative is one serial walk per segment); MJ_HUFFMAN=sync forces it, wave / lanes
         // exclude it.  With the GPU marker scan the segment lengths are not known here: possible when every image is one
         // segment (no DRI), whose byte range bounds its length.
+        if (const char *e = getenv("MJ_SYNC_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536 && v % 4 == 0) p->sync_chunk_bytes = v; }
         bool one_seg_each = true;
         for (const auto &jb : jobs) one_seg_each = one_seg_each && jb.n_seg == 1;
         if (!jobs.empty() && one_seg_each)

@@ -1,19 +1,22 @@
 // Stage 1, sub-segment synchronisation passes: parallelism inside long restart segments (files without DRI).
 //
 // A restart segment is cut into chunks of `cbits` bits of its stage-0 stream, one per lane.  A count-only decode of a
-// chunk from a given entry state (bit position, block within the MCU, coefficient index) yields its exit state — the
-// first symbol that starts at or behind the chunk's end — and the number of blocks it completed.  Run once from the
-// guess "a block starts at the chunk's first bit" and then from the predecessor's exit state until nothing changes,
-// this finds the true state at every chunk boundary (Huffman streams re-synchronise), i.e. places inside a segment
-// where an independent decoder can start.  The counting rounds also note, per chunk, the first MCU boundary inside it
-// and the DC differences summed up to there and over the whole chunk; k_build_vsegs turns that into "virtual
-// segments" (runs of whole MCUs with their start bit and DC predictors) which the lane-parallel kernel decodes like
-// restart segments.  Measured on 1024 x 1080p: 99.7 % of 2 KiB chunks are already right after the speculative
-// round, the second true-state round changes nothing.
+// chunk from an entry state (bit position, block within the MCU, coefficient index) yields its exit state — the first
+// symbol that starts at or behind the chunk's end — and, on the way, the number of blocks it completed, the first MCU
+// boundary inside the chunk and the DC differences summed up to there and over the whole chunk.
+// Round 0: a lane cannot know its chunk's entry state, so it starts half a chunk EARLIER from the guess "a block
+// starts here" and decodes towards its chunk; Huffman streams re-synchronise (and a wrong MCU phase desynchronises
+// again quickly, the luma and chroma tables being different), so the state in which it crosses into the chunk is
+// almost always the true one.  Round 1..: every chunk whose assumed entry state is not its predecessor's exit state
+// is redone from that state, until a round changes no exit state (the host reads one counter per round).
+// k_build_vsegs then turns the records into "virtual segments" (runs of whole MCUs with their start bit and DC
+// predictors) which the lane-parallel kernel decodes like restart segments.
 //
 // Tables: the 11-bit LUTs in the unified format  len << 11 | run << 4 | size  (DC tables: run 0, size = the symbol;
 // AC tables: end of block = run 64); a lane looks up the DC table of its block's component when its coefficient
 // index is 0 and the AC table otherwise, so DC and AC symbols take the same straight-line step.
+#include <stdlib.h>
+
 #include "mijpeg_internal.h"
 
 namespace mj {
@@ -52,13 +55,16 @@ __device__ __forceinline__ int long_code(const DevHuff *t, uint32_t p16) {
 // state word: bit position within the segment's stream (32) | block within the MCU (8) | coefficient index (8)
 __device__ __forceinline__ uint64_t pack_state(uint32_t pos, int b, int k) { return (uint64_t)pos | ((uint64_t)(uint32_t)b << 32) | ((uint64_t)(uint32_t)k << 40); }
 
-// EMIT = false: the speculative round, exit states only.  EMIT = true: a true-state round — exit states, block counts,
-// the first MCU boundary and the DC sums; chunks whose entry state is the one their record was computed from are skipped.
-template <bool EMIT>
+// WARM = true: the first round.  A chunk cannot know its entry state, so its lane starts `warm` bits EARLIER, assuming
+// a block starts there, decodes towards its own first bit — by then it has almost always re-synchronised — takes the
+// state in which it crosses into the chunk as its entry state and records the chunk from there.
+// WARM = false: a repair round — every chunk starts from its predecessor's exit state; chunks whose record was computed
+// from exactly that state (nearly all, after the first round) are skipped.
+template <bool WARM>
 __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__ stream, const int32_t *__restrict__ seg_bits,
                                                     const DevSegment *__restrict__ segs, const DevImage *__restrict__ images,
                                                     const DevHuff *__restrict__ huff, const uint16_t *__restrict__ lut11u,
-                                                    int n_huff, const DevChunk *__restrict__ chunks, int64_t n_chunks, int cbits,
+                                                    int n_huff, const DevChunk *__restrict__ chunks, int64_t n_chunks, int cbits, int warm,
                                                     const uint64_t *__restrict__ entry, uint64_t *__restrict__ exit_out,
                                                     DevChunkOut *__restrict__ outs, int32_t *__restrict__ changed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -90,16 +96,19 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
     uint32_t pos;
     int b, k;
     uint64_t my_entry;
+    const uint32_t own_start = (uint32_t)((int64_t)ch.j * cbits);
     if (ch.j == 0) my_entry = pack_state(0, 0, 0);
-    else if (EMIT) my_entry = entry[c - 1];
-    else my_entry = pack_state((uint32_t)((int64_t)ch.j * cbits), 0, 0);
+    else if (!WARM) my_entry = entry[c - 1];
+    else my_entry = pack_state(own_start > (uint32_t)warm ? own_start - (uint32_t)warm : 0u, 0, 0);     // the guess
     pos = (uint32_t)my_entry; b = (int)((my_entry >> 32) & 0xFF); k = (int)((my_entry >> 40) & 0xFF);
     bool skip = false;
-    if constexpr (EMIT) {
+    if constexpr (!WARM) {
         // a record computed from this very entry state is still right: keep it, keep its exit state
         skip = have && outs[c].entry == my_entry && outs[c].blocks >= 0;
         if (skip) limit = 0;
     }
+    const uint32_t final_limit = limit;
+    if (WARM && ch.j > 0) limit = own_start < final_limit ? own_start : final_limit;      // first: up to the chunk's own first bit
 
     const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
     const uint32_t voff0 = (uint32_t)(((sg.begin >> 2) + ch.seg) * 4);
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
     int blocks = 0;
     int dc0 = 0, dc1 = 0, dc2 = 0;                        // DC differences summed per component
     int bnd_pos = -1, bnd_blocks = 0, bd0 = 0, bd1 = 0, bd2 = 0;
-    if (EMIT && b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;      // the chunk is entered at an MCU boundary
+    if ((!WARM || ch.j == 0) && b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;      // entered at an MCU boundary
     const unsigned char *lutb = reinterpret_cast<const unsigned char *>(s_lut);
 
     auto symbol = [&](bool allow) {
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const int kk = k + run;
         const bool val = kk < 64;
         const int n = val ? size : 0;
-        if constexpr (EMIT) {                                          // the DC difference (EXTEND, :818-820)
+        {                                                              // the DC difference (EXTEND, :818-820)
             const uint32_t hw = hi << ln;
             const uint32_t lead = (uint32_t)((int32_t)hw >> 31);
             const uint32_t raw = __builtin_amdgcn_ubfe(hw, (uint32_t)(32 - n) & 31u, (uint32_t)n);
@@ -156,20 +165,34 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const bool wrap = be && b1 == bpm;                            // ... and its MCU
         b = be ? (wrap ? 0 : b1) : b;
         blocks += be ? 1 : 0;
-        if constexpr (EMIT) {
+        {
             const bool take = wrap && bnd_pos < 0 && pos < limit;
             bnd_pos = take ? (int)pos : bnd_pos;
             bnd_blocks = take ? blocks : bnd_blocks;
             bd0 = take ? dc0 : bd0; bd1 = take ? dc1 : bd1; bd2 = take ? dc2 : bd2;
         }
     };
+    if constexpr (WARM) {
+        while (__builtin_amdgcn_ballot_w64(pos < limit) != 0) {           // warm-up: reach the chunk's own first bit
+            refill(br, streamb);
+            symbol(true);
+            symbol(br.bc >= 31);
+        }
+        if (ch.j > 0) {                                                    // the chunk starts here, as far as this lane can tell
+            my_entry = pack_state(pos, b, k);
+            blocks = 0; dc0 = dc1 = dc2 = 0;
+            bnd_pos = -1; bnd_blocks = 0; bd0 = bd1 = bd2 = 0;
+            limit = final_limit;
+            if (b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;
+        }
+    }
     while (__builtin_amdgcn_ballot_w64(pos < limit) != 0) {
         refill(br, streamb);
         symbol(true);
         symbol(br.bc >= 31);
     }
     if (have) {
-        if constexpr (EMIT) {
+        if constexpr (!WARM) {
             const uint64_t ex = skip ? entry[c] : pack_state(pos, b, k);      // entry[] holds last round's exit states
             if (!skip) {
                 DevChunkOut o;
@@ -181,6 +204,11 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
             if (ex != entry[c]) atomicAdd(changed, 1);
             exit_out[c] = ex;
         } else {
+            DevChunkOut o;
+            o.entry = my_entry; o.blocks = blocks; o.bnd_pos = bnd_pos; o.bnd_blocks = bnd_blocks;
+            o.dc_bnd[0] = (int16_t)bd0; o.dc_bnd[1] = (int16_t)bd1; o.dc_bnd[2] = (int16_t)bd2;
+            o.dc_sum[0] = (int16_t)dc0; o.dc_sum[1] = (int16_t)dc1; o.dc_sum[2] = (int16_t)dc2;
+            outs[c] = o;
             exit_out[c] = pack_state(pos, b, k);
         }
     }
@@ -237,12 +265,13 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
     if (n_chunks == 0) return hipSuccess;
     const size_t lds = (size_t)n_huff * kLSize * 2 + 16;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
+    const int warm = getenv("MJ_SYNC_WARM") ? atoi(getenv("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
     if (entry)
-        hipLaunchKernelGGL(k_sync_count<true>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, entry, exit_out, outs, changed);
-    else
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, entry, exit_out, outs, changed);
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed);
+    else
+        hipLaunchKernelGGL(k_sync_count<true>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed);
     return hipGetLastError();
 }
 
