@@ -17,6 +17,8 @@
 // index is 0 and the AC table otherwise, so DC and AC symbols take the same straight-line step.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mijpeg_internal.h"
 
 namespace mj {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         if (skip) limit = 0;
     }
     const uint32_t final_limit = limit;
-    if (WARM && ch.j > 0) limit = own_start < final_limit ? own_start : final_limit;      // first: up to the chunk's own first bit
+    if (WARM) limit = ch.j > 0 ? (own_start < final_limit ? own_start : final_limit) : 0u;   // first: up to the chunk's own first bit
 
     const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
     const uint32_t voff0 = (uint32_t)(((sg.begin >> 2) + ch.seg) * 4);
@@ -124,10 +126,11 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
     int blocks = 0;
     int dc0 = 0, dc1 = 0, dc2 = 0;                        // DC differences summed per component
     int bnd_pos = -1, bnd_blocks = 0, bd0 = 0, bd1 = 0, bd2 = 0;
-    if ((!WARM || ch.j == 0) && b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;      // entered at an MCU boundary
+    if (!WARM && b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;                     // entered at an MCU boundary
     const unsigned char *lutb = reinterpret_cast<const unsigned char *>(s_lut);
 
-    auto symbol = [&](bool allow) {
+    auto symbol = [&](bool allow, auto acc_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;      // false during the run-up: nothing is recorded there
         const bool on = allow && pos < limit;
         const int comp = (int)((comp_pk >> (4 * b)) & 15u);
         const bool isdc = k == 0;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const int kk = k + run;
         const bool val = kk < 64;
         const int n = val ? size : 0;
-        {                                                              // the DC difference (EXTEND, :818-820)
+        if constexpr (ACC) {                                           // the DC difference (EXTEND, :818-820)
             const uint32_t hw = hi << ln;
             const uint32_t lead = (uint32_t)((int32_t)hw >> 31);
             const uint32_t raw = __builtin_amdgcn_ubfe(hw, (uint32_t)(32 - n) & 31u, (uint32_t)n);
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const bool wrap = be && b1 == bpm;                            // ... and its MCU
         b = be ? (wrap ? 0 : b1) : b;
         blocks += be ? 1 : 0;
-        {
+        if constexpr (ACC) {
             const bool take = wrap && bnd_pos < 0 && pos < limit;
             bnd_pos = take ? (int)pos : bnd_pos;
             bnd_blocks = take ? blocks : bnd_blocks;
@@ -173,23 +176,21 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         }
     };
     if constexpr (WARM) {
-        while (__builtin_amdgcn_ballot_w64(pos < limit) != 0) {           // warm-up: reach the chunk's own first bit
+        while (__builtin_amdgcn_ballot_w64(pos < limit) != 0) {           // run-up: reach the chunk's own first bit
             refill(br, streamb);
-            symbol(true);
-            symbol(br.bc >= 31);
+            symbol(true, std::false_type{});
+            symbol(br.bc >= 31, std::false_type{});
         }
-        if (ch.j > 0) {                                                    // the chunk starts here, as far as this lane can tell
-            my_entry = pack_state(pos, b, k);
-            blocks = 0; dc0 = dc1 = dc2 = 0;
-            bnd_pos = -1; bnd_blocks = 0; bd0 = bd1 = bd2 = 0;
-            limit = final_limit;
-            if (b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;
-        }
+        // the chunk starts here, as far as this lane can tell (the first chunk of a segment knows)
+        my_entry = pack_state(pos, b, k);
+        blocks = 0;
+        limit = final_limit;
+        if (b == 0 && k == 0 && pos < limit) bnd_pos = (int)pos;
     }
     while (__builtin_amdgcn_ballot_w64(pos < limit) != 0) {
         refill(br, streamb);
-        symbol(true);
-        symbol(br.bc >= 31);
+        symbol(true, std::true_type{});
+        symbol(br.bc >= 31, std::true_type{});
     }
     if (have) {
         if constexpr (!WARM) {
