@@ -555,7 +555,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         const bool lanes_ok = ordered && b->n_huff <= mj::kMaxLaneTables && !both_roles && !prog &&
                               (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
-        p->use_lanes = lanes_ok && (int64_t)segs.size() >= 8192;
+        p->use_lanes = lanes_ok && (int64_t)segs.size() >= 1024;       // measured crossover with the wave form: ~1000 segments
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
         if (force && !strcmp(force, "lanes") && lanes_ok) p->use_lanes = true;
         // Long segments (no DRI, or a very large restart interval) leave the chip empty at one lane each: they are cut
