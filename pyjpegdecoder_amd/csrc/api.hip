@@ -53,6 +53,9 @@ struct mj_plan {
     uint64_t *d_stateA = nullptr, *d_stateB = nullptr;
     mj::DevChunkOut *d_couts = nullptr;
     mj::DevVSeg *d_vsegs = nullptr;
+    mj::DevPiece *d_pieces = nullptr;   // stage 0 of long segments, piece by piece
+    int64_t n_pieces = 0;
+    int32_t *d_piece_kept = nullptr;
     int32_t *d_changed = nullptr;
     mj::DevScanJob *d_jobs = nullptr;   // MJ_FLAG_GPU_SEGMENT: per-image byte ranges for the marker scan
     int n_jobs = 0;
@@ -232,7 +235,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -593,6 +596,16 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 MJ_HIP(ctx, hipMalloc((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
                 MJ_HIP(ctx, hipMalloc((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
                 MJ_HIP(ctx, hipMalloc((void **)&p->d_changed, 16));
+                // stage 0 of long segments runs piece by piece (16 KiB of source bytes per wavefront)
+                std::vector<mj::DevPiece> pcs;
+                for (size_t i = 0; i < segs.size(); ++i) {
+                    const int32_t first = (int32_t)pcs.size();
+                    for (int off = 0; off == 0 || off < segs[i].len; off += 16384)
+                        pcs.push_back(mj::DevPiece{(int32_t)i, first, off, std::min(16384, std::max(0, segs[i].len - off))});
+                }
+                p->n_pieces = (int64_t)pcs.size();
+                if ((rc = upload(ctx, &p->d_pieces, pcs.data(), pcs.size())) != MJ_OK) return rc;
+                MJ_HIP(ctx, hipMalloc((void **)&p->d_piece_kept, pcs.size() * sizeof(int32_t) + 16));
                 p->use_sync = true;
             }
         }
@@ -664,7 +677,10 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
     if (p->n_jobs)      // restart markers and the end of each scan, found on the GPU
         MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     if (p->use_lanes) {
-        MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
+        if (p->d_pieces)
+            MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_segs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
+        else
+            MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
         if (p->use_sync) {
             // round 0 guesses, round 1.. start every chunk from its predecessor's exit state until no exit state changes
             // (typically the second true-state round changes nothing), then the pieces are decoded like restart segments

@@ -104,6 +104,164 @@ __global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blo
     if (lane == 0) seg_bits[seg] = total * 8;
 }
 
+// ---- long segments: the same rules, piece by piece ------------------------------------------------------------------
+// One wavefront per restart segment is fine for restart segments of ordinary size; a file without DRI is ONE segment
+// of hundreds of kilobytes and a batch of them left the chip to ~1000 serial walks (2.3 ms per 1024 x 1080p).  So long
+// segments are processed in pieces of source bytes, one wavefront each, in two launches: k_destuff_pieces<false>
+// counts the bytes each piece keeps, k_destuff_pieces<true> writes them at the offset the counts of the earlier pieces
+// add up to.  What a piece must know about its predecessors is little: whether its first byte is dropped — the parity
+// of the run of 0xFF bytes right in front of it — and, when writing, that the first and last output dword may be shared
+// with its neighbours (those bytes are stored one by one).
+namespace {
+
+// is the byte at `pos` dropped?  = is the run of 0xFF bytes ending at pos - 1 (inside [seg_begin, pos)) of odd length
+__device__ __forceinline__ uint32_t carry_in_at(const uint8_t *blob, int64_t seg_begin, int64_t pos, int lane) {
+    int run = 0;
+    for (int64_t q = pos - 1;; q -= 64) {
+        const int64_t mine = q - lane;
+        const bool in = mine >= seg_begin;
+        const bool ff = in && blob[mine] == 0xFFu;
+        const uint64_t notff = ~__ballot(ff);
+        if (notff) { run += __builtin_ctzll(notff); break; }
+        run += 64;
+    }
+    return (uint32_t)run & 1u;
+}
+
+// stream dword `d` (big-endian in memory) from four stream bytes, of which only those in `mask` (bit i = stream byte i)
+// belong to this piece
+__device__ __forceinline__ void store_stream_dword(uint32_t *d, uint32_t ring_dword, uint32_t mask) {
+    if (mask == 0xFu) { *d = __builtin_bswap32(ring_dword); return; }
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((mask >> i) & 1) bytes[3 - i] = (uint8_t)(ring_dword >> (8 * i));
+}
+
+}  // namespace
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_destuff_pieces(const uint8_t *__restrict__ blob, const DevSegment *__restrict__ segs,
+                                                        const DevPiece *__restrict__ pieces, int64_t n_pieces,
+                                                        int32_t *__restrict__ kept, uint32_t *__restrict__ stream,
+                                                        int32_t *__restrict__ seg_bits) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kRing];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t pi = (int64_t)blockIdx.x * 4 + wave;
+    if (pi >= n_pieces) return;                                  // wave-uniform; no block barriers below
+    uint8_t *stage = s_stage[wave];
+    const DevPiece pc = pieces[pi];
+    const int64_t seg_begin = segs[pc.seg].begin;
+    const int seg_len = __builtin_amdgcn_readfirstlane(segs[pc.seg].len);    // may be shorter than the host's bound (GPU scan)
+    const int p_off = __builtin_amdgcn_readfirstlane(pc.off);
+    const int p_end = min(p_off + pc.len, seg_len);
+    const bool empty = p_off >= p_end;
+    const bool last = p_off + pc.len >= seg_len && (p_off < seg_len || p_off == 0);    // this piece holds the segment's end
+    if (empty && !(WRITE && last)) { if (!WRITE && lane == 0) kept[pi] = 0; return; }
+
+    const int64_t begin = seg_begin + p_off;
+    const int len = empty ? 0 : p_end - p_off;
+    const int64_t abase = begin & ~(int64_t)3;
+    const int lead = (int)(begin - abase);
+    const int span = lead + len;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(blob + abase);
+
+    // where this piece's bytes go: behind everything the segment's earlier pieces keep
+    int o = 0;
+    if constexpr (WRITE) {
+        int part = 0;
+        for (int64_t q = pc.first + lane; q < pi; q += 64) part += kept[q];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+        o = __builtin_amdgcn_readfirstlane(part);
+    }
+    uint32_t *out = stream + (seg_begin >> 2) + pc.seg + (o >> 2);
+    int fill = o & 3, base = 0, total = 0;                       // the first o & 3 ring bytes stand for the predecessor's
+    uint32_t head_mask = (0xFu << (o & 3)) & 0xFu;               // ... bytes of the first dword, which are not ours to write
+    uint32_t carry = (p_off > 0 && !empty) ? carry_in_at(blob, seg_begin, begin, lane) : 0u;
+
+    for (int c0 = 0; c0 < span; c0 += 256) {
+        const int p = c0 + 4 * lane;
+        const uint32_t w = p < span ? src[p >> 2] : 0u;
+        uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 1, vm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = p + i >= lead && p + i < span;
+            const bool isff = ((w >> (8 * i)) & 0xFFu) == 0xFFu;
+            vm |= valid ? 1u << i : 0u;
+            k0 |= (valid && !s0) ? 1u << i : 0u;
+            k1 |= (valid && !s1) ? 1u << i : 0u;
+            s0 = valid ? (s0 ? 0u : (uint32_t)isff) : s0;
+            s1 = valid ? (s1 ? 0u : (uint32_t)isff) : s1;
+        }
+        const uint64_t A = __ballot(s0 != 0), B = __ballot(s1 != 0);
+        const uint64_t V = __ballot(vm != 0);
+        uint64_t S = (A << 1) | carry;
+        uint32_t carry_out = (uint32_t)(A >> 63);
+        uint64_t dep = (A ^ B) & V;
+        while (dep) {
+            const int L = __builtin_ctzll(dep);
+            dep &= dep - 1;
+            const uint32_t ov = (uint32_t)((((S >> L) & 1) ? B : A) >> L) & 1u;
+            if (L == 63) carry_out = ov;
+            else S = (S & ~(2ull << L)) | ((uint64_t)ov << (L + 1));
+        }
+        const uint32_t keep = ((S >> lane) & 1) ? k1 : k0;
+        const int cnt = __builtin_popcount(keep);
+        const uint64_t b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+        const int tot = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+        if constexpr (WRITE) {
+            const uint64_t below = (1ull << lane) - 1;
+            int pos = base + fill + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below) +
+                      4 * __builtin_popcountll(b2 & below);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((keep >> i) & 1) {
+                    stage[pos & (kRing - 1)] = (uint8_t)(w >> (8 * i));
+                    ++pos;
+                }
+            }
+            fill += tot;
+            if (fill >= 256) {                                   // one full 256-byte line, coalesced
+                const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
+                store_stream_dword(out + lane, d, lane == 0 ? head_mask : 0xFu);
+                head_mask = 0xFu;
+                out += 64;
+                base = (base + 256) & (kRing - 1);
+                fill -= 256;
+            }
+        }
+        total += tot;
+        carry = carry_out;
+    }
+    if constexpr (!WRITE) {
+        if (lane == 0) kept[pi] = total;
+    } else {
+        // tail: the segment's last piece zero-pads to a whole dword; any other piece leaves the rest of its last dword to
+        // its successor
+        const int rem = fill & 3;
+        if (last && lane < 4) stage[(base + fill + lane) & (kRing - 1)] = 0;
+        const int n_dw = (fill + 3) >> 2;
+        if (lane < n_dw) {
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
+            uint32_t mask = lane == 0 ? head_mask : 0xFu;
+            if (lane == n_dw - 1 && rem != 0 && !last) mask &= (1u << rem) - 1u;
+            store_stream_dword(out + lane, d, mask);
+        }
+        if (last && lane == 0) seg_bits[pc.seg] = (o + total) * 8;
+    }
+}
+
+hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, const DevPiece *pieces,
+                                 int64_t n_pieces, int32_t *kept, uint32_t *out_stream, int32_t *seg_bits) {
+    if (n_pieces == 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_pieces + 3) / 4));
+    hipLaunchKernelGGL(k_destuff_pieces<false>, grid, dim3(256), 0, stream, blob, segs, pieces, n_pieces, kept, out_stream, seg_bits);
+    hipLaunchKernelGGL(k_destuff_pieces<true>, grid, dim3(256), 0, stream, blob, segs, pieces, n_pieces, kept, out_stream, seg_bits);
+    return hipGetLastError();
+}
+
 // Restart-marker scan: with MJ_FLAG_GPU_SEGMENT the caller hands over ONE byte range per image —
 // first entropy-coded byte up to any bound at or behind the end of the scan (normally the end of the file) — and
 // this kernel does what pyjpegdecoder_amd/_parse.py does on the host otherwise (find_entropy_end,

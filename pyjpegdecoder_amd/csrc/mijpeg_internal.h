@@ -71,6 +71,12 @@ struct DevChunk {
     int32_t seg;          // index of the DevSegment
     int32_t j;            // chunk number within the segment: bits [j * cbits, (j + 1) * cbits)
 };
+// One piece of a long restart segment for stage 0 (destuff.hip): `len` source bytes from byte `off` of the segment
+struct DevPiece {
+    int32_t seg;
+    int32_t first;        // index of the segment's first piece
+    int32_t off, len;
+};
 // What a counting pass learns about a chunk, decoded from the entry state its predecessor handed over.
 struct DevChunkOut {
     uint64_t entry;       // the entry state this record was computed from (a later round skips the chunk if unchanged)
@@ -141,6 +147,8 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
                              DevChunkOut *outs, int32_t *changed);
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
                               const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs);
+hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, const DevPiece *pieces,
+                                 int64_t n_pieces, int32_t *kept, uint32_t *out_stream, int32_t *seg_bits);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits,
                                 const DevSegment *segs, int64_t n_segs,

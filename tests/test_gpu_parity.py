@@ -768,3 +768,23 @@ def test_sync_form_batch_and_damage(dec, monkeypatch):
         except JpegError:
             pass
     assert np.array_equal(dec.decode([raw])[0], oracle.decode(raw)["rgb"])
+
+
+def test_sync_form_piece_boundaries_inside_stuffing(dec, monkeypatch):
+    """Stage 0 of long segments works in 16 KiB pieces; a piece whose first byte is the 00 of an FF 00 pair must drop it
+    on the word of the piece before.  A big, noisy, quality-100 file has hundreds of pieces and an 0xFF every ~100
+    bytes: make sure some boundaries do split a pair, then require the reference's coefficients."""
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import parse_jpeg
+    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    hits = 0
+    for seed in (1, 2, 3):
+        raw = synth.synth_jpeg(900 + seed, 1600, 1200, 100, "420", 0, 70.0)
+        sc = parse_jpeg(raw).scans[0]
+        hits += sum(1 for pos in range(sc.entropy_start + 16384, sc.entropy_end, 16384) if raw[pos - 1] == 0xFF)
+        ref = oracle.decode(raw)
+        (img,), (seam,) = dec.decode([raw], return_seams=True)
+        assert np.array_equal(seam["coef"], ref["coef"]), seed
+        assert np.array_equal(img, ref["rgb"]), seed
+    assert hits >= 1, "no piece boundary fell between an 0xFF and its stuffed zero: enlarge the test"
