@@ -322,8 +322,14 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         }
-        const int64_t per = (int64_t)16 * cus;
-        const int64_t want = (n_segs + per - 1) / per;
+        // ... and when there are more segments than one such round holds, as many equal rounds as needed: lanes per wave
+        // capped where four workgroups still fit a CU's LDS, then spread evenly over the rounds
+        auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_huff * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16; };
+        int fit = 64;
+        while (fit > 8 && 4 * lds_of(fit) > 160 * 1024) --fit;
+        const int64_t per = (int64_t)16 * cus;                   // waves of one round: 4 workgroups x 4 waves x CUs
+        const int64_t rounds = (n_segs + per * fit - 1) / (per * fit);
+        const int64_t want = (n_segs + per * rounds - 1) / (per * rounds);
         use = (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
     }
     const int lpw_run = use;
