@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                     --eobrun;
                 } else {
                     int k = ss;
+                    // which coefficients are non-zero: one ballot per block, then kept up to date in scalar registers (a
+                    // correction never clears a coefficient, a newly placed one is +-1 << al)
+                    uint64_t nz = __ballot(cf != 0);
                     while (k <= se) {
                         br.refill();
                         const int hv = decode_symbol(br, lut, tab);
@@ -264,7 +267,6 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                         if (hv == 0) { eobrun = 1; break; }
                         if (s == 0 && r != 15) { eobrun = (1 << r) + (int)take32(br, r); break; }
                         int zr = (hv == 0xF0) ? 16 : r;
-                        uint64_t nz = __ballot(cf != 0);
                         // pass zr zero coefficients from k on (:1184-1193)
                         uint64_t zeros = ~nz & bits_from(k);
                         int pnext = k;
@@ -284,13 +286,13 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                             queue |= nz & bits_range(k, pz);
                             k = pz;
                             if (lane == k) cf = (int)(int16_t)(val << al);      // (:1225)
+                            nz |= (uint64_t)((int16_t)(val << al) != 0) << k;
                             dirty = true;
                             ++k;
                         }
                         refine_queue(br, queue, al, lane, cf, dirty, spec);     // (:1231-1232)
                     }
                     if (!err && eobrun > 0) {       // rest of this band, then the run continues in the next blocks
-                        const uint64_t nz = __ballot(cf != 0);
                         refine_queue(br, nz & bits_range(k, se + 1), al, lane, cf, dirty, spec);
                         --eobrun;
                     }
