@@ -707,6 +707,15 @@ def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
     for d, fix in ((dec, lambda a: a), (dec_rm, lambda a: np.swapaxes(a, 0, 1)), (dec_gs, lambda a: a)):
         for i, (img, ref) in enumerate(zip(d.decode(files), refs)):
             assert np.array_equal(fix(img), ref), i
+    # and once more with every stage-1 form forced (the sync form then cuts even these small segments where it can)
+    import os
+    for mode in ("wave", "lanes", "sync"):
+        os.environ["MJ_HUFFMAN"] = mode
+        try:
+            for i, (img, ref) in enumerate(zip(dec.decode(files), refs)):
+                assert np.array_equal(img, ref), (mode, i)
+        finally:
+            os.environ.pop("MJ_HUFFMAN", None)
 
 
 # ---- long segments: synchronisation passes + virtual segments (huffman_sync.hip) ---------------------------------------
