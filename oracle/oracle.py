@@ -1,7 +1,7 @@
 """ctypes front-end of oracle/jpeg_oracle.c — the CPU restatement of the reference's hot path.
 
 TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's
-cpu_baseline leg.  The product package never imports this module (tests/test_no_oracle_in_product.py
+cpu_baseline leg.  The product package never imports this module (tests/test_cabi.py
 greps for it).  Parity status: pinned against vectors captured from the reference itself
 (tools/make_goldens.py -> tests/golden/), checked by tests/test_oracle_golden.py.
 """
