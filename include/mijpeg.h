@@ -172,8 +172,8 @@ int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off
 /* Launch stage 1 (Huffman) + stage 2 (dequant/IDCT/upsample/colour) on `stream` (a hipStream_t passed as
  * void*, NULL = the context's own stream).  `rgb_device` is a device buffer of rgb_bytes bytes, or NULL to
  * use a plan-owned one.  Asynchronous — except for batches of long restart segments (files without DRI), whose
- * stage 1 waits on `stream` after each synchronisation round to learn whether another round is needed (two to
- * four short waits); everything it queues after that is asynchronous again. */
+ * stage 1 waits on `stream` once after its synchronisation rounds to learn whether more are needed (usually not);
+ * everything it queues after that is asynchronous again. */
 int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
 /* The two stages separately (profiling, config 2). */
 int mj_plan_execute_stage1(mj_plan *plan, void *stream);

@@ -689,14 +689,20 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
                                               p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
+            // repair rounds: three are queued without looking (a chain of wrongly guessed entry states gets one link
+            // shorter per round), then the host reads the third round's change counter, and goes on one round at a time
+            // only if that was not yet zero
+            MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, 4 * sizeof(int32_t), s));
             for (int round = 1;; ++round) {
-                MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, sizeof(int32_t), s));
+                int32_t *counter = p->d_changed + (round <= 3 ? round - 1 : 3);
+                if (round > 3) MJ_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int32_t), s));
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed));
-                int32_t changed = 0;
-                MJ_HIP(ctx, hipMemcpyAsync(&changed, p->d_changed, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                MJ_HIP(ctx, hipStreamSynchronize(s));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter));
                 std::swap(in, out);
+                if (round < 3) continue;
+                int32_t changed = 0;
+                MJ_HIP(ctx, hipMemcpyAsync(&changed, counter, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                MJ_HIP(ctx, hipStreamSynchronize(s));
                 if (changed == 0 || round > 4096) break;
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
