@@ -53,6 +53,10 @@ struct mj_plan {
     uint64_t *d_stateA = nullptr, *d_stateB = nullptr;
     mj::DevChunkOut *d_couts = nullptr;
     mj::DevVSeg *d_vsegs = nullptr;
+    hipGraphExec_t graph_exec = nullptr;   // captured launches of one execute (see mj_plan_execute)
+    hipStream_t graph_stream = nullptr;
+    uint8_t *graph_rgb = nullptr;
+    bool executed_once = false;
     mj::DevPiece *d_pieces = nullptr;   // stage 0 of long segments, piece by piece
     int64_t n_pieces = 0;
     int32_t *d_piece_kept = nullptr;
@@ -235,6 +239,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
@@ -749,9 +754,44 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
 }
 
 int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (!p) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // Re-executions of a plan with the same stream and output buffer replay a captured graph of its launches (one
+    // submission instead of a memset and three or four kernel launches).  The first execute runs plainly (it also
+    // sizes grids and allocates the plan-owned output); plans whose stage 1 has to look at the device (long segments)
+    // are never captured.
+    const bool graphable = !p->use_sync && !p->progressive && p->d_blob && p->executed_once && (rgb_device || p->d_rgb) &&
+                           !getenv("MJ_NO_GRAPH");
+    if (graphable && p->graph_exec && p->graph_stream == s && p->graph_rgb == (rgb_device ? rgb_device : p->d_rgb)) {
+        p->last_rgb = p->graph_rgb;
+        MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
+        return MJ_OK;
+    }
+    if (graphable && s != nullptr) {
+        if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = mj_plan_execute_stage1(p, s);
+            if (rc == MJ_OK) rc = mj_plan_execute_stage2(p, s, rgb_device);
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (rc == MJ_OK && ce == hipSuccess && g && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(g);
+                p->graph_stream = s;
+                p->graph_rgb = p->last_rgb;
+                MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
+                return MJ_OK;
+            }
+            if (g) (void)hipGraphDestroy(g);
+            p->graph_exec = nullptr;
+            (void)hipGetLastError();
+        }
+    }
     int rc = mj_plan_execute_stage1(p, stream);
     if (rc != MJ_OK) return rc;
-    return mj_plan_execute_stage2(p, stream, rgb_device);
+    rc = mj_plan_execute_stage2(p, stream, rgb_device);
+    p->executed_once = rc == MJ_OK;
+    return rc;
 }
 
 int mj_plan_sync(mj_plan *p) {
