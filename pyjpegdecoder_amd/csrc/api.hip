@@ -57,6 +57,8 @@ struct mj_plan {
     hipStream_t graph_stream = nullptr;
     uint8_t *graph_rgb = nullptr;
     bool executed_once = false;
+    hipStream_t prev_stream = nullptr;      // of the last plain execute
+    uint8_t *prev_rgb = nullptr;
     mj::DevPiece *d_pieces = nullptr;   // stage 0 of long segments, piece by piece
     int64_t n_pieces = 0;
     int32_t *d_piece_kept = nullptr;
@@ -768,7 +770,10 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
         MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
         return MJ_OK;
     }
-    if (graphable && s != nullptr) {
+    // capture only what is evidently a loop: the previous execute used this very stream and buffer (a caller that
+    // alternates output buffers keeps launching plainly instead of re-capturing every time)
+    uint8_t *want_rgb = rgb_device ? rgb_device : p->d_rgb;
+    if (graphable && s != nullptr && p->prev_stream == s && p->prev_rgb == want_rgb) {
         if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -791,6 +796,8 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (rc != MJ_OK) return rc;
     rc = mj_plan_execute_stage2(p, stream, rgb_device);
     p->executed_once = rc == MJ_OK;
+    p->prev_stream = s;
+    p->prev_rgb = p->last_rgb;
     return rc;
 }
 
