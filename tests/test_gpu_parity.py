@@ -432,7 +432,7 @@ def test_progressive_batch_and_class_surface(dec, tmp_path):
 
 def test_progressive_larger_random_against_oracle(dec):
     import io
-    from PIL import Image
+    Image = pytest.importorskip("PIL.Image")      # Pillow writes the progressive test files; skip where it is absent
     from oracle import oracle
     from tools import synth
     for i, (w, h, ss, q) in enumerate([(333, 211, 2, 85), (256, 192, 0, 92), (200, 120, 1, 70)]):
@@ -451,7 +451,7 @@ def test_progressive_spec_refinement_switch(dec):
     T.81 says.  Default = the reference's behaviour (pinned above); with spec_refine=True the progressive decode of a
     file must give exactly the coefficients of the same pixels coded baseline (libjpeg quantises both identically)."""
     import io
-    from PIL import Image
+    Image = pytest.importorskip("PIL.Image")      # Pillow writes the progressive test files; skip where it is absent
     from pyjpegdecoder_amd import BatchDecoder
     from tools import synth
     rgb = synth.synth_rgb(77, 96, 80, 30.0)
