@@ -797,3 +797,31 @@ def test_sync_form_piece_boundaries_inside_stuffing(dec, monkeypatch):
         assert np.array_equal(seam["coef"], ref["coef"]), seed
         assert np.array_equal(img, ref["rgb"]), seed
     assert hits >= 1, "no piece boundary fell between an 0xFF and its stuffed zero: enlarge the test"
+
+
+def test_progressive_randomised_sweep(dec, dec_rm):
+    """30 Pillow-written progressive files over size x sampling x quality x restart rows (libjpeg's scan script with
+    successive approximation): batches of mixed geometry, every pixel against the oracle, both layouts."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from oracle import oracle
+    from tools import synth
+    rng = np.random.default_rng(77)
+    files = []
+    for i in range(30):
+        w, h = int(rng.integers(8, 300)), int(rng.integers(8, 220))
+        rgb = synth.synth_rgb(2000 + i, w, h, float(rng.choice([0.0, 8.0, 30.0])))
+        kw = dict(quality=int(rng.choice([30, 60, 85, 95])), progressive=True)
+        grey = i % 7 == 3
+        if not grey:
+            kw["subsampling"] = int(rng.integers(0, 3))
+        if i % 3 == 0:
+            kw["restart_marker_rows"] = int(rng.integers(1, 4))
+        b = io.BytesIO()
+        Image.fromarray(rgb[..., 1] if grey else rgb).save(b, "JPEG", **kw)
+        files.append(b.getvalue())
+    refs = [oracle.decode(f)["rgb"] for f in files]
+    for i, (img, ref) in enumerate(zip(dec.decode(files), refs)):
+        assert np.array_equal(img, ref), i
+    for i, (img, ref) in enumerate(zip(dec_rm.decode(files), refs)):
+        assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
