@@ -104,7 +104,18 @@ struct DevProgScan {
     int32_t dc_tab[3], ac_tab[3];   // indices into the batch's DevHuff array
     int32_t ss, se, ah, al;
     int32_t mcu_count_h, mcu_count_v;
-    int32_t pad;
+    int32_t level;                  // dependency level: scans of level L need the same rows of level L - 1 scans done
+};
+
+// What a scan's restart segment carries from one band of MCU rows to the next (progressive.hip).
+struct DevProgState {
+    uint64_t bb;
+    int32_t pos, bc, pad;
+    int32_t eobrun;
+    int32_t pred[3];
+    int32_t err;
+    int32_t mcu_next;               // first MCU the next band starts with
+    int32_t reserved;
 };
 
 // One restart segment of one progressive scan.
@@ -121,7 +132,8 @@ struct DevProgSeg {
 namespace mj {
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status, int spec_refine, int transposed);
+                                   int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,
+                                   int step, int rows_per_band);
 }
 
 // stage-1 / stage-2 launchers (defined in huffman.hip / reconstruct.hip)

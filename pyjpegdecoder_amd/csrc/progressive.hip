@@ -64,12 +64,14 @@ __device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int 
 
 }  // namespace
 
+template <bool BANDED>
 __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restrict__ blob,
                                                           const DevProgSeg *__restrict__ segs, int n_segs,
                                                           const DevProgScan *__restrict__ scans,
                                                           const DevImage *__restrict__ images,
                                                           const DevHuff *__restrict__ huff, int16_t *__restrict__ coef,
-                                                          int32_t *__restrict__ status, int spec_refine, int tr) {
+                                                          int32_t *__restrict__ status, int spec_refine, int tr,
+                                                          DevProgState *__restrict__ states, int step, int rows_per_band) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][3 tables][kLutSize]
     const bool spec = spec_refine != 0;
     const int lane = threadIdx.x & 63;
@@ -87,6 +89,31 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     const bool is_dc = ss == 0 && !sequential;
     const int nsc = sc->n_comp;
 
+    // ---- which part of the scan this launch does.  The scans of an image are pipelined over bands of `rows_per_band`
+    // frame MCU rows: launch number `step` lets a scan of dependency level L work on band step - L, so a refining scan
+    // runs one band behind the scan it refines instead of waiting for all of it.  Between two of its bands a scan
+    // keeps its bit reader, EOB run and DC predictors in `states`.
+    // (Without BANDED the launch holds the segments of one dependency level only and each does its whole scan.)
+    const int band = BANDED ? step - sc->level : 0;
+    if (band < 0) return;
+    int b_lo = sg->mcu0, b_hi = sg->mcu0 + sg->n_mcu;
+    if (!BANDED) {
+    } else if (sequential) {
+        if (band != 0) return;                       // the whole scan at once (baseline scans of separate components depend on nothing)
+    } else {
+        const int v_scan = (nsc == 1 && im->ncomp > 1 && sc->comp[0] == 0) ? im->vmax : 1;   // block rows per frame MCU row
+        const int64_t mpb = (int64_t)sc->mcu_count_h * rows_per_band * v_scan;
+        const int64_t lo = (int64_t)band * mpb, hi = lo + mpb;
+        b_lo = (int)max((int64_t)b_lo, lo);
+        b_hi = (int)min((int64_t)b_hi, hi);
+        if (b_lo >= b_hi) return;
+    }
+    const bool resume = BANDED && b_lo != sg->mcu0, finish = !BANDED || b_hi == sg->mcu0 + sg->n_mcu;
+    // (read at the point of use when the scan is done in one piece: fewer scalars live through the symbol loops)
+    #define m_lo (BANDED ? b_lo : sg->mcu0)
+    #define m_hi (BANDED ? b_hi : sg->mcu0 + sg->n_mcu)
+    DevProgState *st = states + seg_id;
+
     // tables of this scan: DC scans use one DC table per scan component, AC scans one AC table, sequential scans both
     const int n_tabs = sequential ? 2 : (is_dc ? (refining ? 0 : nsc) : 1);
     for (int t = 0; t < n_tabs; ++t) {
@@ -96,6 +123,12 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
 
     BitReader br;
     br.init(blob, sg->begin, sg->len, lane);
+    int st_eobrun = 0, st_pred0 = 0, st_pred1 = 0, st_pred2 = 0;
+    if (resume) {
+        if (st->err != 0 || st->mcu_next != m_lo) return;        // the scan failed earlier (its status is set)
+        br.restore(st->pos, st->bb, st->bc, st->pad);
+        st_eobrun = st->eobrun; st_pred0 = st->pred[0]; st_pred1 = st->pred[1]; st_pred2 = st->pred[2];
+    }
 
     // frame geometry (interleaved block order of the coefficient store)
     const int hmax = im->hmax, vmax = im->vmax, bpm = im->blocks_per_mcu, fmx = im->mcu_count_h;
@@ -112,13 +145,22 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     auto store_pos = [&](int z) { const int n = c_nat_of_zz_p[z]; return tr ? ((n & 7) << 3 | n >> 3) : n; };
     const int nat = store_pos(lane);
     int err = 0;
+    // what a scan carries from band to band is written by the branch that owns it (kept local there: as function-wide
+    // variables they cost the refining loop a dozen scalar moves per block)
+    auto save_state = [&](int eob, int p0, int p1, int p2) {
+        if (BANDED && !finish && lane == 0) {
+            st->pos = br.pos; st->bb = br.bb; st->bc = br.bc; st->pad = br.pad;
+            st->eobrun = eob; st->pred[0] = p0; st->pred[1] = p1; st->pred[2] = p2;
+            st->err = err; st->mcu_next = m_hi;
+        }
+    };
 
     if (sequential) {
         // ------------------------------------------------------------ one component of a non-interleaved baseline file:
         // the scan's MCU is one 8x8 block, blocks in raster order of the component (:612-619, :771-866)
         const int c = sc->comp[0];
         int pred = 0;
-        for (int m = sg->mcu0; m < sg->mcu0 + sg->n_mcu && !err; ++m) {
+        for (int m = m_lo; m < m_hi && !err; ++m) {
             const int by = m / smh, bx = m - by * smh;
             int16_t *p = block_ptr(c, bx, by);
             br.refill();
@@ -146,14 +188,14 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
         }
     } else if (is_dc) {
         // ------------------------------------------------------------ DC scans (:974-1057)
-        int pred0 = 0, pred1 = 0, pred2 = 0;
+        int pred0 = st_pred0, pred1 = st_pred1, pred2 = st_pred2;
         if (refining) {
             // One bit per block (:1038), blocks in scan order: lane i takes the i-th block of a group of 64, so the
             // read-modify-write of 64 DC values is one load and one store instead of 64 dependent round trips.
             int bps = 0;                                   // blocks per MCU of this scan
             for (int i = 0; i < nsc; ++i) { const int c = sc->comp[i]; bps += (nsc > 1 && c == 0) ? hmax * vmax : 1; }
-            const int total = sg->n_mcu * bps;
-            for (int t0 = 0; t0 < total; t0 += 64) {
+            const int total = (m_hi - sg->mcu0) * bps;
+            for (int t0 = (m_lo - sg->mcu0) * bps; t0 < total; t0 += 64) {
                 const int n = min(64, total - t0);
                 br.refill();
                 const uint32_t w0 = take32(br, min(32, n));
@@ -178,7 +220,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 }
             }
         } else
-        for (int m = sg->mcu0; m < sg->mcu0 + sg->n_mcu && !err; ++m) {
+        for (int m = m_lo; m < m_hi && !err; ++m) {
             const int mcy = m / smh, mcx = m - mcy * smh;
             for (int i = 0; i < nsc && !err; ++i) {
                 const int c = sc->comp[i];
@@ -203,22 +245,23 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 }
             }
         }
+        save_state(0, pred0, pred1, pred2);
     } else {
         // ------------------------------------------------------------ AC scans (:1060-1298)
         const int c = sc->comp[0];
         const uint16_t *lut = my_lut;
         const DevHuff *tab = huff + sc->ac_tab[0];
         const uint64_t band = bits_range(ss, se + 1);
-        int eobrun = 0;
-        const int m_end = sg->mcu0 + sg->n_mcu;
+        const int m_end = m_hi;
+        int eobrun = st_eobrun;
         // refining scans read every block before they touch it: the next block's coefficients are requested while
         // this one is being worked on (a dependent load per block was most of a refining scan's time)
         int cf_next = 0;
-        if (refining && sg->n_mcu > 0) {
-            const int by0 = sg->mcu0 / smh, bx0 = sg->mcu0 - by0 * smh;
+        if (refining && m_lo < m_hi) {
+            const int by0 = m_lo / smh, bx0 = m_lo - by0 * smh;
             cf_next = block_ptr(c, bx0, by0)[nat];
         }
-        for (int m = sg->mcu0; m < m_end && !err; ++m) {
+        for (int m = m_lo; m < m_end && !err; ++m) {
             const int by = m / smh, bx = m - by * smh;
             int16_t *p = block_ptr(c, bx, by);
             const int cf_cur = cf_next;
@@ -302,23 +345,32 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 if (dirty && lane >= ss && lane <= se) p[nat] = (int16_t)cf;
             }
         }
+        save_state(eobrun, 0, 0, 0);
     }
 
-    if (!err) {
+    if (!err && finish) {
         if (br.pad > 0 && br.bc < br.pad) err = MJ_ST_OVERRUN;
         else if (!sg->last && (((br.bc - br.pad) >> 3) > 0 || br.pos < br.end)) err = MJ_ST_DESYNC;
     }
     if (err && lane == 0) atomicMax(status + sc->image, err);
 }
 
+#undef m_lo
+#undef m_hi
+
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                   int16_t *coef, int32_t *status, int spec_refine, int transposed) {
+                                   int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,
+                                   int step, int rows_per_band) {
     if (n_segs == 0) return hipSuccess;
     const int blocks = (n_segs + 3) / 4;
     const size_t lds = (size_t)4 * 3 * kLutSize * sizeof(uint16_t);
-    hipLaunchKernelGGL(k_progressive_scan, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs, scans,
-                       images, huff, coef, status, spec_refine, transposed);
+    if (rows_per_band > 0)
+        hipLaunchKernelGGL(k_progressive_scan<true>, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+                           scans, images, huff, coef, status, spec_refine, transposed, states, step, rows_per_band);
+    else            // every scan in one piece: `step` is the dependency level whose scans run
+        hipLaunchKernelGGL(k_progressive_scan<false>, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+                           scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
     return hipGetLastError();
 }
 

@@ -34,6 +34,14 @@ struct BitReader {
         pad = 0;
     }
 
+    // continue where an earlier launch stopped (after init() with the same segment)
+    __device__ __forceinline__ void restore(int pos_, uint64_t bb_, int bc_, int pad_) {
+        pos = pos_; bb = bb_; bc = bc_; pad = pad_;
+        cd0 = pos_ >> 2;
+        cur = words[cd0 + lane];
+        nxt = words[cd0 + 63 + lane];
+    }
+
     // dwords [i], [i+1] of the stream around byte `p`, shifted so that byte p is the low byte
     __device__ __forceinline__ uint32_t peek_raw(int p) {
         int i = (p >> 2) - cd0;
