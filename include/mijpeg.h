@@ -206,6 +206,42 @@ int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *st
  * reference's InverseDCT.idct_table (:1541-1553).  Lets CPU tests pin it bit-for-bit. */
 void mj_host_idct_table(double *tt);
 
+/* ---- host front end (no GPU work, no context) -------------------------------------------------------
+ * Header parse + batch assembly for the everyday case, on host threads: what pyjpegdecoder_amd/_parse.py
+ * (parse_jpeg(headers_only=True): the reference's marker loop :78-110 and its SOF0/DHT/DQT/DRI/SOS handlers
+ * :112-650, stopped at the SOS) and batch.prepare_batch do in Python, file by file.  For every file: walk the
+ * segments in front of the scan, copy the file to blob + file_off[i], fill images[i] and its one byte range
+ * (seg_begin[i] = first entropy-coded byte, seg_end[i] = end of the file: the arrays of a MJ_FLAG_GPU_SEGMENT
+ * batch), and number the distinct Huffman / quantisation tables of the batch in order of first use.
+ *
+ * Accepted: SOF0, 8 bit, 1 or 3 components, a first SOS naming every frame component in frame order, with only
+ * APPn / COM / DQT / DHT / DRI / SOF0 segments in front of it.  Everything else (progressive, scans of single
+ * components, DNL, unknown markers, short or inconsistent headers) is not diagnosed here: the call returns
+ * MJ_HOST_DECLINED with declined_file = the first such file and the caller runs the full marker loop, which
+ * raises what the reference raises.  All arrays are the caller's (mj_image_desc images[n_files], int64
+ * seg_begin/seg_end[n_files], huff[huff_cap], qt[qt_cap * 64]; 6 / 3 per file always suffice); file_off must be
+ * ascending multiples of 4 with file_off[i] + sizes[i] <= file_off[i + 1] (blob_len for the last); the gaps and the
+ * tail of the blob are zeroed (stage 1 reads ahead of a segment's end). */
+#define MJ_HOST_DECLINED 1
+typedef struct {
+    int32_t n_files;
+    const uint8_t *const *files;          /* in: the files' bytes                                             */
+    const int64_t *sizes;                 /* in                                                                */
+    const int64_t *file_off;              /* in: blob offset of every file                                     */
+    uint8_t *blob;                        /* out: host buffer of blob_len bytes                                */
+    int64_t blob_len;
+    mj_image_desc *images;                /* out                                                               */
+    int64_t *seg_begin, *seg_end;         /* out                                                               */
+    mj_huff_spec *huff;                   /* out */
+    int32_t huff_cap;
+    uint16_t *qt;                         /* out: zig-zag order, like mj_batch.qt                              */
+    int32_t qt_cap;
+    int32_t n_threads;                    /* in: host threads to use (>= 1)                                    */
+    int32_t n_huff, n_qt;                 /* out: distinct tables written                                      */
+    int32_t declined_file;                /* out: -1, or the first file this front end does not take           */
+} mj_host_job;
+int mj_host_assemble(mj_host_job *job);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,8 +26,9 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table", "mj_host_assemble",
 )
+MJ_HOST_DECLINED = 1
 
 
 class HuffSpecC(ctypes.Structure):
@@ -59,6 +60,15 @@ class BatchC(ctypes.Structure):
                 ("n_qt", ctypes.c_int32), ("qt", ctypes.c_void_p),
                 ("layout", ctypes.c_int32), ("flags", ctypes.c_uint32),
                 ("n_scans", ctypes.c_int32), ("scans", ctypes.POINTER(ScanDescC))]
+
+
+class HostJobC(ctypes.Structure):
+    _fields_ = [("n_files", ctypes.c_int32), ("files", ctypes.POINTER(ctypes.c_char_p)), ("sizes", ctypes.c_void_p),
+                ("file_off", ctypes.c_void_p), ("blob", ctypes.c_void_p), ("blob_len", ctypes.c_int64),
+                ("images", ctypes.POINTER(ImageDescC)), ("seg_begin", ctypes.c_void_p), ("seg_end", ctypes.c_void_p),
+                ("huff", ctypes.POINTER(HuffSpecC)), ("huff_cap", ctypes.c_int32),
+                ("qt", ctypes.c_void_p), ("qt_cap", ctypes.c_int32), ("n_threads", ctypes.c_int32),
+                ("n_huff", ctypes.c_int32), ("n_qt", ctypes.c_int32), ("declined_file", ctypes.c_int32)]
 
 
 class PlanInfoC(ctypes.Structure):
@@ -105,6 +115,7 @@ def load_library():
     L.mj_plan_time_stages.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.mj_host_idct_table.argtypes = [vp]
     L.mj_host_idct_table.restype = None
+    L.mj_host_assemble.argtypes = [ctypes.POINTER(HostJobC)]
     _lib = L
     return L
 

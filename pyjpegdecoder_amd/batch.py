@@ -247,6 +247,61 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
                          huff=huff, n_huff=len(huff_list), qt=qt, layout=layout, flags=flags, shapes=shapes)
 
 
+# numpy view of mj_image_desc (include/mijpeg.h), to read what the native front end filled in without a Python loop
+_DESC_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("ncomp", "<i4"), ("hs", "<i4", 3), ("vs", "<i4", 3),
+                        ("qt_sel", "<i4", 3), ("dc_sel", "<i4", 3), ("ac_sel", "<i4", 3), ("restart_interval", "<i4"),
+                        ("mcu_count_h", "<i4"), ("mcu_count_v", "<i4"), ("n_segments", "<i4"), ("first_segment", "<i8")])
+assert _DESC_DTYPE.itemsize == ctypes.sizeof(B.ImageDescC)
+
+
+def prepare_batch_native(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flags: int = 0, n_threads: int = 0,
+                         staging: Optional[np.ndarray] = None) -> Optional[PreparedBatch]:
+    """`prepare_batch` for a GPU-segmented batch of everyday baseline files through libmijpeg.so's host front end
+    (``mj_host_assemble``: header parse and assembly on host threads).  Returns None when the front end declines a file
+    or the batch mixes sampling layouts — the caller then takes the Python path, which also raises the reference's
+    exceptions.  ``staging``: a uint8 buffer to build the blob in (reused between batches by BatchDecoder)."""
+    n = len(files)
+    if n == 0 or not all(type(f) is bytes for f in files):
+        return None
+    lib = B.load_library()
+    sizes = np.fromiter(map(len, files), dtype=np.int64, count=n)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum((sizes + 3) & ~3, out=offs[1:])
+    blob_len = int(offs[-1]) + 1024
+    blob = staging[:blob_len] if staging is not None and staging.size >= blob_len else np.empty(blob_len, dtype=np.uint8)
+    descs = (B.ImageDescC * n)()
+    seg_b, seg_e = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    huff = (B.HuffSpecC * (6 * n))()
+    qt = np.empty((3 * n, 64), dtype=np.uint16)
+    job = B.HostJobC()
+    job.n_files = n
+    ptrs = (ctypes.c_char_p * n)(*files)
+    job.files = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_char_p))
+    job.sizes, job.file_off = sizes.ctypes.data, offs.ctypes.data
+    job.blob, job.blob_len = blob.ctypes.data, blob_len
+    job.images = ctypes.cast(descs, ctypes.POINTER(B.ImageDescC))
+    job.seg_begin, job.seg_end = seg_b.ctypes.data, seg_e.ctypes.data
+    job.huff, job.huff_cap = ctypes.cast(huff, ctypes.POINTER(B.HuffSpecC)), 6 * n
+    job.qt, job.qt_cap = qt.ctypes.data, 3 * n
+    if n_threads <= 0:
+        import os
+        n_threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    job.n_threads = n_threads
+    rc = lib.mj_host_assemble(ctypes.byref(job))
+    if rc == B.MJ_HOST_DECLINED:
+        return None
+    if rc != B.MJ_OK:
+        raise B.BackendError(f"mj_host_assemble failed ({rc})")
+    d = np.frombuffer(descs, dtype=_DESC_DTYPE)
+    lay = np.concatenate([d["ncomp"][:, None], d["hs"], d["vs"]], axis=1)
+    if (lay != lay[0]).any():
+        return None                         # several sampling layouts: one plan each, grouped by the Python path
+    shapes = list(zip(d["width"].tolist(), d["height"].tolist(), d["ncomp"].tolist()))
+    return PreparedBatch(parsed=[None] * n, blob=blob, file_offsets=offs, descs=descs, seg_begin=seg_b, seg_end=seg_e,
+                         huff=huff, n_huff=int(job.n_huff), qt=np.ascontiguousarray(qt[:max(1, int(job.n_qt))]),
+                         layout=layout, flags=flags | B.MJ_FLAG_GPU_SEGMENT, shapes=shapes)
+
+
 def raise_for_status(status: np.ndarray):
     bad = np.flatnonzero(status)
     if bad.size:
@@ -262,7 +317,7 @@ class BatchDecoder:
     """
 
     def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False,
-                 segment: str = "host"):
+                 segment: str = "host", native_host: bool = True):
         self.ctx = B.Context(device)
         self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
         # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
@@ -274,6 +329,10 @@ class BatchDecoder:
         if segment not in ("host", "gpu"):
             raise ValueError("segment must be 'host' or 'gpu'")
         self.gpu_segment = segment == "gpu"
+        # native_host: with segment="gpu", decode_device reads headers and assembles batches in libmijpeg.so's
+        # multi-threaded host front end instead of _parse.py (identical arrays; anything unusual is handed back to Python)
+        self.native_host = native_host
+        self._staging: Optional[np.ndarray] = None
 
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
         parsed = [parse_jpeg(f, headers_only=True) for f in files] if self.gpu_segment else None
@@ -336,24 +395,44 @@ class BatchDecoder:
                 plan.close()
         return (results, seams) if return_seams else results
 
+    def _staging_for(self, files: Sequence[bytes]) -> np.ndarray:
+        """Host buffer the native front end builds the blob in, kept between calls (first touch of a fresh 300 MB
+        allocation costs as much as the parse)."""
+        need = sum(map(len, files)) + 3 * len(files) + 1024
+        if self._staging is None or self._staging.size < need:
+            self._staging = np.empty(need + need // 4, dtype=np.uint8)
+        return self._staging
+
     def decode_device(self, files: Sequence[bytes]):
         """Like :meth:`decode`, but the pixels stay in HBM: a list of ``torch.uint8`` tensors on this decoder's GPU,
         views into one packed buffer per plan (zero-copy for any DLPack consumer via ``tensor.__dlpack__()``).
-        torch is only the allocator here; import it before this package."""
+        torch is only the allocator here; import it before this package.
+
+        With ``segment="gpu"`` a batch of everyday baseline files never meets the Python parser: libmijpeg.so's host
+        front end (``mj_host_assemble``) reads the headers and assembles the batch on host threads; whatever it declines
+        takes the Python path below, which raises the reference's exceptions."""
         import torch
         dev = torch.device("cuda", self.ctx.device)
-        parsed = [parse_jpeg(f, headers_only=self.gpu_segment) for f in files]
-        groups: Dict[tuple, List[int]] = {}
-        for i, p in enumerate(parsed):
-            check_supported(p)
-            comps = list(p.color_components.values())
-            key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
-            groups.setdefault(key, []).append(i)
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
-        work = list(groups.values())
+        parsed: Dict[int, ParsedJpeg] = {}
+        work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
+        if self.gpu_segment and self.native_host and len(files):
+            prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
+            if prep is not None:
+                work.append((list(range(len(files))), prep))
+        if not work:
+            groups: Dict[tuple, List[int]] = {}
+            for i, f in enumerate(files):
+                p = parsed[i] = parse_jpeg(f, headers_only=self.gpu_segment)
+                check_supported(p)
+                comps = list(p.color_components.values())
+                key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+                groups.setdefault(key, []).append(i)
+            work = [(idxs, None) for idxs in groups.values()]
         while work:
-            idxs = work.pop(0)
-            prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
+            idxs, prep = work.pop(0)
+            if prep is None:
+                prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
             d_blob = torch.from_numpy(prep.blob).to(dev)
             plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(idxs)})
             try:
@@ -366,7 +445,7 @@ class BatchDecoder:
                     for i in redo:
                         parsed[i] = parse_jpeg(files[i])
                         check_supported(parsed[i])
-                    work.append(redo)
+                    work.append((redo, None))
                     status[[k for k, i in enumerate(idxs) if i in redo]] = 0
                 raise_for_status(status)
                 off = 0

@@ -557,6 +557,63 @@ def test_device_resident_output_and_dlpack(dec, dec_rm):
         assert np.array_equal(t.cpu().numpy(), np.swapaxes(want, 0, 1)), n
 
 
+def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
+    """segment="gpu" + decode_device: a one-layout batch of baseline files is parsed and assembled by mj_host_assemble
+    (never by _parse.py); mixed layouts, progressive files and files with a tail behind the scan fall back to the Python
+    path.  Same pixels every way."""
+    import torch
+    from tools import synth
+    from oracle import oracle
+    import pyjpegdecoder_amd.batch as batch_mod
+    files = [synth.synth_jpeg(300 + i, 96 + 16 * (i % 4), 80 + 8 * i, 60 + 3 * i, "420", (0, 6, 0, 3)[i % 4], 20.0) for i in range(12)]
+    want = [oracle.decode(f)["rgb"] for f in files]
+    calls = {"native": 0, "python": 0}
+    real_native, real_parse = batch_mod.prepare_batch_native, batch_mod.parse_jpeg
+
+    def spy_native(*a, **k):
+        r = real_native(*a, **k)
+        calls["native"] += r is not None
+        return r
+
+    def spy_parse(*a, **k):
+        calls["python"] += 1
+        return real_parse(*a, **k)
+    monkeypatch.setattr(batch_mod, "prepare_batch_native", spy_native)
+    monkeypatch.setattr(batch_mod, "parse_jpeg", spy_parse)
+    outs = dec_gs.decode_device(files)
+    assert calls == {"native": 1, "python": 0}
+    for t, w in zip(outs, want):
+        assert t.is_cuda and np.array_equal(t.cpu().numpy(), w)
+    outs = dec_gs.decode_device(files)                         # the staging buffer is reused
+    assert all(np.array_equal(t.cpu().numpy(), w) for t, w in zip(outs, want))
+    # a tail behind one file's scan: that file alone is redone through the Python path
+    with_com = files[3][:-2] + b"\xff\xfe\x00\x06abcd" + b"\xff\xd9"
+    calls.update(native=0, python=0)
+    outs = dec_gs.decode_device(files[:3] + [with_com] + files[4:])
+    assert calls == {"native": 1, "python": 1}
+    assert all(np.array_equal(t.cpu().numpy(), w) for t, w in zip(outs, want))
+    # mixed layouts / a progressive file: the whole batch takes the Python path
+    other = synth.synth_jpeg(400, 64, 64, 85, "444", 0, 20.0)
+    praw, pvec = load_golden(prog_names()[0])
+    calls.update(native=0, python=0)
+    outs = dec_gs.decode_device(files[:2] + [other, praw])
+    assert calls["native"] == 0 and calls["python"] >= 4
+    assert np.array_equal(outs[2].cpu().numpy(), oracle.decode(other)["rgb"]) and np.array_equal(outs[3].cpu().numpy(), pvec["rgb"])
+    assert np.array_equal(outs[0].cpu().numpy(), want[0])
+    # native_host=False: the Python path alone, same pixels
+    from pyjpegdecoder_amd import BatchDecoder, NotJpeg
+    d2 = BatchDecoder(0, segment="gpu", native_host=False)
+    try:
+        calls.update(native=0, python=0)
+        outs = d2.decode_device(files)
+        assert calls["native"] == 0 and calls["python"] == len(files)
+        assert all(np.array_equal(t.cpu().numpy(), w) for t, w in zip(outs, want))
+    finally:
+        d2.close()
+    with pytest.raises(NotJpeg):                               # declined natively, diagnosed by the Python loop
+        dec_gs.decode_device(files[:2] + [b"not a jpeg at all"])
+
+
 def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
     """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
     reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""
