@@ -459,5 +459,77 @@ class BatchDecoder:
                 plan.close()
         return results
 
+    def decode_device_iter(self, batches):
+        """Decode a stream of batches (an iterable of lists of file bytes) with the host work and the upload of batch
+        k+1 overlapping the GPU work of batch k; yields, per batch and in order, what :meth:`decode_device` returns.
+
+        Per batch: the native host front end assembles the blob in pinned memory (host threads), the upload is queued on
+        a copy stream, the plan is created (this waits for the device, i.e. for the previous batch's kernels and this
+        batch's upload) and its kernels are queued; only then is the previous batch handed out.  Batches the front end
+        declines are decoded by :meth:`decode_device` in place (no overlap for those)."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        copy_stream = torch.cuda.Stream(device=dev)
+        pinned = None
+        pending = None          # (plan, prep, d_rgb, d_blob) of the batch in flight
+
+        def finish(job):
+            plan, prep, d_rgb, _ = job
+            try:
+                plan.sync()
+                status = plan.read(rgb=False)["status"]
+                if (status == B.MJ_ST_TAIL).any():
+                    return None                                   # something behind a scan: redo the batch the long way
+                raise_for_status(status)
+                out, off = [], 0
+                for (w, h, nc) in prep.shapes:
+                    n = w * h * nc
+                    shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
+                    out.append(d_rgb[off:off + n].view(shape))
+                    off += n
+                return out
+            finally:
+                plan.close()
+
+        for files in batches:
+            files = list(files)
+            prep = None
+            if self.gpu_segment and self.native_host and files:
+                need = sum(map(len, files)) + 3 * len(files) + 1024
+                if pinned is None or pinned.numel() < need:
+                    if pending is not None:                       # its upload may still be reading the old buffer
+                        torch.cuda.synchronize(dev)
+                    pinned = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
+                prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned.numpy())
+            if prep is None:
+                if pending is not None:
+                    done, pending_files = finish(pending[0]), pending[1]
+                    pending = None
+                    yield done if done is not None else self.decode_device(pending_files)
+                yield self.decode_device(files)
+                continue
+            with torch.cuda.stream(copy_stream):
+                d_blob = pinned[:prep.blob.size].to(dev, non_blocking=True)
+            # creating a plan waits for the device: the previous batch's kernels and this batch's upload are done after it,
+            # so the previous batch is collected here, before this one's kernels go onto the (shared) context stream
+            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
+            done = None
+            if pending is not None:
+                try:
+                    done = finish(pending[0])
+                    if done is None:
+                        done = self.decode_device(pending[1])
+                except BaseException:
+                    plan.close()
+                    raise
+            d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            plan.execute(0, d_rgb.data_ptr())
+            had, pending = pending is not None, ((plan, prep, d_rgb, d_blob), files)
+            if had:
+                yield done
+        if pending is not None:
+            done = finish(pending[0])
+            yield done if done is not None else self.decode_device(pending[1])
+
     def close(self):
         self.ctx.close()

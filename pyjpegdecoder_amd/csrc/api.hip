@@ -12,10 +12,72 @@
 
 #include "mijpeg_internal.h"
 
+// Device buffers of destroyed plans, kept by the context for the next plan.  A decode service creates one plan per
+// batch; hipMalloc / hipFree of its multi-gigabyte coefficient store every time costs more than the decode (the
+// runtime hands freed memory back lazily: measured 300-700 ms stalls every few batches of 512 x 1080p), and
+// hipFree waits for the device.  Sizes are rounded up to 1/8-octave steps so that batches of similar size reuse each
+// other's buffers; the cache is bounded (a quarter of the device's memory, MJ_CACHE_MB overrides) and evicts the
+// least recently released buffers.
+struct DevBufferCache {
+    struct Block { void *ptr; size_t size; uint64_t stamp; };
+    std::vector<Block> free_blocks;
+    std::vector<Block> live;            // handed out (size needed again at release)
+    size_t cached_bytes = 0, limit_bytes = 0;
+    uint64_t clock = 0;
+    static size_t bucket(size_t n) {
+        if (n <= 4096) return 4096;
+        size_t p2 = (size_t)1 << (63 - __builtin_clzll((unsigned long long)n));
+        const size_t step = p2 >> 3;
+        return (n + step - 1) / step * step;
+    }
+    hipError_t get(void **out, size_t bytes) {
+        const size_t want = bucket(bytes);
+        int best = -1;
+        for (int i = 0; i < (int)free_blocks.size(); ++i)
+            if (free_blocks[i].size == want && (best < 0 || free_blocks[i].stamp > free_blocks[best].stamp)) best = i;
+        if (best >= 0) {
+            *out = free_blocks[best].ptr;
+            cached_bytes -= want;
+            free_blocks.erase(free_blocks.begin() + best);
+        } else {
+            hipError_t e = hipMalloc(out, want);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, want); }
+            if (e != hipSuccess) return e;
+        }
+        live.push_back({*out, want, 0});
+        return hipSuccess;
+    }
+    void put(void *ptr) {
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].ptr == ptr) {
+                Block b = live[i];
+                live[i] = live.back();
+                live.pop_back();
+                b.stamp = ++clock;
+                free_blocks.push_back(b);
+                cached_bytes += b.size;
+                trim(limit_bytes);
+                return;
+            }
+        (void)hipFree(ptr);             // not one of ours
+    }
+    void trim(size_t keep) {
+        while (cached_bytes > keep && !free_blocks.empty()) {
+            int old = 0;
+            for (int i = 1; i < (int)free_blocks.size(); ++i)
+                if (free_blocks[i].stamp < free_blocks[old].stamp) old = i;
+            (void)hipFree(free_blocks[old].ptr);
+            cached_bytes -= free_blocks[old].size;
+            free_blocks.erase(free_blocks.begin() + old);
+        }
+    }
+};
+
 struct mj_context {
     int device = 0;
     hipStream_t stream = nullptr;
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
+    DevBufferCache cache;
     std::string err;
 };
 
@@ -168,7 +230,7 @@ bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
 
 template <typename T>
 int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
-    MJ_HIP(ctx, hipMalloc((void **)dst, n * sizeof(T) + pad_bytes + 16));
+    MJ_HIP(ctx, ctx->cache.get((void **)dst, n * sizeof(T) + pad_bytes + 16));
     if (pad_bytes) MJ_HIP(ctx, hipMemset((char *)*dst + n * sizeof(T), 0, pad_bytes));
     if (n) MJ_HIP(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return MJ_OK;
@@ -226,6 +288,12 @@ int mj_create(int device_id, mj_context **out) {
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
     MJ_HIP(nullptr, hipMemcpy(ctx->d_idct_tt, tt.data(), tt.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+        ctx->cache.limit_bytes = total_b / 4;
+        if (const char *e = getenv("MJ_CACHE_MB")) ctx->cache.limit_bytes = (size_t)atoll(e) << 20;
+    }
     *out = ctx;
     return MJ_OK;
 }
@@ -233,6 +301,8 @@ int mj_create(int device_id, mj_context **out) {
 void mj_destroy(mj_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->cache.trim(0);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -245,11 +315,14 @@ void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    // the buffers go back to the context for the next plan: nothing may still be running on them
+    if (p->prev_stream && p->prev_stream != p->ctx->stream) (void)hipStreamSynchronize(p->prev_stream);
+    if (p->graph_stream && p->graph_stream != p->ctx->stream && p->graph_stream != p->prev_stream) (void)hipStreamSynchronize(p->graph_stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) p->ctx->cache.put(q);
     delete p;
 }
 
@@ -607,9 +680,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (p->use_lanes) {
             // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
             const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
-            MJ_HIP(ctx, hipMalloc((void **)&p->d_stream, sbytes));
+            MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stream, sbytes));
             MJ_HIP(ctx, hipMemset(p->d_stream, 0, sbytes));
-            MJ_HIP(ctx, hipMalloc((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
+            MJ_HIP(ctx, ctx->cache.get((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
             if (want_sync) {
                 const int cb = p->sync_chunk_bytes;
                 std::vector<mj::DevChunk> ck;
@@ -617,11 +690,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     for (int j = 0; j < std::max(1, (segs[i].len + cb - 1) / cb); ++j) ck.push_back(mj::DevChunk{(int32_t)i, j});
                 p->n_chunks = (int64_t)ck.size();
                 if ((rc = upload(ctx, &p->d_chunks, ck.data(), ck.size())) != MJ_OK) return rc;
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_stateA, ck.size() * 8 + 16));
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_stateB, ck.size() * 8 + 16));
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_changed, 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stateA, ck.size() * 8 + 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stateB, ck.size() * 8 + 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_changed, 16));
                 // stage 0 of long segments runs piece by piece (16 KiB of source bytes per wavefront)
                 std::vector<mj::DevPiece> pcs;
                 for (size_t i = 0; i < segs.size(); ++i) {
@@ -631,7 +704,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 }
                 p->n_pieces = (int64_t)pcs.size();
                 if ((rc = upload(ctx, &p->d_pieces, pcs.data(), pcs.size())) != MJ_OK) return rc;
-                MJ_HIP(ctx, hipMalloc((void **)&p->d_piece_kept, pcs.size() * sizeof(int32_t) + 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_piece_kept, pcs.size() * sizeof(int32_t) + 16));
                 p->use_sync = true;
             }
         }
@@ -645,7 +718,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
             if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
             p->n_psegs = (int64_t)psegs.size();
-            MJ_HIP(ctx, hipMalloc((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
+            MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
         }
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
@@ -657,12 +730,12 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->d_blob = b->blob;
         }
     }
-    MJ_HIP(ctx, hipMalloc((void **)&p->d_coef, (size_t)blk * 64 * sizeof(int16_t) + 16));
+    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_coef, (size_t)blk * 64 * sizeof(int16_t) + 16));
     MJ_HIP(ctx, hipMemset(p->d_coef, 0, (size_t)blk * 64 * sizeof(int16_t)));
-    MJ_HIP(ctx, hipMalloc((void **)&p->d_status, (size_t)b->n_images * sizeof(int32_t)));
+    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_status, (size_t)b->n_images * sizeof(int32_t)));
     MJ_HIP(ctx, hipMemset(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t)));
-    if (b->flags & MJ_FLAG_KEEP_PLANES) MJ_HIP(ctx, hipMalloc((void **)&p->d_planes, (size_t)rgb * sizeof(int16_t) + 16));
-    if (b->flags & MJ_FLAG_KEEP_IDCT) MJ_HIP(ctx, hipMalloc((void **)&p->d_idct, (size_t)blk * 64 * sizeof(int16_t) + 16));
+    if (b->flags & MJ_FLAG_KEEP_PLANES) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_planes, (size_t)rgb * sizeof(int16_t) + 16));
+    if (b->flags & MJ_FLAG_KEEP_IDCT) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_idct, (size_t)blk * 64 * sizeof(int16_t) + 16));
     // hipMemset on device memory returns before it is done and runs on the null stream, which the (non-blocking)
     // context stream and a caller's stream do not wait for: without this the tail of the 6 GB clear above could land
     // after the first blocks the first execute writes.
@@ -761,7 +834,7 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
     mj_context *ctx = p->ctx;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (!rgb_device) {
-        if (!p->d_rgb) MJ_HIP(ctx, hipMalloc((void **)&p->d_rgb, (size_t)p->info.rgb_bytes + 16));
+        if (!p->d_rgb) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb, (size_t)p->info.rgb_bytes + 16));
         rgb_device = p->d_rgb;
     }
     p->last_rgb = rgb_device;
@@ -857,7 +930,7 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
         MJ_HIP(ctx, hipMemcpy(rgb_host, p->last_rgb, (size_t)p->info.rgb_bytes, hipMemcpyDeviceToHost));
     }
     if (coef_host) {   // the :869 seam is in zig-zag order; the device keeps blocks in natural order
-        if (!p->d_tmp_coef) MJ_HIP(ctx, hipMalloc((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
+        if (!p->d_tmp_coef) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
         MJ_HIP(ctx, mj::launch_permute_blocks(ctx->stream, p->d_coef, p->d_tmp_coef, p->info.total_blocks, 0, p->transposed ? 1 : 0));
         MJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         MJ_HIP(ctx, hipMemcpy(coef_host, p->d_tmp_coef, (size_t)p->info.total_blocks * 128, hipMemcpyDeviceToHost));
@@ -879,7 +952,7 @@ int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
     mj_context *ctx = p->ctx;
     const int16_t *src = coef;
     if (mem != MJ_MEM_DEVICE) {
-        if (!p->d_tmp_coef) MJ_HIP(ctx, hipMalloc((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
+        if (!p->d_tmp_coef) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_tmp_coef, (size_t)p->info.total_blocks * 128 + 16));
         MJ_HIP(ctx, hipMemcpy(p->d_tmp_coef, coef, (size_t)p->info.total_blocks * 128, hipMemcpyHostToDevice));
         src = p->d_tmp_coef;
     }

@@ -614,6 +614,47 @@ def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
         dec_gs.decode_device(files[:2] + [b"not a jpeg at all"])
 
 
+def test_pipelined_stream_of_batches(dec_gs):
+    """decode_device_iter: batch k+1 is assembled and uploaded while batch k is on the GPU; results come in order and are
+    the same pixels, also when a batch is declined by the front end, has a tail behind a scan, or is empty-handed."""
+    from tools import synth
+    from oracle import oracle
+    from pyjpegdecoder_amd import CorruptedJpeg
+    pool = [synth.synth_jpeg(500 + i, 120 + 8 * (i % 5), 64 + 4 * i, 70 + i, "420", (0, 4, 9)[i % 3], 18.0) for i in range(10)]
+    want = [oracle.decode(f)["rgb"] for f in pool]
+    praw, pvec = load_golden(prog_names()[0])
+    with_com = pool[1][:-2] + b"\xff\xfe\x00\x06abcd" + b"\xff\xd9"
+    batches = [[0, 1, 2, 3], [4, 5], [6, 7, 8, 9, 0, 1, 2], "prog", [3, 4], "tail", [9], [5, 6, 7, 8, 9, 0, 1, 2, 3, 4]]
+
+    def gen():
+        for b in batches:
+            if b == "prog":
+                yield [pool[0], praw]
+            elif b == "tail":
+                yield [pool[0], with_com, pool[2]]
+            else:
+                yield [pool[i] for i in b]
+    outs = list(dec_gs.decode_device_iter(gen()))
+    assert len(outs) == len(batches)
+    for b, o in zip(batches, outs):
+        if b == "prog":
+            assert np.array_equal(o[0].cpu().numpy(), want[0]) and np.array_equal(o[1].cpu().numpy(), pvec["rgb"])
+        elif b == "tail":
+            assert [np.array_equal(t.cpu().numpy(), want[i]) for t, i in zip(o, (0, 1, 2))] == [True] * 3
+        else:
+            assert len(o) == len(b)
+            for t, i in zip(o, b):
+                assert t.is_cuda and np.array_equal(t.cpu().numpy(), want[i])
+    # results of earlier batches stay valid while later ones are decoded (their buffers are theirs)
+    assert np.array_equal(outs[0][0].cpu().numpy(), want[0])
+    # a corrupt file surfaces as the reference's exception when its batch is handed out
+    s0 = pool[1].find(b"\xff\xda")
+    broken = pool[1][:s0 + 40] + bytes(200) + pool[1][s0 + 240:]
+    with pytest.raises(CorruptedJpeg):
+        list(dec_gs.decode_device_iter([[pool[0]], [broken, pool[2]], [pool[3]]]))
+    assert np.array_equal(dec_gs.decode_device([pool[4]])[0].cpu().numpy(), want[4])      # the decoder is still usable
+
+
 def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
     """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
     reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""

@@ -26,3 +26,14 @@ for label, kw in (("host segmentation, Python host code", dict(segment="host")),
         pr = cProfile.Profile(); pr.enable(); dec.decode_device(files); torch.cuda.synchronize(); pr.disable()
         pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
     dec.close()
+
+# a serving loop: batches back to back, host work and upload of the next batch under the GPU work of the current one
+dec = BatchDecoder(0, segment="gpu")
+for _ in dec.decode_device_iter([files[:8], files, files]): pass
+torch.cuda.synchronize()
+nb = 24
+t = time.perf_counter()
+for out in dec.decode_device_iter(files for _ in range(nb)): pass
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nb
+print("%-42s decode_device_iter, %d batches of 512 x 1080p: %.4f s per batch = %.0f MP/s" % ("pipelined, native host front end", nb, dt, 512 * W * H / 1e6 / dt))
+dec.close()
