@@ -655,6 +655,28 @@ def test_pipelined_stream_of_batches(dec_gs):
     assert np.array_equal(dec_gs.decode_device([pool[4]])[0].cpu().numpy(), want[4])      # the decoder is still usable
 
 
+@pytest.mark.parametrize("cache_mb", ["0", "1", "64"])
+def test_device_buffer_cache_limits(cache_mb, monkeypatch):
+    """A context keeps the device buffers of destroyed plans for the next plan (bounded, MJ_CACHE_MB).  Whatever the bound
+    — nothing kept, less than one plan's worth, plenty — plans of changing sizes decode the same pixels, and recycled
+    buffers (which hold another plan's bytes, not zeros) change nothing."""
+    from pyjpegdecoder_amd import BatchDecoder
+    monkeypatch.setenv("MJ_CACHE_MB", cache_mb)
+    d = BatchDecoder(0)
+    try:
+        names = golden_names()
+        files = {n: load_golden(n) for n in names}
+        rng = np.random.default_rng(int(cache_mb))
+        for rep in range(12):
+            pick = [names[i] for i in rng.integers(0, len(names), int(rng.integers(1, 9)))]
+            for n, img in zip(pick, d.decode([files[n][0] for n in pick])):
+                assert np.array_equal(img, files[n][1]["rgb"]), (rep, n)
+        pn = prog_names()[0]
+        assert np.array_equal(d.decode([load_golden(pn)[0]])[0], load_golden(pn)[1]["rgb"])
+    finally:
+        d.close()
+
+
 def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
     """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
     reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""
