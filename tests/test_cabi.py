@@ -67,3 +67,34 @@ def test_product_never_touches_the_oracle():
         src = f.read_text()
         assert "oracle" not in src.lower() or f.name in (), f"{f} mentions the oracle"
     assert "oracle" not in (ROOT / "include" / "mijpeg.h").read_text().lower()
+
+
+def test_header_is_plain_c_and_layouts_match_the_binding(tmp_path):
+    """include/mijpeg.h compiles as C (the boundary is a C ABI, not C++), and every struct has the size and field
+    offsets the ctypes binding assumes."""
+    import ctypes
+    import shutil
+    import subprocess
+    from pyjpegdecoder_amd import _binding as B
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = [("mj_huff_spec", B.HuffSpecC), ("mj_image_desc", B.ImageDescC), ("mj_scan_desc", B.ScanDescC),
+             ("mj_batch", B.BatchC), ("mj_plan_info", B.PlanInfoC), ("mj_host_job", B.HostJobC)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mijpeg.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        got = line.split()
+        assert got[0] == cname
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in got[1:]] == want, cname
