@@ -62,7 +62,7 @@ def encode_rgb(rgb: np.ndarray, quality: int = 85, subsampling: str = "420", res
     """Encode a row-major (H, W, 3) uint8 array as a baseline JPEG file."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     h, w = rgb.shape[:2]
-    cap = w * h * 3 + 65536
+    cap = w * h * 12 + 65536          # quality 100 on noise: up to ~27 bits per coefficient
     buf = np.empty(cap, dtype=np.uint8)
     n = _load().mjenc_encode_rgb(_u8p(rgb), w, h, quality, SUBSAMPLING[subsampling], restart_interval, _u8p(buf), cap)
     if n < 0:
