@@ -178,7 +178,7 @@ int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
 /* The two stages separately (profiling, config 2). */
 int mj_plan_execute_stage1(mj_plan *plan, void *stream);
 int mj_plan_execute_stage2(mj_plan *plan, void *stream, uint8_t *rgb_device);
-int mj_plan_sync(mj_plan *plan);
+int mj_plan_sync(mj_plan *plan);   /* waits for the context's stream and for the stream of the plan's last execute */
 
 /* Device pointers of plan-owned buffers (valid until mj_plan_destroy): zero-copy hand-off to torch etc. */
 int mj_plan_device_buffers(mj_plan *plan, int16_t **coef, uint8_t **rgb, int16_t **planes, int16_t **idct);

@@ -119,6 +119,7 @@ struct mj_plan {
     hipStream_t graph_stream = nullptr;
     uint8_t *graph_rgb = nullptr;
     bool executed_once = false;
+    bool last_was_graph = false;
     hipStream_t prev_stream = nullptr;      // of the last plain execute
     uint8_t *prev_rgb = nullptr;
     mj::DevPiece *d_pieces = nullptr;   // stage 0 of long segments, piece by piece
@@ -871,6 +872,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
                            !getenv("MJ_NO_GRAPH");
     if (graphable && p->graph_exec && p->graph_stream == s && p->graph_rgb == (rgb_device ? rgb_device : p->d_rgb)) {
         p->last_rgb = p->graph_rgb;
+        p->last_was_graph = true;
         MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
         return MJ_OK;
     }
@@ -888,6 +890,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
                 (void)hipGraphDestroy(g);
                 p->graph_stream = s;
                 p->graph_rgb = p->last_rgb;
+                p->last_was_graph = true;
                 MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
                 return MJ_OK;
             }
@@ -900,6 +903,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (rc != MJ_OK) return rc;
     rc = mj_plan_execute_stage2(p, stream, rgb_device);
     p->executed_once = rc == MJ_OK;
+    p->last_was_graph = false;
     p->prev_stream = s;
     p->prev_rgb = p->last_rgb;
     return rc;
@@ -908,6 +912,9 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
 int mj_plan_sync(mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
     MJ_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    // ... and the caller's stream, if the last execute went there
+    hipStream_t last = p->graph_exec && p->last_was_graph ? p->graph_stream : p->prev_stream;
+    if (last && last != p->ctx->stream) MJ_HIP(p->ctx, hipStreamSynchronize(last));
     return MJ_OK;
 }
 
