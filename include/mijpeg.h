@@ -166,6 +166,15 @@ int mj_version(void);
 int mj_plan_create(mj_context *ctx, const mj_batch *batch, mj_plan **out);
 void mj_plan_destroy(mj_plan *plan);
 int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
+/* Which form of stage 1 the plan chose: one restart segment per wavefront, one per lane, long segments
+ * cut into self-synchronised pieces, or scan by scan (progressive / non-interleaved); MJ_FORM_WG_TABLES is or-ed in when
+ * the batch has more Huffman tables than LDS holds and every workgroup loads only the tables of its own images. */
+#define MJ_FORM_WAVE      0
+#define MJ_FORM_LANES     1
+#define MJ_FORM_SYNC      2
+#define MJ_FORM_SCANS     3
+#define MJ_FORM_WG_TABLES 16
+int mj_plan_stage1_form(const mj_plan *plan);
 /* offsets (in elements of the respective output) of image i inside the packed outputs */
 int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off, int64_t *rgb_off);
 

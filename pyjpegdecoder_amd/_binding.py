@@ -26,8 +26,9 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table", "mj_host_assemble",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form",
 )
+MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES = 0, 1, 2, 3, 16
 MJ_HOST_DECLINED = 1
 
 
@@ -116,6 +117,7 @@ def load_library():
     L.mj_host_idct_table.argtypes = [vp]
     L.mj_host_idct_table.restype = None
     L.mj_host_assemble.argtypes = [ctypes.POINTER(HostJobC)]
+    L.mj_plan_stage1_form.argtypes = [vp]
     _lib = L
     return L
 
@@ -180,6 +182,10 @@ class Plan:
 
     def sync(self):
         self.ctx.check(self.ctx.lib.mj_plan_sync(self.handle))
+
+    def stage1_form(self) -> int:
+        """MJ_FORM_* (| MJ_FORM_WG_TABLES): which stage-1 form the library chose for this batch."""
+        return int(self.ctx.lib.mj_plan_stage1_form(self.handle))
 
     def write_coef(self, coef: np.ndarray):
         coef = np.ascontiguousarray(coef, dtype=np.int16)

@@ -104,6 +104,9 @@ struct mj_plan {
     mj::DevImage *d_images = nullptr;
     mj::DevHuff *d_huff = nullptr;
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
+    // batches with more tables than LDS holds (files with their own optimised tables): per workgroup, the tables its
+    // units of work use — one list for the lane kernel's launch, one for the counting rounds (256 chunks per workgroup)
+    int32_t *d_wg_tabs_lanes = nullptr, *d_wg_tabs_count = nullptr;
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
@@ -320,7 +323,7 @@ void mj_plan_destroy(mj_plan *p) {
     if (p->prev_stream && p->prev_stream != p->ctx->stream) (void)hipStreamSynchronize(p->prev_stream);
     if (p->graph_stream && p->graph_stream != p->ctx->stream && p->graph_stream != p->prev_stream) (void)hipStreamSynchronize(p->graph_stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -656,7 +659,40 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         } else {
             for (size_t i = 1; i < jobs.size() && ordered; ++i) ordered = jobs[i].begin >= jobs[i - 1].end;
         }
-        const bool lanes_ok = ordered && b->n_huff <= mj::kMaxLaneTables && !both_roles && !prog &&
+        // More tables than LDS holds (every file with its own optimised tables): a workgroup's segments belong to one or
+        // two images, so it loads just their tables — if every workgroup of the launch gets by with kMaxLaneTables.
+        const bool many_tabs = b->n_huff > mj::kMaxLaneTables;
+        auto wg_lists = [&](const std::vector<int32_t> &unit_image, int64_t units_per_wg, std::vector<int32_t> &lists) -> bool {
+            const int64_t n_wg = ((int64_t)unit_image.size() + units_per_wg - 1) / units_per_wg;
+            lists.assign((size_t)n_wg * mj::kMaxLaneTables, -1);
+            for (int64_t g = 0; g < n_wg; ++g) {
+                int32_t *l = lists.data() + (size_t)g * mj::kMaxLaneTables;
+                int n = 0, last_img = -1;
+                const int64_t u1 = std::min<int64_t>((g + 1) * units_per_wg, (int64_t)unit_image.size());
+                for (int64_t u = g * units_per_wg; u < u1; ++u) {
+                    const int img = unit_image[(size_t)u];
+                    if (img == last_img) continue;
+                    last_img = img;
+                    for (int k2 = 0; k2 < imgs[img].n_tabs; ++k2) {
+                        const int t = imgs[img].tab_index[k2];
+                        bool seen = false;
+                        for (int j = 0; j < n; ++j) seen = seen || l[j] == t;
+                        if (seen) continue;
+                        if (n == mj::kMaxLaneTables) return false;
+                        l[n++] = t;
+                    }
+                }
+            }
+            return true;
+        };
+        std::vector<int32_t> seg_image, chunk_image, wl_lanes, wl_count;
+        bool many_ok_dri = true, many_ok_sync = true;
+        if (many_tabs && !prog && !both_roles) {
+            seg_image.reserve(segs.size());
+            for (const auto &g : segs) seg_image.push_back(g.image);
+            many_ok_dri = wg_lists(seg_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)segs.size(), mj::kMaxLaneTables), wl_lanes);
+        }
+        const bool lanes_ok = ordered && (!many_tabs || many_ok_dri) && !both_roles && !prog &&
                               (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
         p->use_lanes = lanes_ok && (int64_t)segs.size() >= 1024;       // measured crossover with the wave form: ~1000 segments
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
@@ -675,9 +711,24 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         int64_t total_len = 0, est_chunks = 0;
         for (const auto &g : segs) { total_len += g.len; est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes); }
         const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 64;
-        const bool sync_ok = lanes_ok && (jobs.empty() || one_seg_each) && dc_fits;
-        const bool want_sync = sync_ok && ((force && !strcmp(force, "sync")) || (!force && long_segs));
+        // (with many tables the synchronisation form needs its own two workgroup shapes to get by with their table lists;
+        // its lane launch runs over chunks, so the restart-segment shape checked above does not matter for it)
+        const bool sync_shape_ok = ordered && !both_roles && !prog && (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
+        bool want_sync = (many_tabs ? sync_shape_ok : lanes_ok) && (jobs.empty() || one_seg_each) && dc_fits &&
+                         ((force && !strcmp(force, "sync")) || (!force && long_segs));
+        if (want_sync && many_tabs) {
+            const int cb = p->sync_chunk_bytes;
+            for (size_t i = 0; i < segs.size(); ++i)
+                for (int j = 0; j < std::max(1, (segs[i].len + cb - 1) / cb); ++j) chunk_image.push_back(segs[i].image);
+            many_ok_sync = wg_lists(chunk_image, 256, wl_count) &&
+                           wg_lists(chunk_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)chunk_image.size(), mj::kMaxLaneTables), wl_lanes);
+            if (!many_ok_sync) want_sync = false;
+        }
         if (want_sync) p->use_lanes = true;
+        if (p->use_lanes && many_tabs) {
+            if ((rc = upload(ctx, &p->d_wg_tabs_lanes, wl_lanes.data(), wl_lanes.size())) != MJ_OK) return rc;
+            if (want_sync && (rc = upload(ctx, &p->d_wg_tabs_count, wl_count.data(), wl_count.size())) != MJ_OK) return rc;
+        }
         if (p->use_lanes) {
             // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
             const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
@@ -746,6 +797,13 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     return MJ_OK;
 }
 
+int mj_plan_stage1_form(const mj_plan *p) {
+    if (!p) return MJ_ERR_INVALID;
+    if (p->progressive) return MJ_FORM_SCANS;
+    const int base = p->use_sync ? MJ_FORM_SYNC : (p->use_lanes ? MJ_FORM_LANES : MJ_FORM_WAVE);
+    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0);
+}
+
 int mj_plan_get_info(const mj_plan *p, mj_plan_info *info) {
     if (!p || !info) return MJ_ERR_INVALID;
     *info = p->info;
@@ -799,7 +857,7 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
             const int cbits = p->sync_chunk_bytes * 8;
             MJ_HIP(ctx, hipMemsetAsync(p->d_couts, 0xFF, (size_t)p->n_chunks * sizeof(mj::DevChunkOut), s));
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
-                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed));
+                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
             // repair rounds: three are queued without looking (a chain of wrongly guessed entry states gets one link
             // shorter per round), then the host reads the third round's change counter, and goes on one round at a time
@@ -809,7 +867,7 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
                 int32_t *counter = p->d_changed + (round <= 3 ? round - 1 : 3);
                 if (round > 3) MJ_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int32_t), s));
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter, p->d_wg_tabs_count));
                 std::swap(in, out);
                 if (round < 3) continue;
                 int32_t changed = 0;
@@ -819,11 +877,11 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
             MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
-                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs));
+                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes));
             return MJ_OK;
         }
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
-                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0));
+                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes));
     } else
         MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
                                        p->d_status, p->lut_slots, p->transposed ? 1 : 0));

@@ -80,6 +80,10 @@ __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_compl
 
 }  // namespace
 
+// WGT: the batch has more tables than LDS holds (files with their own optimised tables): every workgroup gets the up
+// to kMaxLaneTables tables its segments' images use (`wg_tabs`, built by api.hip for exactly this launch shape); a
+// lane's table numbers are then positions in that list.  Without WGT the LDS slot of a table is its index in the batch.
+template <bool WGT>
 __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restrict__ stream,   // stage 0's output
                                                        const int32_t *__restrict__ seg_bits,  // bits per segment
                                                        const DevSegment *__restrict__ segs, int64_t n_segs,
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                                                        const uint16_t *__restrict__ lut11,   // [n_huff][kLSize]
                                                        int n_huff, int16_t *__restrict__ coef,
                                                        int32_t *__restrict__ status, int lpw, int tr,
-                                                       const DevVSeg *__restrict__ vsegs /* or null */) {
+                                                       const DevVSeg *__restrict__ vsegs /* or null */,
+                                                       const int32_t *__restrict__ wg_tabs /* WGT: [gridDim.x][kMaxLaneTables], -1 = unused */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,8 +109,18 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     uint16_t *s_null = reinterpret_cast<uint16_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4 + (size_t)4 * lpw2 * 8);
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));
 
-    for (int i = tid; i < n_huff * kLSize / 8; i += 256)
-        reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
+    const int32_t *my_tabs = WGT ? wg_tabs + (size_t)blockIdx.x * kMaxLaneTables : nullptr;
+    if (WGT) {
+        for (int j = 0; j < n_huff; ++j) {                  // n_huff = slots in LDS here
+            const int t = my_tabs[j];
+            if (t < 0) continue;
+            for (int i = tid; i < kLSize / 8; i += 256)
+                reinterpret_cast<uint4 *>(s_lut + j * kLSize)[i] = reinterpret_cast<const uint4 *>(lut11 + (size_t)t * kLSize)[i];
+        }
+    } else {
+        for (int i = tid; i < n_huff * kLSize / 8; i += 256)
+            reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11)[i];
+    }
     for (int i = tid; i < 4 * wstride; i += 256)
         (reinterpret_cast<uint32_t *>(smem + (size_t)n_huff * kLSize * 2))[i] = 0;
     __syncthreads();
@@ -139,6 +154,20 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
         }
         if (!(seen & 2)) { dcT[1] = dcT[0]; acT[1] = acT[0]; }
         if (!(seen & 4)) { dcT[2] = dcT[0]; acT[2] = acT[0]; }
+    }
+    // the tables' indices in the batch (for the canonical search of long codes) and their LDS slots (for everything else)
+    int dcG[3] = {dcT[0], dcT[1], dcT[2]}, acG[3] = {acT[0], acT[1], acT[2]};
+    if (WGT) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int d = 0, a = 0;
+            for (int j = 0; j < kMaxLaneTables; ++j) {
+                const int t = my_tabs[j];
+                d = t == dcG[c] ? j : d;
+                a = t == acG[c] ? j : a;
+            }
+            dcT[c] = d; acT[c] = a;
+        }
     }
     const int n_mcu = have ? sg.n_mcu : 0;
     int max_mcu = n_mcu;
@@ -179,6 +208,8 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             const int comp = (int)((comp_pk_u >> (8 * b)) & 0xFF);          // wave-uniform
             const int dct = comp == 0 ? dcT[0] : (comp == 1 ? dcT[1] : dcT[2]);
             const int act_ = comp == 0 ? acT[0] : (comp == 1 ? acT[1] : acT[2]);
+            const int dcg = WGT ? (comp == 0 ? dcG[0] : (comp == 1 ? dcG[1] : dcG[2])) : dct;
+            const int acg = WGT ? (comp == 0 ? acG[0] : (comp == 1 ? acG[1] : acG[2])) : act_;
             const bool act = in_mcu && err == 0;
 
             // ---- DC (:810-820): one symbol per lane, straight-line
@@ -190,7 +221,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 int len = e >> 8, s = e & 0xFF;
                 if (__builtin_amdgcn_ballot_w64(act && len == 0) != 0) {                              // code longer than 11 bits: rare
                     if (act && len == 0) {
-                        const int r = long_code(huff + dct, p16);
+                        const int r = long_code(huff + dcg, p16);
                         len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF;
                     }
                 }
@@ -224,7 +255,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 const int e = *(on ? ep : s_null);
                 int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
                 if (e < 2048) {                                               // code longer than 11 bits: rare (the branch
-                    const int r = long_code(huff + act_, hi >> 16);           // is skipped when no lane has one)
+                    const int r = long_code(huff + acg, hi >> 16);            // is skipped when no lane has one)
                     err = r < 0 ? MJ_ST_BAD_CODE : err;
                     const int hv = r & 0xFF;
                     ln = r < 0 ? 0 : r >> 8;
@@ -304,45 +335,54 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     }
 }
 
-hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
-                                const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs) {
-    if (n_segs == 0) return hipSuccess;
+// Lanes per wavefront for `n_segs` units of work with `n_slots` tables in LDS (api.hip asks too: a batch with more
+// tables than LDS holds gets per-workgroup table lists, which depend on how the launch groups the segments).
+int lanes_per_wave(int64_t n_segs, int n_slots) {
     static int lpw = 0;
     if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
-    int use = lpw;
-    if (use < 0) {
-        // measured on MI355X: the kernel is instruction-issue bound, every instruction costing the same
-        // whatever the number of active lanes, and latency bound below ~2 waves per SIMD.  All workgroups are resident
-        // at once and run equally long, so what matters besides ~3-4 waves per SIMD is that every CU gets the SAME
-        // number of workgroups: lanes per wave = segments / (4 workgroups x 4 waves x CUs), rounded up.
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        }
-        // ... and when there are more segments than one such round holds, as many equal rounds as needed: lanes per wave
-        // capped where four workgroups still fit a CU's LDS, then spread evenly over the rounds
-        auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_huff * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16; };
-        int fit = 64;
-        while (fit > 8 && 4 * lds_of(fit) > 160 * 1024) --fit;
-        const int64_t per = (int64_t)16 * cus;                   // waves of one round: 4 workgroups x 4 waves x CUs
-        const int64_t rounds = (n_segs + per * fit - 1) / (per * fit);
-        const int64_t want = (n_segs + per * rounds - 1) / (per * rounds);
-        use = (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
+    if (lpw > 0) return lpw;
+    // measured on MI355X: the kernel is instruction-issue bound, every instruction costing the same
+    // whatever the number of active lanes, and latency bound below ~2 waves per SIMD.  All workgroups are resident
+    // at once and run equally long, so what matters besides ~3-4 waves per SIMD is that every CU gets the SAME
+    // number of workgroups: lanes per wave = segments / (4 workgroups x 4 waves x CUs), rounded up.
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     }
-    const int lpw_run = use;
+    // ... and when there are more segments than one such round holds, as many equal rounds as needed: lanes per wave
+    // capped where four workgroups still fit a CU's LDS, then spread evenly over the rounds
+    auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_slots * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16; };
+    int fit = 64;
+    while (fit > 8 && 4 * lds_of(fit) > 160 * 1024) --fit;
+    const int64_t per = (int64_t)16 * cus;                   // waves of one round: 4 workgroups x 4 waves x CUs
+    const int64_t rounds = (n_segs + per * fit - 1) / (per * fit);
+    const int64_t want = (n_segs + per * rounds - 1) / (per * rounds);
+    return (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
+}
+
+hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
+                                const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
+                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs, const int32_t *wg_tabs) {
+    if (n_segs == 0) return hipSuccess;
+    const int n_slots = wg_tabs ? kMaxLaneTables : n_huff;
+    const int lpw_run = lanes_per_wave(n_segs, n_slots);
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
-    const size_t lds = (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;
+    const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_huffman_lanes, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
-                       lut11, n_huff, coef, status, lpw_run, transposed, vsegs);
+    if (wg_tabs)
+        hipLaunchKernelGGL(k_huffman_lanes<true>, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images,
+                           huff, lut11, n_slots, coef, status, lpw_run, transposed, vsegs, wg_tabs);
+    else
+        hipLaunchKernelGGL(k_huffman_lanes<false>, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images,
+                           huff, lut11, n_slots, coef, status, lpw_run, transposed, vsegs, wg_tabs);
     return hipGetLastError();
 }
 

@@ -68,13 +68,28 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
                                                     const DevHuff *__restrict__ huff, const uint16_t *__restrict__ lut11u,
                                                     int n_huff, const DevChunk *__restrict__ chunks, int64_t n_chunks, int cbits, int warm,
                                                     const uint64_t *__restrict__ entry, uint64_t *__restrict__ exit_out,
-                                                    DevChunkOut *__restrict__ outs, int32_t *__restrict__ changed) {
+                                                    DevChunkOut *__restrict__ outs, int32_t *__restrict__ changed,
+                                                    const int32_t *__restrict__ wg_tabs /* or null: [gridDim.x][kMaxLaneTables] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
-    uint16_t *s_null = s_lut + (size_t)n_huff * kLSize;
+    uint16_t *s_null = s_lut + (size_t)n_huff * kLSize;                 // n_huff = table slots in LDS
+    int32_t *s_glob = reinterpret_cast<int32_t *>(s_null + 8);           // slot -> index of the table in the batch
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_huff * kLSize / 8; i += 256)
-        reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11u)[i];
+    // a batch with more tables than LDS holds: this workgroup's chunks use the (at most kMaxLaneTables) tables listed in
+    // wg_tabs, and "slot" below is a position in that list
+    const int32_t *my_tabs = wg_tabs ? wg_tabs + (size_t)blockIdx.x * kMaxLaneTables : nullptr;
+    if (my_tabs) {
+        for (int j = 0; j < n_huff; ++j) {
+            const int t = my_tabs[j];
+            if (t < 0) continue;
+            for (int i = tid; i < kLSize / 8; i += 256)
+                reinterpret_cast<uint4 *>(s_lut + j * kLSize)[i] = reinterpret_cast<const uint4 *>(lut11u + (size_t)t * kLSize)[i];
+        }
+    } else {
+        for (int i = tid; i < n_huff * kLSize / 8; i += 256)
+            reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11u)[i];
+    }
+    if (tid < kMaxLaneTables) s_glob[tid] = my_tabs ? my_tabs[tid] : tid;
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));          // length 0, run 64, size 0: a lane that is done
     __syncthreads();
 
@@ -89,8 +104,14 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
     for (int b = 0; b < 8 && b < im->blocks_per_mcu; ++b) {
         const int cc = im->blk_comp[b];
         comp_pk |= (uint32_t)cc << (4 * b);
-        slots_pk |= (uint32_t)im->tab_index[im->blk_dc_slot[b]] << (4 * cc);
-        slots_pk |= (uint32_t)im->tab_index[im->blk_ac_slot[b]] << (4 * (cc + 3));
+        int dslot = im->tab_index[im->blk_dc_slot[b]], aslot = im->tab_index[im->blk_ac_slot[b]];
+        if (my_tabs) {
+            int d = 0, a = 0;
+            for (int j = 0; j < kMaxLaneTables; ++j) { d = my_tabs[j] == dslot ? j : d; a = my_tabs[j] == aslot ? j : a; }
+            dslot = d; aslot = a;
+        }
+        slots_pk |= (uint32_t)dslot << (4 * cc);
+        slots_pk |= (uint32_t)aslot << (4 * (cc + 3));
     }
     const int nbits = have ? seg_bits[ch.seg] : 0;
     const int64_t lim64 = (int64_t)(ch.j + 1) * cbits;
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const int e = *reinterpret_cast<const uint16_t *>(on ? ep : reinterpret_cast<const unsigned char *>(s_null));
         int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
         if (e < 2048) {                                               // longer than 11 bits: rare
-            const int r = long_code(huff + slot, hi >> 16);
+            const int r = long_code(huff + s_glob[slot], hi >> 16);
             const int hv = r & 0xFF;
             ln = r < 0 ? 1 : r >> 8;                                  // no code at all: skip a bit (the data is garbage anyway)
             run = r < 0 ? 0 : (isdc ? 0 : (hv == 0 ? 64 : hv >> 4));
@@ -262,17 +283,18 @@ __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chu
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed) {
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs) {
     if (n_chunks == 0) return hipSuccess;
-    const size_t lds = (size_t)n_huff * kLSize * 2 + 16;
+    if (wg_tabs) n_huff = kMaxLaneTables;                       // table slots in LDS
+    const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxLaneTables * 4;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
     const int warm = getenv("MJ_SYNC_WARM") ? atoi(getenv("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed);
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs);
     else
         hipLaunchKernelGGL(k_sync_count<true>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed);
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs);
     return hipGetLastError();
 }
 

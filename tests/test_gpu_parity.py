@@ -677,6 +677,57 @@ def test_device_buffer_cache_limits(cache_mb, monkeypatch):
         d.close()
 
 
+def _pil_files(n, size, noise=6.0, **kw):
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    from tools import synth
+    out = []
+    for i in range(n):
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(700 + i, size[0], size[1], noise + 3 * (i % 5))).save(b, "JPEG", quality=70 + i % 20, **kw)
+        out.append(b.getvalue())
+    return out
+
+
+@pytest.mark.parametrize("seg", ["host", "gpu"])
+def test_files_with_their_own_huffman_tables_keep_the_fast_forms(seg):
+    """Every file with optimised tables of its own: far more tables in the batch than LDS holds.  Each workgroup then loads
+    the tables of the images its segments belong to (MJ_FORM_WG_TABLES) instead of the batch falling back to one
+    wavefront per segment.  With restart markers (lane form) and without (synchronisation form)."""
+    from oracle import oracle
+    from pyjpegdecoder_amd import BatchDecoder, _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from pyjpegdecoder_amd._parse import parse_jpeg
+    d = BatchDecoder(0, segment=seg)
+    try:
+        # (the synchronisation form groups 256 chunks of 2 KiB per workgroup: files of >= 512 KiB keep that to two images)
+        for kw, base, n, size, noise in ((dict(optimize=True, subsampling=2, restart_marker_rows=1), B.MJ_FORM_LANES, 18, (1024, 1040), 6.0),
+                                         (dict(optimize=True, subsampling=2), B.MJ_FORM_SYNC, 10, (1920, 1088), 30.0)):
+            files = _pil_files(n, size, noise, **kw)
+            assert base != B.MJ_FORM_SYNC or min(len(f) for f in files) > 600 * 1024
+            assert len({bytes(parse_jpeg(f).scans[0].huffman[0x10].vals.tobytes()) + bytes(parse_jpeg(f).scans[0].huffman[0x10].bits.tobytes()) for f in files}) > 8
+            prep, plan = d.plan(files)
+            try:
+                assert prep.n_huff > 16
+                assert plan.stage1_form() == base | B.MJ_FORM_WG_TABLES, plan.stage1_form()
+            finally:
+                plan.close()
+            for f, img in zip(files, d.decode(files)):
+                assert np.array_equal(img, oracle.decode(f)["rgb"])
+        # small images: a workgroup's segments span more images than its table list holds -> the wave form, same pixels
+        small = _pil_files(40, (96, 80), optimize=True, subsampling=2, restart_marker_rows=1)
+        prep, plan = d.plan(small)
+        try:
+            assert plan.stage1_form() == B.MJ_FORM_WAVE
+        finally:
+            plan.close()
+        for f, img in zip(small, d.decode(small)):
+            assert np.array_equal(img, oracle.decode(f)["rgb"])
+    finally:
+        d.close()
+
+
 def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
     """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
     reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""
