@@ -107,6 +107,7 @@ struct mj_plan {
     // batches with more tables than LDS holds (files with their own optimised tables): per workgroup, the tables its
     // units of work use — one list for the lane kernel's launch, one for the counting rounds (256 chunks per workgroup)
     int32_t *d_wg_tabs_lanes = nullptr, *d_wg_tabs_count = nullptr;
+    int wg_slots_lanes = 0, wg_slots_count = 0;      // 8 or 16 LUTs per workgroup
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
@@ -660,13 +661,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             for (size_t i = 1; i < jobs.size() && ordered; ++i) ordered = jobs[i].begin >= jobs[i - 1].end;
         }
         // More tables than LDS holds (every file with its own optimised tables): a workgroup's segments belong to one or
-        // two images, so it loads just their tables — if every workgroup of the launch gets by with kMaxLaneTables.
+        // two images, so it loads just their tables — if every workgroup of the launch gets by with 8, or else 16, of them
+        // (16 LUTs = 64 KiB leave room for two workgroups per CU instead of four: slower, but not the wave form).
         const bool many_tabs = b->n_huff > mj::kMaxLaneTables;
-        auto wg_lists = [&](const std::vector<int32_t> &unit_image, int64_t units_per_wg, std::vector<int32_t> &lists) -> bool {
+        auto wg_lists = [&](const std::vector<int32_t> &unit_image, int64_t units_per_wg, int cap, std::vector<int32_t> &lists) -> bool {
             const int64_t n_wg = ((int64_t)unit_image.size() + units_per_wg - 1) / units_per_wg;
-            lists.assign((size_t)n_wg * mj::kMaxLaneTables, -1);
+            lists.assign((size_t)n_wg * mj::kMaxWgTables, -1);
             for (int64_t g = 0; g < n_wg; ++g) {
-                int32_t *l = lists.data() + (size_t)g * mj::kMaxLaneTables;
+                int32_t *l = lists.data() + (size_t)g * mj::kMaxWgTables;
                 int n = 0, last_img = -1;
                 const int64_t u1 = std::min<int64_t>((g + 1) * units_per_wg, (int64_t)unit_image.size());
                 for (int64_t u = g * units_per_wg; u < u1; ++u) {
@@ -678,7 +680,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                         bool seen = false;
                         for (int j = 0; j < n; ++j) seen = seen || l[j] == t;
                         if (seen) continue;
-                        if (n == mj::kMaxLaneTables) return false;
+                        if (n == cap) return false;
                         l[n++] = t;
                     }
                 }
@@ -690,7 +692,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (many_tabs && !prog && !both_roles) {
             seg_image.reserve(segs.size());
             for (const auto &g : segs) seg_image.push_back(g.image);
-            many_ok_dri = wg_lists(seg_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)segs.size(), mj::kMaxLaneTables), wl_lanes);
+            many_ok_dri = false;
+            for (int cap = 8; cap <= mj::kMaxWgTables && !many_ok_dri; cap *= 2) {
+                many_ok_dri = wg_lists(seg_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)segs.size(), cap), cap, wl_lanes);
+                p->wg_slots_lanes = cap;
+            }
         }
         const bool lanes_ok = ordered && (!many_tabs || many_ok_dri) && !both_roles && !prog &&
                               (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
@@ -720,8 +726,16 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             const int cb = p->sync_chunk_bytes;
             for (size_t i = 0; i < segs.size(); ++i)
                 for (int j = 0; j < std::max(1, (segs[i].len + cb - 1) / cb); ++j) chunk_image.push_back(segs[i].image);
-            many_ok_sync = wg_lists(chunk_image, 256, wl_count) &&
-                           wg_lists(chunk_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)chunk_image.size(), mj::kMaxLaneTables), wl_lanes);
+            bool ok_count = false, ok_lanes = false;
+            for (int cap = 8; cap <= mj::kMaxWgTables && !ok_count; cap *= 2) {
+                ok_count = wg_lists(chunk_image, 256, cap, wl_count);
+                p->wg_slots_count = cap;
+            }
+            for (int cap = 8; cap <= mj::kMaxWgTables && !ok_lanes; cap *= 2) {
+                ok_lanes = wg_lists(chunk_image, 4 * (int64_t)mj::lanes_per_wave((int64_t)chunk_image.size(), cap), cap, wl_lanes);
+                p->wg_slots_lanes = cap;
+            }
+            many_ok_sync = ok_count && ok_lanes;
             if (!many_ok_sync) want_sync = false;
         }
         if (want_sync) p->use_lanes = true;
@@ -857,7 +871,7 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
             const int cbits = p->sync_chunk_bytes * 8;
             MJ_HIP(ctx, hipMemsetAsync(p->d_couts, 0xFF, (size_t)p->n_chunks * sizeof(mj::DevChunkOut), s));
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
-                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count));
+                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
             // repair rounds: three are queued without looking (a chain of wrongly guessed entry states gets one link
             // shorter per round), then the host reads the third round's change counter, and goes on one round at a time
@@ -867,7 +881,7 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
                 int32_t *counter = p->d_changed + (round <= 3 ? round - 1 : 3);
                 if (round > 3) MJ_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int32_t), s));
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter, p->d_wg_tabs_count));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter, p->d_wg_tabs_count, p->wg_slots_count));
                 std::swap(in, out);
                 if (round < 3) continue;
                 int32_t changed = 0;
@@ -877,11 +891,11 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
             MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
-                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes));
+                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes, p->wg_slots_lanes));
             return MJ_OK;
         }
         MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
-                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes));
+                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes, p->wg_slots_lanes));
     } else
         MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
                                        p->d_status, p->lut_slots, p->transposed ? 1 : 0));

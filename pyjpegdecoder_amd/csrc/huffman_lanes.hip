@@ -81,7 +81,7 @@ __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_compl
 }  // namespace
 
 // WGT: the batch has more tables than LDS holds (files with their own optimised tables): every workgroup gets the up
-// to kMaxLaneTables tables its segments' images use (`wg_tabs`, built by api.hip for exactly this launch shape); a
+// to 8 or 16 (kMaxWgTables) tables its segments' images use (`wg_tabs`, built by api.hip for exactly this launch shape); a
 // lane's table numbers are then positions in that list.  Without WGT the LDS slot of a table is its index in the batch.
 template <bool WGT>
 __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restrict__ stream,   // stage 0's output
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                                                        int n_huff, int16_t *__restrict__ coef,
                                                        int32_t *__restrict__ status, int lpw, int tr,
                                                        const DevVSeg *__restrict__ vsegs /* or null */,
-                                                       const int32_t *__restrict__ wg_tabs /* WGT: [gridDim.x][kMaxLaneTables], -1 = unused */) {
+                                                       const int32_t *__restrict__ wg_tabs /* WGT: [gridDim.x][kMaxWgTables], -1 = unused */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     uint16_t *s_null = reinterpret_cast<uint16_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4 + (size_t)4 * lpw2 * 8);
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));
 
-    const int32_t *my_tabs = WGT ? wg_tabs + (size_t)blockIdx.x * kMaxLaneTables : nullptr;
+    const int32_t *my_tabs = WGT ? wg_tabs + (size_t)blockIdx.x * kMaxWgTables : nullptr;
     if (WGT) {
         for (int j = 0; j < n_huff; ++j) {                  // n_huff = slots in LDS here
             const int t = my_tabs[j];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             int d = 0, a = 0;
-            for (int j = 0; j < kMaxLaneTables; ++j) {
+            for (int j = 0; j < kMaxWgTables; ++j) {
                 const int t = my_tabs[j];
                 d = t == dcG[c] ? j : d;
                 a = t == acG[c] ? j : a;
@@ -364,9 +364,9 @@ int lanes_per_wave(int64_t n_segs, int n_slots) {
 
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
-                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs, const int32_t *wg_tabs) {
+                                int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs, const int32_t *wg_tabs, int wg_slots) {
     if (n_segs == 0) return hipSuccess;
-    const int n_slots = wg_tabs ? kMaxLaneTables : n_huff;
+    const int n_slots = wg_tabs ? wg_slots : n_huff;
     const int lpw_run = lanes_per_wave(n_segs, n_slots);
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;

@@ -69,15 +69,15 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
                                                     int n_huff, const DevChunk *__restrict__ chunks, int64_t n_chunks, int cbits, int warm,
                                                     const uint64_t *__restrict__ entry, uint64_t *__restrict__ exit_out,
                                                     DevChunkOut *__restrict__ outs, int32_t *__restrict__ changed,
-                                                    const int32_t *__restrict__ wg_tabs /* or null: [gridDim.x][kMaxLaneTables] */) {
+                                                    const int32_t *__restrict__ wg_tabs /* or null: [gridDim.x][kMaxWgTables] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
     uint16_t *s_null = s_lut + (size_t)n_huff * kLSize;                 // n_huff = table slots in LDS
     int32_t *s_glob = reinterpret_cast<int32_t *>(s_null + 8);           // slot -> index of the table in the batch
     const int tid = threadIdx.x;
-    // a batch with more tables than LDS holds: this workgroup's chunks use the (at most kMaxLaneTables) tables listed in
+    // a batch with more tables than LDS holds: this workgroup's chunks use the (at most n_huff = 8 or 16) tables listed in
     // wg_tabs, and "slot" below is a position in that list
-    const int32_t *my_tabs = wg_tabs ? wg_tabs + (size_t)blockIdx.x * kMaxLaneTables : nullptr;
+    const int32_t *my_tabs = wg_tabs ? wg_tabs + (size_t)blockIdx.x * kMaxWgTables : nullptr;
     if (my_tabs) {
         for (int j = 0; j < n_huff; ++j) {
             const int t = my_tabs[j];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         for (int i = tid; i < n_huff * kLSize / 8; i += 256)
             reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(lut11u)[i];
     }
-    if (tid < kMaxLaneTables) s_glob[tid] = my_tabs ? my_tabs[tid] : tid;
+    if (tid < kMaxWgTables) s_glob[tid] = my_tabs ? my_tabs[tid] : tid;
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));          // length 0, run 64, size 0: a lane that is done
     __syncthreads();
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         int dslot = im->tab_index[im->blk_dc_slot[b]], aslot = im->tab_index[im->blk_ac_slot[b]];
         if (my_tabs) {
             int d = 0, a = 0;
-            for (int j = 0; j < kMaxLaneTables; ++j) { d = my_tabs[j] == dslot ? j : d; a = my_tabs[j] == aslot ? j : a; }
+            for (int j = 0; j < kMaxWgTables; ++j) { d = my_tabs[j] == dslot ? j : d; a = my_tabs[j] == aslot ? j : a; }
             dslot = d; aslot = a;
         }
         slots_pk |= (uint32_t)dslot << (4 * cc);
@@ -283,11 +283,17 @@ __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chu
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs) {
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs, int wg_slots) {
     if (n_chunks == 0) return hipSuccess;
-    if (wg_tabs) n_huff = kMaxLaneTables;                       // table slots in LDS
-    const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxLaneTables * 4;
+    if (wg_tabs) n_huff = wg_slots;                             // table slots in LDS
+    const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
+    static bool attr_set = false;
+    if (!attr_set) {                                            // 16 table slots: just over the 64 KiB default
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
     const int warm = getenv("MJ_SYNC_WARM") ? atoi(getenv("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,

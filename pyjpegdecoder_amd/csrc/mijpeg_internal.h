@@ -145,6 +145,8 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegm
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
 constexpr int kLaneLutBits = 11;
 constexpr int kMaxLaneTables = 8;
+// per-workgroup table lists (batches with more tables than that): entries per workgroup; 8 or 16 of them are used
+constexpr int kMaxWgTables = 16;
 // stage 0 (destuff.hip): per restart segment, the bytes the bit reader keeps, as big-endian dwords at dword
 // (begin >> 2) + segment index of `out_stream`; seg_bits[i] = 8 x kept bytes
 hipError_t launch_destuff(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, int64_t n_segs,
@@ -156,7 +158,7 @@ hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const De
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr);   // wg_tabs: per 256 chunks
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr, int wg_slots = 0);   // wg_tabs: per 256 chunks
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
                               const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs);
 hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, const DevPiece *pieces,
@@ -166,7 +168,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
                                 const DevSegment *segs, int64_t n_segs,
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
                                 int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs = nullptr,
-                                const int32_t *wg_tabs = nullptr);
+                                const int32_t *wg_tabs = nullptr, int wg_slots = 0);   // wg_tabs: [workgroups][kMaxWgTables]
 // how that launch groups its units of work: lanes per wavefront (a workgroup = 4 waves = 4 x this many consecutive units)
 int lanes_per_wave(int64_t n_segs, int n_slots);
 

@@ -715,6 +715,18 @@ def test_files_with_their_own_huffman_tables_keep_the_fast_forms(seg):
                 plan.close()
             for f, img in zip(files, d.decode(files)):
                 assert np.array_equal(img, oracle.decode(f)["rgb"])
+        # medium files: three or four images per workgroup -> sixteen LUTs per workgroup instead of eight, still not the wave form
+        for kw, base in ((dict(optimize=True, subsampling=2, restart_marker_rows=1), B.MJ_FORM_LANES), (dict(optimize=True, subsampling=2), B.MJ_FORM_SYNC)):
+            files = _pil_files(24, (640, 480), 25.0, **kw)
+            prep, plan = d.plan(files)
+            try:
+                form_medium = plan.stage1_form()
+                # (whether a given size still fits is the planner's business; what is pinned is: never a wrong picture)
+                assert form_medium in (base | B.MJ_FORM_WG_TABLES, B.MJ_FORM_WAVE)
+            finally:
+                plan.close()
+            for f, img in zip(files, d.decode(files)):
+                assert np.array_equal(img, oracle.decode(f)["rgb"]), (base, form_medium)
         # small images: a workgroup's segments span more images than its table list holds -> the wave form, same pixels
         small = _pil_files(40, (96, 80), optimize=True, subsampling=2, restart_marker_rows=1)
         prep, plan = d.plan(small)
