@@ -266,6 +266,30 @@ def main():
                 plan2.close()
             except Exception as exc:
                 line["without_restart_markers"] = {"error": str(exc)}
+            # and the PCIe-inclusive rate of the public API (never `value`): file bytes in host memory -> pixels in HBM,
+            # batches back to back (BatchDecoder.decode_device_iter: the next batch's header parse + upload run under the
+            # current batch's kernels), restart markers found on the GPU
+            try:
+                from pyjpegdecoder_amd import BatchDecoder
+                nb = 512
+                files = [raws[i % len(raws)] for i in range(nb)]
+                bd = BatchDecoder(dev.index or 0, layout=args.layout, segment="gpu")
+                for _ in bd.decode_device_iter(files for _ in range(3)):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_it = 8
+                for out in bd.decode_device_iter(files for _ in range(n_it)):
+                    pass
+                torch.cuda.synchronize()
+                dt3 = (time.perf_counter() - t0) / n_it
+                del out
+                bd.close()
+                line["host_bytes_to_device_pixels"] = {"value": round(nb * W * H / 1e6 / dt3, 1), "unit": "MP/s", "ms_per_batch": round(dt3 * 1e3, 3),
+                                                       "workload": f"{n_it} batches of {nb} of the files above through BatchDecoder(segment='gpu').decode_device_iter",
+                                                       "note": "includes header parse, batch assembly, H2D of the files and plan creation; PCIe-inclusive, not `value`"}
+            except Exception as exc:
+                line["host_bytes_to_device_pixels"] = {"error": str(exc)}
         print(json.dumps(line), flush=True)
 
     plan.close()          # (idempotent)
