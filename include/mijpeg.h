@@ -161,6 +161,9 @@ int mj_create(int device_id, mj_context **out);
 void mj_destroy(mj_context *ctx);
 const char *mj_last_error(const mj_context *ctx);   /* ctx may be NULL: error of the failed mj_create */
 int mj_version(void);
+/* Make the context's stream wait for a hipEvent_t (passed as void*) recorded elsewhere — e.g. behind the upload of a
+ * batch's files on a copy stream — before anything queued on it afterwards runs. */
+int mj_context_wait_event(mj_context *ctx, void *hip_event);
 
 /* ---- plan: upload once, execute many times (bench.py times mj_plan_execute only) ------------------ */
 int mj_plan_create(mj_context *ctx, const mj_batch *batch, mj_plan **out);
@@ -187,7 +190,7 @@ int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
 /* The two stages separately (profiling, config 2). */
 int mj_plan_execute_stage1(mj_plan *plan, void *stream);
 int mj_plan_execute_stage2(mj_plan *plan, void *stream, uint8_t *rgb_device);
-int mj_plan_sync(mj_plan *plan);   /* waits for the context's stream and for the stream of the plan's last execute */
+int mj_plan_sync(mj_plan *plan);   /* waits for this plan's latest execute (on whichever stream it went), not for other work on that stream */
 
 /* Device pointers of plan-owned buffers (valid until mj_plan_destroy): zero-copy hand-off to torch etc. */
 int mj_plan_device_buffers(mj_plan *plan, int16_t **coef, uint8_t **rgb, int16_t **planes, int16_t **idct);

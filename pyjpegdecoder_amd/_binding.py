@@ -22,7 +22,7 @@ MJ_FLAG_GPU_SEGMENT = 32
 
 # every symbol include/mijpeg.h declares (tests check the library exports all of them)
 EXPORTS = (
-    "mj_create", "mj_destroy", "mj_last_error", "mj_version",
+    "mj_create", "mj_destroy", "mj_last_error", "mj_version", "mj_context_wait_event",
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
@@ -99,6 +99,7 @@ def load_library():
     L.mj_destroy.restype = None
     L.mj_last_error.argtypes = [vp]
     L.mj_last_error.restype = ctypes.c_char_p
+    L.mj_context_wait_event.argtypes = [vp, vp]
     L.mj_plan_create.argtypes = [vp, ctypes.POINTER(BatchC), ctypes.POINTER(vp)]
     L.mj_plan_destroy.argtypes = [vp]
     L.mj_plan_destroy.restype = None
@@ -145,6 +146,11 @@ class Context:
                 from .errors import UnsupportedJpeg
                 raise UnsupportedJpeg(msg)
             raise BackendError(f"libmijpeg error {rc}: {msg}")
+
+    def wait_event(self, hip_event: int):
+        """Everything queued on the context's stream from now on runs after `hip_event` (a hipEvent_t handle, e.g.
+        ``torch.cuda.Event.cuda_event``) has happened."""
+        self.check(self.lib.mj_context_wait_event(self.handle, hip_event))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -463,15 +463,19 @@ class BatchDecoder:
         """Decode a stream of batches (an iterable of lists of file bytes) with the host work and the upload of batch
         k+1 overlapping the GPU work of batch k; yields, per batch and in order, what :meth:`decode_device` returns.
 
-        Per batch: the native host front end assembles the blob in pinned memory (host threads), the upload is queued on
-        a copy stream, the plan is created (this waits for the device, i.e. for the previous batch's kernels and this
-        batch's upload) and its kernels are queued; only then is the previous batch handed out.  Batches the front end
-        declines are decoded by :meth:`decode_device` in place (no overlap for those)."""
+        Per batch: the native host front end assembles the blob in one of two pinned buffers (host threads), the upload is
+        queued on a copy stream, the plan is created (its buffer clears run on the context's setup stream), its kernels
+        are queued on the context's stream behind the previous batch's, waiting for the upload by event — and only then is the
+        previous batch collected (``mj_plan_sync`` waits for that plan's own work) and handed out.  The GPU goes from one
+        batch's kernels straight into the next's.  Batches the front end declines are decoded by :meth:`decode_device`
+        in place (no overlap for those)."""
         import torch
         dev = torch.device("cuda", self.ctx.device)
         copy_stream = torch.cuda.Stream(device=dev)
-        pinned = None
-        pending = None          # (plan, prep, d_rgb, d_blob) of the batch in flight
+        pinned = [None, None]
+        uploaded = [None, None]     # event behind the latest upload out of each pinned buffer
+        turn = 0
+        pending = None              # ((plan, prep, d_rgb, d_blob), files) of the batch in flight
 
         def finish(job):
             plan, prep, d_rgb, _ = job
@@ -491,45 +495,50 @@ class BatchDecoder:
             finally:
                 plan.close()
 
+        def collect(job):
+            done = finish(job[0])
+            return done if done is not None else self.decode_device(job[1])
+
         for files in batches:
             files = list(files)
             prep = None
             if self.gpu_segment and self.native_host and files:
+                buf, turn = turn, turn ^ 1
                 need = sum(map(len, files)) + 3 * len(files) + 1024
-                if pinned is None or pinned.numel() < need:
-                    if pending is not None:                       # its upload may still be reading the old buffer
-                        torch.cuda.synchronize(dev)
-                    pinned = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
-                prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned.numpy())
+                if uploaded[buf] is not None:
+                    uploaded[buf].synchronize()                   # two batches ago: long done
+                if pinned[buf] is None or pinned[buf].numel() < need:
+                    pinned[buf] = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
+                prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned[buf].numpy())
             if prep is None:
                 if pending is not None:
-                    done, pending_files = finish(pending[0]), pending[1]
-                    pending = None
-                    yield done if done is not None else self.decode_device(pending_files)
+                    job, pending = pending, None
+                    yield collect(job)
                 yield self.decode_device(files)
                 continue
             with torch.cuda.stream(copy_stream):
-                d_blob = pinned[:prep.blob.size].to(dev, non_blocking=True)
-            # creating a plan waits for the device: the previous batch's kernels and this batch's upload are done after it,
-            # so the previous batch is collected here, before this one's kernels go onto the (shared) context stream
+                d_blob = pinned[buf][:prep.blob.size].to(dev, non_blocking=True)
+                uploaded[buf] = torch.cuda.Event()
+                uploaded[buf].record(copy_stream)
             plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
-            done = None
-            if pending is not None:
+            try:
+                # (both tensors outlive the kernels that touch them: they stay in `pending` until the plan has been collected)
+                d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+                self.ctx.wait_event(uploaded[buf].cuda_event)
+                plan.execute(0, d_rgb.data_ptr())
+            except BaseException:
+                plan.close()
+                raise
+            job, pending = pending, ((plan, prep, d_rgb, d_blob), files)
+            if job is not None:
                 try:
-                    done = finish(pending[0])
-                    if done is None:
-                        done = self.decode_device(pending[1])
+                    done = collect(job)
                 except BaseException:
-                    plan.close()
+                    pending[0][0].close()
                     raise
-            d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
-            plan.execute(0, d_rgb.data_ptr())
-            had, pending = pending is not None, ((plan, prep, d_rgb, d_blob), files)
-            if had:
                 yield done
         if pending is not None:
-            done = finish(pending[0])
-            yield done if done is not None else self.decode_device(pending[1])
+            yield collect(pending)
 
     def close(self):
         self.ctx.close()

@@ -76,6 +76,15 @@ struct DevBufferCache {
 struct mj_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    // plan creation clears a plan's big buffers here, beside whatever the context stream is running (another plan's
+    // kernels, in a serving loop); the plan's first use waits for its `ready` event
+    hipStream_t setup_stream = nullptr;
+    // pinned staging for a plan's small uploads (descriptors, tables, segment lists: a few MB), so that they too are
+    // queued on the setup stream instead of each blocking the host behind whatever the copy engine is busy with (in a
+    // serving loop: the next batch's 300 MB of files).  A plan holds one arena until it is destroyed.
+    struct Arena { char *base = nullptr; size_t cap = 0, used = 0; };
+    std::vector<Arena> free_arenas;
+    Arena *cur = nullptr;          // the arena of the plan being created
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
     DevBufferCache cache;
     std::string err;
@@ -123,6 +132,12 @@ struct mj_plan {
     hipStream_t graph_stream = nullptr;
     uint8_t *graph_rgb = nullptr;
     bool executed_once = false;
+    mj_context::Arena arena;               // pinned staging of this plan's uploads (back to the context at destroy)
+    hipEvent_t ready = nullptr;             // recorded behind the creation-time clears on the context's setup stream
+    bool ready_done = false;
+    hipStream_t ready_stream = nullptr;     // the stream that was made to wait for `ready`
+    hipEvent_t done = nullptr;              // recorded behind the plan's latest execute: what mj_plan_sync / _read / _destroy wait for
+    bool done_valid = false;
     bool last_was_graph = false;
     hipStream_t prev_stream = nullptr;      // of the last plain execute
     uint8_t *prev_rgb = nullptr;
@@ -236,8 +251,18 @@ bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
 template <typename T>
 int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
     MJ_HIP(ctx, ctx->cache.get((void **)dst, n * sizeof(T) + pad_bytes + 16));
-    if (pad_bytes) MJ_HIP(ctx, hipMemset((char *)*dst + n * sizeof(T), 0, pad_bytes));
-    if (n) MJ_HIP(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (pad_bytes) MJ_HIP(ctx, hipMemsetAsync((char *)*dst + n * sizeof(T), 0, pad_bytes, ctx->setup_stream));
+    const size_t bytes = n * sizeof(T);
+    if (!bytes) return MJ_OK;
+    mj_context::Arena *a = ctx->cur;
+    const size_t at = a ? (a->used + 63) & ~(size_t)63 : 0;
+    if (a && at + bytes <= a->cap) {
+        memcpy(a->base + at, src, bytes);
+        a->used = at + bytes;
+        MJ_HIP(ctx, hipMemcpyAsync(*dst, a->base + at, bytes, hipMemcpyHostToDevice, ctx->setup_stream));
+    } else {
+        MJ_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // big (a host blob) or no arena: the plain way
+    }
     return MJ_OK;
 }
 
@@ -289,6 +314,7 @@ int mj_create(int device_id, mj_context **out) {
     ctx->device = device_id;
     MJ_HIP(nullptr, hipSetDevice(device_id));
     MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking));
     std::vector<double> tt(64 * 64);
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
@@ -307,10 +333,18 @@ void mj_destroy(mj_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->setup_stream) { (void)hipStreamSynchronize(ctx->setup_stream); (void)hipStreamDestroy(ctx->setup_stream); }
     ctx->cache.trim(0);
+    for (auto &a : ctx->free_arenas) (void)hipHostFree(a.base);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int mj_context_wait_event(mj_context *ctx, void *hip_event) {
+    if (!ctx || !hip_event) return MJ_ERR_INVALID;
+    MJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+    return MJ_OK;
 }
 
 /* Host-side table export for tests: the IDCT table exactly as the library builds it ([u*8+v][x*8+y]). */
@@ -319,10 +353,14 @@ void mj_host_idct_table(double *tt) { build_idct_tt(tt); }
 void mj_plan_destroy(mj_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
-    // the buffers go back to the context for the next plan: nothing may still be running on them
-    if (p->prev_stream && p->prev_stream != p->ctx->stream) (void)hipStreamSynchronize(p->prev_stream);
-    if (p->graph_stream && p->graph_stream != p->ctx->stream && p->graph_stream != p->prev_stream) (void)hipStreamSynchronize(p->graph_stream);
+    // the buffers go back to the context for the next plan: nothing of this plan may still be running on them (other
+    // plans' work on the same streams is none of its business: a serving loop destroys batch k while batch k+1 runs)
+    if (p->ready) { (void)hipEventSynchronize(p->ready); (void)hipEventDestroy(p->ready); }
+    if (p->done) { if (p->done_valid) (void)hipEventSynchronize(p->done); (void)hipEventDestroy(p->done); }
+    if (p->arena.base) {
+        if (p->ctx->free_arenas.size() < 4) p->ctx->free_arenas.push_back(p->arena);
+        else (void)hipHostFree(p->arena.base);
+    }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_planes, p->d_idct, p->d_status};
@@ -347,7 +385,12 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->layout = b->layout;
     p->flags = b->flags;
     p->transposed = b->layout == MJ_LAYOUT_ROWMAJOR && !(b->flags & MJ_FLAG_EXACT_ONLY);
-    struct Guard { mj_plan *p; ~Guard() { if (p) mj_plan_destroy(p); } } guard{p};
+    struct Guard { mj_plan *p; mj_context *c; ~Guard() { c->cur = nullptr; if (p) mj_plan_destroy(p); } } guard{p, ctx};
+    if (!ctx->free_arenas.empty()) { p->arena = ctx->free_arenas.back(); ctx->free_arenas.pop_back(); }
+    else if (hipHostMalloc((void **)&p->arena.base, (size_t)8 << 20, hipHostMallocDefault) == hipSuccess) p->arena.cap = (size_t)8 << 20;
+    else { (void)hipGetLastError(); p->arena = mj_context::Arena{}; }
+    p->arena.used = 0;
+    ctx->cur = p->arena.base ? &p->arena : nullptr;
 
     const bool have_entropy = b->blob_mem != MJ_MEM_NONE && b->blob != nullptr;
     const bool prog = have_entropy && b->n_scans > 0;
@@ -747,7 +790,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
             const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stream, sbytes));
-            MJ_HIP(ctx, hipMemset(p->d_stream, 0, sbytes));
+            MJ_HIP(ctx, hipMemsetAsync(p->d_stream, 0, sbytes, ctx->setup_stream));
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
             if (want_sync) {
                 const int cb = p->sync_chunk_bytes;
@@ -797,15 +840,18 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
     }
     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_coef, (size_t)blk * 64 * sizeof(int16_t) + 16));
-    MJ_HIP(ctx, hipMemset(p->d_coef, 0, (size_t)blk * 64 * sizeof(int16_t)));
+    MJ_HIP(ctx, hipMemsetAsync(p->d_coef, 0, (size_t)blk * 64 * sizeof(int16_t), ctx->setup_stream));
     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_status, (size_t)b->n_images * sizeof(int32_t)));
-    MJ_HIP(ctx, hipMemset(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t)));
+    MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t), ctx->setup_stream));
     if (b->flags & MJ_FLAG_KEEP_PLANES) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_planes, (size_t)rgb * sizeof(int16_t) + 16));
     if (b->flags & MJ_FLAG_KEEP_IDCT) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_idct, (size_t)blk * 64 * sizeof(int16_t) + 16));
-    // hipMemset on device memory returns before it is done and runs on the null stream, which the (non-blocking)
-    // context stream and a caller's stream do not wait for: without this the tail of the 6 GB clear above could land
-    // after the first blocks the first execute writes.
-    MJ_HIP(ctx, hipDeviceSynchronize());
+    // The clears above run on the setup stream, which neither the context stream nor a caller's stream waits for: the
+    // plan's first use waits (on the host) for this event, or the tail of the 6 GB clear could land after the first
+    // blocks the first execute writes.  Not waiting here lets a serving loop create the next batch's plan while this
+    // context's stream is still busy with the current batch.
+    MJ_HIP(ctx, hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
+    MJ_HIP(ctx, hipEventRecord(p->ready, ctx->setup_stream));
+    MJ_HIP(ctx, hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
     guard.p = nullptr;
     *out = p;
     return MJ_OK;
@@ -831,9 +877,46 @@ int mj_plan_image_offsets(const mj_plan *p, int32_t image, int64_t *block_off, i
     return MJ_OK;
 }
 
+// The plan's buffers are usable once the creation-time uploads and clears are done (see mj_plan_create): the host waits
+// for them here — except in the plan's first execute, whose stream waits instead (the host goes on).
+static int plan_ready(mj_plan *p, hipStream_t first_use = nullptr) {
+    if (p->ready && !p->ready_done) {
+        if (first_use && !p->ready_stream) {
+            MJ_HIP(p->ctx, hipStreamWaitEvent(first_use, p->ready, 0));
+            p->ready_stream = first_use;
+            return MJ_OK;
+        }
+        if (first_use && first_use == p->ready_stream) return MJ_OK;       // same stream: ordered behind the wait above
+        MJ_HIP(p->ctx, hipEventSynchronize(p->ready));
+        p->ready_done = true;
+    }
+    return MJ_OK;
+}
+
+static int mark_done(mj_plan *p, hipStream_t s) {
+    MJ_HIP(p->ctx, hipEventRecord(p->done, s));
+    p->done_valid = true;
+    return MJ_OK;
+}
+
+static int stage1_impl(mj_plan *p, void *stream);
+static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device);
+
 int mj_plan_execute_stage1(mj_plan *p, void *stream) {
     if (!p) return MJ_ERR_INVALID;
+    const int rc = stage1_impl(p, stream);
+    return rc != MJ_OK ? rc : mark_done(p, stream ? (hipStream_t)stream : p->ctx->stream);
+}
+
+int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (!p) return MJ_ERR_INVALID;
+    const int rc = stage2_impl(p, stream, rgb_device);
+    return rc != MJ_OK ? rc : mark_done(p, stream ? (hipStream_t)stream : p->ctx->stream);
+}
+
+static int stage1_impl(mj_plan *p, void *stream) {
     mj_context *ctx = p->ctx;
+    if (int rc = plan_ready(p, stream ? (hipStream_t)stream : ctx->stream)) return rc;
     if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data (stage 1 unavailable)");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
@@ -902,8 +985,8 @@ int mj_plan_execute_stage1(mj_plan *p, void *stream) {
     return MJ_OK;
 }
 
-int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
-    if (!p) return MJ_ERR_INVALID;
+static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (int rc = plan_ready(p, stream ? (hipStream_t)stream : p->ctx->stream)) return rc;
     mj_context *ctx = p->ctx;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (!rgb_device) {
@@ -934,6 +1017,7 @@ int mj_plan_execute_stage2(mj_plan *p, void *stream, uint8_t *rgb_device) {
 
 int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (!p) return MJ_ERR_INVALID;
+    if (int rc = plan_ready(p, stream ? (hipStream_t)stream : p->ctx->stream)) return rc;
     mj_context *ctx = p->ctx;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // Re-executions of a plan with the same stream and output buffer replay a captured graph of its launches (one
@@ -946,7 +1030,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
         p->last_rgb = p->graph_rgb;
         p->last_was_graph = true;
         MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
-        return MJ_OK;
+        return mark_done(p, s);
     }
     // capture only what is evidently a loop: the previous execute used this very stream and buffer (a caller that
     // alternates output buffers keeps launching plainly instead of re-capturing every time)
@@ -955,8 +1039,8 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
         if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = mj_plan_execute_stage1(p, s);
-            if (rc == MJ_OK) rc = mj_plan_execute_stage2(p, s, rgb_device);
+            int rc = stage1_impl(p, s);
+            if (rc == MJ_OK) rc = stage2_impl(p, s, rgb_device);
             const hipError_t ce = hipStreamEndCapture(s, &g);
             if (rc == MJ_OK && ce == hipSuccess && g && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 (void)hipGraphDestroy(g);
@@ -964,34 +1048,34 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
                 p->graph_rgb = p->last_rgb;
                 p->last_was_graph = true;
                 MJ_HIP(ctx, hipGraphLaunch(p->graph_exec, s));
-                return MJ_OK;
+                return mark_done(p, s);
             }
             if (g) (void)hipGraphDestroy(g);
             p->graph_exec = nullptr;
             (void)hipGetLastError();
         }
     }
-    int rc = mj_plan_execute_stage1(p, stream);
+    int rc = stage1_impl(p, stream);
     if (rc != MJ_OK) return rc;
-    rc = mj_plan_execute_stage2(p, stream, rgb_device);
+    rc = stage2_impl(p, stream, rgb_device);
     p->executed_once = rc == MJ_OK;
     p->last_was_graph = false;
     p->prev_stream = s;
     p->prev_rgb = p->last_rgb;
-    return rc;
+    return rc != MJ_OK ? rc : mark_done(p, s);
 }
 
 int mj_plan_sync(mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
-    MJ_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
-    // ... and the caller's stream, if the last execute went there
-    hipStream_t last = p->graph_exec && p->last_was_graph ? p->graph_stream : p->prev_stream;
-    if (last && last != p->ctx->stream) MJ_HIP(p->ctx, hipStreamSynchronize(last));
+    // this plan's latest execute, on whichever stream it went; not the rest of that stream (in a serving loop the next
+    // batch's kernels are queued behind it)
+    if (p->done_valid) MJ_HIP(p->ctx, hipEventSynchronize(p->done));
     return MJ_OK;
 }
 
 int mj_plan_device_buffers(mj_plan *p, int16_t **coef, uint8_t **rgb, int16_t **planes, int16_t **idct) {
     if (!p) return MJ_ERR_INVALID;
+    if (int rc = plan_ready(p)) return rc;
     if (coef) *coef = p->d_coef;
     if (rgb) *rgb = p->last_rgb ? p->last_rgb : p->d_rgb;
     if (planes) *planes = p->d_planes;
@@ -1003,7 +1087,7 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
                  int32_t *status_host) {
     if (!p) return MJ_ERR_INVALID;
     mj_context *ctx = p->ctx;
-    MJ_HIP(ctx, hipDeviceSynchronize());
+    if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
     if (rgb_host) {
         if (!p->last_rgb) return fail(ctx, MJ_ERR_INVALID, "mj_plan_read: nothing executed yet");
         MJ_HIP(ctx, hipMemcpy(rgb_host, p->last_rgb, (size_t)p->info.rgb_bytes, hipMemcpyDeviceToHost));
@@ -1028,6 +1112,7 @@ int mj_plan_read(mj_plan *p, uint8_t *rgb_host, int16_t *coef_host, int16_t *pla
 
 int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
     if (!p || !coef) return MJ_ERR_INVALID;
+    if (int rc = plan_ready(p)) return rc;
     mj_context *ctx = p->ctx;
     const int16_t *src = coef;
     if (mem != MJ_MEM_DEVICE) {
@@ -1080,9 +1165,9 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
     if (stage1_ms) {
         *stage1_ms = 0.f;
         if (p->d_blob) {
-            if ((rc = mj_plan_execute_stage1(p, s)) != MJ_OK) return rc;   // warm
+            if ((rc = stage1_impl(p, s)) != MJ_OK) return rc;   // warm
             MJ_HIP(ctx, hipEventRecord(e0, s));
-            for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = mj_plan_execute_stage1(p, s);
+            for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = stage1_impl(p, s);
             MJ_HIP(ctx, hipEventRecord(e1, s));
             MJ_HIP(ctx, hipEventSynchronize(e1));
             MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
@@ -1090,9 +1175,9 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
         }
     }
     if (stage2_ms && rc == MJ_OK) {
-        if ((rc = mj_plan_execute_stage2(p, s, rgb_device)) != MJ_OK) return rc;   // warm
+        if ((rc = stage2_impl(p, s, rgb_device)) != MJ_OK) return rc;   // warm
         MJ_HIP(ctx, hipEventRecord(e0, s));
-        for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = mj_plan_execute_stage2(p, s, rgb_device);
+        for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = stage2_impl(p, s, rgb_device);
         MJ_HIP(ctx, hipEventRecord(e1, s));
         MJ_HIP(ctx, hipEventSynchronize(e1));
         MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
