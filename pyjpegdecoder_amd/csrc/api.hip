@@ -770,11 +770,17 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         for (const auto &g : segs) est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes);
         const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 64;
+        // ... and so do small batches of ordinary restart segments: below ~20 000 segments the lane form cannot fill the
+        // chip (its time is one segment's serial walk, ~3.3 ms for a 1080p MCU row, however few there are), while chunks
+        // can (measured, 1080p with one restart interval per MCU row: 1 image 3.3 -> 1.4 ms, 32 images 3.9 -> 2.1 ms,
+        // 128 images 4.9 -> 3.8 ms, break-even at ~300 images = 20 000 segments).  Segments shorter than a few chunks
+        // gain nothing from being cut.
+        const bool few_segs = !segs.empty() && (int64_t)segs.size() < 20000 && total_len / (int64_t)segs.size() >= 2048 && est_chunks >= 64;
         // (with many tables the synchronisation form needs its own two workgroup shapes to get by with their table lists;
         // its lane launch runs over chunks, so the restart-segment shape checked above does not matter for it)
         const bool sync_shape_ok = ordered && !both_roles && !prog && (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
         bool want_sync = (many_tabs ? sync_shape_ok : lanes_ok) && (jobs.empty() || one_seg_each) && dc_fits &&
-                         ((force && !strcmp(force, "sync")) || (!force && long_segs));
+                         ((force && !strcmp(force, "sync")) || (!force && (long_segs || few_segs)));
         if (want_sync && many_tabs) {
             // (shorter chunks = less stream per workgroup = fewer images per workgroup: if the chunk size chosen above
             // leaves some workgroup with too many tables, shorter chunks get a try)

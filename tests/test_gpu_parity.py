@@ -710,7 +710,9 @@ def test_files_with_their_own_huffman_tables_keep_the_fast_forms(seg):
             prep, plan = d.plan(files)
             try:
                 assert prep.n_huff > 16
-                assert plan.stage1_form() == base | B.MJ_FORM_WG_TABLES, plan.stage1_form()
+                # (small batches of restart segments are cut into chunks as well: either fast form will do for those)
+                want = {base | B.MJ_FORM_WG_TABLES, B.MJ_FORM_SYNC | B.MJ_FORM_WG_TABLES}
+                assert plan.stage1_form() in want, plan.stage1_form()
             finally:
                 plan.close()
             for f, img in zip(files, d.decode(files)):
@@ -722,7 +724,7 @@ def test_files_with_their_own_huffman_tables_keep_the_fast_forms(seg):
             try:
                 form_medium = plan.stage1_form()
                 # (whether a given size still fits is the planner's business; what is pinned is: never a wrong picture)
-                assert form_medium in (base | B.MJ_FORM_WG_TABLES, B.MJ_FORM_WAVE)
+                assert form_medium in (base | B.MJ_FORM_WG_TABLES, B.MJ_FORM_SYNC | B.MJ_FORM_WG_TABLES, B.MJ_FORM_WAVE)
             finally:
                 plan.close()
             for f, img in zip(files, d.decode(files)):
