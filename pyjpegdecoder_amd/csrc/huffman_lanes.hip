@@ -359,7 +359,16 @@ int lanes_per_wave(int64_t n_segs, int n_slots) {
     const int64_t per = (int64_t)16 * cus;                   // waves of one round: 4 workgroups x 4 waves x CUs
     const int64_t rounds = (n_segs + per * fit - 1) / (per * fit);
     const int64_t want = (n_segs + per * rounds - 1) / (per * rounds);
-    return (int)(want < 8 ? 8 : (want > 64 ? 64 : want));
+    if (want < 8) {
+        // not enough segments for four workgroups of 8-lane waves per CU: as many workgroups per CU as 8 lanes per wave
+        // allow, and again the same number on every CU (26 112 segments: 9 lanes = 3 per CU, 7.4 ms; 8 lanes = 3.2 per
+        // CU, i.e. four on some, 8.3 ms)
+        int64_t m = n_segs / ((int64_t)4 * cus * 8);
+        m = m < 1 ? 1 : (m > 4 ? 4 : m);
+        const int64_t l = (n_segs + 4 * m * cus - 1) / (4 * m * cus);
+        return (int)(l < 8 ? 8 : (l > 64 ? 64 : l));
+    }
+    return (int)(want > 64 ? 64 : want);
 }
 
 hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
