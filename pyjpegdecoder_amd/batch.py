@@ -416,14 +416,17 @@ class BatchDecoder:
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
         parsed: Dict[int, ParsedJpeg] = {}
         work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
-        if self.gpu_segment and self.native_host and len(files):
+        # a handful of files: segmenting on the host costs ~0.6 ms per 1080p file and lets files with restart markers take
+        # the chunked stage-1 form, which needs the segment lengths at plan time (one such file: 2.3 ms instead of 6.6)
+        gpu_segment = self.gpu_segment and len(files) >= 8
+        if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
             if prep is not None:
                 work.append((list(range(len(files))), prep))
         if not work:
             groups: Dict[tuple, List[int]] = {}
             for i, f in enumerate(files):
-                p = parsed[i] = parse_jpeg(f, headers_only=self.gpu_segment)
+                p = parsed[i] = parse_jpeg(f, headers_only=gpu_segment)
                 check_supported(p)
                 comps = list(p.color_components.values())
                 key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
