@@ -317,7 +317,7 @@ class BatchDecoder:
     """
 
     def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False,
-                 segment: str = "host", native_host: bool = True):
+                 segment: str = "host", native_host: bool = True, gpu_segment_min_files: int = 8):
         self.ctx = B.Context(device)
         self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
         # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
@@ -332,6 +332,10 @@ class BatchDecoder:
         # native_host: with segment="gpu", decode_device reads headers and assembles batches in libmijpeg.so's
         # multi-threaded host front end instead of _parse.py (identical arrays; anything unusual is handed back to Python)
         self.native_host = native_host
+        # segment="gpu" applies from this many files per call on: a handful is segmented on the host, which costs ~0.6 ms
+        # per 1080p file and lets files with restart markers take the chunked stage-1 form (it needs the segment lengths at
+        # plan time; one such file: 2.3 ms instead of 6.6)
+        self.gpu_segment_min_files = gpu_segment_min_files
         self._staging: Optional[np.ndarray] = None
 
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
@@ -354,7 +358,8 @@ class BatchDecoder:
 
     def decode(self, files: Sequence[bytes], return_seams: bool = False):
         """Decode files that may mix sampling layouts (one plan per layout)."""
-        parsed = [parse_jpeg(f, headers_only=self.gpu_segment) for f in files]
+        gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
+        parsed = [parse_jpeg(f, headers_only=gpu_segment) for f in files]
         groups: Dict[tuple, List[int]] = {}
         for i, p in enumerate(parsed):
             check_supported(p)
@@ -416,9 +421,7 @@ class BatchDecoder:
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
         parsed: Dict[int, ParsedJpeg] = {}
         work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
-        # a handful of files: segmenting on the host costs ~0.6 ms per 1080p file and lets files with restart markers take
-        # the chunked stage-1 form, which needs the segment lengths at plan time (one such file: 2.3 ms instead of 6.6)
-        gpu_segment = self.gpu_segment and len(files) >= 8
+        gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
         if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
             if prep is not None:

@@ -478,7 +478,7 @@ def test_progressive_spec_refinement_switch(dec):
 @pytest.fixture(scope="module")
 def dec_gs():
     from pyjpegdecoder_amd import BatchDecoder
-    d = BatchDecoder(device=0, segment="gpu")
+    d = BatchDecoder(device=0, segment="gpu", gpu_segment_min_files=1)     # single files too: these tests are about the GPU scan
     yield d
     d.close()
 
@@ -943,7 +943,7 @@ def test_sync_form_batch_and_damage(dec, monkeypatch):
         assert np.array_equal(img, oracle.decode(f)["rgb"])
     # the same files with headers-only parsing: the GPU finds the end of each scan, then the chunks
     from pyjpegdecoder_amd import BatchDecoder
-    d2 = BatchDecoder(device=0, segment="gpu", layout="rowmajor")
+    d2 = BatchDecoder(device=0, segment="gpu", layout="rowmajor", gpu_segment_min_files=1)
     try:
         for f, img in zip(files[:12], d2.decode(files[:12])):
             assert np.array_equal(np.swapaxes(img, 0, 1), oracle.decode(f)["rgb"])
