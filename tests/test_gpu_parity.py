@@ -814,6 +814,13 @@ def test_caller_stream_and_device_blob(dec):
                 assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
             assert torch.equal(flipped, 255 - d_rgb)
             assert not plan.read(rgb=False)["status"].any()
+            # mj_plan_sync waits for the plan's own latest execute on whichever stream it went: no stream synchronisation by
+            # the caller, and the pixels are complete
+            d_rgb2 = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            plan.execute(st.cuda_stream, d_rgb2.data_ptr())
+            plan.sync()
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                assert torch.equal(d_rgb2.to("cpu", non_blocking=False), d_rgb.cpu())
         finally:
             plan.close()
 
