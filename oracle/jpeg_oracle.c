@@ -115,13 +115,13 @@ void orc_idct_xy(const int16_t *blk, const double *T, int16_t *out_xy) {
  * sum(n_i * v_i)/15 can never be a half-integer (15 is odd), so the float64 result of griddata
  * (accurate to ~1e-14) rounds the same way as this exact form.
  */
-void orc_upsample(const int16_t *in, int n_in, const int8_t *W /* [n_out][n_in] numerators over 15 */,
+void orc_upsample(const int16_t *in, int n_in, const int8_t *W /* [n_out][n_in] numerators; a row sums to its denominator */,
                   int n_out, int16_t *out) {
     for (int o = 0; o < n_out; o++) {
-        long acc = 0;
+        long acc = 0, den = 0;              /* 15 for the x2 operators, 31 for 8x8 -> 32x8 (4:1:1): odd either way */
         const int8_t *w = W + (size_t)o * n_in;
-        for (int k = 0; k < n_in; k++) acc += (long)w[k] * in[k];
-        out[o] = (int16_t)nearbyint((double)acc / 15.0);
+        for (int k = 0; k < n_in; k++) { acc += (long)w[k] * in[k]; den += w[k]; }
+        out[o] = (int16_t)nearbyint((double)acc / (double)den);
     }
 }
 

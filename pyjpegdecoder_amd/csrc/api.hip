@@ -245,7 +245,7 @@ bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
     if (d.ncomp != 3) return false;
     if (d.hs[1] != 1 || d.vs[1] != 1 || d.hs[2] != 1 || d.vs[2] != 1) return false;
     hmax = d.hs[0]; vmax = d.vs[0];
-    return (hmax == 1 || hmax == 2) && (vmax == 1 || vmax == 2);
+    return ((hmax == 1 || hmax == 2) && (vmax == 1 || vmax == 2)) || (hmax == 4 && vmax == 1);
 }
 
 template <typename T>
@@ -384,7 +384,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->n_images = b->n_images;
     p->layout = b->layout;
     p->flags = b->flags;
-    p->transposed = b->layout == MJ_LAYOUT_ROWMAJOR && !(b->flags & MJ_FLAG_EXACT_ONLY);
+    // 4:1:1 (luma 4x1) has no fast stage 2: the exact-order kernel takes it, in either pixel layout
+    if (b->images[0].ncomp == 3 && b->images[0].hs[0] == 4) p->flags |= MJ_FLAG_EXACT_ONLY;
+    p->transposed = b->layout == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY);
     struct Guard { mj_plan *p; mj_context *c; ~Guard() { c->cur = nullptr; if (p) mj_plan_destroy(p); } } guard{p, ctx};
     if (!ctx->free_arenas.empty()) { p->arena = ctx->free_arenas.back(); ctx->free_arenas.pop_back(); }
     else if (hipHostMalloc((void **)&p->arena.base, (size_t)8 << 20, hipHostMallocDefault) == hipSuccess) p->arena.cap = (size_t)8 << 20;
@@ -417,7 +419,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (!sampling_class(d, hmax, vmax))
             return fail(ctx, MJ_ERR_UNSUPPORTED,
                         "image %d: sampling layout not supported by the MI355X path (ncomp=%d, Y %dx%d, Cb %dx%d, Cr %dx%d); "
-                        "supported: greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0", i, d.ncomp, d.hs[0], d.vs[0], d.hs[1], d.vs[1], d.hs[2], d.vs[2]);
+                        "supported: greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1", i, d.ncomp, d.hs[0], d.vs[0], d.hs[1], d.vs[1], d.hs[2], d.vs[2]);
         if (i == 0) { p->hmax = hmax; p->vmax = vmax; p->ncomp = d.ncomp; }
         else if (hmax != p->hmax || vmax != p->vmax || d.ncomp != p->ncomp)
             return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: a plan holds one sampling layout; split the batch by layout", i);

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
 
     for (int i = tid; i < 64 * 64; i += 256) s_tt[i] = a.idct_tt[i];
     if constexpr (G::SUB) {
-        const uint32_t *taps = (HS == 2 && VS == 2) ? UP_TAPS_16x16 : (HS == 2 ? UP_TAPS_16x8 : UP_TAPS_8x16);
+        const uint32_t *taps = HS == 4 ? UP_TAPS2_32x8 : ((HS == 2 && VS == 2) ? UP_TAPS_16x16 : (HS == 2 ? UP_TAPS_16x8 : UP_TAPS_8x16));
         for (int i = tid; i < G::NPIX; i += 256) s_taps[i] = taps[i];
     }
     __syncthreads();
@@ -191,14 +191,25 @@ __global__ __launch_bounds__(256) void k_reconstruct(ReconArgs a) {
                 if constexpr (G::SUB) {
                     const uint32_t tp = s_taps[x * G::MH + y];
                     int sb = 0, sr = 0;
+                    if constexpr (HS == 4) {                                    // 4:1:1: two taps over 31
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int idx = (tp >> (10 * t)) & 63, w = (tp >> (10 * t + 6)) & 15;
-                        sb += w * cbp[idx];
-                        sr += w * crp[idx];
+                        for (int t = 0; t < 2; ++t) {
+                            const int idx = (tp >> (11 * t)) & 63, w = (tp >> (11 * t + 6)) & 31;
+                            sb += w * cbp[idx];
+                            sr += w * crp[idx];
+                        }
+                        Cbv = (int)(int16_t)floordiv<62, 65536>(2 * sb + 31);   // round(s/31), never a tie (31 is odd)
+                        Crv = (int)(int16_t)floordiv<62, 65536>(2 * sr + 31);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            const int idx = (tp >> (10 * t)) & 63, w = (tp >> (10 * t + 6)) & 15;
+                            sb += w * cbp[idx];
+                            sr += w * crp[idx];
+                        }
+                        Cbv = (int)(int16_t)floordiv<30, 65536>(2 * sb + 15);   // round(s/15), never a tie
+                        Crv = (int)(int16_t)floordiv<30, 65536>(2 * sr + 15);
                     }
-                    Cbv = (int)(int16_t)floordiv<30, 65536>(2 * sb + 15);   // round(s/15), never a tie
-                    Crv = (int)(int16_t)floordiv<30, 65536>(2 * sr + 15);
                 } else {
                     Cbv = cbp[x * 8 + y];
                     Crv = crp[x * 8 + y];
@@ -275,6 +286,7 @@ hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, 
     if (hmax == 2 && vmax == 1) return launch_t<2, 1, 3>(stream, a);
     if (hmax == 1 && vmax == 2) return launch_t<1, 2, 3>(stream, a);
     if (hmax == 2 && vmax == 2) return launch_t<2, 2, 3>(stream, a);
+    if (hmax == 4 && vmax == 1) return launch_t<4, 1, 3>(stream, a);      // 4:1:1 (this kernel only: no fast form)
     return hipErrorInvalidValue;
 }
 

@@ -505,7 +505,7 @@ def test_gpu_segmentation_batches_and_1080p(dec_gs, mode, monkeypatch):
     assert sha(seam["coef"]) == meta["sha256"]["coef"] and sha(img) == meta["sha256"]["rgb"]
     from tools import synth
     from oracle import oracle
-    files = [synth.synth_jpeg(90 + i, 40 + 24 * i, 200 - 8 * i, 70 + i, ("420", "444", "422", "440", "grey")[i % 5], (i * 3) % 11, 25.0)
+    files = [synth.synth_jpeg(90 + i, 40 + 24 * i, 200 - 8 * i, 70 + i, ("420", "444", "422", "440", "grey", "411")[i % 6], (i * 3) % 11, 25.0)
              for i in range(20)]
     for f, img in zip(files, dec_gs.decode(files)):
         assert np.array_equal(img, oracle.decode(f)["rgb"])
@@ -889,7 +889,7 @@ def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
     rng = np.random.default_rng(20261003)
     files = []
     for i in range(80):
-        ss = ("420", "444", "422", "440", "grey", "444ni")[int(rng.integers(0, 6))]
+        ss = ("420", "444", "422", "440", "grey", "444ni", "411")[int(rng.integers(0, 7))]
         w, h = int(rng.integers(1, 260)), int(rng.integers(1, 200))
         q = int(rng.choice([20, 50, 75, 85, 92, 98, 100]))
         ri = int(rng.choice([0, 0, 1, 2, 3, 7, 16, 50]))

@@ -30,7 +30,7 @@ def one(args):
     noise = float(rng.choice([0.0, 8.0, 30.0, 90.0]))
     kind = int(rng.integers(0, 10))
     if kind < 7:
-        lay = ("420", "444", "422", "440", "grey")[int(rng.integers(0, 5))]
+        lay = ("420", "444", "422", "440", "grey", "411")[int(rng.integers(0, 6))]
         ri = int(rng.choice([0, 0, 1, 2, 5, 9]))
         raw = synth.synth_jpeg(int(rng.integers(0, 1 << 30)), w, h, q, lay, ri, noise)
         desc = f"baseline {w}x{h} q{q} {lay} ri{ri} noise{noise}"

@@ -193,17 +193,17 @@ static void put_marker_seg(BitW *w, uint8_t m, const uint8_t *data, int len) {
 }
 
 /*
- * subsamp: 0 = 4:4:4, 1 = 4:2:2 (h2v1), 2 = 4:2:0 (h2v2), 3 = 4:4:0 (h1v2), 4 = greyscale.
+ * subsamp: 0 = 4:4:4, 1 = 4:2:2 (h2v1), 2 = 4:2:0 (h2v2), 3 = 4:4:0 (h1v2), 4 = greyscale, 6 = 4:1:1 (h4v1).
  * rgb: row-major [H][W][3].  Returns bytes written, or -1 on overflow / bad argument.
  */
 long mjenc_encode_rgb(const uint8_t *rgb, int W, int H, int quality, int subsamp,
                       int restart_interval, uint8_t *out, size_t cap) {
     if (!fd_ready) fd_init();
-    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || subsamp < 0 || subsamp > 5) return -1;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || subsamp < 0 || subsamp > 6) return -1;
     const int non_interleaved = subsamp == 5;     /* 4:4:4 with one scan per component */
     if (non_interleaved) subsamp = 0;
     int ncomp = subsamp == 4 ? 1 : 3;
-    int hs = (subsamp == 1 || subsamp == 2) ? 2 : 1;
+    int hs = subsamp == 6 ? 4 : ((subsamp == 1 || subsamp == 2) ? 2 : 1);     /* 6 = 4:1:1 (h4v1) */
     int vs = (subsamp == 2 || subsamp == 3) ? 2 : 1;
     if (ncomp == 1) { hs = vs = 1; }
     int mcu_w = 8 * hs, mcu_h = 8 * vs;

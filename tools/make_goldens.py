@@ -180,6 +180,9 @@ def file_fixtures(big: bool):
     fx.append(("48x80_440", synth.encode_rgb(S(10, 48, 80), 85, "440", 0)))
     fx.append(("72x40_422_dri2", synth.encode_rgb(S(11, 72, 40), 85, "422", 2)))
     fx.append(("40x40_444_dri5", synth.encode_rgb(S(12, 40, 40), 85, "444", 5)))
+    # 4:1:1 (luma 4x1: MCU 32x8, chroma upsampled 8x8 -> 32x8): multiple of the MCU, and cropped with restart markers
+    fx.append(("96x24_411", synth.encode_rgb(S(40, 96, 24), 85, "411", 0)))
+    fx.append(("100x36_411_dri3", synth.encode_rgb(synth.synth_rgb(41, 100, 36, 25.0), 90, "411", 3)))
     # high quality + strong noise: long codes, many 0xFF stuffing bytes, large coefficient categories
     fx.append(("96x64_420_q100_noise", synth.encode_rgb(synth.synth_rgb(13, 96, 64, 60.0), 100, "420", 6)))
     fx.append(("64x64_444_q98_pil", pil_jpeg(synth.synth_rgb(14, 64, 64, 50.0), quality=98, subsampling=0)))
@@ -213,7 +216,9 @@ def sha(a: np.ndarray) -> str:
 
 
 def capture_W(src, dst) -> np.ndarray:
-    """Upsample operator of ResizeGrid for (src -> dst), as integer numerators over 15."""
+    """Upsample operator of ResizeGrid for (src -> dst), as integer numerators over 15 (x2 along an axis: SURVEY F5) or
+    over 31 (x4 along one axis, x1 along the other: the mesh points then lie on grid lines and two taps remain)."""
+    den = 31 if max(dst[0] // src[0], dst[1] // src[1]) == 4 else 15
     r = jd.ResizeGrid()
     n = src[0] * src[1]
     r(np.zeros(src, dtype=np.int16), dst)           # fill the mesh caches exactly as the reference does
@@ -221,10 +226,10 @@ def capture_W(src, dst) -> np.ndarray:
     W = np.zeros((dst[0] * dst[1], n))
     for k in range(n):
         b = np.zeros(n)
-        b[k] = 15.0 * 64
+        b[k] = float(den) * 64
         W[:, k] = jd.griddata(old_xy, b, new_xy).ravel() / 64
     Wi = np.rint(W).astype(np.int8)
-    assert np.abs(W - Wi).max() < 1e-9 and (Wi.sum(1) == 15).all() and ((Wi != 0).sum(1) <= 3).all()
+    assert np.abs(W - Wi).max() < 1e-9 and (Wi.sum(1) == den).all() and ((Wi != 0).sum(1) <= 3).all()
     return Wi
 
 
@@ -269,6 +274,12 @@ def main():
         return
     FILES.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(20261002)
+    # upsample operators added after the first capture: made when missing, also with --only
+    for src, dst in (((8, 8), (32, 8)),):
+        f = GOLD / f"upsample_W_{src[0]}x{src[1]}_{dst[0]}x{dst[1]}.npy"
+        if not f.exists():
+            np.save(f, capture_W(src, dst))
+            print("captured", f.name)
 
     if not args.only:
         # --- constant tables -------------------------------------------------------------------

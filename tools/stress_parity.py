@@ -12,7 +12,7 @@ from pyjpegdecoder_amd import BatchDecoder
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-layouts = ("420", "444", "422", "440", "grey")
+layouts = ("420", "444", "422", "440", "grey", "411")
 files, want = [], []
 t0 = time.time()
 for i in range(n_files):

@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 _SO = _HERE / "libjpegenc.so"
 _SRC = _HERE / "jpegenc.c"
 
-SUBSAMPLING = {"444": 0, "422": 1, "420": 2, "440": 3, "grey": 4, "444ni": 5}   # 444ni: one scan per component
+SUBSAMPLING = {"444": 0, "422": 1, "420": 2, "440": 3, "grey": 4, "444ni": 5, "411": 6}   # 444ni: one scan per component
 
 
 def build(force: bool = False) -> Path:
