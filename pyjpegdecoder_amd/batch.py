@@ -255,11 +255,12 @@ assert _DESC_DTYPE.itemsize == ctypes.sizeof(B.ImageDescC)
 
 
 def prepare_batch_native(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flags: int = 0, n_threads: int = 0,
-                         staging: Optional[np.ndarray] = None) -> Optional[PreparedBatch]:
+                         staging: Optional[np.ndarray] = None):
     """`prepare_batch` for a GPU-segmented batch of everyday baseline files through libmijpeg.so's host front end
-    (``mj_host_assemble``: header parse and assembly on host threads).  Returns None when the front end declines a file
-    or the batch mixes sampling layouts — the caller then takes the Python path, which also raises the reference's
-    exceptions.  ``staging``: a uint8 buffer to build the blob in (reused between batches by BatchDecoder)."""
+    (``mj_host_assemble``: header parse and assembly on host threads).  Returns None when the front end declines a file —
+    the caller then takes the Python path, which also raises the reference's exceptions — and, when the files are fine but
+    do not belong in one plan (several sampling layouts; files with and without restart markers), the groups they fall
+    into as lists of indices.  ``staging``: a uint8 buffer to build the blob in (reused between batches by BatchDecoder)."""
     n = len(files)
     if n == 0 or not all(type(f) is bytes for f in files):
         return None
@@ -293,9 +294,13 @@ def prepare_batch_native(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJO
     if rc != B.MJ_OK:
         raise B.BackendError(f"mj_host_assemble failed ({rc})")
     d = np.frombuffer(descs, dtype=_DESC_DTYPE)
-    lay = np.concatenate([d["ncomp"][:, None], d["hs"], d["vs"]], axis=1)
+    lay = np.concatenate([d["ncomp"][:, None], d["hs"], d["vs"], (d["restart_interval"] > 0)[:, None]], axis=1)
     if (lay != lay[0]).any():
-        return None                         # several sampling layouts: one plan each, grouped by the Python path
+        # several sampling layouts, or files with and without restart markers (only a batch without any can be cut into
+        # chunks when the GPU finds the markers): one plan each — the caller gets the groups (lists of file indices)
+        _, inverse = np.unique(lay, axis=0, return_inverse=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        return [np.flatnonzero(inverse == g).tolist() for g in range(int(inverse.max()) + 1)]
     shapes = list(zip(d["width"].tolist(), d["height"].tolist(), d["ncomp"].tolist()))
     return PreparedBatch(parsed=[None] * n, blob=blob, file_offsets=offs, descs=descs, seg_begin=seg_b, seg_end=seg_e,
                          huff=huff, n_huff=int(job.n_huff), qt=np.ascontiguousarray(qt[:max(1, int(job.n_qt))]),
@@ -364,7 +369,7 @@ class BatchDecoder:
         for i, p in enumerate(parsed):
             check_supported(p)
             comps = list(p.color_components.values())
-            key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+            key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p), p.headers_only and p.restart_interval > 0) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
             groups.setdefault(key, []).append(i)
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)
@@ -424,7 +429,10 @@ class BatchDecoder:
         gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
         if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
-            if prep is not None:
+            if isinstance(prep, list):                            # fine files, several plans: one native assembly per group
+                for idxs in prep:                                 # (each builds its blob when its turn comes: one staging buffer)
+                    work.append((idxs, "native"))
+            elif prep is not None:
                 work.append((list(range(len(files))), prep))
         if not work:
             groups: Dict[tuple, List[int]] = {}
@@ -432,11 +440,19 @@ class BatchDecoder:
                 p = parsed[i] = parse_jpeg(f, headers_only=gpu_segment)
                 check_supported(p)
                 comps = list(p.color_components.values())
-                key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p)) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
+                key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p), p.headers_only and p.restart_interval > 0) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
                 groups.setdefault(key, []).append(i)
             work = [(idxs, None) for idxs in groups.values()]
         while work:
             idxs, prep = work.pop(0)
+            if isinstance(prep, str):
+                sub = [files[i] for i in idxs]
+                prep = prepare_batch_native(sub, self.layout, self.base_flags, staging=self._staging_for(sub))
+                if not isinstance(prep, PreparedBatch):           # cannot happen for a group the front end just formed
+                    prep = None
+                    for i in idxs:
+                        parsed[i] = parse_jpeg(files[i], headers_only=True)
+                        check_supported(parsed[i])
             if prep is None:
                 prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
             d_blob = torch.from_numpy(prep.blob).to(dev)
@@ -516,6 +532,8 @@ class BatchDecoder:
                 if pinned[buf] is None or pinned[buf].numel() < need:
                     pinned[buf] = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
                 prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned[buf].numpy())
+            if not isinstance(prep, PreparedBatch):               # declined, or several plans' worth: the one-call path sorts it out
+                prep = None
             if prep is None:
                 if pending is not None:
                     job, pending = pending, None

@@ -24,6 +24,7 @@ struct DevBufferCache {
     std::vector<Block> live;            // handed out (size needed again at release)
     size_t cached_bytes = 0, limit_bytes = 0;
     uint64_t clock = 0;
+    uint64_t n_hit = 0, n_miss = 0, n_evict = 0;    // MJ_CACHE_STATS=1 prints them when the context goes
     static size_t bucket(size_t n) {
         if (n <= 4096) return 4096;
         size_t p2 = (size_t)1 << (63 - __builtin_clzll((unsigned long long)n));
@@ -38,8 +39,10 @@ struct DevBufferCache {
         if (best >= 0) {
             *out = free_blocks[best].ptr;
             cached_bytes -= want;
+            ++n_hit;
             free_blocks.erase(free_blocks.begin() + best);
         } else {
+            ++n_miss;
             hipError_t e = hipMalloc(out, want);
             if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, want); }
             if (e != hipSuccess) return e;
@@ -67,6 +70,7 @@ struct DevBufferCache {
             for (int i = 1; i < (int)free_blocks.size(); ++i)
                 if (free_blocks[i].stamp < free_blocks[old].stamp) old = i;
             (void)hipFree(free_blocks[old].ptr);
+            ++n_evict;
             cached_bytes -= free_blocks[old].size;
             free_blocks.erase(free_blocks.begin() + old);
         }
@@ -334,6 +338,9 @@ void mj_destroy(mj_context *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->setup_stream) { (void)hipStreamSynchronize(ctx->setup_stream); (void)hipStreamDestroy(ctx->setup_stream); }
+    if (getenv("MJ_CACHE_STATS"))
+        fprintf(stderr, "[mijpeg] device buffer cache: %llu hits, %llu misses (hipMalloc), %llu evictions, %.1f MB cached at the end\n",
+                (unsigned long long)ctx->cache.n_hit, (unsigned long long)ctx->cache.n_miss, (unsigned long long)ctx->cache.n_evict, ctx->cache.cached_bytes / 1048576.0);
     ctx->cache.trim(0);
     for (auto &a : ctx->free_arenas) (void)hipHostFree(a.base);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
@@ -771,7 +778,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 if (total_len / cb <= 330000) { p->sync_chunk_bytes = cb; break; }
         }
         for (const auto &g : segs) est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes);
-        const bool long_segs = !segs.empty() && total_len / (int64_t)segs.size() >= 32768 && est_chunks >= 64;
+        // (one long segment is enough: in a batch that mixes files with and without restart markers, an image without
+        // them would otherwise be one lane's — or one wavefront's — serial walk, 220 ms for a 1080p file)
+        int32_t max_len = 0;
+        for (const auto &g : segs) max_len = std::max(max_len, g.len);
+        const bool long_segs = !segs.empty() && (total_len / (int64_t)segs.size() >= 32768 || max_len >= 65536) && est_chunks >= 64;
         // ... and so do small batches of ordinary restart segments: below ~20 000 segments the lane form cannot fill the
         // chip (its time is one segment's serial walk, ~3.3 ms for a 1080p MCU row, however few there are), while chunks
         // can (measured, 1080p with one restart interval per MCU row: 1 image 3.3 -> 1.4 ms, 32 images 3.9 -> 2.1 ms,

@@ -572,7 +572,7 @@ def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
 
     def spy_native(*a, **k):
         r = real_native(*a, **k)
-        calls["native"] += r is not None
+        calls["native"] += isinstance(r, batch_mod.PreparedBatch)      # (a list = fine files, several plans: not an assembly yet)
         return r
 
     def spy_parse(*a, **k):
@@ -581,7 +581,7 @@ def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
     monkeypatch.setattr(batch_mod, "prepare_batch_native", spy_native)
     monkeypatch.setattr(batch_mod, "parse_jpeg", spy_parse)
     outs = dec_gs.decode_device(files)
-    assert calls == {"native": 1, "python": 0}
+    assert calls == {"native": 2, "python": 0}                 # files with and without restart markers: two plans
     for t, w in zip(outs, want):
         assert t.is_cuda and np.array_equal(t.cpu().numpy(), w)
     outs = dec_gs.decode_device(files)                         # the staging buffer is reused
@@ -590,10 +590,16 @@ def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
     with_com = files[3][:-2] + b"\xff\xfe\x00\x06abcd" + b"\xff\xd9"
     calls.update(native=0, python=0)
     outs = dec_gs.decode_device(files[:3] + [with_com] + files[4:])
-    assert calls == {"native": 1, "python": 1}
+    assert calls == {"native": 2, "python": 1}
     assert all(np.array_equal(t.cpu().numpy(), w) for t, w in zip(outs, want))
-    # mixed layouts / a progressive file: the whole batch takes the Python path
+    # fine files of several kinds (another sampling layout; with and without restart markers): one native assembly per kind
     other = synth.synth_jpeg(400, 64, 64, 85, "444", 0, 20.0)
+    calls.update(native=0, python=0)
+    outs = dec_gs.decode_device(files + [other, other])
+    assert calls["python"] == 0 and calls["native"] == 3          # 4:2:0 without markers, 4:2:0 with markers, 4:4:4
+    assert all(np.array_equal(t.cpu().numpy(), w) for t, w in zip(outs, want))
+    assert np.array_equal(outs[-1].cpu().numpy(), oracle.decode(other)["rgb"])
+    # a progressive file: the whole batch takes the Python path
     praw, pvec = load_golden(prog_names()[0])
     calls.update(native=0, python=0)
     outs = dec_gs.decode_device(files[:2] + [other, praw])

@@ -10,7 +10,7 @@ import pytest
 from conftest import golden_index, load_golden
 from pyjpegdecoder_amd import _binding as B
 from pyjpegdecoder_amd._parse import parse_jpeg
-from pyjpegdecoder_amd.batch import prepare_batch, prepare_batch_native
+from pyjpegdecoder_amd.batch import PreparedBatch, prepare_batch, prepare_batch_native
 from tools import synth
 
 
@@ -44,12 +44,14 @@ def test_every_baseline_fixture_alone(name):
 
 
 def test_batch_with_shared_and_distinct_tables():
-    # three qualities (distinct quantisation tables), with and without DRI, odd sizes (alignment gaps in the blob)
+    # three qualities (distinct quantisation tables), several restart intervals, odd sizes (alignment gaps in the blob)
     files = [synth.synth_jpeg(s, 72 + 8 * (s % 3), 40 + s, q, "420", ri) for s, (q, ri) in
-             enumerate([(85, 0), (85, 5), (60, 0), (95, 3), (60, 2), (85, 0), (95, 0)])]
+             enumerate([(85, 1), (85, 5), (60, 7), (95, 3), (60, 2), (85, 4), (95, 9)])]
     for threads in (1, 3, 16):
         _same(prepare_batch_native(files, n_threads=threads), _py(files))
     assert _py(files).qt.shape[0] > 2
+    nodri = [synth.synth_jpeg(20 + s, 72 + 8 * (s % 3), 40 + s, 85 - 10 * (s % 3), "420", 0) for s in range(5)]
+    _same(prepare_batch_native(nodri), _py(nodri))
 
 
 def test_rowmajor_and_flags_pass_through():
@@ -126,8 +128,12 @@ def test_which_file_was_declined():
 def test_mixed_layouts_go_to_the_python_path():
     a = synth.synth_jpeg(0, 48, 32, 85, "420", 0)
     b = synth.synth_jpeg(1, 48, 32, 85, "444", 0)
-    assert prepare_batch_native([a, b]) is None
-    assert prepare_batch_native([a, a]) is not None
+    # fine files that do not belong in one plan: the groups they fall into (sampling layout; with / without restart markers)
+    assert prepare_batch_native([a, b]) == [[0], [1]] or prepare_batch_native([a, b]) == [[1], [0]]
+    assert isinstance(prepare_batch_native([a, a]), PreparedBatch)
+    c = synth.synth_jpeg(2, 48, 32, 85, "420", 3)
+    groups = prepare_batch_native([a, c, b, a, c])
+    assert sorted(map(tuple, groups)) == [(0, 3), (1, 4), (2,)]
 
 
 def test_fuzzed_headers_accept_only_what_python_builds_identically():
@@ -152,7 +158,7 @@ def test_fuzzed_headers_accept_only_what_python_builds_identically():
                 raw[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 4)), dtype=np.uint8))
         f = bytes(raw)
         nat = prepare_batch_native([f])
-        if nat is None:
+        if not isinstance(nat, PreparedBatch):
             continue
         accepted += 1
         try:
