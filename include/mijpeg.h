@@ -251,6 +251,10 @@ typedef struct {
     int32_t n_threads;                    /* in: host threads to use (>= 1)                                    */
     int32_t n_huff, n_qt;                 /* out: distinct tables written                                      */
     int32_t declined_file;                /* out: -1, or the first file this front end does not take           */
+    uint8_t *skip;                        /* in, optional: n_files bytes.  Non-NULL: files the front end does not take are
+                                             marked 1 here and left out (their slot in the blob stays zeroed) instead of
+                                             ending the call; the output arrays then hold the accepted files only, in order */
+    int32_t n_accepted;                   /* out: files assembled (= n_files without `skip`)                   */
 } mj_host_job;
 int mj_host_assemble(mj_host_job *job);
 

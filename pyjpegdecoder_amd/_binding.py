@@ -69,7 +69,8 @@ class HostJobC(ctypes.Structure):
                 ("images", ctypes.POINTER(ImageDescC)), ("seg_begin", ctypes.c_void_p), ("seg_end", ctypes.c_void_p),
                 ("huff", ctypes.POINTER(HuffSpecC)), ("huff_cap", ctypes.c_int32),
                 ("qt", ctypes.c_void_p), ("qt_cap", ctypes.c_int32), ("n_threads", ctypes.c_int32),
-                ("n_huff", ctypes.c_int32), ("n_qt", ctypes.c_int32), ("declined_file", ctypes.c_int32)]
+                ("n_huff", ctypes.c_int32), ("n_qt", ctypes.c_int32), ("declined_file", ctypes.c_int32),
+                ("skip", ctypes.c_void_p), ("n_accepted", ctypes.c_int32)]
 
 
 class PlanInfoC(ctypes.Structure):

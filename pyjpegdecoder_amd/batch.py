@@ -255,12 +255,14 @@ assert _DESC_DTYPE.itemsize == ctypes.sizeof(B.ImageDescC)
 
 
 def prepare_batch_native(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flags: int = 0, n_threads: int = 0,
-                         staging: Optional[np.ndarray] = None):
+                         staging: Optional[np.ndarray] = None, split: bool = False):
     """`prepare_batch` for a GPU-segmented batch of everyday baseline files through libmijpeg.so's host front end
     (``mj_host_assemble``: header parse and assembly on host threads).  Returns None when the front end declines a file —
     the caller then takes the Python path, which also raises the reference's exceptions — and, when the files are fine but
     do not belong in one plan (several sampling layouts; files with and without restart markers), the groups they fall
-    into as lists of indices.  ``staging``: a uint8 buffer to build the blob in (reused between batches by BatchDecoder)."""
+    into as lists of indices.  ``split=True``: files the front end does not take do not sink the batch; the result is then
+    ``(groups, declined)`` — index lists for the front end, grouped as above, and the indices left for the Python path.
+    ``staging``: a uint8 buffer to build the blob in (reused between batches by BatchDecoder)."""
     n = len(files)
     if n == 0 or not all(type(f) is bytes for f in files):
         return None
@@ -288,20 +290,29 @@ def prepare_batch_native(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJO
         import os
         n_threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     job.n_threads = n_threads
+    skip = np.zeros(n, dtype=np.uint8)
+    if split:
+        job.skip = skip.ctypes.data
     rc = lib.mj_host_assemble(ctypes.byref(job))
     if rc == B.MJ_HOST_DECLINED:
-        return None
+        return ([], list(range(n))) if split else None
     if rc != B.MJ_OK:
         raise B.BackendError(f"mj_host_assemble failed ({rc})")
-    d = np.frombuffer(descs, dtype=_DESC_DTYPE)
+    m = int(job.n_accepted)
+    accepted = np.flatnonzero(skip == 0)
+    d = np.frombuffer(descs, dtype=_DESC_DTYPE)[:m]
     lay = np.concatenate([d["ncomp"][:, None], d["hs"], d["vs"], (d["restart_interval"] > 0)[:, None]], axis=1)
-    if (lay != lay[0]).any():
+    mixed = bool((lay != lay[0]).any())
+    if mixed or m < n:
         # several sampling layouts, or files with and without restart markers (only a batch without any can be cut into
         # chunks when the GPU finds the markers): one plan each — the caller gets the groups (lists of file indices)
         _, inverse = np.unique(lay, axis=0, return_inverse=True)
         inverse = np.asarray(inverse).reshape(-1)
-        return [np.flatnonzero(inverse == g).tolist() for g in range(int(inverse.max()) + 1)]
+        groups = [accepted[np.flatnonzero(inverse == g)].tolist() for g in range(int(inverse.max()) + 1)]
+        return (groups, np.flatnonzero(skip).tolist()) if split else groups
     shapes = list(zip(d["width"].tolist(), d["height"].tolist(), d["ncomp"].tolist()))
+    if split:
+        return ([list(range(n))], [])         # (the caller assembles group by group; this pass only sorted the files)
     return PreparedBatch(parsed=[None] * n, blob=blob, file_offsets=offs, descs=descs, seg_begin=seg_b, seg_end=seg_e,
                          huff=huff, n_huff=int(job.n_huff), qt=np.ascontiguousarray(qt[:max(1, int(job.n_qt))]),
                          layout=layout, flags=flags | B.MJ_FLAG_GPU_SEGMENT, shapes=shapes)
@@ -426,23 +437,28 @@ class BatchDecoder:
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
         parsed: Dict[int, ParsedJpeg] = {}
         work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
+        rest: List[int] = []
         gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
         if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
-            if isinstance(prep, list):                            # fine files, several plans: one native assembly per group
-                for idxs in prep:                                 # (each builds its blob when its turn comes: one staging buffer)
-                    work.append((idxs, "native"))
-            elif prep is not None:
+            if isinstance(prep, PreparedBatch):                   # the everyday case: one pass, one plan
                 work.append((list(range(len(files))), prep))
-        if not work:
+            else:
+                # files of several kinds (sampling layouts; with / without restart markers), or some the front end does not
+                # take (progressive, ...): it sorts them — one native assembly per kind when its turn comes (one staging
+                # buffer), the Python path for the rest
+                groups_n, rest = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files), split=True)
+                work += [(idxs, "native") for idxs in groups_n]
+        if not work or rest:
+            todo = rest if work else range(len(files))          # everything, unless the front end kept some of it
             groups: Dict[tuple, List[int]] = {}
-            for i, f in enumerate(files):
-                p = parsed[i] = parse_jpeg(f, headers_only=gpu_segment)
+            for i in todo:
+                p = parsed[i] = parse_jpeg(files[i], headers_only=gpu_segment)
                 check_supported(p)
                 comps = list(p.color_components.values())
                 key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p), p.headers_only and p.restart_interval > 0) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
                 groups.setdefault(key, []).append(i)
-            work = [(idxs, None) for idxs in groups.values()]
+            work += [(idxs, None) for idxs in groups.values()]
         while work:
             idxs, prep = work.pop(0)
             if isinstance(prep, str):

@@ -11,6 +11,8 @@
 // headers — is DECLINED, not diagnosed: the caller then runs the full Python marker loop over the batch, which
 // raises exactly what the reference raises.  Declining is always safe; accepting is only done when the result is
 // what `_parse.py` + `batch.py` would have produced (tests/test_host_frontend.py compares the arrays byte for byte).
+// With mj_host_job.skip the declined files are marked and left out instead of ending the call: a service's batch with a
+// few progressive files in it keeps the front end for the rest.
 #include <string.h>
 
 #include <algorithm>
@@ -143,6 +145,9 @@ extern "C" int mj_host_assemble(mj_host_job *job) {
     const int n = job->n_files;
     job->n_huff = job->n_qt = 0;
     job->declined_file = -1;
+    job->n_accepted = 0;
+    uint8_t *skip = job->skip;              // non-null: declined files are marked and left out, the rest is assembled
+    if (skip) memset(skip, 0, (size_t)n);
     for (int i = 0; i < n; ++i) {
         const int64_t next = i + 1 < n ? job->file_off[i + 1] : job->blob_len;
         if (job->sizes[i] < 0 || job->file_off[i] < 0 || (job->file_off[i] & 3) || job->file_off[i] + job->sizes[i] > next)
@@ -155,13 +160,17 @@ extern "C" int mj_host_assemble(mj_host_job *job) {
     auto worker = [&]() {
         for (;;) {
             const int i = next_file.fetch_add(1);
-            if (i >= n || declined.load(std::memory_order_relaxed) < n) return;
+            if (i >= n || (!skip && declined.load(std::memory_order_relaxed) < n)) return;
             const uint8_t *raw = job->files[i];
             const int64_t sz = job->sizes[i];
             if (!raw || !parse_headers(raw, sz, hdr[(size_t)i])) {
                 int cur = declined.load();
                 while (i < cur && !declined.compare_exchange_weak(cur, i)) {}
-                return;
+                if (!skip) return;
+                skip[i] = 1;                                            // its slot in the blob stays empty (zeroed)
+                const int64_t end = i + 1 < n ? job->file_off[i + 1] : job->blob_len;
+                memset(job->blob + job->file_off[i], 0, (size_t)(end - job->file_off[i]));
+                continue;
             }
             // the file into the blob, the gap up to the next file (alignment / the read-ahead slack) zeroed
             uint8_t *dst = job->blob + job->file_off[i];
@@ -178,7 +187,7 @@ extern "C" int mj_host_assemble(mj_host_job *job) {
     for (auto &t : pool) t.join();
     if (declined.load() < n) {
         job->declined_file = declined.load();
-        return MJ_HOST_DECLINED;
+        if (!skip) return MJ_HOST_DECLINED;
     }
     if (job->file_off[0] > 0) memset(job->blob, 0, (size_t)job->file_off[0]);
 
@@ -206,7 +215,9 @@ extern "C" int mj_host_assemble(mj_host_job *job) {
         qt_ids.emplace(std::move(k), id);
         return id;
     };
+    int k = 0;                               // accepted files so far = index into the output arrays
     for (int i = 0; i < n; ++i) {
+        if (skip && skip[i]) continue;
         const FileHeader &h = hdr[(size_t)i];
         mj_image_desc d;
         memset(&d, 0, sizeof d);
@@ -225,12 +236,14 @@ extern "C" int mj_host_assemble(mj_host_job *job) {
         d.mcu_count_h = (h.width + 8 * hmax - 1) / (8 * hmax);             // (:609-611)
         d.mcu_count_v = (h.height + 8 * vmax - 1) / (8 * vmax);
         d.n_segments = 1;                                                  // MJ_FLAG_GPU_SEGMENT: one byte range per image
-        d.first_segment = i;
-        job->images[i] = d;
-        job->seg_begin[i] = job->file_off[i] + h.entropy_start;
-        job->seg_end[i] = job->file_off[i] + job->sizes[i];
+        d.first_segment = k;
+        job->images[k] = d;
+        job->seg_begin[k] = job->file_off[i] + h.entropy_start;
+        job->seg_end[k] = job->file_off[i] + job->sizes[i];
+        ++k;
     }
+    job->n_accepted = k;
     job->n_huff = (int32_t)huff_ids.size();
     job->n_qt = (int32_t)qt_ids.size();
-    return MJ_OK;
+    return k > 0 ? MJ_OK : MJ_HOST_DECLINED;
 }

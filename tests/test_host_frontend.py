@@ -168,3 +168,23 @@ def test_fuzzed_headers_accept_only_what_python_builds_identically():
         assert py.flags & B.MJ_FLAG_GPU_SEGMENT, f"trial {trial}: the Python path does not treat this as a one-scan baseline file"
         _same(nat, py)
     assert accepted > 50
+
+
+def test_split_keeps_what_it_can():
+    """split=True: files the front end does not take (progressive, one scan per component, not a JPEG) are left to the
+    Python path by index, the rest is grouped by kind — a stray progressive file no longer sinks a batch."""
+    a = synth.synth_jpeg(0, 48, 32, 85, "420", 0)
+    b = synth.synth_jpeg(1, 48, 32, 85, "444", 0)
+    c = synth.synth_jpeg(2, 48, 32, 85, "420", 3)
+    prog = load_golden([n for n in golden_index() if n.startswith("prog_")][0])[0]
+    files = [a, prog, c, b"junk", a, b, c, prog]
+    groups, rest = prepare_batch_native(files, split=True)
+    assert rest == [1, 3, 7]
+    assert sorted(map(tuple, groups)) == [(0, 4), (2, 6), (5,)]
+    assert prepare_batch_native(files) is None                                  # without split: all or nothing
+    assert prepare_batch_native([prog, b"junk"], split=True) == ([], [0, 1])
+    assert prepare_batch_native([a, a, a], split=True) == ([[0, 1, 2]], [])
+    # the groups assemble like batches of their own
+    for g in groups:
+        sub = [files[i] for i in g]
+        _same(prepare_batch_native(sub), _py(sub))
