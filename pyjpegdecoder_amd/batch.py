@@ -459,42 +459,66 @@ class BatchDecoder:
                 key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p), p.headers_only and p.restart_interval > 0) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
                 groups.setdefault(key, []).append(i)
             work += [(idxs, None) for idxs in groups.values()]
+        # Several plans (a batch of several kinds of files): all are submitted before the first is collected, on a few
+        # streams in turn, so that small plans share the GPU instead of queueing behind each other's host round trips
+        # (mj_plan_sync waits for a plan's own work only).  Files handed back by the GPU scan go round again.
+        streams = None
         while work:
-            idxs, prep = work.pop(0)
-            if isinstance(prep, str):
-                sub = [files[i] for i in idxs]
-                prep = prepare_batch_native(sub, self.layout, self.base_flags, staging=self._staging_for(sub))
-                if not isinstance(prep, PreparedBatch):           # cannot happen for a group the front end just formed
-                    prep = None
-                    for i in idxs:
-                        parsed[i] = parse_jpeg(files[i], headers_only=True)
-                        check_supported(parsed[i])
-            if prep is None:
-                prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
-            d_blob = torch.from_numpy(prep.blob).to(dev)
-            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(idxs)})
+            flying = []
             try:
-                d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
-                plan.execute(0, d_rgb.data_ptr())
-                plan.sync()
-                status = plan.read(rgb=False)["status"]
-                redo = [i for k, i in enumerate(idxs) if status[k] == B.MJ_ST_TAIL]
-                if redo:
-                    for i in redo:
-                        parsed[i] = parse_jpeg(files[i])
-                        check_supported(parsed[i])
-                    work.append((redo, None))
-                    status[[k for k, i in enumerate(idxs) if i in redo]] = 0
-                raise_for_status(status)
-                off = 0
-                for k, i in enumerate(idxs):
-                    w, h, nc = prep.shapes[k]
-                    n = w * h * nc
-                    shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
-                    results[i] = d_rgb[off:off + n].view(shape)
-                    off += n
+                while work:
+                    idxs, prep = work.pop(0)
+                    if isinstance(prep, str):
+                        sub = [files[i] for i in idxs]
+                        prep = prepare_batch_native(sub, self.layout, self.base_flags, staging=self._staging_for(sub))
+                        if not isinstance(prep, PreparedBatch):   # cannot happen for a group the front end just formed
+                            prep = None
+                            for i in idxs:
+                                parsed[i] = parse_jpeg(files[i], headers_only=True)
+                                check_supported(parsed[i])
+                    if prep is None:
+                        prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
+                    if work or flying:
+                        # more than one plan: keep off the null stream, whose copies would wait for the other plans' kernels
+                        if streams is None:
+                            streams = [torch.cuda.Stream(device=dev) for _ in range(5)]
+                        with torch.cuda.stream(streams[4]):
+                            d_blob = torch.from_numpy(prep.blob).to(dev)         # (pageable source: the staging buffer is free on return)
+                    else:
+                        d_blob = torch.from_numpy(prep.blob).to(dev)
+                    plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(idxs)})
+                    flying.append((idxs, prep, plan, None, d_blob))
+                    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+                    flying[-1] = (idxs, prep, plan, d_rgb, d_blob)
+                    if streams is None:
+                        plan.execute(0, d_rgb.data_ptr())                        # the everyday case: one plan, the context's stream
+                    else:
+                        st = streams[(len(flying) - 1) % 4]
+                        st.wait_stream(streams[4])                               # the upload above
+                        d_rgb.record_stream(st)
+                        d_blob.record_stream(st)
+                        plan.execute(st.cuda_stream, d_rgb.data_ptr())
+                for idxs, prep, plan, d_rgb, _ in flying:
+                    plan.sync()
+                    status = plan.read(rgb=False)["status"]
+                    redo = [i for k, i in enumerate(idxs) if status[k] == B.MJ_ST_TAIL]
+                    if redo:
+                        for i in redo:
+                            parsed[i] = parse_jpeg(files[i])
+                            check_supported(parsed[i])
+                        work.append((redo, None))
+                        status[[k for k, i in enumerate(idxs) if i in redo]] = 0
+                    raise_for_status(status)
+                    off = 0
+                    for k, i in enumerate(idxs):
+                        w, h, nc = prep.shapes[k]
+                        n = w * h * nc
+                        shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
+                        results[i] = d_rgb[off:off + n].view(shape)
+                        off += n
             finally:
-                plan.close()
+                for item in flying:
+                    item[2].close()
         return results
 
     def decode_device_iter(self, batches):
