@@ -458,7 +458,9 @@ class BatchDecoder:
                 comps = list(p.color_components.values())
                 key = (p.scan_mode, len(comps), p.headers_only, is_scan_list(p), p.headers_only and p.restart_interval > 0) + (tuple((c.horizontal_sampling, c.vertical_sampling) for c in comps) if len(comps) > 1 else ())
                 groups.setdefault(key, []).append(i)
-            work += [(idxs, None) for idxs in groups.values()]
+            # (first in line: what the front end left over is mostly progressive files, whose decode is a long serial chain
+            # the other plans can run beside)
+            work = [(idxs, None) for idxs in groups.values()] + work
         # Several plans (a batch of several kinds of files): all are submitted before the first is collected, on a few
         # streams in turn, so that small plans share the GPU instead of queueing behind each other's host round trips
         # (mj_plan_sync waits for a plan's own work only).  Files handed back by the GPU scan go round again.
@@ -493,6 +495,8 @@ class BatchDecoder:
                     if streams is None:
                         plan.execute(0, d_rgb.data_ptr())                        # the everyday case: one plan, the context's stream
                     else:
+                        # (streams only overlap when they sit on different hardware queues: the package asks the runtime for
+                        # eight instead of four, see __init__.py)
                         st = streams[(len(flying) - 1) % 4]
                         st.wait_stream(streams[4])                               # the upload above
                         d_rgb.record_stream(st)

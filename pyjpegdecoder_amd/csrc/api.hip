@@ -89,6 +89,8 @@ struct mj_context {
     struct Arena { char *base = nullptr; size_t cap = 0, used = 0; };
     std::vector<Arena> free_arenas;
     Arena *cur = nullptr;          // the arena of the plan being created
+    int32_t *h_word = nullptr;     // pinned: where a stream hands one counter to the host (a pageable target would make the
+                                   // copy synchronous for the whole device, i.e. wait for other plans' kernels on other streams)
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
     DevBufferCache cache;
     std::string err;
@@ -319,6 +321,7 @@ int mj_create(int device_id, mj_context **out) {
     MJ_HIP(nullptr, hipSetDevice(device_id));
     MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking));
+    MJ_HIP(nullptr, hipHostMalloc((void **)&ctx->h_word, 64, hipHostMallocDefault));
     std::vector<double> tt(64 * 64);
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
@@ -343,6 +346,7 @@ void mj_destroy(mj_context *ctx) {
                 (unsigned long long)ctx->cache.n_hit, (unsigned long long)ctx->cache.n_miss, (unsigned long long)ctx->cache.n_evict, ctx->cache.cached_bytes / 1048576.0);
     ctx->cache.trim(0);
     for (auto &a : ctx->free_arenas) (void)hipHostFree(a.base);
+    if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1002,9 +1006,9 @@ static int stage1_impl(mj_plan *p, void *stream) {
                                                   p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter, p->d_wg_tabs_count, p->wg_slots_count));
                 std::swap(in, out);
                 if (round < 3) continue;
-                int32_t changed = 0;
-                MJ_HIP(ctx, hipMemcpyAsync(&changed, counter, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                MJ_HIP(ctx, hipMemcpyAsync(ctx->h_word, counter, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 MJ_HIP(ctx, hipStreamSynchronize(s));
+                const int32_t changed = *ctx->h_word;
                 if (changed == 0 || round > 4096) break;
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
