@@ -348,9 +348,9 @@ class BatchDecoder:
         # native_host: with segment="gpu", decode_device reads headers and assembles batches in libmijpeg.so's
         # multi-threaded host front end instead of _parse.py (identical arrays; anything unusual is handed back to Python)
         self.native_host = native_host
-        # segment="gpu" applies from this many files per call on: a handful is segmented on the host, which costs ~0.6 ms
-        # per 1080p file and lets files with restart markers take the chunked stage-1 form (it needs the segment lengths at
-        # plan time; one such file: 2.3 ms instead of 6.6)
+        # segment="gpu" applies from this many files per call on (or from 4 MiB of files on): a handful of ordinary files is
+        # segmented on the host, which costs ~1 ms per MB and lets files with restart markers take the chunked stage-1 form
+        # (it needs the segment lengths at plan time; one 1080p file: 2.3 ms instead of 6.6)
         self.gpu_segment_min_files = gpu_segment_min_files
         self._staging: Optional[np.ndarray] = None
 
@@ -374,7 +374,7 @@ class BatchDecoder:
 
     def decode(self, files: Sequence[bytes], return_seams: bool = False):
         """Decode files that may mix sampling layouts (one plan per layout)."""
-        gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
+        gpu_segment = self.gpu_segment and (len(files) >= self.gpu_segment_min_files or sum(map(len, files)) > (4 << 20))
         parsed = [parse_jpeg(f, headers_only=gpu_segment) for f in files]
         groups: Dict[tuple, List[int]] = {}
         for i, p in enumerate(parsed):
@@ -438,7 +438,7 @@ class BatchDecoder:
         parsed: Dict[int, ParsedJpeg] = {}
         work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
         rest: List[int] = []
-        gpu_segment = self.gpu_segment and len(files) >= self.gpu_segment_min_files
+        gpu_segment = self.gpu_segment and (len(files) >= self.gpu_segment_min_files or sum(map(len, files)) > (4 << 20))
         if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
             if isinstance(prep, PreparedBatch):                   # the everyday case: one pass, one plan
