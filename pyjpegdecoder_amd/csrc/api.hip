@@ -777,9 +777,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // 512-byte chunks, 3.0 ms with 2 KiB ones — six wavefronts' worth), big ones fewer long ones (the run-up in
             // front of every chunk and the per-chunk records cost; 1024 images: 19.0 ms at 2 KiB, 20.2 ms at 512 bytes).
             // Measured optimum: the shortest of 512 / 1024 / 2048 bytes that keeps the batch under ~330 000 chunks.
+            // ... and a single segment not in more than ~12 000 of them: wrongly guessed entry states are repaired one link
+            // of a chain per round, and chains grow with the chunks of a segment (one 24-megapixel image, 10 MB of
+            // stream: 5.4 ms with 512-byte chunks, 3.8 ms with 1 KiB).
+            int32_t longest = 0;
+            for (const auto &g : segs) longest = std::max(longest, g.len);
             p->sync_chunk_bytes = 2048;
             for (int cb : {512, 1024})
-                if (total_len / cb <= 330000) { p->sync_chunk_bytes = cb; break; }
+                if (total_len / cb <= 330000 && longest / cb <= 12000) { p->sync_chunk_bytes = cb; break; }
         }
         for (const auto &g : segs) est_chunks += std::max(1, (g.len + p->sync_chunk_bytes - 1) / p->sync_chunk_bytes);
         // (one long segment is enough: in a batch that mixes files with and without restart markers, an image without
