@@ -64,7 +64,12 @@ __device__ __forceinline__ void refine_queue(BitReader &br, uint64_t queue, int 
 
 }  // namespace
 
-template <bool BANDED>
+// KIND 1 = the refining AC scans only, KIND 0 = every other kind of scan, KIND 2 = all of them.  Two smaller kernels instead
+// of one that holds all five code paths: the refining loop is scalar-register starved (23-42 spilled scalars in the combined
+// kernel, 0-5 in the split ones); each launch's waves of the other kind leave at once.  The split costs a second launch
+// whose kernels run one after the other, so the band-pipelined variant — whose launches are short and whose scans of all
+// kinds are meant to run side by side — keeps the combined kernel.
+template <bool BANDED, int KIND>
 __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restrict__ blob,
                                                           const DevProgSeg *__restrict__ segs, int n_segs,
                                                           const DevProgScan *__restrict__ scans,
@@ -88,6 +93,8 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     const bool sequential = ss == 0 && se == 63;          // one component, DC + AC per block (baseline_dct_scan, :734-866)
     const bool is_dc = ss == 0 && !sequential;
     const int nsc = sc->n_comp;
+    if (KIND != 2 && (KIND == 1) != (refining && !is_dc && !sequential)) return;
+    const bool ac_refining = KIND == 1 ? true : (KIND == 0 ? false : refining);      // in the AC branch below
 
     // ---- which part of the scan this launch does.  The scans of an image are pipelined over bands of `rows_per_band`
     // frame MCU rows: launch number `step` lets a scan of dependency level L work on band step - L, so a refining scan
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
         }
     };
 
-    if (sequential) {
+    if (KIND != 1 && sequential) {
         // ------------------------------------------------------------ one component of a non-interleaved baseline file:
         // the scan's MCU is one 8x8 block, blocks in raster order of the component (:612-619, :771-866)
         const int c = sc->comp[0];
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                 ++k;
             }
         }
-    } else if (is_dc) {
+    } else if (KIND != 1 && is_dc) {
         // ------------------------------------------------------------ DC scans (:974-1057)
         int pred0 = st_pred0, pred1 = st_pred1, pred2 = st_pred2;
         if (refining) {
@@ -260,18 +267,18 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
         // block coordinates are stepped, not divided out of m for every block (two integer divisions per block were
         // some 4 % of a refining scan)
         const int by_lo = m_lo / smh, bx_lo = m_lo - by_lo * smh;
-        if (refining && m_lo < m_hi) cf_next = block_ptr(c, bx_lo, by_lo)[nat];
+        if (ac_refining && m_lo < m_hi) cf_next = block_ptr(c, bx_lo, by_lo)[nat];
         // (only in the band-pipelined variant: in the other one the same change made the compiler's loop 5 % slower)
         for (int m = m_lo, bx = bx_lo, by = by_lo; m < m_end && !err; ++m, bx = (bx + 1 == smh ? 0 : bx + 1), by += (bx == 0)) {
             if (!BANDED) { by = m / smh; bx = m - by * smh; }
             int16_t *p = block_ptr(c, bx, by);
             const int cf_cur = cf_next;
-            if (refining && m + 1 < m_end) {
+            if (ac_refining && m + 1 < m_end) {
                 int bx1 = bx + 1 == smh ? 0 : bx + 1, by1 = by + (bx1 == 0);
                 if (!BANDED) { by1 = (m + 1) / smh; bx1 = (m + 1) - by1 * smh; }
                 cf_next = block_ptr(c, bx1, by1)[nat];
             }
-            if (!refining) {
+            if (!ac_refining) {
                 // -------- first scan of the band: only writes (:1177-1179, :1225, :1248-1250)
                 if (eobrun > 0) { --eobrun; continue; }
                 int k = ss;
@@ -367,12 +374,15 @@ hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, cons
     if (n_segs == 0) return hipSuccess;
     const int blocks = (n_segs + 3) / 4;
     const size_t lds = (size_t)4 * 3 * kLutSize * sizeof(uint16_t);
-    if (rows_per_band > 0)
-        hipLaunchKernelGGL(k_progressive_scan<true>, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+    if (rows_per_band > 0) {
+        hipLaunchKernelGGL((k_progressive_scan<true, 2>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
                            scans, images, huff, coef, status, spec_refine, transposed, states, step, rows_per_band);
-    else            // every scan in one piece: `step` is the dependency level whose scans run
-        hipLaunchKernelGGL(k_progressive_scan<false>, dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+    } else {        // every scan in one piece: `step` is the dependency level whose scans run
+        hipLaunchKernelGGL((k_progressive_scan<false, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
                            scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
+        hipLaunchKernelGGL((k_progressive_scan<false, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+                           scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
+    }
     return hipGetLastError();
 }
 
