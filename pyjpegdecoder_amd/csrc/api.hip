@@ -92,6 +92,7 @@ struct mj_context {
     int32_t *h_word = nullptr;     // pinned: where a stream hands one counter to the host (a pageable target would make the
                                    // copy synchronous for the whole device, i.e. wait for other plans' kernels on other streams)
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
+    uint8_t *d_dump = nullptr;     // stage 2's dump lines (mj::kStage2DumpBytes)
     DevBufferCache cache;
     std::string err;
 };
@@ -326,6 +327,8 @@ int mj_create(int device_id, mj_context **out) {
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
     MJ_HIP(nullptr, hipMemcpy(ctx->d_idct_tt, tt.data(), tt.size() * sizeof(double), hipMemcpyHostToDevice));
+    MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_dump, mj::kStage2DumpBytes));
+    MJ_HIP(nullptr, hipMemset(ctx->d_dump, 0, mj::kStage2DumpBytes));
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
@@ -348,6 +351,7 @@ void mj_destroy(mj_context *ctx) {
     for (auto &a : ctx->free_arenas) (void)hipHostFree(a.base);
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
+    if (ctx->d_dump) (void)hipFree(ctx->d_dump);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1041,7 +1045,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     mj::ReconArgs a{};
     a.images = p->d_images; a.n_images = p->n_images; a.mcu_prefix = p->d_mcu_prefix;
     a.total_mcus = p->info.total_mcus; a.coef = p->d_coef; a.qt = p->d_qt; a.idct_tt = ctx->d_idct_tt;
-    a.up_taps = nullptr; a.rgb = rgb_device; a.planes = p->d_planes; a.idct_out = p->d_idct;
+    a.up_taps = nullptr; a.rgb = rgb_device; a.dump = ctx->d_dump; a.planes = p->d_planes; a.idct_out = p->d_idct;
     a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
 #ifdef MJ_DIAGNOSTIC      // phase ablations of the diagnostic build (make DIAG=1); the product never looks at the environment here
     a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
@@ -1226,6 +1230,20 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
         MJ_HIP(ctx, hipEventSynchronize(e1));
         MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
         *stage2_ms = ms / iters;
+#ifdef MJ_DIAGNOSTIC      // the wait probe of the diagnostic build (MJ_DEBUG_STAGE2=8/9): sums the kernel left in the dump buffer
+        if (getenv("MJ_DEBUG_STAGE2") && atoi(getenv("MJ_DEBUG_STAGE2")) >= 8) {
+            unsigned long long h[3] = {0, 0, 0};
+            (void)hipMemcpy(h, ctx->d_dump + 393216 * 8, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mijpeg diag] wait cycles %.4g of kernel cycles %.4g per wave (%llu waves) = %.1f %%\n", (double)h[0] / (double)(h[2] ? h[2] : 1),
+                    (double)h[1] / (double)(h[2] ? h[2] : 1), h[2], 100.0 * (double)h[0] / (double)(h[1] ? h[1] : 1));
+            unsigned long long ph[6];
+            (void)hipMemcpy(ph, ctx->d_dump + (393216 + 8) * 8, sizeof(ph), hipMemcpyDeviceToHost);
+            double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)ph[i];
+            if (tot > 0) fprintf(stderr, "[mijpeg diag] phase shares: rounds %.1f %%, level3+next fetch %.1f %%, pixels %.1f %%, staging+stores %.1f %%, slow paths %.1f %%, loop head %.1f %%\n",
+                                 100 * ph[0] / tot, 100 * ph[1] / tot, 100 * ph[2] / tot, 100 * ph[3] / tot, 100 * ph[4] / tot, 100 * ph[5] / tot);
+            (void)hipMemset(ctx->d_dump + 393216 * 8, 0, 128);
+        }
+#endif
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

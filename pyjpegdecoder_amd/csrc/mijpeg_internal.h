@@ -172,6 +172,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
 // how that launch groups its units of work: lanes per wavefront (a workgroup = 4 waves = 4 x this many consecutive units)
 int lanes_per_wave(int64_t n_segs, int n_slots);
 
+constexpr size_t kStage2DumpBytes = 4096 * 1024;    // 1 KiB per workgroup of the largest persistent grid
 struct ReconArgs {
     const DevImage *images;
     int32_t n_images;
@@ -183,6 +184,9 @@ struct ReconArgs {
     const double *idct_tt;       // [64 (u*8+v)][64 (x*8+y)] transposed reference table
     const uint32_t *up_taps;     // packed upsample taps, see reconstruct.hip
     uint8_t *rgb;
+    uint8_t *dump;               // kStage2DumpBytes of writable memory: where stage 2's store instructions send the 16-byte
+                                 // pieces that must not land in the image (lanes past an edge, strips that take the
+                                 // slow stores) — the store phase stays branch-free, see reconstruct_fast.hip
     int16_t *planes;             // optional
     int16_t *idct_out;           // optional
     int32_t layout;

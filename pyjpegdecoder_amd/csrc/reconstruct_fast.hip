@@ -3,13 +3,17 @@
 // Same contract and same results as reconstruct.hip (the exact-order kernel); what changes is how a
 // block's 64 samples are obtained:
 //
-//   fast path   separable fp64 IDCT (row pass, LDS transpose, column pass; even/odd split, 36 flops per
-//               8-point transform).  It differs from the reference's 64-term float64 sum S_ref only by
-//               rounding noise: |S_fast - S_ref| < 1e-8 for every int16 input (typically 1e-13).
-//   decision    a sample is accepted when S_fast is at least 2^-20 away from the nearest half-integer:
-//               then round(S_fast) == round(S_ref).  Otherwise the whole block is recomputed by the
-//               exact-order routine (the reference's summation order, bit for bit).  Random data hits this
-//               about once per 10^4 blocks.
+//   level 1     separable fp32 IDCT (row pass, LDS transpose, column pass; even/odd split, 36 flops per
+//               8-point transform, constants as literals: on gfx950 v_add/v_mul/v_fma_f32 with VGPR or literal
+//               operands issue in 2 cycles per wave, fp64 and almost everything else in 4 — tools/issue_rate_probe.hip).
+//               Every operation rounds once, so with A = sum |dequantised coefficient| of the block
+//               |S_fp32 - S_true| <= 3 * 2^-24 * A  (6 roundings per term and pass, |K| < 1/2 — DESIGN.md section 3);
+//               a sample is accepted when S_fp32 is at least  kTieA * A + kTie0  away from the nearest half-integer:
+//               then round(S_fp32) == round(S_ref).  About 1.6 % of the blocks of a noisy photograph fail that.
+//   level 2     those blocks again, eight at a time, by the separable fp64 IDCT: |S_fp64 - S_ref| < 1e-8 for every
+//               int16 input (typically 1e-13); accepted when at least 2^-20 away from a half-integer.
+//   level 3     what is left (about one block in 10^4) is recomputed by the exact-order routine (the reference's
+//               summation order, bit for bit).
 //   DC-only     blocks (frequent in smooth images, and exact ties whenever DC*q = 4 mod 8) need no
 //               sum at all: every sample is round(DC*q * T[0,0,0,0]) — one product, same as the reference
 //               whose 63 other products are zeros.
@@ -58,6 +62,36 @@ __device__ __forceinline__ void idct8(const double f[8], double t[8]) {
     t[1] = e1 + o1; t[6] = e1 - o1;
     t[2] = e2 + o2; t[5] = e2 - o2;
     t[3] = e3 + o3; t[4] = e3 - o3;
+}
+
+// the same transform in fp32 (level 1).  Constants are literals of the instructions (a constant held in an SGPR
+// would halve the issue rate of the instruction that reads it).
+constexpr float fA = 0.35355339059327373f;
+constexpr float fC2 = 0.46193976625564337f, fC6 = 0.19134171618254492f;
+constexpr float fC1 = 0.4903926402016152f, fC3 = 0.4157348061512726f, fC5 = 0.27778511650980114f, fC7 = 0.09754516100806417f;
+__device__ __forceinline__ void idct8f(const float f[8], float t[8]) {
+    const float p = fA * (f[0] + f[4]), q = fA * (f[0] - f[4]);
+    const float r = __builtin_fmaf(fC6, f[6], fC2 * f[2]);
+    const float s = __builtin_fmaf(-fC2, f[6], fC6 * f[2]);
+    const float e0 = p + r, e3 = p - r, e1 = q + s, e2 = q - s;
+    const float o0 = __builtin_fmaf(fC7, f[7], __builtin_fmaf(fC5, f[5], __builtin_fmaf(fC3, f[3], fC1 * f[1])));
+    const float o1 = __builtin_fmaf(-fC5, f[7], __builtin_fmaf(-fC1, f[5], __builtin_fmaf(-fC7, f[3], fC3 * f[1])));
+    const float o2 = __builtin_fmaf(fC3, f[7], __builtin_fmaf(fC7, f[5], __builtin_fmaf(-fC1, f[3], fC5 * f[1])));
+    const float o3 = __builtin_fmaf(-fC1, f[7], __builtin_fmaf(fC3, f[5], __builtin_fmaf(-fC5, f[3], fC7 * f[1])));
+    t[0] = e0 + o0; t[7] = e0 - o0;
+    t[1] = e1 + o1; t[6] = e1 - o1;
+    t[2] = e2 + o2; t[5] = e2 - o2;
+    t[3] = e3 + o3; t[4] = e3 - o3;
+}
+// level-1 acceptance: distance to a half-integer must exceed kTieA * A + kTie0.  3 * 2^-24 = 1.79e-7 is the proven
+// bound; the margin covers its second-order terms and the reference's own float64 noise (< 1e-9).
+constexpr float kTieA = 2.0e-7f, kTie0 = 1.0e-6f;
+// sum over the 8 lanes of a group (lanes 8g..8g+7), result in every lane: quad xor 1, quad xor 2, half-row mirror
+__device__ __forceinline__ float group_sum8(float a) {
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xF, 0xF, true));
+    return a;
 }
 
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
@@ -164,32 +198,53 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
     }
 }
 
-// Green of one lane's pixel run, again, where the fp32 quotient of the fast path may be one off or sits on a tie
-// (|17207 cb + 35707 cr  mod 50000| within 1 of 25000): the reference's float64 expression for exactly those pixels,
-// patched into the bytes the fast path has already stored.  Integer upsample, so nothing here depends on fp32.
+// Green of some pixels of one lane's run again, where the fp32 quotient of the fast path may be one off or sits on a tie
+// (|17207 cb + 35707 cr  mod 50000| within 1 of 25000): the reference's float64 expression for exactly those pixels, patched
+// into the staged bytes before they leave LDS.  Everything it touches is LDS, addressed as such (a generic pointer would make
+// these flat accesses, which count on both memory counters), so the patch never waits for the pixel stores in flight.
+// Integer upsample, so nothing here depends on fp32.  `halves`: bit b = rows 8b..8b+7 need the check.
+typedef const int16_t __attribute__((address_space(3))) *lds_ci16;
+typedef const float __attribute__((address_space(3))) *lds_cf32;
+typedef unsigned char __attribute__((address_space(3))) *lds_u8;
+__device__ __forceinline__ uint32_t lds_off(const void *p) {
+    return (uint32_t)(uintptr_t)(const unsigned char __attribute__((address_space(3))) *)p;
+}
 template <int HS, int VS, bool T>
-__device__ __noinline__ void green_again(const int16_t *mt, int px, unsigned char *dst) {
+__device__ __noinline__ void green_fix_lds(uint32_t mt_off, uint32_t w_off, uint32_t stag_off, int px, int halves) {
     using G = FGeo<HS, VS, 3>;
-    const uint16_t *w4 = w4_table<HS, VS, T>();
+    lds_ci16 mt = (lds_ci16)(uintptr_t)mt_off;
+    lds_cf32 wrow = (lds_cf32)(uintptr_t)w_off;
+    lds_u8 stag = (lds_u8)(uintptr_t)stag_off;
     const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
 #pragma unroll 1
     for (int y = 0; y < G::MH; ++y) {
+        if (!((halves >> (y >> 3)) & 1)) continue;
         int Cbv, Crv;
         if constexpr (G::SUB) {
-            const uint32_t w = w4[px * G::MH + y];
-            Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
-            Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
+            const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
+            const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
+            const int w00 = (int)(wrow[4 * y] * 15.0f + 0.5f), w01 = (int)(wrow[4 * y + 1] * 15.0f + 0.5f);
+            const int w10 = (int)(wrow[4 * y + 2] * 15.0f + 0.5f), w11 = (int)(wrow[4 * y + 3] * 15.0f + 0.5f);
+            auto up = [&](lds_ci16 cp) {
+                auto v = [&](int i) { return (int)(int16_t)(cp[i] + 128); };        // strip holds chroma without the level shift
+                const int sum = w00 * v(sx0 * 8 + sy0) + w01 * v(sx0 * 8 + sy1) + w10 * v(sx1 * 8 + sy0) + w11 * v(sx1 * 8 + sy1);
+                return (int)(int16_t)((int)((unsigned)(2 * sum + 15 + 30 * 65536) / 30u) - 65536);
+            };
+            Cbv = up(mt + G::NBY * 64);
+            Crv = up(mt + (G::NBY + 1) * 64);
         } else {
             Cbv = (int)(int16_t)(mt[G::NBY * 64 + px * 8 + y] + 128);
             Crv = (int)(int16_t)(mt[(G::NBY + 1) * 64 + px * 8 + y] + 128);
         }
-        int r = (17207 * (Cbv - 128) + 35707 * (Crv - 128)) % 50000;
+        const int n = 17207 * (Cbv - 128) + 35707 * (Crv - 128);          // |n| < 2^24 on this path (|c| < 250)
+        const int q = (int)__builtin_rintf((float)n * 2e-5f);
+        int r = n - 50000 * q;
         r = r < 0 ? -r : r;
-        if (r >= 24999 && r <= 25001) {
+        if (r >= 24999) {
             const int yb = T ? (px >> 3) * VS + (y >> 3) : (y >> 3) * HS + (px >> 3);
             const uint32_t p = ycc_to_rgb_f64(mt[yb * 64 + (px & 7) * 8 + (y & 7)], Cbv, Crv);
-            dst[3 * y + 1] = (unsigned char)(p >> 8);
+            stag[3 * y + 1] = (unsigned char)(p >> 8);
         }
     }
 }
@@ -237,11 +292,13 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int16_t *s_strip = reinterpret_cast<int16_t *>(smem + wave * G::WAVE_BYTES);
-    double *scr = reinterpret_cast<double *>(smem + wave * G::WAVE_BYTES + G::STRIP_BYTES) + (lane >> 3) * 72;
+    double *scr = reinterpret_cast<double *>(smem + wave * G::WAVE_BYTES + G::STRIP_BYTES) + (lane >> 3) * 72;      // level 2
+    // level 1's 8x8 transpose: element (x, v) of group g at float g*124 + x*16 + v — the ds_read_b128 of lane x is
+    // conflict-free over the instruction's 16-lane sets, the eight ds_write_b32 are 2-way (free)
+    float *scrf = reinterpret_cast<float *>(smem + wave * G::WAVE_BYTES + G::STRIP_BYTES) + (lane >> 3) * 124;
     uint16_t *s_qt = reinterpret_cast<uint16_t *>(smem + wave * G::WAVE_BYTES + G::STRIP_BYTES + G::SCR_BYTES);
     const float4 *s_wts = reinterpret_cast<const float4 *>(smem + 4 * G::WAVE_BYTES);
     const int grp = lane >> 3, j = lane & 7;
-    const double T0 = a.idct_tt[0];     // T[x,y,0,0], identical for every (x,y)
 
     if constexpr (G::SUB) {             // four corner weights / 15 as floats, [x][y]
         const uint16_t *w4 = w4_table<HS, VS, T>();
@@ -256,7 +313,6 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 
     // phase-B identity of this lane: column px of MCU pk of the strip
     const int px = lane / G::TMW, pk = lane % G::TMW;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
 
     // A strip = TMW vertically adjacent MCUs of one MCU column (strips never wrap to the next column, so a
     // lane's MCU row is strip*TMW + k and every index below is either wave-uniform or a 24-bit multiply).
@@ -309,20 +365,36 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             const int k = bt / G::NB, b = bt - k * G::NB;
             const int my = st.y_first + (k < st.n_valid ? k : 0);
             cw[r] = *reinterpret_cast<const uint4 *>(st.cbase + __mul24(my, st.row_elems) + b * 64 + j * 8);
+            asm volatile("" ::: "memory");     // keep the loads in round order: the waits in front of the rounds count on it
         }
     };
 
 #ifdef MJ_DIAGNOSTIC   // clock probe / phase ablations: separate diagnostic build only (make DIAG=1), never in the product
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t dbg_wait = 0, dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = dbg_t0;
+#define MJ_STAMP(i) do { if (a.debug == 10) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dbg_acc[i] += s_ - dbg_last; dbg_last = s_; } } while (0)
 #endif
-    const uint32_t n_tiles = (uint32_t)total_tiles, stride_tiles = (uint32_t)n_waves;
-    uint32_t tg = blockIdx.x * 4 + wave;
-    if (tg >= n_tiles) return;
+    // A workgroup owns a contiguous range of strips and its four waves take them in turn: consecutive strips are
+    // vertically adjacent (same image columns), so the 192-byte column runs that share a 128-byte line are written by
+    // one CU within a few microseconds and merge in its XCD's L2 instead of leaving it as partial lines from eight L2s.
+    const uint32_t n_tiles = (uint32_t)total_tiles, stride_tiles = 4u;
+    const uint32_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    uint32_t tg = blockIdx.x * per_wg + wave;
+    const uint32_t tg_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
+    if (tg >= tg_end) return;
     Strip cur = strip_of(tg);
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
     fetch(cur, cw);
-    for (; tg < n_tiles; tg += stride_tiles) {
+    if constexpr (!SEAMS) {
+        // as many stores behind the first fetch as every later fetch has behind it (see the store phase): otherwise the
+        // loop entry is the path "no store after the loads" and the wait in front of phase A becomes vmcnt(0) for every strip
+        constexpr int NT0 = (4 * G::MH * NC + 63) / 64;
+        unsigned char *dump0 = a.dump + ((size_t)(blockIdx.x & 4095) * 64 + lane) * 16;
+#pragma unroll
+        for (int t = 0; t < NT0; ++t) *reinterpret_cast<volatile u32x4_a4 *>(dump0) = u32x4_a4{0u, 0u, 0u, (uint32_t)t};
+    }
+    for (; tg < tg_end; tg += stride_tiles) {
         const DevImage *im_g = cur.im;
         const ConstImage im = cimg(im_g);
         const int W = T ? im->height : im->width, H = T ? im->width : im->height;
@@ -344,8 +416,23 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             }
         }
 
+#ifdef MJ_DIAGNOSTIC
+        MJ_STAMP(5);          // loop head (and, first time round, everything before the loop)
+        if (a.debug == 8 || a.debug == 9) {   // how long does this strip's prefetch (9: and the previous strip's stores) still take here?
+            uint64_t s0, s1;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0) :: "memory");
+            if (a.debug == 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1) :: "memory");
+            dbg_wait += s1 - s0;
+        }
+#endif
         // ================= phase A: blocks ==================
-        uint32_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine
+        // One block's result row, packed, into the strip; t[] is what level 1 or 2 computed, ow the packed int16 row.
+        auto store_row = [&](int k, int b, const uint4 &ow) {
+            *reinterpret_cast<uint4 *>(s_strip + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
+        };
+        // ---- level 1: fp32, ROUNDS rounds of 8 blocks
+        uint32_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine (level 3)
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
 #ifdef MJ_DIAGNOSTIC
@@ -357,61 +444,98 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             const int shift = qc == 0 ? 128 : 0;          // chroma stays centred in the strip
             const uint4 qw = *reinterpret_cast<const uint4 *>(s_qt + qc * 64 + j * 8);
             const uint32_t p0 = deq2(cw[r].x, qw.x), p1 = deq2(cw[r].y, qw.y), p2 = deq2(cw[r].z, qw.z), p3 = deq2(cw[r].w, qw.w);
-            int d[8];
-            d[0] = lo16(p0); d[1] = hi16(p0); d[2] = lo16(p1); d[3] = hi16(p1);
-            d[4] = lo16(p2); d[5] = hi16(p2); d[6] = lo16(p3); d[7] = hi16(p3);
             const uint32_t ac = (j == 0 ? (p0 & 0xFFFF0000u) : p0) | p1 | p2 | p3;   // any AC coefficient of this row
             const uint64_t acb = __ballot(ac != 0);
-            const bool dconly = ((acb >> (lane & 56)) & 0xFF) == 0;
-            const int dc = __shfl(d[0], lane & 56);
-
-            double f[8], t[8];
+            float f[8], t[8];
+            f[0] = (float)lo16(p0); f[1] = (float)hi16(p0); f[2] = (float)lo16(p1); f[3] = (float)hi16(p1);
+            f[4] = (float)lo16(p2); f[5] = (float)hi16(p2); f[6] = (float)lo16(p3); f[7] = (float)hi16(p3);
+            // A = sum of |coefficient| over the block: the scale of the fp32 error bound
+            const float asum = group_sum8(((__builtin_fabsf(f[0]) + __builtin_fabsf(f[1])) + (__builtin_fabsf(f[2]) + __builtin_fabsf(f[3]))) +
+                                          ((__builtin_fabsf(f[4]) + __builtin_fabsf(f[5])) + (__builtin_fabsf(f[6]) + __builtin_fabsf(f[7]))));
+            idct8f(f, t);                                  // lane v: t[x] = sum_u K[x][u] B[u][v]
 #pragma unroll
-            for (int u = 0; u < 8; ++u) f[u] = (double)d[u];
-            idct8(f, t);                                   // lane v: t[x] = sum_u K[x][u] B[u][v]
-#pragma unroll
-            for (int x = 0; x < 8; ++x) scr[x * 9 + j] = t[x];
-#pragma unroll
-            for (int v = 0; v < 8; ++v) f[v] = scr[j * 9 + v];   // lane x: row x of the intermediate
-            idct8(f, t);                                   // lane x: t[y] = out[x][y]
-
-            int o[8];
-            double err = 0.0;
+            for (int x = 0; x < 8; ++x) scrf[x * 16 + j] = t[x];
+            {
+                const float4 lo = *reinterpret_cast<const float4 *>(scrf + j * 16), hi = *reinterpret_cast<const float4 *>(scrf + j * 16 + 4);
+                f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;   // lane x: row x
+            }
+            idct8f(f, t);                                  // lane x: t[y] = out[x][y]
+            // round(t) + shift as the low 16 bits of  t + (1.5 * 2^23 + shift)  (one rounding, to an integer; the int16
+            // wrap of :1573 comes with taking 16 bits); its distance from t is the distance to the nearest integer
+            const float magic = 12582912.0f + (float)shift;
+            uint32_t rb[8];
+            float err = 0.0f;
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
-                const double rr = __builtin_rint(t[y]);
-                err = fmax(err, __builtin_fabs(t[y] - rr));
-                o[y] = (int)(int16_t)((int)(int16_t)(int)rr + shift);
+                const float rr = t[y] + magic;
+                err = __builtin_fmaxf(err, __builtin_fabsf(t[y] - (rr - magic)));
+                rb[y] = __builtin_bit_cast(uint32_t, rr);
             }
-            if (dconly) {
-                const int vdc = (int)(int16_t)((int)(int16_t)(int)__builtin_rint((double)dc * T0) + shift);
-#pragma unroll
-                for (int y = 0; y < 8; ++y) o[y] = vdc;
-            }
-            const bool susp = !dconly && err > (0.5 - 9.5367431640625e-07);
-            const uint64_t sb = __ballot(susp);
-#pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8)
-                if ((sb >> (8 * g8)) & 0xFF) susp_bits |= 1u << (r * 8 + g8);
-
             uint4 ow;
-            ow.x = (uint32_t)(o[0] & 0xFFFF) | ((uint32_t)o[1] << 16);
-            ow.y = (uint32_t)(o[2] & 0xFFFF) | ((uint32_t)o[3] << 16);
-            ow.z = (uint32_t)(o[4] & 0xFFFF) | ((uint32_t)o[5] << 16);
-            ow.w = (uint32_t)(o[6] & 0xFFFF) | ((uint32_t)o[7] << 16);
-            *reinterpret_cast<uint4 *>(s_strip + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
-            if constexpr (SEAMS) {
-                if (a.idct_out && k < n_valid) {
-                    int16_t *io = a.idct_out + (mcu_block(k) + b) * 64;     // seam order is the original [x][y]
-                    const int back = 128 - shift;          // the :872 seam carries the level shift on every component
+            ow.x = __builtin_amdgcn_perm(rb[1], rb[0], 0x05040100u);
+            ow.y = __builtin_amdgcn_perm(rb[3], rb[2], 0x05040100u);
+            ow.z = __builtin_amdgcn_perm(rb[5], rb[4], 0x05040100u);
+            ow.w = __builtin_amdgcn_perm(rb[7], rb[6], 0x05040100u);
+            bool flagged = err >= (0.5f - kTie0) - kTieA * asum;
+            if (acb != ~0ull) {                            // some group's block has no AC coefficient at all (wave-uniform test)
+                // DC-only blocks need no sum: every sample is round(DC*q * T[0,0,0,0]) and T[0,0,0,0] is a hair above 1/8, so
+                // the product rounds half AWAY from zero (equal to the reference over the whole int16 range)
+                const bool dconly = ((acb >> (lane & 56)) & 0xFF) == 0;
+                const int dc = __shfl(lo16(p0), lane & 56);
+                const int sg = dc >> 31, ad = (dc ^ sg) - sg;
+                const int vdc = ((((ad + 4) >> 3) ^ sg) - sg + shift) & 0xFFFF;
+                const uint32_t vv = (uint32_t)vdc | ((uint32_t)vdc << 16);
+                ow.x = dconly ? vv : ow.x; ow.y = dconly ? vv : ow.y; ow.z = dconly ? vv : ow.z; ow.w = dconly ? vv : ow.w;
+                flagged = flagged && !dconly;
+            }
+            store_row(k, b, ow);
+            // ---- level 2 (about one round in eight on noisy images): the groups whose block failed do it again in fp64
+            if (__ballot(flagged) != 0) {
+#ifdef MJ_DIAGNOSTIC
+                if (a.debug == 5) continue;                // timing only (wrong pixels): what level 2 costs
+#endif
+                int gf = flagged ? 1 : 0;                  // any lane of my group?
+                gf |= __builtin_amdgcn_update_dpp(0, gf, 0xB1, 0xF, 0xF, true);
+                gf |= __builtin_amdgcn_update_dpp(0, gf, 0x4E, 0xF, 0xF, true);
+                gf |= __builtin_amdgcn_update_dpp(0, gf, 0x141, 0xF, 0xF, true);
+                const bool mine = gf != 0;
+                double fd[8], td[8];
+                fd[0] = (double)lo16(p0); fd[1] = (double)hi16(p0); fd[2] = (double)lo16(p1); fd[3] = (double)hi16(p1);
+                fd[4] = (double)lo16(p2); fd[5] = (double)hi16(p2); fd[6] = (double)lo16(p3); fd[7] = (double)hi16(p3);
+                idct8(fd, td);
 #pragma unroll
-                    for (int y = 0; y < 8; ++y) io[T ? y * 8 + j : j * 8 + y] = (int16_t)(o[y] + back);   // T: lane x' = original y
+                for (int x = 0; x < 8; ++x) scr[x * 9 + j] = td[x];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) fd[v] = scr[j * 9 + v];
+                idct8(fd, td);
+                int o[8];
+                double errd = 0.0;
+#pragma unroll
+                for (int y = 0; y < 8; ++y) {
+                    const double rr = __builtin_rint(td[y]);
+                    errd = fmax(errd, __builtin_fabs(td[y] - rr));
+                    o[y] = (int)(int16_t)((int)(int16_t)(int)rr + shift);
+                }
+                const uint64_t sb = __ballot(mine && errd > (0.5 - 9.5367431640625e-07));
+                uint4 ow2;
+                ow2.x = (uint32_t)(o[0] & 0xFFFF) | ((uint32_t)o[1] << 16);
+                ow2.y = (uint32_t)(o[2] & 0xFFFF) | ((uint32_t)o[3] << 16);
+                ow2.z = (uint32_t)(o[4] & 0xFFFF) | ((uint32_t)o[5] << 16);
+                ow2.w = (uint32_t)(o[6] & 0xFFFF) | ((uint32_t)o[7] << 16);
+                if (mine) store_row(k, b, ow2);
+                if (sb != 0) {
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; ++g8)
+                        if ((sb >> (8 * g8)) & 0xFF) susp_bits |= 1u << (r * 8 + g8);
                 }
             }
         }
-
-        // ---- rare: blocks with a sample too close to a rounding boundary -> exact-order recompute
         susp_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)susp_bits);
+#ifdef MJ_DIAGNOSTIC
+        MJ_STAMP(0);          // phase A rounds
+#endif
+
+        // ---- level 3, rare: blocks with a sample too close to a rounding boundary even in fp64 -> exact-order recompute
         while (susp_bits) {
             const int bt = __builtin_ctz(susp_bits);
             susp_bits &= susp_bits - 1;
@@ -419,19 +543,37 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             if (k >= n_valid) continue;
             const int64_t blk = mcu_block(k) + b;
             const int qi = (NC == 1 || b < G::NBY) ? q0i : (b == G::NBY ? q1i : q2i);
-            block_exact(a.coef + blk * 64, qbase + qi, a.idct_tt, s_strip + k * G::MCU_STRIDE + b * 64,
-                        (SEAMS && a.idct_out) ? a.idct_out + blk * 64 : nullptr, T, NC == 3 && b >= G::NBY);
+            block_exact(a.coef + blk * 64, qbase + qi, a.idct_tt, s_strip + k * G::MCU_STRIDE + b * 64, nullptr, T, NC == 3 && b >= G::NBY);
+        }
+        if constexpr (SEAMS) {        // the :872 seam, from the finished strip (seam order is the original [x][y], level shift on every component)
+            if (a.idct_out) {
+#pragma unroll
+                for (int r = 0; r < G::ROUNDS; ++r) {
+                    const int bt = r * 8 + grp;
+                    const int k = bt / G::NB, b = bt - k * G::NB;
+                    const int back = (NC == 1 || b < G::NBY) ? 0 : 128;
+                    if (k < n_valid) {
+                        const int16_t *row = s_strip + k * G::MCU_STRIDE + b * 64 + j * 8;
+                        int16_t *io = a.idct_out + (mcu_block(k) + b) * 64;
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) io[T ? y * 8 + j : j * 8 + y] = (int16_t)(row[y] + back);   // T: lane x' = original y
+                    }
+                }
+            }
         }
 
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
         // they are consumed one iteration later, so HBM latency hides behind the pixel phase
-        const bool has_next = tg + stride_tiles < n_tiles;
+        const bool has_next = tg + stride_tiles < tg_end;
         Strip nxt = cur;
         if (has_next) {
             nxt = strip_of(tg + stride_tiles);
             fetch(nxt, cw);
         }
 
+#ifdef MJ_DIAGNOSTIC
+        MJ_STAMP(1);          // level 3, next strip's geometry and fetch
+#endif
         // ================= phase B: pixels ==================
         {
 #ifdef MJ_DIAGNOSTIC
@@ -455,7 +597,8 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 uint32_t ob[(NBYTES + 3) / 4];
 #pragma unroll
                 for (int i = 0; i < (NBYTES + 3) / 4; ++i) ob[i] = 0;
-                bool slow = false, regreen = false;
+                bool slow = false;
+                int rg = 0;
                 if (have) {
                 if constexpr (NC == 3) {
                     // chroma source rows sx0, sx0+1 of this lane's column, as floats
@@ -478,7 +621,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
                     // largest |Cb-128|, |Cr-128| among the source samples (an upsampled value lies between its sources)
                     // and largest |remainder| of the green term: both decide, once per lane, whether fp32 was exact
-                    float crange = 0.0f, remmax = 0.0f;
+                    float crange = 0.0f;
                     constexpr float MAGIC = 12582912.0f;                       // 1.5 * 2^23: x + MAGIC rounds x to an integer
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
@@ -500,14 +643,12 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                                 }
                             }
                         }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int y = by * 8 + i;
-                            const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
-                            f32x2 C;                                               // (cb, cr) = (Cb - 128, Cr - 128)
+                        // (cb, cr) = (Cb - 128, Cr - 128) of pixel i of this half
+                        auto chroma_of = [&](int i) -> f32x2 {
                             if constexpr (G::SUB) {
                                 // sum(n_i v_i)/15 is never within 1/30 of a half-integer and the fp32 evaluation is
                                 // within 0.012 of it for any int16 inputs, so rintf() returns the reference's value
+                                const int y = by * 8 + i;
                                 const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
                                 const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
                                 const float4 wq = s_wts[px * G::WTS_ROW + y];
@@ -517,10 +658,17 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                                     sv = __builtin_elementwise_fma(cB[sy0], f32x2{wq.z, wq.z}, sv);
                                     sv = __builtin_elementwise_fma(cB[sy1], f32x2{wq.w, wq.w}, sv);
                                 }
-                                C = f32x2{__builtin_rintf(sv.x), __builtin_rintf(sv.y)};
+                                return f32x2{__builtin_rintf(sv.x), __builtin_rintf(sv.y)};
                             } else {
-                                C = cA[i];
+                                return cA[i];
                             }
+                        };
+                        float remmax = 0.0f;                                       // largest |remainder| of the green term in this half
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int y = by * 8 + i;
+                            const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
+                            const f32x2 C = chroma_of(i);
                             // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact.
                             // B, R: 1.772 cb = 443 cb / 250 and 1.402 cr = 701 cr / 500 hit an exact .5 first at |cb| = 125,
                             // |cr| = 250 and are otherwise >= 0.002 away from one, far more than the fp32 constants are off;
@@ -541,9 +689,9 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                             ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
                             ob[o2 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.x, o2 & 3, ob[o2 >> 2]);
                         }
+                        rg |= remmax >= 24998.5f ? (1 << by) : 0;      // this half of the column has a pixel whose green must be redone
                     }
                     slow |= crange >= 250.0f;
-                    regreen = remmax >= 24998.5f;
                 } else {
                     const uint4 yw = *reinterpret_cast<const uint4 *>(mt + (px & 7) * 8);
                     const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
@@ -557,17 +705,30 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 const bool active = have && gx < W;
                 const bool fast = active && !slow && nrows == G::MH;
 #ifdef MJ_DIAGNOSTIC
-                if (a.debug == 3) { uint32_t acc = 0;
+                MJ_STAMP(2);      // pixel arithmetic
+#endif
+#ifdef MJ_DIAGNOSTIC
+                const bool dbg_nostore = a.debug == 3;
+                if (dbg_nostore) { uint32_t acc = 0;
 #pragma unroll
                     for (int i = 0; i < (NBYTES + 3) / 4; ++i) acc ^= ob[i];
                     if (acc == 0x12345678u && slow) dst[0] = 1; }
-                else
+#else
+                constexpr bool dbg_nostore = false;
 #endif
+                if (!dbg_nostore) {
                 // ---- stores.  A lane holds NBYTES consecutive bytes of one image column and the TMW lanes of a column
                 // hold one contiguous run; written lane by lane, one store instruction would touch 64 separate
                 // 16-byte pieces.  So the wave's bytes go through LDS (the transpose scratch is free now) and come back
                 // as 16-byte pieces in run order: consecutive lanes write consecutive addresses.
-                if (n_valid == G::TMW && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0) {
+                // The NT store instructions below are executed for EVERY strip, branch-free: pieces that must not land in
+                // the image (columns past the right edge; all of them when the strip takes the per-lane stores further
+                // down) go to this workgroup's dump line instead.  Why: vmcnt counts loads and stores together, in order,
+                // and the compiler's s_waitcnt in front of the next strip's phase A allows as many younger operations as
+                // the path with the FEWEST stores issues behind the coefficient prefetch — a branch around the stores
+                // made that zero, and every strip waited for its predecessor's pixels to reach L2 (1.1 ms per launch).
+                const bool staged = n_valid == G::TMW && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
+                {
                     constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
                     static_assert(RUN % 16 == 0 && NBYTES % 8 == 0, "column runs are whole 16-byte pieces");
                     unsigned char *s_out = smem + wave * G::WAVE_BYTES + G::STRIP_BYTES;
@@ -580,23 +741,50 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 #pragma unroll
                         for (int i = 0; i < NBYTES / 8; ++i) reinterpret_cast<uint2 *>(mine)[i] = make_uint2(ob[2 * i], ob[2 * i + 1]);
                     }
-                    const uint64_t am = __ballot(active);
-                    unsigned char *sbase = a.rgb + im->rgb_off + ((int64_t)(mcu_x * G::MW) * H + (int64_t)y_first * G::MH) * NC;
-#pragma unroll
-                    for (int t = 0; t * 64 < NPIECE; ++t) {
-                        const int pce = t * 64 + lane;                       // 16-byte piece of the wave's 64 runs
-                        const int c = (16 * pce) / RUN, o = (16 * pce) % RUN;
-                        const int src_lane = c * G::TMW + o / NBYTES;        // columns are active or inactive as a whole
-                        if (pce < NPIECE && ((am >> src_lane) & 1)) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(s_out + 16 * pce);
-                            *reinterpret_cast<u32x4_a4 *>(sbase + (int64_t)c * (H * NC) + o) = u32x4_a4{v.x, v.y, v.z, v.w};
+                    if constexpr (NC == 3) {
+                        // green again where the fp32 quotient may be one off or sits on a tie (about 6 % of the strips have such a
+                        // pixel in some lane): patched into the staged bytes, all in LDS
+                        if (staged && __builtin_amdgcn_ballot_w64(fast && rg != 0) != 0) {
+                            if (fast && rg != 0)
+                                green_fix_lds<HS, VS, T>(lds_off(mt), lds_off(s_wts + px * G::WTS_ROW), lds_off(mine), px, rg);
                         }
                     }
-                    if constexpr (NC == 3) {
-                        if (regreen && fast) green_again<HS, VS, T>(mt, px, dst);
+                    // columns are active or inactive as a whole: column c of the strip exists iff mcu_x*MW + c < W
+#ifdef MJ_DIAGNOSTIC
+                    const int ncol = (staged && a.debug != 7) ? W - mcu_x * G::MW : 0;    // 7 = timing only: every piece to the dump line
+#else
+                    const int ncol = staged ? W - mcu_x * G::MW : 0;
+#endif
+                    unsigned char *sbase = a.rgb + im->rgb_off + ((int64_t)(mcu_x * G::MW) * H + (int64_t)y_first * G::MH) * NC;
+                    // (the piece geometry is recomputed from the lane number every strip: as loop invariants the compiler
+                    // keeps them in registers it does not have, and a spill reload is a vector-memory load that waits —
+                    // vmcnt is in order — for the coefficient prefetch and for the previous piece's store)
+                    int lane_o = lane;
+                    asm volatile("" : "+v"(lane_o));
+                    lane_o &= 63;
+                    unsigned char *dump = a.dump + ((size_t)(blockIdx.x & 4095) * 64 + lane_o) * 16;
+                    constexpr int NT = (NPIECE + 63) / 64;
+                    uint4 pv[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)          // all reads first: one LDS round trip, not one per store
+                        pv[t] = *reinterpret_cast<const uint4 *>(s_out + 16 * ((t * 64 + lane_o) % NPIECE));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int pce = t * 64 + lane_o;                     // 16-byte piece of the wave's 64 runs
+                        const int c = (pce * 16) / RUN, o = (pce * 16) - c * RUN;
+                        unsigned char *dp = sbase + (int64_t)c * (H * NC) + o;
+#ifdef MJ_DIAGNOSTIC
+                        if (a.debug == 6) dp = a.rgb + (int64_t)tg * 3024 + pce * 16;    // timing only: the same bytes, contiguous per wave
+#endif
+                        dp = (pce < NPIECE && c < ncol) ? dp : dump;
+                        *reinterpret_cast<u32x4_a4 *>(dp) = u32x4_a4{pv[t].x, pv[t].y, pv[t].z, pv[t].w};
                     }
-                } else if (active) {
-                    if (slow || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
+                }
+#ifdef MJ_DIAGNOSTIC
+                MJ_STAMP(3);      // staging through LDS + the NT stores
+#endif
+                if (!staged && active) {
+                    if (slow || rg != 0 || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
                         pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows, nullptr, 0);
                     } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
 #pragma unroll
@@ -610,16 +798,27 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 #pragma unroll
                         for (int i = 0; i < NBYTES / 4; ++i) reinterpret_cast<uint32_t *>(dst)[i] = ob[i];
                     }
-                    if constexpr (NC == 3) {
-                        if (regreen && !slow && nrows == G::MH && ((uintptr_t)dst & 3) == 0) green_again<HS, VS, T>(mt, px, dst);
-                    }
                 }
+                }   // !dbg_nostore
             }
         }
+#ifdef MJ_DIAGNOSTIC
+        MJ_STAMP(4);              // slow-path pixels, green patches
+#endif
         // the strip is private to this wave and LDS operations of one wave complete in order: no barrier
         cur = nxt;
     }
 #ifdef MJ_DIAGNOSTIC
+    if (a.debug == 10 && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dump) + 393216 + 8;
+        for (int i = 0; i < 6; ++i) atomicAdd(o + i, (unsigned long long)dbg_acc[i]);
+    }
+    if ((a.debug == 8 || a.debug == 9) && lane == 0) {   // sums over all waves: cycles in that wait, cycles in the kernel, waves
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dump) + 393216;
+        atomicAdd(o, (unsigned long long)dbg_wait);
+        atomicAdd(o + 1, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
+        atomicAdd(o + 2, 1ull);
+    }
     if (a.debug == 4 && blockIdx.x == 7 && tid == 0) {   // diagnostic only: shader clock vs 100 MHz wall clock
         uint64_t *o = reinterpret_cast<uint64_t *>(a.rgb);
         o[0] = __builtin_amdgcn_s_memtime() - dbg_t0;

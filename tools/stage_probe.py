@@ -1,0 +1,68 @@
+"""Stage timing probe (GPU box): builds the config-3 plan once and prints stage-1 / stage-2 HIP-event times under a list of
+environment settings, one line each.  Usage:
+    python tools/stage_probe.py [--lib pyjpegdecoder_amd/libmijpeg_diag.so] [--batch 1024] [--distinct 64] \
+        [--ri 120] [--layout xmajor] [--subsampling 420] NAME=VALUE[,NAME=VALUE]... (one experiment per argument; "" = defaults)
+Settings that the library reads at plan creation (MJ_HUFFMAN, MJ_LANES_PER_WAVE, ...) get a fresh plan."""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--distinct", type=int, default=64)
+    ap.add_argument("--ri", type=int, default=120)
+    ap.add_argument("--layout", default="xmajor")
+    ap.add_argument("--subsampling", default="420")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warm", type=int, default=15, help="untimed executes before the timed ones (clock ramp)")
+    ap.add_argument("exps", nargs="*", default=[""])
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from pyjpegdecoder_amd import _binding as B
+    if args.lib:
+        B.LIB_PATH = Path(args.lib).resolve()
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import synth
+    dev = torch.device("cuda", 0)
+    blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, args.ri)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(args.distinct)]
+    files = [raws[i % args.distinct] for i in range(args.batch)]
+    layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    prep = prepare_batch(files, layout, 0)
+    ctx = B.Context(0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    d_rgb = None
+    for exp in args.exps:
+        sets = [kv.split("=", 1) for kv in exp.split(",") if kv]
+        old = {k: os.environ.get(k) for k, _ in sets}
+        for k, v in sets:
+            os.environ[k] = v
+        plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
+        if d_rgb is None:
+            d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        for _ in range(args.warm):
+            plan.execute(torch.cuda.current_stream().cuda_stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        s1, s2 = plan.time_stages(args.iters, d_rgb.data_ptr())
+        print(f"{exp or 'default':50s} stage0+1 {s1:7.3f} ms   stage2 {s2:7.3f} ms", flush=True)
+        plan.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
