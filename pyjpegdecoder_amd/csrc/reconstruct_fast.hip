@@ -96,6 +96,17 @@ __device__ __forceinline__ float group_sum8(float a) {
 
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
+// int16 half of a packed pair -> float in one instruction (the sub-dword select and the sign extension ride on the convert)
+__device__ __forceinline__ float cvt_lo16(uint32_t w) {
+    float r;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ float cvt_hi16(uint32_t w) {
+    float r;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(w));
+    return r;
+}
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int deq(int c, uint32_t q) { return (int)(int16_t)__mul24(c, (int)q); }   // int16 wrap (:869)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         const int16_t *cbase;            // coefficients of (MCU row 0, this MCU column)
         int row_elems;                   // int16 elements per MCU row
         int mcu_x, y_first, n_valid;
+        uint32_t tile;                   // strip number within the image
     };
     auto strip_of = [&](uint32_t tg) -> Strip {
         uint32_t img, tile;
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         // MCU grid of the (possibly transposed) image: mch columns, mcv rows
         const int mch = T ? cimg(st.im)->mcu_count_v : cimg(st.im)->mcu_count_h, mcv = T ? cimg(st.im)->mcu_count_h : cimg(st.im)->mcu_count_v;
         const uint32_t spc = (uint32_t)(mcv + G::TMW - 1) / G::TMW;     // strips per MCU column
+        st.tile = tile;
         st.mcu_x = __builtin_amdgcn_readfirstlane((int)(tile / spc));
         st.y_first = (int)(tile - (uint32_t)st.mcu_x * spc) * G::TMW;
         st.n_valid = min(G::TMW, mcv - st.y_first);
@@ -355,6 +368,23 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             st.cbase = a.coef + (cimg(st.im)->block_off + (int64_t)st.mcu_x * G::NB) * 64;
             st.row_elems = mch * G::NB * 64;
         }
+        return st;
+    };
+    // The strip `step` strips further on in the same workgroup's range: inside an image a few scalar additions (strip_of's
+    // two divisions by run-time values are some fifty instructions, a tenth of them on the vector unit)
+    auto strip_after = [&](const Strip &c, uint32_t tg_next, int step) -> Strip {
+        const int mch = T ? cimg(c.im)->mcu_count_v : cimg(c.im)->mcu_count_h, mcv = T ? cimg(c.im)->mcu_count_h : cimg(c.im)->mcu_count_v;
+        const int spc = (mcv + G::TMW - 1) / G::TMW;
+        const uint32_t tile = c.tile + (uint32_t)step;
+        if (tile >= (uint32_t)(spc * mch)) return strip_of(tg_next);       // the next image: once per image and wave
+        Strip st = c;
+        st.tile = tile;
+        int row = c.y_first / G::TMW + step, col = c.mcu_x;
+        while (row >= spc) { row -= spc; ++col; }
+        st.mcu_x = col;
+        st.y_first = row * G::TMW;
+        st.n_valid = min(G::TMW, mcv - st.y_first);
+        st.cbase = c.cbase + (int64_t)(col - c.mcu_x) * (T ? mcv * G::NB * 64 : G::NB * 64);
         return st;
     };
     // all rounds' coefficient rows of a strip: ROUNDS x 16 B per lane
@@ -447,8 +477,8 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             const uint32_t ac = (j == 0 ? (p0 & 0xFFFF0000u) : p0) | p1 | p2 | p3;   // any AC coefficient of this row
             const uint64_t acb = __ballot(ac != 0);
             float f[8], t[8];
-            f[0] = (float)lo16(p0); f[1] = (float)hi16(p0); f[2] = (float)lo16(p1); f[3] = (float)hi16(p1);
-            f[4] = (float)lo16(p2); f[5] = (float)hi16(p2); f[6] = (float)lo16(p3); f[7] = (float)hi16(p3);
+            f[0] = cvt_lo16(p0); f[1] = cvt_hi16(p0); f[2] = cvt_lo16(p1); f[3] = cvt_hi16(p1);
+            f[4] = cvt_lo16(p2); f[5] = cvt_hi16(p2); f[6] = cvt_lo16(p3); f[7] = cvt_hi16(p3);
             // A = sum of |coefficient| over the block: the scale of the fp32 error bound
             const float asum = group_sum8(((__builtin_fabsf(f[0]) + __builtin_fabsf(f[1])) + (__builtin_fabsf(f[2]) + __builtin_fabsf(f[3]))) +
                                           ((__builtin_fabsf(f[4]) + __builtin_fabsf(f[5])) + (__builtin_fabsf(f[6]) + __builtin_fabsf(f[7]))));
@@ -567,7 +597,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
         const bool has_next = tg + stride_tiles < tg_end;
         Strip nxt = cur;
         if (has_next) {
-            nxt = strip_of(tg + stride_tiles);
+            nxt = strip_after(cur, tg + stride_tiles, (int)stride_tiles);
             fetch(nxt, cw);
         }
 
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
                     // largest |Cb-128|, |Cr-128| among the source samples (an upsampled value lies between its sources)
                     // and largest |remainder| of the green term: both decide, once per lane, whether fp32 was exact
-                    float crange = 0.0f;
+                    float crange = 0.0f, tie125 = 1.0f;
                     constexpr float MAGIC = 12582912.0f;                       // 1.5 * 2^23: x + MAGIC rounds x to an integer
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
@@ -667,23 +697,27 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int y = by * 8 + i;
-                            const float Yf = (float)((i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]));
+                            // Y + MAGIC as a float, straight from the integer: MAGIC = 1.5 * 2^23 is 0x4B400000 and its
+                            // neighbours within +-2^22 are its bit pattern plus the distance
+                            const int Yi = (i & 1) ? hi16(ywd[i >> 1]) : lo16(ywd[i >> 1]);
+                            const float Ym = __builtin_bit_cast(float, 0x4B400000 + Yi);
                             const f32x2 C = chroma_of(i);
                             // Colour (jpeg_decoder.py:1693-1700) in fp32 where that is exact.
                             // B, R: 1.772 cb = 443 cb / 250 and 1.402 cr = 701 cr / 500 hit an exact .5 first at |cb| = 125,
                             // |cr| = 250 and are otherwise >= 0.002 away from one, far more than the fp32 constants are off;
                             // one fma rounds  cb * 1.772 + (Y + MAGIC)  straight to  MAGIC + Y + round(1.772 cb).
-                            const float Ym = Yf + MAGIC;
                             const f32x2 br2 = __builtin_elementwise_fma(C, f32x2{1.772f, 1.402f}, f32x2{Ym, Ym}) - MAGIC;   // (B, R)
                             // G: N = 17207 cb + 35707 cr is an exact fp32 integer for |c| < 250; q = round(N / 50000) may
-                            // be off by one only when the remainder is within 1.6 of +-25000, which also covers the ties
+                            // be off by one only when the remainder is within 1.6 of +-25000, which also covers the ties.
+                            // qm = MAGIC + q comes out of one fma; (Y + MAGIC) - (q + MAGIC) = Y - q exactly.
                             const f32x2 n2 = C * f32x2{17207.0f, 35707.0f};               // both products exact
                             const float N = n2.x + n2.y;                                  // exact: |N| < 2^24
-                            const float q = __builtin_rintf(N * 2e-5f);
-                            const float rem = __builtin_fmaf(-50000.0f, q, N);
+                            const float qm = __builtin_fmaf(N, 2e-5f, MAGIC);
+                            const float Gf = Ym - qm;
+                            const float rem = __builtin_fmaf(-50000.0f, qm - MAGIC, N);
                             remmax = __builtin_fmaxf(__builtin_fabsf(rem), remmax);
-                            const float Gf = Yf - q;
-                            slow |= __builtin_fabsf(C.x) == 125.0f;
+                            // |cb| = 125 somewhere in the run -> the B tie: the whole run goes the float64 way
+                            tie125 = __builtin_fminf(tie125, __builtin_fabsf(__builtin_fabsf(C.x) - 125.0f));
                             const int o0 = 3 * y, o1 = 3 * y + 1, o2 = 3 * y + 2;
                             ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.y, o0 & 3, ob[o0 >> 2]);
                             ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
@@ -691,7 +725,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                         }
                         rg |= remmax >= 24998.5f ? (1 << by) : 0;      // this half of the column has a pixel whose green must be redone
                     }
-                    slow |= crange >= 250.0f;
+                    slow |= crange >= 250.0f || tie125 == 0.0f;
                 } else {
                     const uint4 yw = *reinterpret_cast<const uint4 *>(mt + (px & 7) * 8);
                     const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
@@ -703,7 +737,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 }
                 }   // have
                 const bool active = have && gx < W;
-                const bool fast = active && !slow && nrows == G::MH;
+                const bool fast = active && !slow;
 #ifdef MJ_DIAGNOSTIC
                 MJ_STAMP(2);      // pixel arithmetic
 #endif
@@ -727,9 +761,13 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 // and the compiler's s_waitcnt in front of the next strip's phase A allows as many younger operations as
                 // the path with the FEWEST stores issues behind the coefficient prefetch — a branch around the stores
                 // made that zero, and every strip waited for its predecessor's pixels to reach L2 (1.1 ms per launch).
-                const bool staged = n_valid == G::TMW && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
+                // bytes of a column run that lie inside the image (the bottom strip of an image whose height is no multiple of
+                // the strip's: its last piece is stored as the 16 bytes that END at the image's edge — rewriting a few bytes of its
+                // predecessor with the same values — so the store stays one 16-byte instruction per piece)
+                constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
+                const int runv = min(RUN, (H - y_first * G::MH) * NC);
+                const bool staged = runv >= 16 && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
                 {
-                    constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
                     static_assert(RUN % 16 == 0 && NBYTES % 8 == 0, "column runs are whole 16-byte pieces");
                     unsigned char *s_out = smem + wave * G::WAVE_BYTES + G::STRIP_BYTES;
                     unsigned char *mine = s_out + lane * NBYTES;
@@ -749,12 +787,12 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                                 green_fix_lds<HS, VS, T>(lds_off(mt), lds_off(s_wts + px * G::WTS_ROW), lds_off(mine), px, rg);
                         }
                     }
-                    // columns are active or inactive as a whole: column c of the strip exists iff mcu_x*MW + c < W
-#ifdef MJ_DIAGNOSTIC
-                    const int ncol = (staged && a.debug != 7) ? W - mcu_x * G::MW : 0;    // 7 = timing only: every piece to the dump line
-#else
-                    const int ncol = staged ? W - mcu_x * G::MW : 0;
-#endif
+                    // Every lane stores one 16-byte piece per instruction, whatever the strip looks like.  Pieces that do not exist
+                    // — columns past the right edge (columns are active or inactive as a whole: column c exists iff
+                    // mcu_x*MW + c < W), bytes past the bottom edge, piece numbers past the last — become copies of an
+                    // existing piece (the same bytes to the same address twice is harmless); a strip that takes the per-lane
+                    // stores below sends its NT instructions to this workgroup's dump line instead.
+                    const int ncol = min(G::MW, W - mcu_x * G::MW);
                     unsigned char *sbase = a.rgb + im->rgb_off + ((int64_t)(mcu_x * G::MW) * H + (int64_t)y_first * G::MH) * NC;
                     // (the piece geometry is recomputed from the lane number every strip: as loop invariants the compiler
                     // keeps them in registers it does not have, and a spill reload is a vector-memory load that waits —
@@ -762,22 +800,40 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     int lane_o = lane;
                     asm volatile("" : "+v"(lane_o));
                     lane_o &= 63;
-                    unsigned char *dump = a.dump + ((size_t)(blockIdx.x & 4095) * 64 + lane_o) * 16;
                     constexpr int NT = (NPIECE + 63) / 64;
                     uint4 pv[NT];
+                    uint32_t doff[NT];                    // byte offset of piece t from sbase
+                    const uint32_t hnc = (uint32_t)(H * NC);
+                    if (runv == RUN && ncol == G::MW) {   // whole runs (wave-uniform; LDS reads may sit behind branches, stores may not)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)          // all reads first: one LDS round trip, not one per store
-                        pv[t] = *reinterpret_cast<const uint4 *>(s_out + 16 * ((t * 64 + lane_o) % NPIECE));
+                        for (int t = 0; t < NT; ++t) {    // all reads first: one LDS round trip, not one per store
+                            const int pce = (t * 64 + lane_o) % NPIECE;
+                            const int c = (pce * 16) / RUN;
+                            doff[t] = (uint32_t)c * hnc + (uint32_t)((pce * 16) - c * RUN);
+                            pv[t] = *reinterpret_cast<const uint4 *>(s_out + 16 * pce);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int pce = (t * 64 + lane_o) % NPIECE;
+                            const int c = min((pce * 16) / RUN, ncol - 1);
+                            const int o = min((pce * 16) % RUN, runv - 16);       // dword aligned: runv is a multiple of 4 here
+                            doff[t] = (uint32_t)c * hnc + (uint32_t)o;
+                            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(s_out + c * RUN + o);
+                            pv[t] = make_uint4(v.x, v.y, v.z, v.w);
+                        }
+                    }
+                    unsigned char *stbase = staged ? sbase : a.dump + (size_t)(blockIdx.x & 4095) * 1024;     // wave-uniform
+#ifdef MJ_DIAGNOSTIC
+                    if (a.debug == 7) stbase = a.dump + (size_t)(blockIdx.x & 4095) * 1024;    // timing only: every piece to the dump line
+#endif
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const int pce = t * 64 + lane_o;                     // 16-byte piece of the wave's 64 runs
-                        const int c = (pce * 16) / RUN, o = (pce * 16) - c * RUN;
-                        unsigned char *dp = sbase + (int64_t)c * (H * NC) + o;
+                        uint32_t off = staged ? doff[t] : (uint32_t)lane_o * 16u;
 #ifdef MJ_DIAGNOSTIC
-                        if (a.debug == 6) dp = a.rgb + (int64_t)tg * 3024 + pce * 16;    // timing only: the same bytes, contiguous per wave
+                        if (a.debug == 7) off = (uint32_t)lane_o * 16u;
 #endif
-                        dp = (pce < NPIECE && c < ncol) ? dp : dump;
-                        *reinterpret_cast<u32x4_a4 *>(dp) = u32x4_a4{pv[t].x, pv[t].y, pv[t].z, pv[t].w};
+                        *reinterpret_cast<u32x4_a4 *>(stbase + off) = u32x4_a4{pv[t].x, pv[t].y, pv[t].z, pv[t].w};
                     }
                 }
 #ifdef MJ_DIAGNOSTIC
