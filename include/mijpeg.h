@@ -56,6 +56,10 @@ extern "C" {
 
 #define MJ_ST_TAIL        4   /* MJ_FLAG_GPU_SEGMENT only: the scan is not followed by EOI (more scans, DNL, ...): the
                                  host-side marker loop (:78-110) has to segment this file                          */
+#define MJ_ST_UNCONVERGED 5   /* long restart segments (files without DRI) are cut into pieces whose decoder states are found
+                                 by a fixed number of synchronisation rounds on the device; this image's states had not
+                                 settled when the rounds were over (a pathological or crafted stream): nothing is wrong
+                                 with the file — decode it again in a plan created with MJ_FLAG_NO_SYNC                */
 
 /* memory spaces */
 #define MJ_MEM_NONE   0
@@ -65,6 +69,9 @@ extern "C" {
 /* pixel layouts of the RGB / grey output */
 #define MJ_LAYOUT_XMAJOR   0   /* reference image_array: (W, H, C), x-major */
 #define MJ_LAYOUT_ROWMAJOR 1   /* (H, W, C) */
+#define MJ_LAYOUT_PLANAR_XMAJOR   2   /* (C, W, H): the components of the array the reference leaves at :1373-1386 as
+                                         three planes per image (one for greyscale), image after image              */
+#define MJ_LAYOUT_PLANAR_ROWMAJOR 3   /* (C, H, W) */
 
 /* flags of mj_batch.flags */
 #define MJ_FLAG_KEEP_COEF    1u   /* keep the zig-zag coefficient array (:869 seam) readable after execute */
@@ -79,6 +86,9 @@ extern "C" {
                                      image then has n_segments = 1 and seg_begin/seg_end = first entropy-coded byte /
                                      any bound at or behind the end of the scan (e.g. the end of the file); the blob
                                      must be 16-byte aligned with 16 readable bytes behind blob_len                */
+
+#define MJ_FLAG_NO_SYNC     64u  /* never cut restart segments into synchronised pieces: one serial walk per segment (the
+                                     fallback for images that came back MJ_ST_UNCONVERGED)                          */
 
 typedef struct mj_context mj_context;
 typedef struct mj_plan mj_plan;
@@ -125,7 +135,9 @@ typedef struct {
     const uint8_t *blob;                  /* the file bytes of all images, back to back or not              */
     int64_t blob_len;
     int32_t blob_mem;                     /* MJ_MEM_HOST or MJ_MEM_DEVICE (device: 4-byte aligned, must stay valid for the
-                                             plan, and be readable 256 bytes past every segment end: stage 1 prefetches) */
+                                             plan, and blob_len must include at least 512 readable bytes behind the last
+                                             segment's end: the stage-1 bit readers fetch ahead; checked at plan creation.
+                                             Host blobs are uploaded with that slack added.) */
 
     int64_t n_segments;                   /* total entries of the two arrays below                          */
     const int64_t *seg_begin;             /* host: blob offset of the first entropy byte of each segment; list them in
@@ -183,9 +195,7 @@ int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off
 
 /* Launch stage 1 (Huffman) + stage 2 (dequant/IDCT/upsample/colour) on `stream` (a hipStream_t passed as
  * void*, NULL = the context's own stream).  `rgb_device` is a device buffer of rgb_bytes bytes, or NULL to
- * use a plan-owned one.  Asynchronous — except for batches of long restart segments (files without DRI), whose
- * stage 1 waits on `stream` once after its synchronisation rounds to learn whether more are needed (usually not);
- * everything it queues after that is asynchronous again. */
+ * use a plan-owned one.  Asynchronous for every kind of batch: nothing in it waits for the device. */
 int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
 /* The two stages separately (profiling, config 2). */
 int mj_plan_execute_stage1(mj_plan *plan, void *stream);

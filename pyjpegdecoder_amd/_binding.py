@@ -14,11 +14,12 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libmijpeg.so"
 
 MJ_OK, MJ_ERR_INVALID, MJ_ERR_HIP, MJ_ERR_UNSUPPORTED = 0, -1, -2, -3
-MJ_ST_OK, MJ_ST_BAD_CODE, MJ_ST_OVERRUN, MJ_ST_DESYNC, MJ_ST_TAIL = 0, 1, 2, 3, 4
+MJ_ST_OK, MJ_ST_BAD_CODE, MJ_ST_OVERRUN, MJ_ST_DESYNC, MJ_ST_TAIL, MJ_ST_UNCONVERGED = 0, 1, 2, 3, 4, 5
 MJ_MEM_NONE, MJ_MEM_HOST, MJ_MEM_DEVICE = 0, 1, 2
-MJ_LAYOUT_XMAJOR, MJ_LAYOUT_ROWMAJOR = 0, 1
+MJ_LAYOUT_XMAJOR, MJ_LAYOUT_ROWMAJOR, MJ_LAYOUT_PLANAR_XMAJOR, MJ_LAYOUT_PLANAR_ROWMAJOR = 0, 1, 2, 3
 MJ_FLAG_KEEP_COEF, MJ_FLAG_KEEP_PLANES, MJ_FLAG_KEEP_IDCT, MJ_FLAG_EXACT_ONLY, MJ_FLAG_SPEC_REFINE = 1, 2, 4, 8, 16
 MJ_FLAG_GPU_SEGMENT = 32
+MJ_FLAG_NO_SYNC = 64
 
 # every symbol include/mijpeg.h declares (tests check the library exports all of them)
 EXPORTS = (

@@ -94,6 +94,7 @@ class ScanInfo:
     mcu_count_h: int = 0
     mcu_count_v: int = 0
     huffman: Dict[int, HuffSpec] = field(default_factory=dict)   # snapshot of the tables in force
+    quantization_zz: Dict[int, np.ndarray] = field(default_factory=dict)   # ... and of the quantisation tables (zig-zag)
     segment_offsets: Optional[np.ndarray] = None   # int64[n_seg+1]: file offsets of restart-segment starts, then entropy_end
 
     @property
@@ -117,6 +118,14 @@ def parse_huffman_segment(data: bytes) -> Dict[int, HuffSpec]:
             vals_by_len.append(data[pos:pos + count])
             pos += count
         if pos > size:
+            raise CorruptedJpeg("Failed to parse Huffman tables.")
+        # more than 256 symbols, or more codes of some length than that length has left (the reference would build a
+        # dict with colliding / overlong keys and fail later on an unknown code, :718-719): corrupt either way, and the
+        # device-side canonical search indexes vals[] by these counts
+        kraft = 0                                 # codes used so far, in units of 2^-16
+        for length, count in enumerate(bits.tolist(), start=1):
+            kraft += count << (16 - length)
+        if int(bits.sum()) > 256 or kraft > (1 << 16):
             raise CorruptedJpeg("Failed to parse Huffman tables.")
         vals = np.frombuffer(b"".join(vals_by_len), dtype=np.uint8).copy()
         out[dest] = HuffSpec(bits=bits, vals=vals)
@@ -301,6 +310,8 @@ def _start_of_frame(p: ParsedJpeg, marker: bytes, data: bytes, say) -> None:
             my_id = data[h]
             sample = data[h + 1]
             hs, vs = sample >> 4, sample & 0x0F
+            if hs == 0 or vs == 0:
+                raise CorruptedJpeg("Failed to parse the start of frame.")     # the reference divides by these (:596-619)
             qt = data[h + 2]
             h += 3
             p.color_components[my_id] = ColorComponent(
@@ -320,22 +331,27 @@ def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, s
     if p.scan_mode is None:
         raise CorruptedJpeg("Start of scan before start of frame.")
     h = 0
-    components_amount = data[h]
-    h += 1
     ids: List[int] = []
     tabs: Dict[int, HuffmanTable] = {}
-    for _ in range(components_amount):
-        cid = data[h]
-        t = data[h + 1]
-        h += 2
-        if cid not in p.color_components:
-            raise CorruptedJpeg("Scan refers to a color component that the frame does not define.")
-        ids.append(cid)
-        tabs[cid] = HuffmanTable(dc=t >> 4, ac=(t & 0x0F) | 0x10)       # :543-544
-    scan = ScanInfo(component_ids=ids, huffman_tables_id=tabs)
-    if p.scan_mode == "progressive_dct":
-        scan.spectral_start, scan.spectral_end = data[h], data[h + 1]
-        scan.bit_high, scan.bit_low = data[h + 2] >> 4, data[h + 2] & 0x0F
+    try:                                    # a truncated header is an IndexError in the reference too; here it has a name
+        components_amount = data[h]
+        h += 1
+        for _ in range(components_amount):
+            cid = data[h]
+            t = data[h + 1]
+            h += 2
+            if cid not in p.color_components:
+                raise CorruptedJpeg("Scan refers to a color component that the frame does not define.")
+            ids.append(cid)
+            tabs[cid] = HuffmanTable(dc=t >> 4, ac=(t & 0x0F) | 0x10)       # :543-544
+        scan = ScanInfo(component_ids=ids, huffman_tables_id=tabs)
+        if p.scan_mode == "progressive_dct":
+            scan.spectral_start, scan.spectral_end = data[h], data[h + 1]
+            scan.bit_high, scan.bit_low = data[h + 2] >> 4, data[h + 2] & 0x0F
+    except IndexError:
+        raise CorruptedJpeg("Failed to parse the start of scan.")
+    if not ids:
+        raise CorruptedJpeg("Failed to parse the start of scan.")
     scan.entropy_start = data_pos + len(data)                             # :572
 
     if p.image_height == 0:                                               # DNL (:575-581)
@@ -373,6 +389,7 @@ def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, s
 
     scan.restart_interval = p.restart_interval
     scan.huffman = dict(p.huffman)
+    scan.quantization_zz = dict(p.quantization_zz)
     if gpu_scan:
         p.scan_amount = 1
         scan.entropy_end = len(p.raw)

@@ -132,7 +132,7 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
     # keep every file 4-byte aligned inside the blob (stage 1 fetches aligned dwords)
     offs = np.zeros(n + 1, dtype=np.int64)
     offs[1:] = np.cumsum((sizes + 3) & ~3)
-    # stage 1 prefetches up to 128 bytes ahead of a segment: keep that much readable slack behind the last file
+    # stage 1 reads up to 512 bytes ahead of a segment (mijpeg.h, mj_batch.blob_mem): keep 1 KiB of readable slack behind the last file
     blob = np.zeros(int(offs[-1]) + 1024, dtype=np.uint8)
     if parsed and any(p.headers_only for p in parsed):
         if not all(p.headers_only for p in parsed):
@@ -177,9 +177,14 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
             for c, cid in enumerate(comp_ids):
                 comp = p.color_components[cid]
                 d.hs[c], d.vs[c] = comp.horizontal_sampling, comp.vertical_sampling
-                if comp.quantization_table_id not in p.quantization_zz:
+                # baseline files decoded scan by scan dequantise each component with the table in force at ITS scan
+                # (:869); progressive files with the tables in force at the final pass (:1348)
+                qsrc = p.quantization_zz
+                if p.scan_mode == "baseline_dct":
+                    qsrc = next((sc.quantization_zz for sc in p.scans if cid in sc.component_ids and sc.quantization_zz), qsrc)
+                if comp.quantization_table_id not in qsrc:
                     raise CorruptedJpeg("Scan uses a quantization table that the file does not define.")
-                d.qt_sel[c] = qt_id(p.quantization_zz[comp.quantization_table_id])
+                d.qt_sel[c] = qt_id(qsrc[comp.quantization_table_id])
             if d.ncomp == 1:
                 d.hs[0] = d.vs[0] = 1
                 mw = mh = 8
@@ -210,6 +215,9 @@ def prepare_batch(files: Sequence[bytes], layout: int = B.MJ_LAYOUT_XMAJOR, flag
             shapes.append((p.image_width, p.image_height, d.ncomp))
             continue
         d.width, d.height, d.ncomp = p.image_width, p.image_height, len(scan.component_ids)
+        if list(scan.component_ids) != list(p.color_components)[:len(scan.component_ids)]:
+            # descriptors are filled by scan position and stage 2 takes position 0 for Y, 1 and 2 for Cb and Cr
+            raise UnsupportedJpeg("The scan lists the color components in another order than the frame.")
         for c, cid in enumerate(scan.component_ids):
             comp = p.color_components[cid]
             d.hs[c], d.vs[c] = comp.horizontal_sampling, comp.vertical_sampling
@@ -335,7 +343,9 @@ class BatchDecoder:
     def __init__(self, device: int = 0, layout: str = "xmajor", exact_only: bool = False, spec_refine: bool = False,
                  segment: str = "host", native_host: bool = True, gpu_segment_min_files: int = 8):
         self.ctx = B.Context(device)
-        self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR}[layout]
+        # "planar" / "planar_rowmajor": the components apart, (3, W, H) / (3, H, W) per colour image
+        self.layout = {"xmajor": B.MJ_LAYOUT_XMAJOR, "rowmajor": B.MJ_LAYOUT_ROWMAJOR, "planar": B.MJ_LAYOUT_PLANAR_XMAJOR,
+                       "planar_rowmajor": B.MJ_LAYOUT_PLANAR_ROWMAJOR}[layout]
         # exact_only: stage 2 uses the reference's summation order for every block (slow; for A/B checks)
         # spec_refine: progressive AC refinement as ITU-T T.81 defines it instead of the reference's behaviour
         self.base_flags = (B.MJ_FLAG_EXACT_ONLY if exact_only else 0) | (B.MJ_FLAG_SPEC_REFINE if spec_refine else 0)
@@ -362,13 +372,18 @@ class BatchDecoder:
         plan = B.Plan(self.ctx, prep.to_c(blob_device_ptr), {"prep": prep, "n_images": len(prep.parsed)})
         return prep, plan
 
+    def _shape(self, w: int, h: int, nc: int) -> tuple:
+        """Array shape of one decoded image in this decoder's layout."""
+        wh = (w, h) if (self.layout & 1) == B.MJ_LAYOUT_XMAJOR else (h, w)
+        if nc != 3:
+            return wh
+        return (3,) + wh if self.layout >= B.MJ_LAYOUT_PLANAR_XMAJOR else wh + (3,)
+
     def split_outputs(self, prep: PreparedBatch, flat: np.ndarray, per_pixel: int = 1) -> List[np.ndarray]:
         out, off = [], 0
         for (w, h, nc) in prep.shapes:
             n = w * h * nc * per_pixel
-            a = flat[off:off + n]
-            shape = (w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)
-            out.append(a.reshape(shape + ((nc,) if nc == 3 else ())))
+            out.append(flat[off:off + n].reshape(self._shape(w, h, nc)))
             off += n
         return out
 
@@ -385,10 +400,10 @@ class BatchDecoder:
         results: List[Optional[np.ndarray]] = [None] * len(files)
         seams: List[Optional[dict]] = [None] * len(files)
         flags = ((B.MJ_FLAG_KEEP_PLANES | B.MJ_FLAG_KEEP_IDCT) if return_seams else 0) | self.base_flags
-        work = list(groups.values())
+        work = [(idxs, 0) for idxs in groups.values()]
         while work:
-            idxs = work.pop(0)
-            prep = prepare_batch([files[i] for i in idxs], self.layout, flags, [parsed[i] for i in idxs])
+            idxs, extra = work.pop(0)
+            prep = prepare_batch([files[i] for i in idxs], self.layout, flags | extra, [parsed[i] for i in idxs])
             plan = B.Plan(self.ctx, prep.to_c(), {"prep": prep, "n_images": len(idxs)})
             try:
                 plan.execute()
@@ -399,11 +414,17 @@ class BatchDecoder:
                     for i in redo:
                         parsed[i] = parse_jpeg(files[i])
                         check_supported(parsed[i])
-                    work.append(redo)
+                    work.append((redo, extra))
                     out["status"][[k for k, i in enumerate(idxs) if i in redo]] = 0
+                again = [i for k, i in enumerate(idxs) if out["status"][k] == B.MJ_ST_UNCONVERGED]
+                if again:                       # the synchronisation rounds had not settled: the serial walk for these
+                    work.append((again, extra | B.MJ_FLAG_NO_SYNC))
+                    out["status"][[k for k, i in enumerate(idxs) if i in again]] = 0
                 raise_for_status(out["status"])
                 imgs = self.split_outputs(prep, out["rgb"])
                 for k, i in enumerate(idxs):
+                    if i in redo or i in again:
+                        continue
                     results[i] = imgs[k]
                     if return_seams:
                         b0, _ = plan.image_offsets(k)
@@ -478,8 +499,8 @@ class BatchDecoder:
                             for i in idxs:
                                 parsed[i] = parse_jpeg(files[i], headers_only=True)
                                 check_supported(parsed[i])
-                    if prep is None:
-                        prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags, [parsed[i] for i in idxs])
+                    if prep is None or isinstance(prep, int):
+                        prep = prepare_batch([files[i] for i in idxs], self.layout, self.base_flags | (prep or 0), [parsed[i] for i in idxs])
                     if work or flying:
                         # more than one plan: keep off the null stream, whose copies would wait for the other plans' kernels
                         if streams is None:
@@ -492,13 +513,21 @@ class BatchDecoder:
                     flying.append((idxs, prep, plan, None, d_blob))
                     d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
                     flying[-1] = (idxs, prep, plan, d_rgb, d_blob)
+                    # d_rgb comes from torch's caching allocator on torch's CURRENT stream: a block a consumer has just
+                    # dropped may still be read by kernels queued there, so the stream that is about to overwrite it waits
+                    # for the current stream first (the allocator only orders reuse within one stream)
+                    cur = torch.cuda.current_stream(dev)
                     if streams is None:
+                        ev = torch.cuda.Event()
+                        ev.record(cur)
+                        self.ctx.wait_event(ev.cuda_event)
                         plan.execute(0, d_rgb.data_ptr())                        # the everyday case: one plan, the context's stream
                     else:
                         # (streams only overlap when they sit on different hardware queues: the package asks the runtime for
                         # eight instead of four, see __init__.py)
                         st = streams[(len(flying) - 1) % 4]
                         st.wait_stream(streams[4])                               # the upload above
+                        st.wait_stream(cur)
                         d_rgb.record_stream(st)
                         d_blob.record_stream(st)
                         plan.execute(st.cuda_stream, d_rgb.data_ptr())
@@ -512,13 +541,21 @@ class BatchDecoder:
                             check_supported(parsed[i])
                         work.append((redo, None))
                         status[[k for k, i in enumerate(idxs) if i in redo]] = 0
+                    again = [i for k, i in enumerate(idxs) if status[k] == B.MJ_ST_UNCONVERGED]
+                    if again:                                    # synchronisation rounds not settled: the serial walk for these
+                        for i in again:
+                            if i not in parsed:
+                                parsed[i] = parse_jpeg(files[i])
+                                check_supported(parsed[i])
+                        work.append((again, B.MJ_FLAG_NO_SYNC))
+                        status[[k for k, i in enumerate(idxs) if i in again]] = 0
                     raise_for_status(status)
                     off = 0
                     for k, i in enumerate(idxs):
                         w, h, nc = prep.shapes[k]
                         n = w * h * nc
-                        shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
-                        results[i] = d_rgb[off:off + n].view(shape)
+                        if i not in redo and i not in again:
+                            results[i] = d_rgb[off:off + n].view(self._shape(w, h, nc))
                         off += n
             finally:
                 for item in flying:
@@ -548,14 +585,13 @@ class BatchDecoder:
             try:
                 plan.sync()
                 status = plan.read(rgb=False)["status"]
-                if (status == B.MJ_ST_TAIL).any():
-                    return None                                   # something behind a scan: redo the batch the long way
+                if ((status == B.MJ_ST_TAIL) | (status == B.MJ_ST_UNCONVERGED)).any():
+                    return None                                   # something behind a scan / rounds not settled: redo the batch the long way
                 raise_for_status(status)
                 out, off = [], 0
                 for (w, h, nc) in prep.shapes:
                     n = w * h * nc
-                    shape = ((w, h) if self.layout == B.MJ_LAYOUT_XMAJOR else (h, w)) + ((nc,) if nc == 3 else ())
-                    out.append(d_rgb[off:off + n].view(shape))
+                    out.append(d_rgb[off:off + n].view(self._shape(w, h, nc)))
                     off += n
                 return out
             finally:
@@ -593,6 +629,9 @@ class BatchDecoder:
                 # (both tensors outlive the kernels that touch them: they stay in `pending` until the plan has been collected)
                 d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
                 self.ctx.wait_event(uploaded[buf].cuda_event)
+                ev = torch.cuda.Event()                            # see decode_device: the context's stream waits for whatever
+                ev.record(torch.cuda.current_stream(dev))          # the current stream still does with a recycled block
+                self.ctx.wait_event(ev.cuda_event)
                 plan.execute(0, d_rgb.data_ptr())
             except BaseException:
                 plan.close()

@@ -93,6 +93,7 @@ struct mj_context {
                                    // copy synchronous for the whole device, i.e. wait for other plans' kernels on other streams)
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
     uint8_t *d_dump = nullptr;     // stage 2's dump lines (mj::kStage2DumpBytes)
+    bool no_graph = false;         // MJ_NO_GRAPH at context creation: never replay captured graphs
     DevBufferCache cache;
     std::string err;
 };
@@ -109,6 +110,8 @@ struct mj_plan {
     bool uniform = false;
     // row-major plans run the fast stage 2 on the transposed problem: blocks and tables are then stored [u][v]
     bool transposed = false;
+    uint8_t *d_rgb_tmp = nullptr;  // planar layouts: the interleaved image stage 2 writes before the components are separated
+    int64_t max_pixels = 0;        // largest width*height of the batch
     int32_t mcus_per_image = 0;
     mj_plan_info info{};
     std::vector<mj::DevImage> h_images;
@@ -128,6 +131,7 @@ struct mj_plan {
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
     bool use_sync = false;
+    int sync_rounds = 4;           // repair rounds of the synchronisation form (MJ_SYNC_ROUNDS at plan creation: tests)
     int sync_chunk_bytes = 2048;
     uint16_t *d_lut11u = nullptr;       // every table as len << 11 | run << 4 | size
     mj::DevChunk *d_chunks = nullptr;
@@ -327,6 +331,7 @@ int mj_create(int device_id, mj_context **out) {
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
     MJ_HIP(nullptr, hipMemcpy(ctx->d_idct_tt, tt.data(), tt.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->no_graph = getenv("MJ_NO_GRAPH") != nullptr;
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_dump, mj::kStage2DumpBytes));
     MJ_HIP(nullptr, hipMemset(ctx->d_dump, 0, mj::kStage2DumpBytes));
     {
@@ -378,7 +383,7 @@ void mj_plan_destroy(mj_plan *p) {
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
-                    p->d_rgb, p->d_planes, p->d_idct, p->d_status};
+                    p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
     delete p;
@@ -389,7 +394,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     if (!b || !out) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: NULL argument");
     *out = nullptr;
     if (b->n_images <= 0 || !b->images) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: empty batch");
-    if (b->layout != MJ_LAYOUT_XMAJOR && b->layout != MJ_LAYOUT_ROWMAJOR)
+    if (b->layout < MJ_LAYOUT_XMAJOR || b->layout > MJ_LAYOUT_PLANAR_ROWMAJOR)
         return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: unknown layout %d", b->layout);
     if (b->n_qt <= 0 || !b->qt) return fail(ctx, MJ_ERR_INVALID, "mj_plan_create: no quantisation tables");
     MJ_HIP(ctx, hipSetDevice(ctx->device));
@@ -401,7 +406,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->flags = b->flags;
     // 4:1:1 (luma 4x1) has no fast stage 2: the exact-order kernel takes it, in either pixel layout
     if (b->images[0].ncomp == 3 && b->images[0].hs[0] == 4) p->flags |= MJ_FLAG_EXACT_ONLY;
-    p->transposed = b->layout == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY);
+    p->transposed = (b->layout & 1) == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY);
     struct Guard { mj_plan *p; mj_context *c; ~Guard() { c->cur = nullptr; if (p) mj_plan_destroy(p); } } guard{p, ctx};
     if (!ctx->free_arenas.empty()) { p->arena = ctx->free_arenas.back(); ctx->free_arenas.pop_back(); }
     else if (hipHostMalloc((void **)&p->arena.base, (size_t)8 << 20, hipHostMallocDefault) == hipSuccess) p->arena.cap = (size_t)8 << 20;
@@ -443,6 +448,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             return fail(ctx, MJ_ERR_INVALID, "image %d: MCU counts %dx%d do not match %dx%d with %dx%d MCUs", i,
                         d.mcu_count_h, d.mcu_count_v, d.width, d.height, mw, mh);
         im.width = d.width; im.height = d.height; im.ncomp = d.ncomp;
+        p->max_pixels = std::max(p->max_pixels, (int64_t)d.width * d.height);
         im.hmax = hmax; im.vmax = vmax;
         im.blocks_per_mcu = d.ncomp == 1 ? 1 : hmax * vmax + 2;
         im.mcu_count_h = d.mcu_count_h; im.mcu_count_v = d.mcu_count_v;
@@ -769,6 +775,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // image already wins: the alternative is one serial walk per segment); MJ_HUFFMAN=sync forces it, wave / lanes
         // exclude it.  With the GPU marker scan the segment lengths are not known here: possible when every image is one
         // segment (no DRI), whose byte range bounds its length.
+        if (const char *e = getenv("MJ_SYNC_ROUNDS")) { const int v = atoi(e); if (v >= 0 && v <= 64) p->sync_rounds = v; }
         if (const char *e = getenv("MJ_SYNC_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536 && v % 4 == 0) p->sync_chunk_bytes = v; }
         bool one_seg_each = true;
         for (const auto &jb : jobs) one_seg_each = one_seg_each && jb.n_seg == 1;
@@ -805,7 +812,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // (with many tables the synchronisation form needs its own two workgroup shapes to get by with their table lists;
         // its lane launch runs over chunks, so the restart-segment shape checked above does not matter for it)
         const bool sync_shape_ok = ordered && !both_roles && !prog && (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
-        bool want_sync = (many_tabs ? sync_shape_ok : lanes_ok) && (jobs.empty() || one_seg_each) && dc_fits &&
+        bool want_sync = !(b->flags & MJ_FLAG_NO_SYNC) && (many_tabs ? sync_shape_ok : lanes_ok) && (jobs.empty() || one_seg_each) && dc_fits &&
                          ((force && !strcmp(force, "sync")) || (!force && (long_segs || few_segs)));
         if (want_sync && many_tabs) {
             // (shorter chunks = less stream per workgroup = fewer images per workgroup: if the chunk size chosen above
@@ -882,6 +889,12 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->d_blob = p->d_blob_owned;
         } else {
             if (((uintptr_t)b->blob & 3) != 0) return fail(ctx, MJ_ERR_INVALID, "device blob must be 4-byte aligned");
+            // the bit readers fetch up to 127 dwords past a segment's aligned start (wave_bits.h) and one dword ahead per
+            // lane: a caller-owned blob must be that much longer than its last segment (uploads get the slack here)
+            int64_t last_end = 0;
+            for (int64_t i = 0; i < b->n_segments; ++i) last_end = b->seg_end[i] > last_end ? b->seg_end[i] : last_end;
+            if (!(b->flags & MJ_FLAG_GPU_SEGMENT) && last_end + 512 > b->blob_len)
+                return fail(ctx, MJ_ERR_INVALID, "device blob: blob_len must include 512 readable bytes behind the last segment");
             if (!jobs.empty() && ((uintptr_t)b->blob & 15) != 0)
                 return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT: device blob must be 16-byte aligned");
             p->d_blob = b->blob;
@@ -1004,23 +1017,19 @@ static int stage1_impl(mj_plan *p, void *stream) {
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
                                               p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
-            // repair rounds: three are queued without looking (a chain of wrongly guessed entry states gets one link
-            // shorter per round), then the host reads the third round's change counter, and goes on one round at a time
-            // only if that was not yet zero
+            // repair rounds: a fixed number, queued without looking (a chain of wrongly guessed entry states gets one link
+            // shorter per round; after round 0's run-up nearly every guess is right and the second repair round changes
+            // nothing).  Whether they sufficed is decided on the device: k_build_vsegs marks the images whose chunk states
+            // had not settled (MJ_ST_UNCONVERGED) and the caller decodes those again with MJ_FLAG_NO_SYNC.  No host
+            // round trip: the execute is asynchronous and can be captured into a graph like every other form.
             MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, 4 * sizeof(int32_t), s));
-            for (int round = 1;; ++round) {
-                int32_t *counter = p->d_changed + (round <= 3 ? round - 1 : 3);
-                if (round > 3) MJ_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(int32_t), s));
+            for (int round = 1; round <= p->sync_rounds; ++round) {
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, counter, p->d_wg_tabs_count, p->wg_slots_count));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + 3, p->d_wg_tabs_count, p->wg_slots_count));
                 std::swap(in, out);
-                if (round < 3) continue;
-                MJ_HIP(ctx, hipMemcpyAsync(ctx->h_word, counter, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                MJ_HIP(ctx, hipStreamSynchronize(s));
-                const int32_t changed = *ctx->h_word;
-                if (changed == 0 || round > 4096) break;
             }
-            MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs));
+            MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,
+                                               in, p->d_status));
             MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
                                                  p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes, p->wg_slots_lanes));
             return MJ_OK;
@@ -1046,7 +1055,14 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.images = p->d_images; a.n_images = p->n_images; a.mcu_prefix = p->d_mcu_prefix;
     a.total_mcus = p->info.total_mcus; a.coef = p->d_coef; a.qt = p->d_qt; a.idct_tt = ctx->d_idct_tt;
     a.up_taps = nullptr; a.rgb = rgb_device; a.dump = ctx->d_dump; a.planes = p->d_planes; a.idct_out = p->d_idct;
-    a.layout = p->layout; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
+    a.layout = p->layout & 1; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
+    // planar layouts: the kernels write the interleaved image of the same orientation into a plan-owned buffer and a copy
+    // kernel separates the components (one extra pass over the pixels; the interleaved layouts are the fast ones)
+    const bool planar = p->layout >= MJ_LAYOUT_PLANAR_XMAJOR && p->ncomp == 3;
+    if (planar) {
+        if (!p->d_rgb_tmp) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb_tmp, (size_t)p->info.rgb_bytes + 16));
+        a.rgb = p->d_rgb_tmp;
+    }
 #ifdef MJ_DIAGNOSTIC      // phase ablations of the diagnostic build (make DIAG=1); the product never looks at the environment here
     a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
 #else
@@ -1060,6 +1076,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
         MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->transposed, p->d_tile_prefix,
                                                p->total_tiles, p->tiles_per_image));
     }
+    if (planar) MJ_HIP(ctx, mj::launch_planes_from_interleaved(s, p->d_images, p->n_images, p->max_pixels, p->d_rgb_tmp, rgb_device));
     return MJ_OK;
 }
 
@@ -1070,10 +1087,9 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // Re-executions of a plan with the same stream and output buffer replay a captured graph of its launches (one
     // submission instead of a memset and three or four kernel launches).  The first execute runs plainly (it also
-    // sizes grids and allocates the plan-owned output); plans whose stage 1 has to look at the device (long segments)
-    // are never captured.
-    const bool graphable = !p->use_sync && !p->progressive && p->d_blob && p->executed_once && (rgb_device || p->d_rgb) &&
-                           !getenv("MJ_NO_GRAPH");
+    // sizes grids and allocates the plan-owned output).  Progressive plans (dozens of launches, latency bound) launch plainly.
+    const bool graphable = !p->progressive && p->d_blob && p->executed_once && (rgb_device || p->d_rgb) &&
+                           !ctx->no_graph;
     if (graphable && p->graph_exec && p->graph_stream == s && p->graph_rgb == (rgb_device ? rgb_device : p->d_rgb)) {
         p->last_rgb = p->graph_rgb;
         p->last_was_graph = true;

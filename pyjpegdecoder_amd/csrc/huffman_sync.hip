@@ -240,11 +240,16 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
 // the restart segment).  Block offsets and DC predictors come from the sums over the segment's earlier chunks.
 __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chunks, const DevChunkOut *__restrict__ outs,
                               const DevSegment *__restrict__ segs, const int32_t *__restrict__ seg_bits,
-                              const DevImage *__restrict__ images, DevVSeg *__restrict__ vsegs) {
+                              const DevImage *__restrict__ images, DevVSeg *__restrict__ vsegs,
+                              const uint64_t *__restrict__ final_exit, int32_t *__restrict__ status) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const DevChunk ch = chunks[c];
     const DevSegment sg = segs[ch.seg];
+    // The repair rounds are a fixed number, queued without looking.  They have settled iff every chunk's record was computed
+    // from the state its predecessor finally left; a chunk for which that is not so (long chains of wrong guesses: a
+    // pathological stream) marks its image, and the host decodes that image again without synchronisation rounds.
+    if (ch.j > 0 && outs[c].entry != final_exit[c - 1]) atomicMax(status + sg.image, MJ_ST_UNCONVERGED);
     const int bpm = images[sg.image].blocks_per_mcu;
     DevVSeg v{};
     v.image = sg.image;
@@ -272,6 +277,11 @@ __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chu
         v.mcu0 = sg.mcu0 + (int32_t)(start_block / bpm);
         v.n_mcu = (int32_t)((end_block - start_block) / bpm);
         if (v.n_mcu < 0 || start_block % bpm != 0) v.n_mcu = 0;        // cannot happen for a consistent stream; decode nothing then
+        // records that have not settled (the image is marked above and decoded again) may add up to anything: whatever they
+        // say, a virtual segment stays inside its restart segment's MCUs — its lane must not write into the next image
+        const int32_t seg_end_mcu = sg.mcu0 + sg.n_mcu;
+        if (v.mcu0 < sg.mcu0 || v.mcu0 >= seg_end_mcu) v.n_mcu = 0;
+        else if (v.n_mcu > seg_end_mcu - v.mcu0) v.n_mcu = seg_end_mcu - v.mcu0;
         v.pred[0] = (int16_t)(d0 + me.dc_bnd[0]);
         v.pred[1] = (int16_t)(d1 + me.dc_bnd[1]);
         v.pred[2] = (int16_t)(d2 + me.dc_bnd[2]);
@@ -305,10 +315,11 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
 }
 
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
-                              const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs) {
+                              const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs,
+                              const uint64_t *final_exit, int32_t *status) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_vsegs, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream, chunks, n_chunks, outs, segs,
-                       seg_bits, images, vsegs);
+                       seg_bits, images, vsegs, final_exit, status);
     return hipGetLastError();
 }
 

@@ -160,7 +160,8 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
                              DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr, int wg_slots = 0);   // wg_tabs: per 256 chunks
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
-                              const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs);
+                              const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs,
+                              const uint64_t *final_exit, int32_t *status);
 hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, const DevPiece *pieces,
                                  int64_t n_pieces, int32_t *kept, uint32_t *out_stream, int32_t *seg_bits);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables
@@ -203,6 +204,9 @@ hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, 
 int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image);
+// MJ_LAYOUT_PLANAR_*: every image's interleaved pixels (x-major or row-major, as stage 2 wrote them) -> its three planes
+hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
+                                          const uint8_t *interleaved, uint8_t *planar);
 // 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
                                  int transposed);

@@ -290,4 +290,43 @@ hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, 
     return hipErrorInvalidValue;
 }
 
+
+// ---- MJ_LAYOUT_PLANAR_XMAJOR / _ROWMAJOR: (.., 3) -> (3, ..) per image.  A thread moves four pixels: three dwords in,
+// one dword to each plane (an image's pixel count need not be a multiple of four, nor its offset of four bytes: the
+// ragged ends go byte by byte).
+__global__ __launch_bounds__(256) void k_planes_from_interleaved(const DevImage *__restrict__ images, const uint8_t *__restrict__ src,
+                                                                 uint8_t *__restrict__ dst) {
+    const DevImage im = images[blockIdx.y];
+    const int64_t n = (int64_t)im.width * im.height;
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;        // first of this thread's four pixels
+    if (q >= n) return;
+    const uint8_t *s = src + im.rgb_off + 3 * q;
+    uint8_t *d = dst + im.rgb_off + q;
+    if (q + 4 <= n && ((im.rgb_off | n) & 3) == 0) {
+        const uint32_t a = reinterpret_cast<const uint32_t *>(s)[0], b = reinterpret_cast<const uint32_t *>(s)[1], c = reinterpret_cast<const uint32_t *>(s)[2];
+        // bytes: a = R0 G0 B0 R1, b = G1 B1 R2 G2, c = B2 R3 G3 B3
+        const uint32_t r = (a & 0xFFu) | ((a >> 24) << 8) | (((b >> 16) & 0xFFu) << 16) | (((c >> 8) & 0xFFu) << 24);
+        const uint32_t g = ((a >> 8) & 0xFFu) | ((b & 0xFFu) << 8) | ((b >> 24) << 16) | (((c >> 16) & 0xFFu) << 24);
+        const uint32_t bl = ((a >> 16) & 0xFFu) | (((b >> 8) & 0xFFu) << 8) | ((c & 0xFFu) << 16) | ((c >> 24) << 24);
+        *reinterpret_cast<uint32_t *>(d) = r;
+        *reinterpret_cast<uint32_t *>(d + n) = g;
+        *reinterpret_cast<uint32_t *>(d + 2 * n) = bl;
+    } else {
+        for (int i = 0; i < 4 && q + i < n; ++i) {
+            d[i] = s[3 * i]; d[n + i] = s[3 * i + 1]; d[2 * n + i] = s[3 * i + 2];
+        }
+    }
+}
+
+hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
+                                          const uint8_t *interleaved, uint8_t *planar) {
+    if (n_images == 0 || max_pixels == 0) return hipSuccess;
+    for (int i0 = 0; i0 < n_images; i0 += 65535) {          // grid.y limit
+        const int ny = n_images - i0 < 65535 ? n_images - i0 : 65535;
+        hipLaunchKernelGGL(k_planes_from_interleaved, dim3((unsigned)((max_pixels + 1023) / 1024), (unsigned)ny), dim3(256), 0, stream,
+                           images + i0, interleaved, planar);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace mj

@@ -18,7 +18,8 @@ from typing import Optional
 import numpy as np
 
 from . import _binding as B
-from ._parse import (ColorComponent, HuffmanTable, ParsedJpeg, parse_jpeg, DHT, DQT, DRI, SOF0, SOF2, SOS, EOI)
+from ._parse import (ColorComponent, HuffmanTable, ParsedJpeg, parse_jpeg, DHT, DQT, DRI, SOF0, SOF2, SOS, EOI, RST, bytes_to_uint,
+                     parse_huffman_segment, parse_quantization_segment, _start_of_frame, _start_of_scan)
 from .batch import check_supported, prepare_batch, raise_for_status
 from .errors import CorruptedJpeg, JpegError, NotJpeg, UnsupportedJpeg  # noqa: F401  (re-exported like the reference)
 
@@ -65,67 +66,123 @@ class JpegDecoder():
         self.image_array = None
         self.scan_count = 0
 
-        # Host side: the marker loop (:78-110) — headers, tables, scan geometry, restart segmentation
-        parsed = parse_jpeg(self.raw_file)
-        self._parsed = parsed
-        for line in parsed.log:
-            self._say(line)
-        self.scan_mode = parsed.scan_mode
-        self.image_width, self.image_height = parsed.image_width, parsed.image_height
-        self.color_components = dict(parsed.color_components)
-        self.sample_shape = parsed.sample_shape
-        self.huffman_tables = {dest: dict(spec.tree) for dest, spec in parsed.huffman.items()}
-        self.quantization_tables = dict(parsed.quantization_tables)
-        self.restart_interval = parsed.restart_interval
-        if not parsed.scans:
-            # the reference falls off the end of the file here (:81-83) leaving image_array = None
+        # Host side: the marker loop (:78-110).  The handlers are the reference's six, with the reference's contract
+        # (called with the segment's payload, `file_header` behind the length field); what differs is that
+        # `start_of_scan` records the scan instead of decoding it in place and `end_of_image` sends the recorded
+        # scans through the GPU path in one go.
+        self._parsed = ParsedJpeg(raw=self.raw_file, file_size=self.file_size)
+        self._arr = np.frombuffer(self.raw_file, dtype=np.uint8)
+        self._device = device
+        self._show = show
+        n = self.file_size
+        while not self.scan_finished:
+            if self.file_header >= n:                     # the reference's IndexError branch (:81-83)
+                break
+            if self.raw_file[self.file_header] == 0xFF:
+                my_marker = self.raw_file[self.file_header:self.file_header + 2]
+                self.file_header += 2
+                if my_marker != b"\xFF\x00" and my_marker not in RST:
+                    my_handler = self.handlers.get(my_marker)
+                    my_size = bytes_to_uint(self.raw_file[self.file_header:self.file_header + 2]) - 2
+                    self.file_header += 2
+                    if my_handler is not None:
+                        my_handler(self.raw_file[self.file_header:self.file_header + my_size] if my_size > 0 else b"")
+                    else:
+                        self.file_header += my_size       # unknown segment: skipped (:104-106)
+            else:
+                self.file_header += 1
+        if not self.scan_finished:
+            # The file ended without EOI.  The reference falls off the end here (:81-83) leaving image_array as the
+            # unconverted int16 array (or None when no scan was seen); the GPU path converts what it decoded.
+            if self._parsed.scans:
+                self._decode_scans()
             del self.raw_file
-            return
-        scan = check_supported(parsed)
-        self.scan_amount = parsed.scan_amount
-        scan = parsed.scans[-1]          # the geometry attributes are those of the last scan decoded (:591-621)
+            del self._arr
+
+    # -- the reference's handlers (:112-652, :1368-1390): same names, same argument, same effect on the attributes ------
+    def start_of_frame(self, data: bytes) -> None:
+        """SOF0 / SOF2 (:112-247): scan mode, dimensions, components, sampling, quantisation table ids."""
+        p = self._parsed
+        _start_of_frame(p, self.raw_file[self.file_header - 4:self.file_header - 2], data, self._say)
+        self.file_header += len(data)
+        self.scan_mode = p.scan_mode
+        self.image_width, self.image_height = p.image_width, p.image_height
+        self.color_components = dict(p.color_components)
+        self.sample_shape = p.sample_shape
+
+    def define_huffman_table(self, data: bytes) -> None:
+        """DHT (:249-390): the tables as the reference's {codeword string: value} dicts; BITS/HUFFVAL kept for the GPU LUTs."""
+        for dest, spec in parse_huffman_segment(data).items():
+            self._parsed.huffman[dest] = spec
+            self.huffman_tables[dest] = dict(spec.tree)
+            self._say(f"Parsed Huffman table - ID: {dest & 0x0F} ({'DC' if dest >> 4 == 0 else 'AC'})")
+        self.file_header += len(data)
+
+    def define_quantization_table(self, data: bytes) -> None:
+        """DQT (:392-472): int16 [x, y] tables (undo_zigzag of the 64 bytes)."""
+        for dest, (zz, xy) in parse_quantization_segment(data).items():
+            self._parsed.quantization_zz[dest] = zz
+            self._parsed.quantization_tables[dest] = xy
+            self.quantization_tables[dest] = xy
+            self._say(f"Parsed quantization table - ID: {dest}")
+        self.file_header += len(data)
+
+    def define_restart_interval(self, data: bytes) -> None:
+        """DRI (:474-503); like the reference the header moves on by 2, not by the segment's size."""
+        self.restart_interval = self._parsed.restart_interval = bytes_to_uint(data[:2])
+        self.file_header += 2
+        self._say(f"Restart interval: {self.restart_interval}")
+
+    def start_of_scan(self, data: bytes) -> None:
+        """SOS (:505-652): table selectors, spectral selection, MCU geometry, restart segmentation.  The scan is
+        recorded; `file_header` moves behind its entropy-coded bytes, where the reference's scan decoder leaves it."""
+        p = self._parsed
+        scan = _start_of_scan(p, data, self.file_header, self._arr, self._say)
+        p.scans.append(scan)
+        self.image_height = p.image_height            # a DNL segment may have supplied it (:575-581)
+        self.scan_amount = p.scan_amount
         self.mcu_width, self.mcu_height = scan.mcu_width, scan.mcu_height
         self.mcu_shape = (scan.mcu_width, scan.mcu_height)
         self.mcu_count_h, self.mcu_count_v, self.mcu_count = scan.mcu_count_h, scan.mcu_count_v, scan.mcu_count
-        self.array_width, self.array_height, self.array_depth = parsed.array_width, parsed.array_height, parsed.array_depth
+        self.array_width, self.array_height, self.array_depth = p.array_width, p.array_height, p.array_depth
+        self._say(f"\nScan {len(p.scans)} of {self.scan_amount}")
+        self._say(f"Color components: {', '.join(p.color_components[c].name for c in scan.component_ids)}")
+        self._say(f"MCU count: {scan.mcu_count}")
+        self.file_header = scan.entropy_end
 
-        # Device side: Huffman decode -> dequantise -> IDCT -> upsample -> crop -> colour  (the hot path)
-        for k, sc in enumerate(parsed.scans, start=1):
-            self._say(f"\nScan {k} of {self.scan_amount}")
-            self._say(f"Color components: {', '.join(parsed.color_components[c].name for c in sc.component_ids)}")
-            self._say(f"MCU count: {sc.mcu_count}")
-        self._say("Decoding MCUs and performing IDCT on the GPU...")
-        ctx = _context(device)
-        prep = prepare_batch([self.raw_file], B.MJ_LAYOUT_XMAJOR, 0, [parsed])
-        plan = B.Plan(ctx, prep.to_c(), {"prep": prep, "n_images": 1})
-        try:
-            plan.execute()
-            plan.sync()
-            out = plan.read(rgb=True)
-        finally:
-            plan.close()
-        raise_for_status(out["status"])
-        self.scan_count = len(parsed.scans)
-        self.file_header = parsed.file_header
-
-        if not parsed.reached_eoi:
-            # The reference only crops / colour-converts in end_of_image (:1368-1390); a file without EOI
-            # leaves an unconverted int16 array there.  The GPU path has already converted; keep that.
-            pass
-        shape = (self.image_width, self.image_height) + ((3,) if self.array_depth == 3 else ())
-        self.image_array = out["rgb"].reshape(shape)
-        self.scan_finished = parsed.reached_eoi
-        # parsed.file_header already includes the EOI marker and the bogus 2-byte length read (:89-98)
-        if show:
+    def end_of_image(self, data: bytes) -> None:
+        """EOI (:1368-1390): decode the recorded scans on the GPU (Huffman -> dequantise -> IDCT -> upsample -> crop ->
+        colour), set `image_array`, finish."""
+        self._parsed.reached_eoi = True
+        if self._parsed.scans:
+            self._decode_scans()
+        self.scan_finished = True
+        if self._show and self.image_array is not None:
             self.show()
         del self.raw_file
+        del self._arr
 
-    # -- the reference's handler names, kept so that `handlers` has the same keys/shape ----------------
-    def start_of_frame(self, data: bytes) -> None:          # (:112) parsed in _parse._start_of_frame
-        raise NotImplementedError("handled by pyjpegdecoder_amd._parse.parse_jpeg")
-
-    define_huffman_table = define_quantization_table = define_restart_interval = start_of_frame
-    start_of_scan = end_of_image = start_of_frame
+    def _decode_scans(self) -> None:
+        parsed = self._parsed
+        parsed.file_header = self.file_header
+        check_supported(parsed)
+        self._say("Decoding MCUs and performing IDCT on the GPU...")
+        ctx = _context(self._device)
+        for flags in (0, B.MJ_FLAG_NO_SYNC):
+            prep = prepare_batch([self.raw_file], B.MJ_LAYOUT_XMAJOR, flags, [parsed])
+            plan = B.Plan(ctx, prep.to_c(), {"prep": prep, "n_images": 1})
+            try:
+                plan.execute()
+                plan.sync()
+                out = plan.read(rgb=True)
+            finally:
+                plan.close()
+            if out["status"][0] != B.MJ_ST_UNCONVERGED:      # (else: once more, one serial walk per segment)
+                break
+        raise_for_status(out["status"])
+        self.scan_count = len(parsed.scans)
+        shape = (self.image_width, self.image_height) + ((3,) if self.array_depth == 3 else ())
+        self.image_array = out["rgb"].reshape(shape)
 
     def _say(self, text: str) -> None:
         if self._verbose:

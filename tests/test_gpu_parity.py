@@ -1023,3 +1023,95 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(img, ref), i
     for i, (img, ref) in enumerate(zip(dec_rm.decode(files), refs)):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
+
+
+# ---- round 2: boundary and fallbacks ---------------------------------------------------------------------------------
+def test_one_shot_entry_point_through_ctypes(dec):
+    """`mj_decode_baseline_batch` is what INTEGRATION.md's reference-side stub binds: call it directly (no Plan wrapper)
+    on two fixtures of different layouts and hold pixels and coefficients to the reference's."""
+    import ctypes
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    lib = B.load_library()
+    for names in (["c1_64x64_444_pil"], ["128x64_420_dri3", "64x64_420_pil"]):
+        raws = [load_golden(n)[0] for n in names]
+        prep = prepare_batch(raws, B.MJ_LAYOUT_XMAJOR, 0)
+        batch = prep.to_c()
+        n_px = sum(w * h * nc for (w, h, nc) in prep.shapes)
+        blocks = sum(int(d.mcu_count_h) * int(d.mcu_count_v) * (1 if d.ncomp == 1 else sum(d.hs[c] * d.vs[c] for c in range(3))) for d in prep.descs)
+        rgb = np.zeros(n_px, dtype=np.uint8)
+        coef = np.zeros((blocks, 64), dtype=np.int16)
+        status = np.full(len(raws), -1, dtype=np.int32)
+        rc = lib.mj_decode_baseline_batch(dec.ctx.handle, ctypes.byref(batch), rgb.ctypes.data, coef.ctypes.data, status.ctypes.data)
+        assert rc == B.MJ_OK, lib.mj_last_error(dec.ctx.handle)
+        assert not status.any()
+        off = boff = 0
+        for n, (w, h, nc) in zip(names, prep.shapes):
+            vec = load_golden(n)[1]
+            assert np.array_equal(rgb[off:off + w * h * nc].reshape(vec["rgb"].shape), vec["rgb"]), n
+            nb = vec["coef"].shape[0]
+            assert np.array_equal(coef[boff:boff + nb], vec["coef"]), n
+            off += w * h * nc
+            boff += nb
+
+
+def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkeypatch):
+    """The synchronisation rounds are a fixed number, queued without a host round trip.  Make them fail on purpose — no
+    run-up in front of the chunks, tiny chunks: nearly every guessed entry state is wrong and a chain of wrong guesses
+    only gets one link shorter per round — and require (a) the device to notice (MJ_ST_UNCONVERGED, not a wrong image,
+    not CorruptedJpeg), (b) the host layer to decode the file again without synchronisation, bit-exact."""
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    monkeypatch.setenv("MJ_SYNC_WARM", "0")
+    monkeypatch.setenv("MJ_SYNC_CHUNK", "256")
+    monkeypatch.setenv("MJ_SYNC_ROUNDS", "0")          # (real streams re-synchronise within a chunk: four rounds always settle them)
+    raw = synth.synth_jpeg(4242, 640, 480, 85, "420", 0, 12.0)
+    prep = prepare_batch([raw], B.MJ_LAYOUT_XMAJOR, 0)
+    plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})
+    try:
+        assert plan.stage1_form() & 15 == B.MJ_FORM_SYNC
+        plan.execute()
+        plan.sync()
+        assert plan.read(rgb=False)["status"][0] == B.MJ_ST_UNCONVERGED
+    finally:
+        plan.close()
+    ref = oracle.decode(raw)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"]) and np.array_equal(img, ref["rgb"])
+    # a plan created with MJ_FLAG_NO_SYNC never takes the form, whatever the environment says
+    prep = prepare_batch([raw], B.MJ_LAYOUT_XMAJOR, B.MJ_FLAG_NO_SYNC)
+    plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})
+    try:
+        assert plan.stage1_form() & 15 != B.MJ_FORM_SYNC
+    finally:
+        plan.close()
+
+
+@pytest.mark.parametrize("layout", ["planar", "planar_rowmajor"])
+def test_planar_layouts(layout):
+    """MJ_LAYOUT_PLANAR_*: the components of the reference's image_array (:1373-1386) as three planes per image — every
+    fixture (all sampling layouts, greyscale, odd sizes), one mixed call, host arrays and device tensors alike."""
+    from pyjpegdecoder_amd import BatchDecoder
+    names = golden_names() + prog_names()[:2]
+    raws = [load_golden(n)[0] for n in names]
+    d = BatchDecoder(device=0, layout=layout)
+    try:
+        for n, img in zip(names, d.decode(raws)):
+            ref = load_golden(n)[1]["rgb"]                      # (W, H, 3) or (W, H)
+            if layout == "planar_rowmajor":
+                ref = np.swapaxes(ref, 0, 1)
+            want = np.moveaxis(ref, 2, 0) if ref.ndim == 3 else ref
+            assert img.shape == want.shape and np.array_equal(img, want), n
+        torch = pytest.importorskip("torch")
+        outs = d.decode_device(raws[:6])
+        for n, t in zip(names[:6], outs):
+            ref = load_golden(n)[1]["rgb"]
+            if layout == "planar_rowmajor":
+                ref = np.swapaxes(ref, 0, 1)
+            want = np.moveaxis(ref, 2, 0) if ref.ndim == 3 else ref
+            assert np.array_equal(t.cpu().numpy(), want), n
+    finally:
+        d.close()

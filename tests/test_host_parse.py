@@ -113,3 +113,51 @@ def test_headers_only_parse_matches_full_parse():
         assert prep.seg_begin[0] == a.entropy_start and prep.seg_end[0] == len(raw)
     for name in (n for n in golden_index() if n.startswith("prog_")):
         assert not parse_jpeg(load_golden(name)[0], headers_only=True).headers_only
+
+
+@pytest.mark.parametrize("name", ["c1_64x64_444_pil", "128x64_420_dri3", "50x70_grey_dri4", "prog_70x50_420_pil"])
+def test_class_handlers_are_the_references_six_and_callable(name):
+    """jpeg_decoder.py:112-652: `handlers` maps markers to bound methods that take the segment payload and update the
+    object's attributes.  Drive them by hand over a golden file, up to (not including) EOI — no GPU involved — and
+    compare the attributes with what the reference left on its object."""
+    import numpy as np
+    from pyjpegdecoder_amd import JpegDecoder
+    from pyjpegdecoder_amd._parse import ParsedJpeg, RST, bytes_to_uint
+    raw, _ = load_golden(name)
+    meta = golden_index()[name]
+    d = JpegDecoder.__new__(JpegDecoder)
+    d._verbose = False
+    d.raw_file, d.file_size, d.file_header = raw, len(raw), 2
+    d._parsed, d._arr = ParsedJpeg(raw=raw, file_size=len(raw)), np.frombuffer(raw, dtype=np.uint8)
+    d.scan_finished, d.scan_mode, d.huffman_tables, d.quantization_tables = False, None, {}, {}
+    d.color_components, d.restart_interval, d.image_array, d.scan_count = {}, 0, None, 0
+    d.handlers = {b"\xFF\xC4": d.define_huffman_table, b"\xFF\xDB": d.define_quantization_table,
+                  b"\xFF\xDD": d.define_restart_interval, b"\xFF\xC0": d.start_of_frame, b"\xFF\xC2": d.start_of_frame,
+                  b"\xFF\xDA": d.start_of_scan}
+    seen = []
+    while d.file_header < len(raw):                      # the reference's loop (:78-110), minus EOI
+        if raw[d.file_header] != 0xFF:
+            d.file_header += 1
+            continue
+        m = raw[d.file_header:d.file_header + 2]
+        d.file_header += 2
+        if m == b"\xFF\x00" or m in RST:
+            continue
+        if m == b"\xFF\xD9":
+            break
+        size = bytes_to_uint(raw[d.file_header:d.file_header + 2]) - 2
+        d.file_header += 2
+        h = d.handlers.get(m)
+        if h is None:
+            d.file_header += size
+        else:
+            seen.append(m)
+            h(raw[d.file_header:d.file_header + size])
+    assert b"\xFF\xDA" in seen and b"\xFF\xDB" in seen and b"\xFF\xC4" in seen
+    assert d.scan_mode == meta["scan_mode"] and (d.image_width, d.image_height) == (meta["image_width"], meta["image_height"])
+    assert {str(k): v for k, v in d.huffman_tables.items()} == meta["huffman_tables"]
+    assert {str(k): v.tolist() for k, v in d.quantization_tables.items()} == meta["quantization_tables"]
+    assert d.restart_interval == meta["restart_interval"] and d.scan_amount == meta["scan_amount"]
+    for k in ("mcu_width", "mcu_height", "mcu_count_h", "mcu_count_v", "mcu_count", "array_width", "array_height", "array_depth"):
+        assert getattr(d, k) == meta[k], k
+    assert len(d._parsed.scans) == meta["scan_count"]
