@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on its configs[2] workload: megapixels/s decoded on a batch of
-1024 synthetic 1920x1080 4:2:0 baseline JPEGs with DRI restart markers, on-GPU Huffman + IDCT.
+"""bench.py — BASELINE.json's metric (megapixels/s decoded on 1080p 4:2:0 baseline batches) on MI355X.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (stage 1 Huffman decode + stage 2 dequant/IDCT/upsample/colour) over
-the rank's whole batch, compressed input already resident in HBM, RGB output left in HBM.  Images are the
-units; they are sharded over ranks with no collective on the data path — weak scaling:
-every rank decodes its own `--batch` images.  Rank 0 prints ONE JSON line.
+Default workload = BASELINE configs[2]: per GPU a batch of 1024 synthetic 1920x1080 4:2:0 baseline JPEGs with DRI
+restart markers, on-GPU Huffman + IDCT.  A "step" = one pass of the hot path (stage 0+1 Huffman decode, stage 2
+dequant/IDCT/upsample/colour) over the rank's whole batch, compressed input already resident in HBM, RGB left in HBM.
+Images are the units; they are sharded over ranks with no collective on the data path — weak scaling:
+every rank decodes its own `--batch` images; the only cross-rank traffic is a gloo barrier and the MAX of the timings.
+
+    python bench.py --total-images 10000 [--gpus N]      BASELINE configs[3]: ONE job of that many images, sharded over
+                                                         the ranks (1 250 per GPU at N = 8), each rank feeding its share
+                                                         through a per-GPU image queue (strong scaling)
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries: `roofline` (+ `roofline_other_stage`), `cpu_baseline` (the C
+oracle on this host's cores + the reference's own timing from the build container), `progressive` (BASELINE
+configs[4]: 1024 x 1080p progressive), `without_restart_markers`, `host_bytes_to_device_pixels`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,8 +35,17 @@ STAGE2_BYTES_PER_IMAGE = BLOCKS_PER_IMAGE * 128 + W * H * 3       # 12 487 680 (
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+def sources_sha16() -> str:
+    """Fingerprint of the kernel sources: PMC summaries under profiles/ are only quoted for the build they came from."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "pyjpegdecoder_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(raws, budget_s: float = 20.0):
-    """The CPU oracle (bit-exact restatement of the reference path) timed on this host, one thread."""
+    """The CPU oracle (bit-exact restatement of the reference path) timed on this host, one thread, then all cores."""
     import ctypes
     from oracle import oracle
     try:
@@ -45,7 +63,6 @@ def cpu_baseline(raws, budget_s: float = 20.0):
     dt = time.perf_counter() - t0
     out = {"value": round(n * W * H / 1e6 / dt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
            "sample": f"{n} of the batch's 1080p images, {dt:.1f} s, oracle/jpeg_oracle.c single-threaded"}
-    # the same port on every host core (one image per thread at a time; the C calls release the GIL)
     try:
         from concurrent.futures import ThreadPoolExecutor
         nc = max(1, min(os.cpu_count() or 1, 64))
@@ -58,26 +75,122 @@ def cpu_baseline(raws, budget_s: float = 20.0):
                             "sample": f"{len(work)} images on {nc} threads, {dt2:.1f} s"}
     except Exception as exc:                     # never let the baseline break the bench line
         out["all_cores"] = {"error": str(exc)}
+    # the reference itself cannot travel to the GPU box: its timing comes from the build container (tools/time_reference.py)
+    ref = ROOT / "profiles" / "reference_python_timing.json"
+    if ref.exists():
+        try:
+            d = json.loads(ref.read_text())
+            out["reference_python"] = {"runs": [{k: r[k] for k in ("processes", "value", "unit", "wall_s")} for r in d["runs"]],
+                                       "host": d["host"], "script": "tools/time_reference.py", "script_commit": d.get("script_commit"),
+                                       "note": "the reference's pure-Python path, timed in the build container, not on this host"}
+        except Exception as exc:
+            out["reference_python"] = {"error": str(exc)}
     return out
+
+
+def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8):
+    """BASELINE configs[4]: a batch of 1080p 4:2:0 progressive files (libjpeg's default 10-scan script, written by Pillow),
+    resident in HBM, decoded scan by scan; parity of two images against the oracle."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import synth
+    raws = []
+    for i in range(n_distinct):
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(500000 + i, W, H)).save(b, "JPEG", quality=85, subsampling=2, progressive=True)
+        raws.append(b.getvalue())
+    files = [raws[i % n_distinct] for i in range(n_images)]
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n_images})
+    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        s1, s2 = plan.time_stages(1, d_rgb.data_ptr())
+        ok = not plan.read(rgb=False)["status"].any()
+        per = W * H * 3
+        host = d_rgb[:2 * per].cpu().numpy()
+        for i in (0, 1):
+            ok = ok and np.array_equal(host[i * per:(i + 1) * per].reshape(W, H, 3), oracle.decode(files[i])["rgb"])
+    finally:
+        plan.close()
+    return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
+            "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3),
+            "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
+                        "scan-by-scan entropy decode + the ordinary stage 2 (BASELINE configs[4])",
+            "entropy_bytes_per_image": int(sum(map(len, raws)) // n_distinct),
+            "parity": "bit-exact vs oracle (images 0 and 1)" if ok else "MISMATCH"}
+
+
+class DeviceImageQueue:
+    """The per-GPU image queue of BASELINE configs[3]: a rank's share of the job, cut into batches whose files are
+    assembled and uploaded once (inputs resident in HBM), then decoded batch after batch — plan k+1 is created and its
+    kernels queued while plan k runs; outputs alternate between two HBM buffers (a consumer would take them from there)."""
+
+    def __init__(self, ctx, dev, torch, files, batch_size, layout):
+        from pyjpegdecoder_amd import _binding as B
+        from pyjpegdecoder_amd.batch import prepare_batch
+        self.B, self.ctx, self.torch = B, ctx, torch
+        self.batches = []
+        for i in range(0, len(files), batch_size):
+            prep = prepare_batch(files[i:i + batch_size], layout, 0)
+            self.batches.append((prep, torch.from_numpy(prep.blob).to(dev), len(files[i:i + batch_size])))
+        cap = max((sum(w * h * nc for (w, h, nc) in p.shapes) for p, _, _ in self.batches), default=0)
+        self.out = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.n_images = len(files)
+        self.bad = 0
+
+    def run(self):
+        """One pass over the whole share; returns when every batch's pixels are in HBM."""
+        B = self.B
+        prev = None
+        for k, (prep, d_blob, n) in enumerate(self.batches):
+            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+            plan.execute(0, self.out[k & 1].data_ptr())
+            if prev is not None:
+                prev.sync()
+                self.bad += int(prev.read(rgb=False)["status"].any())
+                prev.close()
+            prev = plan
+        if prev is not None:
+            prev.sync()
+            self.bad += int(prev.read(rgb=False)["status"].any())
+            prev.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
-    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to --batch)")
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: ~3 s of GPU time at the default workload)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU (weak-scaling workload)")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to the workload's size)")
+    ap.add_argument("--total-images", type=int, default=0,
+                    help="BASELINE configs[3]: ONE job of this many images sharded over the ranks, per-GPU image queue (strong scaling)")
+    ap.add_argument("--queue-batch", type=int, default=250, help="images per plan in the per-GPU queue (--total-images)")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--segment", default="host", choices=["host", "gpu"],
                     help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
     ap.add_argument("--restart-interval", type=int, default=120,
                     help="MCUs per restart segment of the synthetic files (120 = one MCU row = BASELINE configs[2]; 0 = no DRI: "
                          "one segment per image, decoded through the synchronisation passes)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for the barrier / MAX of timings (gloo: self-test on a box with fewer GPUs than ranks)")
-    ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the side measurements")
+    ap.add_argument("--no-progressive", action="store_true")
+    ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
+                    help="process group for the barrier / MAX of timings (gloo: nothing of this job needs RCCL)")
+    ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,38 +213,52 @@ def main():
 
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
+    from pyjpegdecoder_amd.sharding import max_over_ranks, shard, sum_over_ranks
     from tools import synth
 
+    layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    queue_mode = args.total_images > 0
+    if queue_mode:
+        lo, hi = shard(args.total_images, rank, world)       # this rank's images of the job
+        n_mine = hi - lo
+    else:
+        n_mine = args.batch
+
     # ---- synthetic inputs (host): the SURVEY §8d family, q85, 4:2:0, DRI = one MCU row --------------------
-    distinct = min(args.distinct, args.batch)
+    distinct = max(1, min(args.distinct, n_mine))
     t0 = time.perf_counter()
     blob, offs = synth.synth_batch(distinct, 100000 * rank, W, H, 85, "420", args.restart_interval)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
     gen_s = time.perf_counter() - t0
-    files = [raws[i % distinct] for i in range(args.batch)]
+    files = [raws[i % distinct] for i in range(n_mine)]
 
-    # ---- host side of the path: header parse + restart segmentation (Python, not timed as "step") ---------
-    t0 = time.perf_counter()
-    layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
-    if args.segment == "gpu":       # headers only; parse each distinct file once, as a caller with real files would each file
-        from pyjpegdecoder_amd import parse_jpeg
-        prep = prepare_batch(files, layout, 0, [parse_jpeg(f, headers_only=True) for f in files])
-    else:
-        prep = prepare_batch(files, layout, 0)
-    host_prep_s = time.perf_counter() - t0
-
-    # ---- device residency: torch owns the HBM buffers, libmijpeg gets raw pointers -----------------------
     ctx = B.Context(local_rank)
-    t0 = time.perf_counter()
-    d_blob = torch.from_numpy(prep.blob).to(dev)
-    torch.cuda.synchronize()
-    h2d_s = time.perf_counter() - t0
-    plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
-    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    if queue_mode:
+        queue = DeviceImageQueue(ctx, dev, torch, files, args.queue_batch, layout)
+        torch.cuda.synchronize()
+        host_prep_s, h2d_s = time.perf_counter() - t0, None
+        step = queue.run
+        plan = None
+    else:
+        # host side of the path: header parse + restart segmentation (Python, not timed as "step")
+        if args.segment == "gpu":       # headers only; parse each distinct file once, as a caller with real files would each file
+            from pyjpegdecoder_amd import parse_jpeg
+            prep = prepare_batch(files, layout, 0, [parse_jpeg(f, headers_only=True) for f in files])
+        else:
+            prep = prepare_batch(files, layout, 0)
+        host_prep_s = time.perf_counter() - t0
+        # device residency: torch owns the HBM buffers, libmijpeg gets raw pointers
+        t0 = time.perf_counter()
+        d_blob = torch.from_numpy(prep.blob).to(dev)
+        torch.cuda.synchronize()
+        h2d_s = time.perf_counter() - t0
+        plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
+        d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
 
-    def step():
-        plan.execute(stream, d_rgb.data_ptr())
+        def step():
+            plan.execute(stream, d_rgb.data_ptr())
 
     def fence():
         torch.cuda.synchronize()
@@ -147,152 +274,193 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    from pyjpegdecoder_amd.sharding import max_over_ranks
-    dt = max_over_ranks(dt, dev if args.backend == "nccl" else None)
+    dt = max_over_ranks(dt, dev if (world > 1 and args.backend == "nccl") else None)
+    images_all_ranks = int(sum_over_ranks(float(n_mine), dev if (world > 1 and args.backend == "nccl") else None))
 
-    # ---- parity spot check of what was just timed (first and last image of the batch vs the oracle) -------
-    out = plan.read(rgb=False)
-    status_bad = int(np.count_nonzero(out["status"]))
-    rgb_host = d_rgb.cpu().numpy()
+    # ---- parity spot check of what was just timed (first and last image of the rank's share vs the oracle) -------
     parity = "unchecked"
+    per = W * H * 3
+    if queue_mode:
+        status_bad = queue.bad
+        k_last = len(queue.batches) - 1
+        n_last = queue.batches[k_last][2]
+        got_last = queue.out[k_last & 1][(n_last - 1) * per:n_last * per].cpu().numpy()
+        queue.batches = queue.batches[:1]                     # image 0: decode the first batch once more
+        queue.run()
+        got_first = queue.out[0][:per].cpu().numpy()
+        checks = [(0, got_first), (n_mine - 1, got_last)]
+    else:
+        out = plan.read(rgb=False)
+        status_bad = int(np.count_nonzero(out["status"]))
+        rgb_host = d_rgb.cpu().numpy()
+        checks = [(i, rgb_host[i * per:(i + 1) * per]) for i in (0, args.batch - 1)]
     if rank == 0:
         from oracle import oracle
-        per = W * H * 3
         ok = status_bad == 0
-        for i in (0, args.batch - 1):
+        for i, got in checks:
             ref = oracle.decode(files[i])["rgb"]
-            got = rgb_host[i * per:(i + 1) * per].reshape(ref.shape if args.layout == "xmajor" else (H, W, 3))
+            got = got.reshape(ref.shape if args.layout == "xmajor" else (H, W, 3))
             if args.layout != "xmajor":
                 got = np.swapaxes(got, 0, 1)
             ok = ok and np.array_equal(got, ref)
-        parity = "bit-exact vs oracle (images 0 and last)" if ok else "MISMATCH"
+        parity = "bit-exact vs oracle (first and last image of rank 0's share)" if ok else "MISMATCH"
 
-    # ---- per-kernel device times, HIP events on the launch stream ------------------------------------------
-    s1_ms, s2_ms = plan.time_stages(5, d_rgb.data_ptr())
-    # second denominator SURVEY 8d asks for: what a plain device-to-device copy of the output buffer achieves here
-    copy_gbs = None
-    try:
-        d_tmp = torch.empty_like(d_rgb)
-        d_tmp.copy_(d_rgb)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            d_tmp.copy_(d_rgb)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = round(2 * d_rgb.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-        del d_tmp
-    except Exception:
-        pass
-    ent_bytes = plan.info.entropy_bytes
-    s1_bytes = ent_bytes + args.batch * BLOCKS_PER_IMAGE * 128
-    s2_bytes = args.batch * STAGE2_BYTES_PER_IMAGE
+    base_cfg = "BASELINE configs[3]" if queue_mode else "BASELINE configs[2]"
+    std = args.restart_interval == 120 and (queue_mode or args.batch == 1024)
+    if queue_mode:
+        workload = (f"one job of {args.total_images} x 1920x1080 4:2:0 baseline JPEG, q85, DRI={args.restart_interval}, sharded over {world} GPU(s) "
+                    f"({n_mine} images on rank 0), per-GPU image queue of {args.queue_batch}-image plans over HBM-resident files, "
+                    f"on-GPU Huffman + dequant/IDCT/upsample/RGB" + (f" ({base_cfg})" if std and args.total_images == 10000 else " (NOT a BASELINE configuration)"))
+    else:
+        workload = (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, " +
+                    ("DRI=120 (one MCU row, 68 segments/image)" if args.restart_interval == 120 else f"restart interval {args.restart_interval}") +
+                    ", on-GPU Huffman + dequant/IDCT/upsample/RGB" + (f" ({base_cfg})" if std else " (NOT the BASELINE configuration)"))
 
-    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench);
-    # only quoted when the workload is the one that was profiled, else null
-    traffic = {}
-    tfiles = sorted((ROOT / "profiles").glob("r*_hbm_traffic_batch1024.json"))      # newest round's passes
-    tfile = tfiles[-1] if tfiles else None
-    if args.batch == 1024 and args.layout == "xmajor" and tfile is not None:
-        for k, d in json.loads(tfile.read_text())["kernels"].items():
-            if "traffic_bytes_per_launch" in d:
-                if "huffman" in k or "destuff" in k or "scan_markers" in k:      # stage 0 + stage 1 launches of one step
-                    traffic["stage1"] = traffic.get("stage1", 0) + int(d["traffic_bytes_per_launch"])
-                elif "reconstruct" in k:
-                    traffic["stage2"] = int(d["traffic_bytes_per_launch"])
-
-    def roof(name, nbytes, ms, note, tkey):
-        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey),
-                "traffic_source": f"profiles/{tfile.name} (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else None,
-                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4),
-                "device_copy_gbs": copy_gbs, "frac_of_device_copy": round(gbs / copy_gbs, 4) if copy_gbs else None,
-                "note": note}
-
-    r1 = roof("k_destuff + k_huffman_lanes (stage 0+1: byte-drop pass + Huffman decode; k_scan_markers too with --segment gpu)", s1_bytes, s1_ms,
-              "entropy bytes read + 128 B/block coefficients written; serial-decode (instruction issue) bound, quoted against HBM as SURVEY §8d asks",
-              "stage1")
-    r2 = roof("k_reconstruct_fast (stage 2: dequant+IDCT+upsample+colour)", s2_bytes, s2_ms,
-              "128 B/block read + 3 B/pixel written = 12 487 680 B per 1080p image", "stage2")
-    dominant, other = (r1, r2) if s1_ms >= s2_ms else (r2, r1)
-
+    line = None
     if rank == 0:
-        mp = world * args.batch * W * H / 1e6
+        mp_total = images_all_ranks * W * H / 1e6
         line = {
             "metric": "megapixels/sec decoded (1080p 4:2:0 baseline batch)",
-            "value": round(mp * args.steps / dt, 1), "unit": "MP/s",
+            "value": round(mp_total * args.steps / dt, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, DRI=120 (one MCU row, 68 segments/image), "
-                                    "on-GPU Huffman + dequant/IDCT/upsample/RGB (BASELINE configs[2])") if args.restart_interval == 120 else
-                                   (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, restart interval {args.restart_interval} "
-                                    "(NOT the BASELINE configuration)"),
-                       "images_per_gpu": args.batch, "distinct_images_per_gpu": distinct, "layout": args.layout, "restart_segmentation": args.segment,
-                       "entropy_bytes_per_image": int(ent_bytes // args.batch), "parallelism": f"image-sharded x{world}, no collective"},
-            "roofline": dominant, "roofline_other_stage": other,
+            "higher_is_better": True, "scaling": "strong" if queue_mode else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "images_per_gpu": n_mine, "images_all_gpus": images_all_ranks,
+                       "distinct_images_per_gpu": distinct, "layout": args.layout,
+                       "restart_segmentation": "host" if queue_mode else args.segment,
+                       "entropy_bytes_per_image": int(sum(map(len, raws)) // distinct),
+                       "parallelism": f"image-sharded x{world}, no collective on the data path (gloo barrier + MAX of timings only)"},
+            "timed_region_s": round(dt, 3),
             "parity": parity,
-            "host": {"synth_encode_s": round(gen_s, 2), "parse_and_segment_s": round(host_prep_s, 2), "h2d_blob_s": round(h2d_s, 3),
+            "host": {"synth_encode_s": round(gen_s, 2), "parse_segment_assemble_s": round(host_prep_s, 2),
+                     "h2d_blob_s": None if h2d_s is None else round(h2d_s, 3),
                      "note": "outside the timed region; inputs are HBM-resident when timing starts"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(raws[:64])
-        if world == 1 and not args.no_cpu_baseline and args.restart_interval == 120:
-            # beside the headline: the same images written WITHOUT restart markers (one serial bitstream per image, the
-            # usual case in the wild), decoded through the synchronisation passes; not BASELINE's configuration
+
+    # ---- roofline of the two stages: HIP events on the launch stream, algorithmic bytes per launch ----------------
+    if rank == 0 and not queue_mode:
+        s1_ms, s2_ms = plan.time_stages(10, d_rgb.data_ptr())
+        copy_gbs = None
+        try:                                    # second denominator SURVEY 8d asks for: a plain device-to-device copy here
+            d_tmp = torch.empty_like(d_rgb)
+            d_tmp.copy_(d_rgb)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                d_tmp.copy_(d_rgb)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(2 * d_rgb.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del d_tmp
+        except Exception:
+            pass
+        ent_bytes = plan.info.entropy_bytes
+        s1_bytes = ent_bytes + args.batch * BLOCKS_PER_IMAGE * 128
+        s2_bytes = args.batch * STAGE2_BYTES_PER_IMAGE
+        # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the bench): quoted
+        # only for the workload that was profiled AND for the kernel sources the passes were taken from
+        traffic, tnote = {}, None
+        tfiles = sorted((ROOT / "profiles").glob("r*_hbm_traffic_batch1024.json"))
+        tfile = tfiles[-1] if tfiles else None
+        if args.batch == 1024 and args.layout == "xmajor" and args.restart_interval == 120 and tfile is not None:
+            td = json.loads(tfile.read_text())
+            if td.get("sources_sha16") == sources_sha16():
+                for k, d in td["kernels"].items():
+                    if "traffic_bytes_per_launch" in d:
+                        if "huffman" in k or "destuff" in k or "scan_markers" in k or "sync" in k or "vsegs" in k:
+                            traffic["stage1"] = traffic.get("stage1", 0) + int(d["traffic_bytes_per_launch"])
+                        elif "reconstruct" in k:
+                            traffic["stage2"] = int(d["traffic_bytes_per_launch"])
+            else:
+                tnote = f"profiles/{tfile.name} was taken from other kernel sources ({td.get('sources_sha16')} != {sources_sha16()}): not quoted"
+
+        def roof(name, nbytes, ms, note, tkey):
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(tkey),
+                    "traffic_source": (f"profiles/{tfile.name} (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)" if tkey in traffic else tnote),
+                    "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(ms, 4),
+                    "device_copy_gbs": copy_gbs, "frac_of_device_copy": round(gbs / copy_gbs, 4) if copy_gbs else None,
+                    "note": note}
+
+        form = {B.MJ_FORM_WAVE: "k_huffman", B.MJ_FORM_LANES: "k_destuff + k_huffman_lanes",
+                B.MJ_FORM_SYNC: "k_destuff + k_sync_count + k_build_vsegs + k_huffman_lanes"}.get(plan.stage1_form() & 15, "stage 1")
+        r1 = roof(f"{form} (stage 0+1: byte-drop pass + Huffman decode; k_scan_markers too with --segment gpu)", s1_bytes, s1_ms,
+                  "entropy bytes read + 128 B/block coefficients written; serial-decode (instruction issue) bound, quoted against HBM as SURVEY §8d asks",
+                  "stage1")
+        r2 = roof("k_reconstruct_fast (stage 2: dequant+IDCT+upsample+colour)", s2_bytes, s2_ms,
+                  "128 B/block read + 3 B/pixel written = 12 487 680 B per 1080p image", "stage2")
+        line["roofline"], line["roofline_other_stage"] = (r1, r2) if s1_ms >= s2_ms else (r2, r1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(raws[:64])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not queue_mode and args.restart_interval == 120:
+        if plan is not None:
+            plan.close()
+        if not args.no_progressive:
             try:
-                plan.close()
-                nb, nd = 256, 32
-                blob2, offs2 = synth.synth_batch(nd, 700000, W, H, 85, "420", 0)
-                raws2 = [blob2[int(offs2[i]):int(offs2[i + 1])].tobytes() for i in range(nd)]
-                prep2 = prepare_batch([raws2[i % nd] for i in range(nb)], layout, 0)
-                d_blob2 = torch.from_numpy(prep2.blob).to(dev)
-                plan2 = B.Plan(ctx, prep2.to_c(d_blob2.data_ptr()), {"prep": prep2, "n_images": nb})
-                d_rgb2 = d_rgb[:plan2.info.rgb_bytes]
-                plan2.execute(stream, d_rgb2.data_ptr()); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    plan2.execute(stream, d_rgb2.data_ptr())
-                torch.cuda.synchronize()
-                dt2 = (time.perf_counter() - t0) / 5
-                ok2 = np.array_equal(d_rgb2[:W * H * 3].cpu().numpy().reshape((W, H, 3) if args.layout == "xmajor" else (H, W, 3)),
-                                     oracle.decode(raws2[0])["rgb"] if args.layout == "xmajor" else np.swapaxes(oracle.decode(raws2[0])["rgb"], 0, 1))
-                line["without_restart_markers"] = {"value": round(nb * W * H / 1e6 / dt2, 1), "unit": "MP/s", "ms_per_step": round(dt2 * 1e3, 3),
-                                                   "workload": f"{nb} x 1920x1080 4:2:0 baseline JPEG, q85, no DRI (one segment per image)",
-                                                   "parity": "bit-exact vs oracle (image 0)" if ok2 else "MISMATCH"}
-                plan2.close()
+                line["progressive"] = progressive_side(ctx, dev, torch)
             except Exception as exc:
-                line["without_restart_markers"] = {"error": str(exc)}
-            # and the PCIe-inclusive rate of the public API (never `value`): file bytes in host memory -> pixels in HBM,
-            # batches back to back (BatchDecoder.decode_device_iter: the next batch's header parse + upload run under the
-            # current batch's kernels), restart markers found on the GPU
-            try:
-                from pyjpegdecoder_amd import BatchDecoder
-                nb = 512
-                files = [raws[i % len(raws)] for i in range(nb)]
-                bd = BatchDecoder(dev.index or 0, layout=args.layout, segment="gpu")
-                for _ in bd.decode_device_iter(files for _ in range(3)):
-                    pass
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                n_it = 8
-                for out in bd.decode_device_iter(files for _ in range(n_it)):
-                    pass
-                torch.cuda.synchronize()
-                dt3 = (time.perf_counter() - t0) / n_it
-                del out
-                bd.close()
-                line["host_bytes_to_device_pixels"] = {"value": round(nb * W * H / 1e6 / dt3, 1), "unit": "MP/s", "ms_per_batch": round(dt3 * 1e3, 3),
-                                                       "workload": f"{n_it} batches of {nb} of the files above through BatchDecoder(segment='gpu').decode_device_iter",
-                                                       "note": "includes header parse, batch assembly, H2D of the files and plan creation; PCIe-inclusive, not `value`"}
-            except Exception as exc:
-                line["host_bytes_to_device_pixels"] = {"error": str(exc)}
+                line["progressive"] = {"error": repr(exc)}
+        # beside the headline: the same images written WITHOUT restart markers (one serial bitstream per image, the
+        # usual case in the wild), decoded through the synchronisation passes; not BASELINE's configuration
+        try:
+            from oracle import oracle
+            nb, nd = 256, 32
+            blob2, offs2 = synth.synth_batch(nd, 700000, W, H, 85, "420", 0)
+            raws2 = [blob2[int(offs2[i]):int(offs2[i + 1])].tobytes() for i in range(nd)]
+            prep2 = prepare_batch([raws2[i % nd] for i in range(nb)], layout, 0)
+            d_blob2 = torch.from_numpy(prep2.blob).to(dev)
+            plan2 = B.Plan(ctx, prep2.to_c(d_blob2.data_ptr()), {"prep": prep2, "n_images": nb})
+            d_rgb2 = d_rgb[:plan2.info.rgb_bytes]
+            for _ in range(3):
+                plan2.execute(stream, d_rgb2.data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                plan2.execute(stream, d_rgb2.data_ptr())
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 10
+            want = oracle.decode(raws2[0])["rgb"]
+            ok2 = np.array_equal(d_rgb2[:W * H * 3].cpu().numpy().reshape((W, H, 3) if args.layout == "xmajor" else (H, W, 3)),
+                                 want if args.layout == "xmajor" else np.swapaxes(want, 0, 1))
+            line["without_restart_markers"] = {"value": round(nb * W * H / 1e6 / dt2, 1), "unit": "MP/s", "ms_per_step": round(dt2 * 1e3, 3),
+                                               "workload": f"{nb} x 1920x1080 4:2:0 baseline JPEG, q85, no DRI (one segment per image)",
+                                               "parity": "bit-exact vs oracle (image 0)" if ok2 else "MISMATCH"}
+            plan2.close()
+        except Exception as exc:
+            line["without_restart_markers"] = {"error": repr(exc)}
+        # and the PCIe-inclusive rate of the public API (never `value`): file bytes in host memory -> pixels in HBM,
+        # batches back to back (BatchDecoder.decode_device_iter: the next batch's header parse + upload run under the
+        # current batch's kernels), restart markers found on the GPU
+        try:
+            from pyjpegdecoder_amd import BatchDecoder
+            nb = 512
+            files3 = [raws[i % len(raws)] for i in range(nb)]
+            bd = BatchDecoder(dev.index or 0, layout=args.layout, segment="gpu")
+            for _ in bd.decode_device_iter(files3 for _ in range(3)):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_it = 8
+            for out3 in bd.decode_device_iter(files3 for _ in range(n_it)):
+                pass
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t0) / n_it
+            del out3
+            bd.close()
+            line["host_bytes_to_device_pixels"] = {"value": round(nb * W * H / 1e6 / dt3, 1), "unit": "MP/s", "ms_per_batch": round(dt3 * 1e3, 3),
+                                                   "workload": f"{n_it} batches of {nb} of the files above through BatchDecoder(segment='gpu').decode_device_iter",
+                                                   "note": "includes header parse, batch assembly, H2D of the files and plan creation; PCIe-inclusive, not `value`"}
+        except Exception as exc:
+            line["host_bytes_to_device_pixels"] = {"error": repr(exc)}
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
-    plan.close()          # (idempotent)
+    if plan is not None:
+        plan.close()          # (idempotent)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_index, golden_names, load_golden
+from conftest import GOLDEN, ROOT, golden_index, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -1115,3 +1115,61 @@ def test_planar_layouts(layout):
             assert np.array_equal(t.cpu().numpy(), want), n
     finally:
         d.close()
+
+
+def test_config5_progressive_1080p_batch_at_size(dec):
+    """BASELINE configs[4] at its stated size: 1024 x 1080p 4:2:0 progressive (libjpeg's default 10-scan script as Pillow
+    writes it; 8 distinct files tiled).  Two images against the oracle, every replica against its first instance."""
+    import io
+    torch = pytest.importorskip("torch")
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, nd, n = 1920, 1080, 8, 1024
+    raws = []
+    for i in range(nd):
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(7700 + i, W, H)).save(b, "JPEG", quality=85, subsampling=2, progressive=True)
+        raws.append(b.getvalue())
+    files = [raws[i % nd] for i in range(n)]
+    dev = torch.device("cuda", 0)
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+    try:
+        assert plan.stage1_form() & 15 == B.MJ_FORM_SCANS
+        d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        plan.execute(0, d_rgb.data_ptr())
+        plan.sync()
+        assert not plan.read(rgb=False)["status"].any()
+        per = W * H * 3
+        imgs = d_rgb.view(n, per)
+        for i in (0, 5):
+            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), oracle.decode(raws[i])["rgb"]), i
+        first = imgs[:nd]
+        for k in range(1, n // nd):
+            assert torch.equal(imgs[k * nd:(k + 1) * nd], first), k
+    finally:
+        plan.close()
+
+
+def test_config4_sharded_queue_two_ranks_on_one_gpu():
+    """BASELINE configs[3]'s driver — `bench.py --total-images N`: one job sharded over the ranks, a per-GPU image queue on
+    each, timings aggregated over gloo — run here as two processes sharing cuda:0 on a small job."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--total-images", "50", "--queue-batch", "8",
+           "--distinct", "6", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["images_all_gpus"] == 50 and line["config"]["images_per_gpu"] == 25
+    assert line["parity"].startswith("bit-exact")
+    assert abs(line["value"] - 50 * 1920 * 1080 / 1e6 * 2 / line["timed_region_s"]) < 0.01 * line["value"]

@@ -10,6 +10,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from bench import sources_sha16       # noqa: E402  (bench.py quotes the traffic only for the sources it was taken from)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01x"
 src = ROOT / "gpurun_out" / f"prof_{tag}"
 dst = ROOT / "profiles"
@@ -27,12 +29,12 @@ def per_kernel(pattern):
     for f in glob.glob(str(src / pattern / "*" / "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if any(w in k for w in ("huffman", "reconstruct", "progressive", "destuff", "scan_markers")):
+            if any(w in k for w in ("huffman", "reconstruct", "progressive", "destuff", "scan_markers", "sync", "vsegs", "planes")):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
-traffic = {"note": "rocprofv3 --pmc passes (one counter set per pass, tools/profile_round.sh) of `python3 bench.py --steps 1 "
+traffic = {"sources_sha16": sources_sha16(), "note": "rocprofv3 --pmc passes (one counter set per pass, tools/profile_round.sh) of `python3 bench.py --steps 1 "
                    "--warmup 1 --no-cpu-baseline` on MI355X, 1024 x 1080p 4:2:0 DRI=120 per launch; values are per kernel launch "
                    "(mean over the launches of the run). FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE counts "
                    "half the bytes of a wide coalesced streaming read on gfx950, so hbm_read_bytes_corrected = 2 * FETCH_SIZE * 1024 "
@@ -53,7 +55,7 @@ for k, d in traffic["kernels"].items():
     d["traffic_bytes_per_launch"] = d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"]
 (dst / f"{tag}_hbm_traffic_batch1024.json").write_text(json.dumps(traffic, indent=1) + "\n")
 
-sq = {"note": "SQ counters per kernel launch (mean), same command as the traffic file; SQ_* are summed over all SEs/CUs.",
+sq = {"sources_sha16": sources_sha16(), "note": "SQ counters per kernel launch (mean), same command as the traffic file; SQ_* are summed over all SEs/CUs.",
       "kernels": {}}
 for pat in ("pmc_SQ_WAVE_CYCLES", "pmc_SQ_LDS_BANK_CO"):
     for k, d in per_kernel(pat).items():
