@@ -1236,6 +1236,9 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
             MJ_HIP(ctx, hipEventSynchronize(e1));
             MJ_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
             *stage1_ms = ms / iters;
+#ifdef MJ_DIAGNOSTIC
+            mj::dbg_lanes_report();
+#endif
         }
     }
     if (stage2_ms && rc == MJ_OK) {

@@ -21,11 +21,25 @@
 //   * coefficients: each lane owns a 128-byte block in LDS (row stride 132 B -> conflict-free scatter of
 //     "coefficient kk of every lane"); a finished round of 64 blocks leaves as 32 store instructions that each
 //     write two full 128-byte lines, in the natural [v][u] order stage 2 reads.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "mijpeg_internal.h"
 
 namespace mj {
+
+#ifdef MJ_DIAGNOSTIC
+__device__ unsigned long long g_dbg_lanes[4];        // MJ_DEBUG_STAGE1=3: cycles per loop segment, summed over waves
+void dbg_lanes_report() {
+    unsigned long long h[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_lanes), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_lanes), z, sizeof(z));
+    const double tot = (double)h[0] + (double)h[1] + (double)h[2] + (double)h[3];
+    if (tot > 0)
+        fprintf(stderr, "[mijpeg diag] lanes kernel, share of wave time: loop test + refill %.1f %%, first symbol %.1f %%, second symbol %.1f %%, "
+                        "DC + flush + clear %.1f %%\n", 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot);
+}
+#endif
 
 namespace {
 
@@ -73,6 +87,17 @@ __device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb
     if (want) s.nxtw = *reinterpret_cast<const uint32_t *>(streamb + s.voff);     // every lane reads its own cache line: only who needs it
 }
 
+__device__ __forceinline__ int opaque(int x) {      // the value, with its provenance hidden from the optimiser (no instruction)
+    asm("" : "+v"(x));
+    return x;
+}
+
+__device__ __forceinline__ uint32_t bfm0(uint32_t n) {      // (1 << n) - 1 in one instruction
+    uint32_t r;
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(r) : "v"(n));
+    return r;
+}
+
 __device__ __forceinline__ int extend(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0
     const int half = (1 << n) >> 1;
     return (int)raw - (((int)raw < half) ? ((1 << n) - 1) : 0);
@@ -95,6 +120,10 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                                                        const DevVSeg *__restrict__ vsegs /* or null */,
                                                        const int32_t *__restrict__ wg_tabs /* WGT: [gridDim.x][kMaxWgTables], -1 = unused */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef MJ_DIAGNOSTIC
+    const int dbg = tr >> 8;          // MJ_DEBUG_STAGE1 of the diagnostic build: 1 = no coefficient stores, 2 = no stream refill loads
+    tr &= 1;
+#endif
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);                          // [n_huff][kLSize]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,6 +231,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
 
     const uint64_t full_mask = lpw >= 64 ? ~0ull : (1ull << lpw) - 1;
+#ifdef MJ_DIAGNOSTIC
+    uint64_t dacc[4] = {0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
+#endif
     for (int m = 0; m < max_mcu; ++m) {
         const bool in_mcu = m < n_mcu;
         for (int b = 0; b < bpm; ++b) {
@@ -245,53 +277,70 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             // LUT entry = len << 11 | run << 4 | size; the end-of-block symbol carries run = 64, so "kk >= 64" covers
             // both :849 and :855-856 (the value bits stay unread in both cases).
             const uint16_t *alut = s_lut + act_ * kLSize;
-            // One symbol of this lane: look up, EXTEND, store, consume.  Lanes that sit this one out (`on` false) read the
-            // null entry instead of their LUT — length 0, run 64, size 0 — and fall through the same straight-line code
-            // without consuming or storing anything; `parked` says whether k may be set to 64 for them (true when they
-            // are at their end of block anyway, false when they only wait for more bits).
-            auto symbol = [&](bool on, bool parked) {
+            // One symbol of this lane: look up, EXTEND, store, consume — straight-line, and written for what gfx950 issues at
+            // full rate (add / sub / and / or / shift-right: 2 cycles per wave; compares, selects, shift-left, bit-field
+            // extracts: 4 — tools/issue_rate_probe.hip).  `onm` is all ones for a lane that takes a symbol now and zero for
+            // one that sits it out (block finished, or — second symbol of an iteration — waiting for more bits): such a
+            // lane looks up whatever its buffer shows and the mask turns everything it would do into nothing: no bits
+            // consumed, the store goes to the row's pad slot, k keeps its value (`keep_k`) or becomes "finished".
+            // k: index of the next coefficient; >= 64 = this lane's block is finished (64 or 65).
+            auto symbol = [&](int onm, bool keep_k) {
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
-                const uint16_t *ep = alut + (hi >> (32 - kLBits));
-                const int e = *(on ? ep : s_null);
-                int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
-                if (e < 2048) {                                               // code longer than 11 bits: rare (the branch
-                    const int r = long_code(huff + acg, hi >> 16);            // is skipped when no lane has one)
+                const int e = alut[hi >> (32 - kLBits)];
+                int ln = e >> 11, run = (e >> 4) & 127, size = e & 15;
+                if (((e - 2048) & onm) < 0) {                                   // code longer than 11 bits: rare (the branch
+                    const int r = long_code(huff + acg, hi >> 16);             // is skipped when no lane has one)
                     err = r < 0 ? MJ_ST_BAD_CODE : err;
                     const int hv = r & 0xFF;
                     ln = r < 0 ? 0 : r >> 8;
                     run = (r < 0 || hv == 0) ? 64 : hv >> 4;
                     size = r < 0 ? 0 : hv & 15;
                 }
+                // (opaque(): keeps the compiler from turning sign-smear masks back into compare + select pairs, 8 cycles
+                // where sub + shift + and are 6 and need no condition register)
                 const int kk = k + run;
-                const bool val = kk < 64;                                      // not end of block (:849), not past it (:855-856)
-                const int n = val ? size : 0;                                  // else the value bits stay unread
-                const uint32_t hw = hi << ln;                                  // ln + n <= 31 <= bc
-                // EXTEND (bin_twos_complement, :1636-1646) of the n bits at the top of hw: a leading 1 is the value
-                // itself, a leading 0 is value - (2^n - 1).  n = 0 (a run of 16, or nothing to do) gives 0, stored over a
-                // coefficient that is still 0, or into the row's pad slot (index 64) when the block is over.
-                const uint32_t lead = (uint32_t)((int32_t)hw >> 31);           // all ones for a leading 1
-                const uint32_t raw = __builtin_amdgcn_ubfe(hw, (uint32_t)(32 - n) & 31u, (uint32_t)n);
-                const uint32_t ones = ((1u << n) - 1u) & ~lead;
-                myblk16[min(kk, 64)] = (int16_t)(raw - ones);                  // zig-zag order; the flush permutes
-                br.bb <<= ln + n;
-                br.bc -= ln + n;
-                const int knew = val ? kk + 1 : 64;
-                k = parked ? knew : (on ? knew : k);
+                const int m = opaque((kk - 64) >> 31) & onm;                   // a value follows: not end of block (:849), not past it (:855-856)
+                const int n = size & m;                                        // else the value bits stay unread
+                const int tot = (ln & onm) + n;                                // <= 31 <= bc
+                // EXTEND (bin_twos_complement, :1636-1646) of the n bits behind the code: a leading 1 is the value itself, a
+                // leading 0 is value - (2^n - 1).  2*raw - (2^n - 1) is negative exactly for a leading 0 (and 0 for n = 0).
+                const uint32_t raw = __builtin_amdgcn_ubfe(hi, (uint32_t)(32 - tot), (uint32_t)n);
+                const uint32_t ones = bfm0((uint32_t)n);                       // 2^n - 1
+                const int lead0 = opaque((int)(raw + (uint32_t)opaque((int)raw)) - (int)ones) >> 31;
+                const int slot = (kk & m) | (64 & ~m);                         // zig-zag order (the flush permutes); 64 = the row's pad slot
+                myblk16[slot] = (int16_t)(raw - (ones & (uint32_t)lead0));
+                br.bb <<= tot;
+                br.bc -= tot;
+                const int knew = slot + 1;                                      // kk + 1, or 65 = finished
+                k = keep_k ? ((knew & onm) | (k & ~onm)) : knew;
             };
             // Two symbols per iteration: the refill, the loop test and the register shuffling at the loop head are paid
             // once.  After a refill the buffer holds >= 33 bits; the second symbol goes ahead when >= 31 are left
             // (16 code bits + 15 value bits is the longest symbol), else it simply waits for the next iteration.
+#ifdef MJ_DIAGNOSTIC
+#define LSTAMP(i) do { if (dbg == 3) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dacc[i] += s_ - dlast; dlast = s_; } } while (0)
+            LSTAMP(3);        // DC symbol, flush, clear, loop set-up
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
             while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
                 refill(br, streamb);
-                symbol(k < 64, true);
-                symbol(k < 64 && br.bc >= 31, false);
+                LSTAMP(0);    // loop test + refill (the wait for the stream word is here)
+                symbol(opaque((k - 64) >> 31), false);
+                LSTAMP(1);    // first symbol
+                symbol(opaque(((k - 64) & (30 - br.bc)) >> 31), true);
+                LSTAMP(2);    // second symbol
             }
             // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
             err = (act && err == 0 && consumed() > nbits) ? MJ_ST_OVERRUN : err;
             // ---- round of 64 blocks done: LDS -> HBM, two full lines per instruction, and clear
             // lane (o, dw) moves the two coefficients of natural positions 2dw, 2dw+1 of block o: they are read from
             // their zig-zag slots, so the block lands in HBM in the natural [v][u] order stage 2 wants
+#ifdef MJ_DIAGNOSTIC
+            const uint64_t act_mask = dbg == 1 ? 0ull : __ballot(in_mcu);
+#else
             const uint64_t act_mask = __ballot(in_mcu);
+#endif
             const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
             const int half = lane >> 5, dw = lane & 31;
             unsigned char *dst0 = reinterpret_cast<unsigned char *>(coef) + blk_byte + dw * 4;
@@ -325,6 +374,11 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
         }
     }
 
+#ifdef MJ_DIAGNOSTIC
+    if (dbg == 3 && lane == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_dbg_lanes[i], (unsigned long long)dacc[i]);
+    }
+#endif
     if (have) {
         // bits left over: a whole unread byte before the next restart marker means the count-driven reference and the
         // marker-driven segmentation disagree (:898-900)
@@ -377,6 +431,9 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     if (n_segs == 0) return hipSuccess;
     const int n_slots = wg_tabs ? wg_slots : n_huff;
     const int lpw_run = lanes_per_wave(n_segs, n_slots);
+#ifdef MJ_DIAGNOSTIC
+    if (const char *e = getenv("MJ_DEBUG_STAGE1")) transposed |= atoi(e) << 8;
+#endif
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
     const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;

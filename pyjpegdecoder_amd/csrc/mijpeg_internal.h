@@ -142,6 +142,9 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegm
                           const DevImage *images, const DevHuff *huff, int16_t *coef, int32_t *status,
                           int lut_slots, int transposed);
 
+#ifdef MJ_DIAGNOSTIC
+void dbg_lanes_report();     // huffman_lanes.hip: prints and clears the in-loop stamps of MJ_DEBUG_STAGE1=3
+#endif
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
 constexpr int kLaneLutBits = 11;
 constexpr int kMaxLaneTables = 8;
