@@ -8,7 +8,7 @@ LAYOUT=${2:-xmajor}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
-timeout 900 python3 "$R/bench.py" --layout "$LAYOUT" > "$O/bench.json" 2> "$O/bench.err"
+timeout 1200 python3 "$R/bench.py" --layout "$LAYOUT" > "$O/bench.json" 2> "$O/bench.err"
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- \
     python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --layout "$LAYOUT" > "$O/stats.log" 2>&1
