@@ -277,42 +277,39 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             // LUT entry = len << 11 | run << 4 | size; the end-of-block symbol carries run = 64, so "kk >= 64" covers
             // both :849 and :855-856 (the value bits stay unread in both cases).
             const uint16_t *alut = s_lut + act_ * kLSize;
-            // One symbol of this lane: look up, EXTEND, store, consume — straight-line, and written for what gfx950 issues at
-            // full rate (add / sub / and / or / shift-right: 2 cycles per wave; compares, selects, shift-left, bit-field
-            // extracts: 4 — tools/issue_rate_probe.hip).  `onm` is all ones for a lane that takes a symbol now and zero for
-            // one that sits it out (block finished, or — second symbol of an iteration — waiting for more bits): such a
-            // lane looks up whatever its buffer shows and the mask turns everything it would do into nothing: no bits
-            // consumed, the store goes to the row's pad slot, k keeps its value (`keep_k`) or becomes "finished".
+            // One symbol of this lane: look up, EXTEND, store, consume — straight-line select code, written for the fewest
+            // instructions: what bounds this kernel is the number of instructions on each wave's serial path (a wave issues
+            // one every ~5 cycles at best, tools/issue_rate_probe.hip, and all segments are in flight at once), not their
+            // cost on the SIMD.  Lanes that sit a symbol out (`on` false: block finished, or — second symbol of an
+            // iteration — waiting for more bits) read the null entry instead of their LUT — length 0, run 64, size 0 —
+            // and fall through the same code without consuming or storing anything.
             // k: index of the next coefficient; >= 64 = this lane's block is finished (64 or 65).
-            auto symbol = [&](int onm, bool keep_k) {
+            auto symbol = [&](bool on, bool keep_k) {
                 const uint32_t hi = (uint32_t)(br.bb >> 32);
-                const int e = alut[hi >> (32 - kLBits)];
-                int ln = e >> 11, run = (e >> 4) & 127, size = e & 15;
-                if (((e - 2048) & onm) < 0) {                                   // code longer than 11 bits: rare (the branch
-                    const int r = long_code(huff + acg, hi >> 16);             // is skipped when no lane has one)
+                const uint16_t *ep = alut + (hi >> (32 - kLBits));
+                const int e = *(on ? ep : s_null);
+                int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
+                if (e < 2048) {                                               // code longer than 11 bits: rare (the branch
+                    const int r = long_code(huff + acg, hi >> 16);            // is skipped when no lane has one)
                     err = r < 0 ? MJ_ST_BAD_CODE : err;
                     const int hv = r & 0xFF;
                     ln = r < 0 ? 0 : r >> 8;
                     run = (r < 0 || hv == 0) ? 64 : hv >> 4;
                     size = r < 0 ? 0 : hv & 15;
                 }
-                // (opaque(): keeps the compiler from turning sign-smear masks back into compare + select pairs, 8 cycles
-                // where sub + shift + and are 6 and need no condition register)
                 const int kk = k + run;
-                const int m = opaque((kk - 64) >> 31) & onm;                   // a value follows: not end of block (:849), not past it (:855-856)
-                const int n = size & m;                                        // else the value bits stay unread
-                const int tot = (ln & onm) + n;                                // <= 31 <= bc
+                const int n = kk < 64 ? size : 0;                              // not end of block (:849), not past it (:855-856): else the value bits stay unread
+                const int tot = ln + n;                                        // <= 31 <= bc
                 // EXTEND (bin_twos_complement, :1636-1646) of the n bits behind the code: a leading 1 is the value itself, a
-                // leading 0 is value - (2^n - 1).  2*raw - (2^n - 1) is negative exactly for a leading 0 (and 0 for n = 0).
+                // leading 0 is value - (2^n - 1); the leading bit is 0 exactly when 2*raw <= 2^n - 1.
                 const uint32_t raw = __builtin_amdgcn_ubfe(hi, (uint32_t)(32 - tot), (uint32_t)n);
-                const uint32_t ones = bfm0((uint32_t)n);                       // 2^n - 1
-                const int lead0 = opaque((int)(raw + (uint32_t)opaque((int)raw)) - (int)ones) >> 31;
-                const int slot = (kk & m) | (64 & ~m);                         // zig-zag order (the flush permutes); 64 = the row's pad slot
-                myblk16[slot] = (int16_t)(raw - (ones & (uint32_t)lead0));
+                const uint32_t ones = bfm0((uint32_t)n);
+                const int slot = min(kk, 64);                                  // zig-zag order (the flush permutes); 64 = the row's pad slot
+                myblk16[slot] = (int16_t)(raw - ((raw << 1) <= ones ? ones : 0u));
                 br.bb <<= tot;
                 br.bc -= tot;
                 const int knew = slot + 1;                                      // kk + 1, or 65 = finished
-                k = keep_k ? ((knew & onm) | (k & ~onm)) : knew;
+                k = keep_k ? (on ? knew : k) : knew;
             };
             // Two symbols per iteration: the refill, the loop test and the register shuffling at the loop head are paid
             // once.  After a refill the buffer holds >= 33 bits; the second symbol goes ahead when >= 31 are left
@@ -326,9 +323,9 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             while (__builtin_amdgcn_ballot_w64(k < 64) != 0) {
                 refill(br, streamb);
                 LSTAMP(0);    // loop test + refill (the wait for the stream word is here)
-                symbol(opaque((k - 64) >> 31), false);
+                symbol(k < 64, false);
                 LSTAMP(1);    // first symbol
-                symbol(opaque(((k - 64) & (30 - br.bc)) >> 31), true);
+                symbol(k < 64 && br.bc >= 31, true);
                 LSTAMP(2);    // second symbol
             }
             // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
