@@ -136,10 +136,12 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
 
 class DeviceImageQueue:
     """The per-GPU image queue of BASELINE configs[3]: a rank's share of the job, cut into batches whose files are
-    assembled and uploaded once (inputs resident in HBM), then decoded batch after batch — plan k+1 is created and its
-    kernels queued while plan k runs; outputs alternate between two HBM buffers (a consumer would take them from there)."""
+    assembled and uploaded once (inputs resident in HBM), then decoded batch after batch.  A batch of a few hundred
+    images does not fill the chip (stage 1's time is one restart segment's serial walk however few segments there
+    are), so `depth` plans are in flight at once, each on its own stream and with its own output buffer: plan k is
+    created and queued, then plan k - depth is collected (a consumer would take its pixels from HBM there)."""
 
-    def __init__(self, ctx, dev, torch, files, batch_size, layout):
+    def __init__(self, ctx, dev, torch, files, batch_size, layout, depth=3):
         from pyjpegdecoder_amd import _binding as B
         from pyjpegdecoder_amd.batch import prepare_batch
         self.B, self.ctx, self.torch = B, ctx, torch
@@ -148,26 +150,29 @@ class DeviceImageQueue:
             prep = prepare_batch(files[i:i + batch_size], layout, 0)
             self.batches.append((prep, torch.from_numpy(prep.blob).to(dev), len(files[i:i + batch_size])))
         cap = max((sum(w * h * nc for (w, h, nc) in p.shapes) for p, _, _ in self.batches), default=0)
-        self.out = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.depth = max(1, min(depth, len(self.batches)))
+        self.out = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)]
         self.n_images = len(files)
         self.bad = 0
+
+    def _collect(self, plan):
+        plan.sync()
+        self.bad += int(plan.read(rgb=False)["status"].any())
+        plan.close()
 
     def run(self):
         """One pass over the whole share; returns when every batch's pixels are in HBM."""
         B = self.B
-        prev = None
+        flying = []
         for k, (prep, d_blob, n) in enumerate(self.batches):
+            if len(flying) == self.depth:                # slot k % depth is still in use by plan k - depth
+                self._collect(flying.pop(0))
             plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
-            plan.execute(0, self.out[k & 1].data_ptr())
-            if prev is not None:
-                prev.sync()
-                self.bad += int(prev.read(rgb=False)["status"].any())
-                prev.close()
-            prev = plan
-        if prev is not None:
-            prev.sync()
-            self.bad += int(prev.read(rgb=False)["status"].any())
-            prev.close()
+            plan.execute(self.streams[k % self.depth].cuda_stream, self.out[k % self.depth].data_ptr())
+            flying.append(plan)
+        for plan in flying:
+            self._collect(plan)
 
 
 def main():
@@ -179,7 +184,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to the workload's size)")
     ap.add_argument("--total-images", type=int, default=0,
                     help="BASELINE configs[3]: ONE job of this many images sharded over the ranks, per-GPU image queue (strong scaling)")
-    ap.add_argument("--queue-batch", type=int, default=250, help="images per plan in the per-GPU queue (--total-images)")
+    ap.add_argument("--queue-batch", type=int, default=417, help="images per plan in the per-GPU queue (--total-images)")
+    ap.add_argument("--queue-depth", type=int, default=3, help="plans in flight at once in the per-GPU queue, one stream each")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--segment", default="host", choices=["host", "gpu"],
                     help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
@@ -236,7 +242,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     if queue_mode:
-        queue = DeviceImageQueue(ctx, dev, torch, files, args.queue_batch, layout)
+        queue = DeviceImageQueue(ctx, dev, torch, files, args.queue_batch, layout, args.queue_depth)
         torch.cuda.synchronize()
         host_prep_s, h2d_s = time.perf_counter() - t0, None
         step = queue.run
@@ -284,7 +290,7 @@ def main():
         status_bad = queue.bad
         k_last = len(queue.batches) - 1
         n_last = queue.batches[k_last][2]
-        got_last = queue.out[k_last & 1][(n_last - 1) * per:n_last * per].cpu().numpy()
+        got_last = queue.out[k_last % queue.depth][(n_last - 1) * per:n_last * per].cpu().numpy()
         queue.batches = queue.batches[:1]                     # image 0: decode the first batch once more
         queue.run()
         got_first = queue.out[0][:per].cpu().numpy()
@@ -309,7 +315,7 @@ def main():
     std = args.restart_interval == 120 and (queue_mode or args.batch == 1024)
     if queue_mode:
         workload = (f"one job of {args.total_images} x 1920x1080 4:2:0 baseline JPEG, q85, DRI={args.restart_interval}, sharded over {world} GPU(s) "
-                    f"({n_mine} images on rank 0), per-GPU image queue of {args.queue_batch}-image plans over HBM-resident files, "
+                    f"({n_mine} images on rank 0), per-GPU image queue of {args.queue_batch}-image plans ({args.queue_depth} in flight) over HBM-resident files, "
                     f"on-GPU Huffman + dequant/IDCT/upsample/RGB" + (f" ({base_cfg})" if std and args.total_images == 10000 else " (NOT a BASELINE configuration)"))
     else:
         workload = (f"{args.batch} x 1920x1080 4:2:0 baseline JPEG per GPU, q85, " +
