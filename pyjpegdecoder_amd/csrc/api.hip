@@ -404,8 +404,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->n_images = b->n_images;
     p->layout = b->layout;
     p->flags = b->flags;
-    // 4:1:1 (luma 4x1) has no fast stage 2: the exact-order kernel takes it, in either pixel layout
-    if (b->images[0].ncomp == 3 && b->images[0].hs[0] == 4) p->flags |= MJ_FLAG_EXACT_ONLY;
     p->transposed = (b->layout & 1) == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY);
     struct Guard { mj_plan *p; mj_context *c; ~Guard() { c->cur = nullptr; if (p) mj_plan_destroy(p); } } guard{p, ctx};
     if (!ctx->free_arenas.empty()) { p->arena = ctx->free_arenas.back(); ctx->free_arenas.pop_back(); }

@@ -142,37 +142,59 @@ struct FGeo {
     static constexpr int MW = NC == 1 ? 8 : 8 * HS;
     static constexpr int MH = NC == 1 ? 8 : 8 * VS;
     static constexpr int TMW = 64 / MW;                  // MCUs per wave strip
-    static constexpr int ROUNDS = TMW * NB / 8;          // 8 blocks per round
+    static constexpr int NBT = TMW * NB;                 // blocks of a strip
+    static constexpr int ROUNDS = (NBT + 7) / 8;         // 8 blocks per round; 4:1:1's 12 blocks leave half of the second round idle
     static constexpr int MCU_STRIDE = NB * 64 + 32;      // int16 elements; +64 B makes phase B's 16-byte reads conflict-free
     static constexpr bool SUB = NC == 3 && NBY > 1;
     static constexpr int STRIP_BYTES = TMW * MCU_STRIDE * 2;
-    static constexpr int SCR_BYTES = 8 * 576;
+    // per-wave scratch: the transposes of phase A (8 groups x 576 B), then the wave's 64 pixel runs on their way out
+    static constexpr int SCR_BYTES = 64 * MH * NC > 8 * 576 ? 64 * MH * NC : 8 * 576;
     static constexpr int QT_BYTES = 3 * 128;              // this wave's image's quantisation tables
     static constexpr int WAVE_BYTES = STRIP_BYTES + SCR_BYTES + QT_BYTES;
     static constexpr int WTS_ROW = MH + 1;                // float4 per row, padded against bank conflicts
     static constexpr int WTS_BYTES = SUB ? MW * WTS_ROW * 16 : 0;
     static constexpr int LDS_BYTES = 4 * WAVE_BYTES + WTS_BYTES;
-    static_assert(TMW * NB % 8 == 0, "strip must be a whole number of 8-block rounds");
     static_assert(WAVE_BYTES % 16 == 0, "16-byte LDS accesses");
 };
 
-// Corner-weight table of a kernel geometry; T = the kernel runs on the transposed image (row-major output)
+// The captured ResizeGrid operators in one form for every geometry: an output sample (x, y) of the kernel's (possibly
+// transposed) MCU interpolates between the corners (sx0 + dx, sy0 + dy) of one source cell with integer weights over
+// kDen — 15 for the factor-2 layouts (three taps of a triangle), 31 for 4:1:1 (two taps along its one subsampled axis).
+template <int HS, int VS> constexpr int kDen = (HS == 4 || VS == 4) ? 31 : 15;
+template <int N> __device__ __forceinline__ constexpr int src_pos(int p) { return N > 1 ? (7 * p) / (8 * N - 1) : p; }
+// weights w[dx][dy] packed one byte each: bits [8*(2*dx+dy), +8).  T = the kernel runs on the transposed image
+// (row-major output): its (x, y) is the original's (y, x).
 template <int HS, int VS, bool T>
-__device__ __forceinline__ const uint16_t *w4_table() {
-    if constexpr (T) return (HS == 2 && VS == 2) ? UP_W4T_16x16 : (HS == 2 ? UP_W4T_16x8 : UP_W4T_8x16);
-    else return (HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16);
+__device__ __forceinline__ uint32_t corner_weights(int x, int y) {
+    if constexpr (HS == 4 || VS == 4) {
+        const int ox = T ? y : x, oy = T ? x : y;                     // sample of the original 32x8 MCU
+        const uint32_t w = UP_TAPS2_32x8[ox * 8 + oy];
+        const int i0 = w & 63, n0 = (w >> 6) & 31, i1 = (w >> 11) & 63, n1 = (w >> 17) & 31;
+        const int sx0 = (7 * ox) / 31;                                // the taps lie on the source row oy, columns sx0 and sx0 + 1
+        uint32_t out = 0;
+        // corner (dx, dy) in kernel coordinates: the original's column step is dx (dy when transposed)
+        out |= (uint32_t)n0 << (8 * ((i0 >> 3) == sx0 ? 0 : (T ? 1 : 2)));
+        if (n1) out |= (uint32_t)n1 << (8 * ((i1 >> 3) == sx0 ? 0 : (T ? 1 : 2)));
+        return out;
+    } else {
+        const uint16_t *w4 = T ? ((HS == 2 && VS == 2) ? UP_W4T_16x16 : (HS == 2 ? UP_W4T_16x8 : UP_W4T_8x16))
+                               : ((HS == 2 && VS == 2) ? UP_W4_16x16 : (HS == 2 ? UP_W4_16x8 : UP_W4_8x16));
+        const uint32_t w = w4[x * (8 * VS) + y];
+        return (w & 15) | (((w >> 4) & 15) << 8) | (((w >> 8) & 15) << 16) | ((w >> 12) << 24);
+    }
 }
 
 // Upsampled chroma of pixel (column px, row y) from the two source rows, integer form (exact):
-// round(sum(n_i*v_i)/15) — jpeg_decoder.py:1624-1626 through the captured operator.
-template <int HS, int VS>
-__device__ __forceinline__ int upsample_int(const int16_t *cp, int sx0, int sx1, int y, uint32_t w) {
-    const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
+// round(sum(n_i*v_i)/kDen) — jpeg_decoder.py:1624-1626 through the captured operator.
+template <int HS, int VS, typename P>
+__device__ __forceinline__ int upsample_int(P cp, int sx0, int sx1, int y, uint32_t w) {
+    constexpr int D = kDen<HS, VS>;
+    const int sy0 = src_pos<VS>(y);
     const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
-    const int w00 = w & 15, w01 = (w >> 4) & 15, w10 = (w >> 8) & 15, w11 = w >> 12;
+    const int w00 = w & 255, w01 = (w >> 8) & 255, w10 = (w >> 16) & 255, w11 = w >> 24;
     auto v = [&](int i) { return (int)(int16_t)(cp[i] + 128); };        // strip holds chroma without the level shift
     const int s = w00 * v(sx0 * 8 + sy0) + w01 * v(sx0 * 8 + sy1) + w10 * v(sx1 * 8 + sy0) + w11 * v(sx1 * 8 + sy1);
-    return (int)(int16_t)((int)((unsigned)(2 * s + 15 + 30 * 65536) / 30u) - 65536);
+    return (int)(int16_t)((int)((unsigned)(2 * s + D + 2 * D * 65536) / (unsigned)(2 * D)) - 65536);
 }
 
 // Slow, always-exact version of one lane's pixel run (rare): integer upsample + float64 colour, straight from
@@ -181,8 +203,7 @@ template <int HS, int VS, int NC, bool T>
 __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned char *dst, int nrows,
                                              int16_t *planes /* or null */, int planes_step /* int16 elements per row */) {
     using G = FGeo<HS, VS, NC>;
-    const uint16_t *w4 = w4_table<HS, VS, T>();
-    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+    const int sx0 = src_pos<HS>(px);
     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
 #pragma unroll 1
     for (int y = 0; y < nrows; ++y) {
@@ -192,7 +213,7 @@ __device__ __noinline__ void pixel_run_exact(const int16_t *mt, int px, unsigned
         if constexpr (NC == 3) {
             int Cbv, Crv;
             if constexpr (G::SUB) {
-                const uint32_t w = w4[px * G::MH + y];
+                const uint32_t w = corner_weights<HS, VS, T>(px, y);
                 Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
                 Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
             } else {
@@ -226,24 +247,18 @@ __device__ __noinline__ void green_fix_lds(uint32_t mt_off, uint32_t w_off, uint
     lds_ci16 mt = (lds_ci16)(uintptr_t)mt_off;
     lds_cf32 wrow = (lds_cf32)(uintptr_t)w_off;
     lds_u8 stag = (lds_u8)(uintptr_t)stag_off;
-    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+    const int sx0 = src_pos<HS>(px);
     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
+    constexpr float D = (float)kDen<HS, VS>;
 #pragma unroll 1
     for (int y = 0; y < G::MH; ++y) {
         if (!((halves >> (y >> 3)) & 1)) continue;
         int Cbv, Crv;
         if constexpr (G::SUB) {
-            const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
-            const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
-            const int w00 = (int)(wrow[4 * y] * 15.0f + 0.5f), w01 = (int)(wrow[4 * y + 1] * 15.0f + 0.5f);
-            const int w10 = (int)(wrow[4 * y + 2] * 15.0f + 0.5f), w11 = (int)(wrow[4 * y + 3] * 15.0f + 0.5f);
-            auto up = [&](lds_ci16 cp) {
-                auto v = [&](int i) { return (int)(int16_t)(cp[i] + 128); };        // strip holds chroma without the level shift
-                const int sum = w00 * v(sx0 * 8 + sy0) + w01 * v(sx0 * 8 + sy1) + w10 * v(sx1 * 8 + sy0) + w11 * v(sx1 * 8 + sy1);
-                return (int)(int16_t)((int)((unsigned)(2 * sum + 15 + 30 * 65536) / 30u) - 65536);
-            };
-            Cbv = up(mt + G::NBY * 64);
-            Crv = up(mt + (G::NBY + 1) * 64);
+            const uint32_t w = (uint32_t)(int)(wrow[4 * y] * D + 0.5f) | ((uint32_t)(int)(wrow[4 * y + 1] * D + 0.5f) << 8) |
+                               ((uint32_t)(int)(wrow[4 * y + 2] * D + 0.5f) << 16) | ((uint32_t)(int)(wrow[4 * y + 3] * D + 0.5f) << 24);
+            Cbv = upsample_int<HS, VS>(mt + G::NBY * 64, sx0, sx1, y, w);
+            Crv = upsample_int<HS, VS>(mt + (G::NBY + 1) * 64, sx0, sx1, y, w);
         } else {
             Cbv = (int)(int16_t)(mt[G::NBY * 64 + px * 8 + y] + 128);
             Crv = (int)(int16_t)(mt[(G::NBY + 1) * 64 + px * 8 + y] + 128);
@@ -296,7 +311,7 @@ __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qb
 // T: the kernel works on the transposed image (x' = y, y' = x) — its x-major output is the row-major image of the
 // original; HS/VS are then the transposed sampling factors, coefficient blocks and tables are stored [u][v].
 template <int HS, int VS, int NC, bool SEAMS, bool T>
-__global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
+__global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
                                                           int64_t total_tiles, int tiles_per_image) {
     using G = FGeo<HS, VS, NC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -311,13 +326,13 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     const float4 *s_wts = reinterpret_cast<const float4 *>(smem + 4 * G::WAVE_BYTES);
     const int grp = lane >> 3, j = lane & 7;
 
-    if constexpr (G::SUB) {             // four corner weights / 15 as floats, [x][y]
-        const uint16_t *w4 = w4_table<HS, VS, T>();
+    if constexpr (G::SUB) {             // four corner weights / kDen as floats, [x][y]
         float4 *wt = reinterpret_cast<float4 *>(smem + 4 * G::WAVE_BYTES);
+        constexpr float D = (float)kDen<HS, VS>;
         for (int i = tid; i < G::MW * G::MH; i += 256) {
-            const uint32_t w = w4[i];
-            wt[(i / G::MH) * G::WTS_ROW + (i % G::MH)] = make_float4((float)(w & 15) / 15.0f, (float)((w >> 4) & 15) / 15.0f, (float)((w >> 8) & 15) / 15.0f,
-                                (float)(w >> 12) / 15.0f);
+            const uint32_t w = corner_weights<HS, VS, T>(i / G::MH, i % G::MH);
+            wt[(i / G::MH) * G::WTS_ROW + (i % G::MH)] = make_float4((float)(w & 255) / D, (float)((w >> 8) & 255) / D, (float)((w >> 16) & 255) / D,
+                                                                   (float)(w >> 24) / D);
         }
         __syncthreads();
     }
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
     auto fetch = [&](const Strip &st, uint4 (&cw)[G::ROUNDS]) {
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
-            const int bt = r * 8 + grp;
+            const int bt = min(r * 8 + grp, G::NBT - 1);        // (groups past the strip's last block repeat it: never stored)
             const int k = bt / G::NB, b = bt - k * G::NB;
             const int my = st.y_first + (k < st.n_valid ? k : 0);
             cw[r] = *reinterpret_cast<const uint4 *>(st.cbase + __mul24(my, st.row_elems) + b * 64 + j * 8);
@@ -462,13 +477,14 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             *reinterpret_cast<uint4 *>(s_strip + k * G::MCU_STRIDE + b * 64 + j * 8) = ow;
         };
         // ---- level 1: fp32, ROUNDS rounds of 8 blocks
-        uint32_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine (level 3)
+        uint64_t susp_bits = 0;       // bit bt set = block bt of the strip needs the exact routine (level 3)
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
 #ifdef MJ_DIAGNOSTIC
             if (a.debug == 1) break;
 #endif
-            const int bt = r * 8 + grp;
+            const int bt = min(r * 8 + grp, G::NBT - 1);
+            const bool real = G::NBT % 8 == 0 || r * 8 + grp < G::NBT;       // (4:1:1: the last round is half empty)
             const int k = bt / G::NB, b = bt - k * G::NB;
             const int qc = (NC == 1 || b < G::NBY) ? 0 : b - G::NBY + 1;
             const int shift = qc == 0 ? 128 : 0;          // chroma stays centred in the strip
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
             ow.y = __builtin_amdgcn_perm(rb[3], rb[2], 0x05040100u);
             ow.z = __builtin_amdgcn_perm(rb[5], rb[4], 0x05040100u);
             ow.w = __builtin_amdgcn_perm(rb[7], rb[6], 0x05040100u);
-            bool flagged = err >= (0.5f - kTie0) - kTieA * asum;
+            bool flagged = real && err >= (0.5f - kTie0) - kTieA * asum;
             if (acb != ~0ull) {                            // some group's block has no AC coefficient at all (wave-uniform test)
                 // DC-only blocks need no sum: every sample is round(DC*q * T[0,0,0,0]) and T[0,0,0,0] is a hair above 1/8, so
                 // the product rounds half AWAY from zero (equal to the reference over the whole int16 range)
@@ -518,7 +534,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 ow.x = dconly ? vv : ow.x; ow.y = dconly ? vv : ow.y; ow.z = dconly ? vv : ow.z; ow.w = dconly ? vv : ow.w;
                 flagged = flagged && !dconly;
             }
-            store_row(k, b, ow);
+            if (real) store_row(k, b, ow);
             // ---- level 2 (about one round in eight on noisy images): the groups whose block failed do it again in fp64
             if (__ballot(flagged) != 0) {
 #ifdef MJ_DIAGNOSTIC
@@ -556,18 +572,19 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 if (sb != 0) {
 #pragma unroll
                     for (int g8 = 0; g8 < 8; ++g8)
-                        if ((sb >> (8 * g8)) & 0xFF) susp_bits |= 1u << (r * 8 + g8);
+                        if ((sb >> (8 * g8)) & 0xFF) susp_bits |= 1ull << (r * 8 + g8);
                 }
             }
         }
-        susp_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)susp_bits);
+        susp_bits = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)susp_bits) |
+                    ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(susp_bits >> 32)) << 32);
 #ifdef MJ_DIAGNOSTIC
         MJ_STAMP(0);          // phase A rounds
 #endif
 
         // ---- level 3, rare: blocks with a sample too close to a rounding boundary even in fp64 -> exact-order recompute
         while (susp_bits) {
-            const int bt = __builtin_ctz(susp_bits);
+            const int bt = __builtin_ctzll(susp_bits);
             susp_bits &= susp_bits - 1;
             const int k = bt / G::NB, b = bt - k * G::NB;
             if (k >= n_valid) continue;
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     const int bt = r * 8 + grp;
                     const int k = bt / G::NB, b = bt - k * G::NB;
                     const int back = (NC == 1 || b < G::NBY) ? 0 : 128;
-                    if (k < n_valid) {
+                    if (bt < G::NBT && k < n_valid) {
                         const int16_t *row = s_strip + k * G::MCU_STRIDE + b * 64 + j * 8;
                         int16_t *io = a.idct_out + (mcu_block(k) + b) * 64;
 #pragma unroll
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                 if (have) {
                 if constexpr (NC == 3) {
                     // chroma source rows sx0, sx0+1 of this lane's column, as floats
-                    const int sx0 = (HS == 2) ? (7 * px) / 15 : px;
+                    const int sx0 = src_pos<HS>(px);
                     const int sx1 = sx0 < 7 ? sx0 + 1 : 7;
                     // (Cb-128, Cr-128) pairs: the two chroma planes ride in the two halves of packed-fp32 registers, so
                     // one v_pk_* instruction serves both components.
@@ -642,7 +659,7 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                     const uint4 ba = *reinterpret_cast<const uint4 *>(cbp + sx0 * 8), ra = *reinterpret_cast<const uint4 *>(crp + sx0 * 8);
                     const uint32_t bw[4] = {ba.x, ba.y, ba.z, ba.w}, rw[4] = {ra.x, ra.y, ra.z, ra.w};
                     uint32_t bw2[4] = {0, 0, 0, 0}, rw2[4] = {0, 0, 0, 0};
-                    if constexpr (HS == 2) {
+                    if constexpr (HS > 1) {
                         const uint4 bb = *reinterpret_cast<const uint4 *>(cbp + sx1 * 8), rb = *reinterpret_cast<const uint4 *>(crp + sx1 * 8);
                         bw2[0] = bb.x; bw2[1] = bb.y; bw2[2] = bb.z; bw2[3] = bb.w;
                         rw2[0] = rb.x; rw2[1] = rb.y; rw2[2] = rb.z; rw2[3] = rb.w;
@@ -659,15 +676,15 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                         const uint4 yw = *reinterpret_cast<const uint4 *>(mt + yb * 64 + (px & 7) * 8);
                         const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};
                         // source samples this half of the column interpolates between
-                        const int s_lo = (G::SUB && VS == 2) ? (7 * (by * 8)) / 15 : 0;
+                        const int s_lo = (G::SUB && VS > 1) ? src_pos<VS>(by * 8) : 0;
                         f32x2 cA[8], cB[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const bool used = !G::SUB || VS == 1 || (i >= s_lo && i <= ((7 * (by * 8 + 7)) / 15) + 1);
+                            const bool used = !G::SUB || VS == 1 || (i >= s_lo && i <= src_pos<VS>(by * 8 + 7) + 1);
                             if (used) {
                                 cA[i] = pairA(i);
                                 crange = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cA[i].x), __builtin_fabsf(cA[i].y)), crange);
-                                if constexpr (HS == 2) {
+                                if constexpr (HS > 1) {
                                     cB[i] = pairB(i);
                                     crange = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cB[i].x), __builtin_fabsf(cB[i].y)), crange);
                                 }
@@ -679,12 +696,12 @@ __global__ __launch_bounds__(256, 4) void k_reconstruct_fast(ReconArgs a, const 
                                 // sum(n_i v_i)/15 is never within 1/30 of a half-integer and the fp32 evaluation is
                                 // within 0.012 of it for any int16 inputs, so rintf() returns the reference's value
                                 const int y = by * 8 + i;
-                                const int sy0 = (VS == 2) ? (7 * y) / 15 : y;
+                                const int sy0 = src_pos<VS>(y);
                                 const int sy1 = sy0 < 7 ? sy0 + 1 : 7;
                                 const float4 wq = s_wts[px * G::WTS_ROW + y];
                                 f32x2 sv = cA[sy0] * wq.x;
                                 sv = __builtin_elementwise_fma(cA[sy1], f32x2{wq.y, wq.y}, sv);
-                                if constexpr (HS == 2) {
+                                if constexpr (HS > 1) {
                                     sv = __builtin_elementwise_fma(cB[sy0], f32x2{wq.z, wq.z}, sv);
                                     sv = __builtin_elementwise_fma(cB[sy1], f32x2{wq.w, wq.w}, sv);
                                 }
@@ -922,6 +939,7 @@ hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int h
     if (hmax == 2 && vmax == 1) return MJ_FAST(2, 1, 3);
     if (hmax == 1 && vmax == 2) return MJ_FAST(1, 2, 3);
     if (hmax == 2 && vmax == 2) return MJ_FAST(2, 2, 3);
+    if (hmax == 4 && vmax == 1) return MJ_FAST(4, 1, 3);
 #undef MJ_FAST
     return hipErrorInvalidValue;
 }

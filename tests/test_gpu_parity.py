@@ -122,6 +122,8 @@ RANDOM_CASES = [
     ("420", 333, 211, 5, 85), ("420", 16, 16, 0, 50), ("420", 17, 9, 1, 95), ("422", 250, 130, 9, 90),
     ("440", 130, 250, 4, 75), ("444", 99, 101, 13, 92), ("grey", 123, 77, 6, 88), ("420", 640, 480, 40, 85),
     ("420", 1, 1, 0, 85), ("444", 8, 8, 1, 30), ("420", 1024, 64, 64, 100),
+    # 4:1:1 (32x8 MCUs, two-tap upsample over 31): strips of 2 MCUs x-major, of 8 (transposed 8x32 MCUs) row-major
+    ("411", 333, 211, 5, 85), ("411", 250, 130, 0, 96), ("411", 31, 7, 1, 90), ("411", 640, 484, 20, 100), ("411", 33, 300, 3, 70),
 ]
 
 
