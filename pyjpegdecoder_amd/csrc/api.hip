@@ -168,6 +168,10 @@ struct mj_plan {
     int64_t n_psegs = 0;
     int prog_rows_per_band = 2, prog_steps = 0;
     bool prog_banded = false;
+    // the refining AC scans read the stage-0 stream of the scans' segments (progressive_refine.hip)
+    mj::DevSegment *d_prog_dsegs = nullptr;  // d_psegs' byte ranges in the form stage 0 takes
+    uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
+    bool prog_refine_fast = false;
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
@@ -382,7 +386,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -878,9 +882,56 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         if (prog) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
-            if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
             p->n_psegs = (int64_t)psegs.size();
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
+            bool any_refining = false;
+            for (const mj::DevProgScan &ps : pscans) any_refining = any_refining || (ps.ah != 0 && ps.ss > 0);
+            p->prog_refine_fast = any_refining;
+            if (const char *e = getenv("MJ_PROG_REFINE")) p->prog_refine_fast = any_refining && atoi(e) != 0;
+            if (p->prog_refine_fast) {
+                // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
+                // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if
+                // they are numbered in blob order — psegs is ordered by dependency level, so each one records its number
+                std::vector<int32_t> order(psegs.size());
+                for (size_t i = 0; i < psegs.size(); ++i) order[i] = (int32_t)i;
+                std::sort(order.begin(), order.end(), [&](int32_t a2, int32_t b2) { return psegs[a2].begin < psegs[b2].begin; });
+                std::vector<mj::DevSegment> ds(psegs.size());
+                std::vector<mj::DevPiece> pcs;
+                for (size_t n = 0; n < psegs.size(); ++n) {
+                    mj::DevProgSeg &g = psegs[order[n]];
+                    g.stream_slot = (int32_t)n;
+                    ds[n] = mj::DevSegment{g.begin, g.len, pscans[g.scan].image, g.mcu0, g.n_mcu, g.last, 0};
+                    const int32_t first = (int32_t)pcs.size();
+                    for (int off = 0; off == 0 || off < g.len; off += 16384)
+                        pcs.push_back(mj::DevPiece{(int32_t)n, first, off, std::min(16384, std::max(0, g.len - off))});
+                }
+                if ((rc = upload(ctx, &p->d_prog_dsegs, ds.data(), ds.size())) != MJ_OK) return rc;
+                p->n_pieces = (int64_t)pcs.size();
+                if ((rc = upload(ctx, &p->d_pieces, pcs.data(), pcs.size())) != MJ_OK) return rc;
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_piece_kept, pcs.size() * sizeof(int32_t) + 16));
+                const size_t sbytes = ((size_t)b->blob_len / 4 + psegs.size() + 256) * 4;
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stream, sbytes));
+                MJ_HIP(ctx, hipMemsetAsync(p->d_stream, 0, sbytes, ctx->setup_stream));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_seg_bits, (psegs.size() + 1) * sizeof(int32_t)));
+                const int LS = 1 << mj::kProgLutBits;
+                std::vector<uint16_t> lp((size_t)b->n_huff * LS, 0);
+                for (int t = 0; t < b->n_huff; ++t) {
+                    int code = 0, k = 0;
+                    for (int l = 1; l <= 16; ++l) {
+                        code <<= 1;
+                        for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                            if (l > mj::kProgLutBits || code >= (1 << l)) continue;
+                            const int shift = mj::kProgLutBits - l;
+                            for (int f = 0; f < (1 << shift); ++f) {
+                                uint16_t &e = lp[(size_t)t * LS + ((code << shift) | f)];
+                                if (e == 0) e = (uint16_t)((l << 8) | b->huff[t].vals[k]);      // the shortest key wins
+                            }
+                        }
+                    }
+                }
+                if ((rc = upload(ctx, &p->d_lut11p, lp.data(), lp.size())) != MJ_OK) return rc;
+            }
+            if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
         }
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
@@ -991,11 +1042,18 @@ static int stage1_impl(mj_plan *p, void *stream) {
                                                         p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0,
                                                         p->transposed ? 1 : 0, p->d_pstates, step, p->prog_rows_per_band));
         } else {        // one launch per dependency level over that level's segments (one band = the whole image)
+            const bool fast = p->prog_refine_fast;
+            if (fast)
+                MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
             for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
                 const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
                 MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images,
                                                         p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0,
-                                                        p->transposed ? 1 : 0, p->d_pstates + s0, (int)o, 0));
+                                                        p->transposed ? 1 : 0, p->d_pstates + s0, (int)o, fast ? -1 : 0));
+                if (fast)
+                    MJ_HIP(ctx, mj::launch_progressive_refine(s, p->d_stream, p->d_seg_bits, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans,
+                                                              p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status,
+                                                              (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, p->transposed ? 1 : 0));
             }
         }
         return MJ_OK;

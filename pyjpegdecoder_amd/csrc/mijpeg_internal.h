@@ -124,12 +124,19 @@ struct DevProgSeg {
     int32_t len;
     int32_t scan;         // index into the DevProgScan array
     int32_t mcu0, n_mcu;  // in units of the scan's own MCUs
-    int32_t last, pad;
+    int32_t last;
+    int32_t stream_slot;  // the segment's number in stage 0's stream buffer (progressive_refine.hip), blob order
 };
 
 }  // namespace mj
 
 namespace mj {
+// the refining AC scans (progressive_refine.hip) read the stage-0 stream (destuff.hip) of the scans' segments — segment
+// number DevProgSeg::stream_slot — and LUTs of kProgLutBits bits, (len << 8 | symbol) per entry, for every table
+constexpr int kProgLutBits = 11;
+hipError_t launch_progressive_refine(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
+                                     int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
+                                     const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed);
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,

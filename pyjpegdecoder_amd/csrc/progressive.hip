@@ -380,8 +380,9 @@ hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, cons
     } else {        // every scan in one piece: `step` is the dependency level whose scans run
         hipLaunchKernelGGL((k_progressive_scan<false, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
                            scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
-        hipLaunchKernelGGL((k_progressive_scan<false, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
-                           scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
+        if (rows_per_band == 0)      // (-1: the refining AC scans are progressive_refine.hip's)
+            hipLaunchKernelGGL((k_progressive_scan<false, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
+                               scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
     }
     return hipGetLastError();
 }
