@@ -173,6 +173,7 @@ struct mj_plan {
     uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
     bool prog_refine_fast = false;
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
+    std::vector<int64_t> ordinal_kind_off;  // [n_ordinals][4]: within a level, where the segments of each kind of scan start
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
     int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
@@ -591,11 +592,21 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             pscans.push_back(ps);
         }
         // segments grouped by ordinal
+        // ... and, inside a level, by the kernel that walks them: DC first scans, AC first scans, AC refining scans, the rest
+        auto kind_of = [&](const mj_scan_desc &sd) {
+            const bool sequential = sd.ss == 0 && sd.se == 63;
+            if (sequential) return 3;
+            if (sd.ah == 0) return sd.ss == 0 ? 0 : 1;
+            return sd.ss > 0 ? 2 : 3;
+        };
         p->ordinal_seg_off.assign(n_ord + 1, 0);
+        p->ordinal_kind_off.assign((size_t)n_ord * 4, 0);
         for (int o = 0; o < n_ord; ++o) {
             p->ordinal_seg_off[o] = (int64_t)psegs.size();
+          for (int kind = 0; kind < 4; ++kind) {
+            p->ordinal_kind_off[(size_t)o * 4 + kind] = (int64_t)psegs.size();
             for (int k = 0; k < b->n_scans; ++k) {
-                if (ordinal_of[k] != o) continue;
+                if (ordinal_of[k] != o || kind_of(b->scans[k]) != kind) continue;
                 const mj_scan_desc &sd = b->scans[k];
                 const int64_t mcus = (int64_t)sd.mcu_count_h * sd.mcu_count_v;
                 const int64_t want = sd.restart_interval > 0 ? (mcus + sd.restart_interval - 1) / sd.restart_interval : 1;
@@ -613,6 +624,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     ent += se - sb;
                 }
             }
+          }
         }
         p->ordinal_seg_off[n_ord] = (int64_t)psegs.size();
         {   // Band pipelining (see mj_plan_execute_stage1): ~34 bands over the tallest image, launches = bands + levels - 1.
@@ -884,10 +896,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
             p->n_psegs = (int64_t)psegs.size();
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
-            bool any_refining = false;
-            for (const mj::DevProgScan &ps : pscans) any_refining = any_refining || (ps.ah != 0 && ps.ss > 0);
-            p->prog_refine_fast = any_refining;
-            if (const char *e = getenv("MJ_PROG_REFINE")) p->prog_refine_fast = any_refining && atoi(e) != 0;
+            // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_first.hip, progressive_refine.hip)
+            p->prog_refine_fast = true;
+            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_refine_fast = atoi(e) != 0;
             if (p->prog_refine_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
                 // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if
@@ -1047,13 +1058,19 @@ static int stage1_impl(mj_plan *p, void *stream) {
                 MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
             for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
                 const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
-                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images,
-                                                        p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0,
-                                                        p->transposed ? 1 : 0, p->d_pstates + s0, (int)o, fast ? -1 : 0));
-                if (fast)
-                    MJ_HIP(ctx, mj::launch_progressive_refine(s, p->d_stream, p->d_seg_bits, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans,
-                                                              p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status,
-                                                              (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, p->transposed ? 1 : 0));
+                const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
+                if (!fast) {
+                    MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images, p->d_huff,
+                                                            p->d_coef, p->d_status, spec, tr, p->d_pstates + s0, (int)o, 0));
+                    continue;
+                }
+                const int64_t *ko = &p->ordinal_kind_off[o * 4];      // DC first | AC first | AC refining | the rest
+                MJ_HIP(ctx, mj::launch_progressive_first(s, p->d_stream, p->d_seg_bits, p->d_psegs + ko[0], (int)(ko[1] - ko[0]), (int)(ko[2] - ko[1]),
+                                                         p->d_pscans, p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status, tr));
+                MJ_HIP(ctx, mj::launch_progressive_refine(s, p->d_stream, p->d_seg_bits, p->d_psegs + ko[2], (int)(ko[3] - ko[2]), p->d_pscans,
+                                                          p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr));
+                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + ko[3], (int)(s1 - ko[3]), p->d_pscans, p->d_images, p->d_huff,
+                                                        p->d_coef, p->d_status, spec, tr, p->d_pstates + ko[3], (int)o, -1));
             }
         }
         return MJ_OK;

@@ -1,0 +1,135 @@
+// What the progressive stage-1 kernels that work on the stage-0 stream share (progressive_refine.hip,
+// progressive_first.hip): the per-wave ring of the segment's stream in LDS, and the packed description of the symbol
+// that would start at a given bit.  See progressive_refine.hip for the design.
+#pragma once
+#include "mijpeg_internal.h"
+
+namespace mj {
+namespace progstream {
+
+constexpr int kRingDw = 256;              // stream ring per wave (dwords)
+constexpr int kPLut = 1 << kProgLutBits;
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t from_bit(int k) { return k >= 64 ? 0 : ~(uint64_t)0 << k; }          // bits k..63
+__device__ __forceinline__ uint64_t bit_range(int a, int b) { return from_bit(a) & ~from_bit(b); }        // bits a..b-1
+__device__ __forceinline__ int mbcnt(uint64_t m) {                                                       // bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// v[lane l] = s (l wave-uniform).  The lane select of v_writelane shares the constant bus with the value: it goes through m0,
+// which nothing else in these kernels uses (gfx950's LDS instructions do not read it).
+__device__ __forceinline__ void write_lane(int &v, int s, int l) {
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(l) : "m0");
+}
+
+__constant__ uint8_t c_nat_of_zz_ps[64] = {
+    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// One wave's view of its restart segment: stage 0 (destuff.hip) wrote the bytes the bit reader keeps as big-endian
+// dwords; a 256-dword ring of them sits in LDS, topped up 64 dwords at a time with one global load in flight.
+// Behind the segment's end the stream reads as zeros (jpeg_decoder.py:689-693).  All members but `pend` are wave-uniform.
+struct Stream {
+    uint32_t *ring;
+    const uint32_t *sw;
+    int n_dw, total_bits;
+    int whi;              // dwords [whi - 256, whi) are in the ring; `pend` holds [whi, whi + 64)
+    uint32_t pend;
+    int bp;               // next bit
+    int lane;
+
+    __device__ __forceinline__ uint32_t chunk(int d0) const { const int d = d0 + lane; return d < n_dw ? sw[d] : 0u; }
+    __device__ __forceinline__ void init(uint32_t *ring_, const uint32_t *stream, const int32_t *seg_bits, const DevProgSeg *sg, int lane_) {
+        ring = ring_; lane = lane_;
+        sw = stream + (sg->begin >> 2) + sg->stream_slot;       // stage 0 wrote it at dword (begin >> 2) + segment number
+        total_bits = seg_bits[sg->stream_slot];
+        n_dw = (total_bits + 31) >> 5;
+        whi = 0; bp = 0;
+        pend = chunk(0);
+        top_up();
+    }
+    // at least 128 dwords ahead of the next bit; call it often enough that no more than ~100 are consumed in between
+    __device__ __forceinline__ void top_up() {
+        while (whi - (bp >> 5) < 128) {
+            ring[(whi + lane) & (kRingDw - 1)] = pend;
+            whi += 64;
+            pend = chunk(whi);
+        }
+    }
+    // the 32 stream bits from bit q on (q per lane)
+    __device__ __forceinline__ uint32_t bits_at(int q) const {
+        const int d = q >> 5, sh = q & 31;
+        const uint32_t a = ring[d & (kRingDw - 1)], b = ring[(d + 1) & (kRingDw - 1)];
+        return (uint32_t)((((uint64_t)a << 32 | b) << sh) >> 32);
+    }
+    // one bit (q per lane)
+    __device__ __forceinline__ int bit_at(int q) const {
+        return (int)((ring[(q >> 5) & (kRingDw - 1)] >> (31 - (q & 31))) & 1u);
+    }
+    // OVERRUN / DESYNC at the end of the segment, as the other stage-1 kernels report them
+    __device__ __forceinline__ int end_status(bool last) const {
+        if (bp > total_bits) return MJ_ST_OVERRUN;                              // bits were read from behind the end
+        if (!last && total_bits - bp >= 8) return MJ_ST_DESYNC;                 // a whole unread byte before the next restart marker
+        return 0;
+    }
+};
+
+__device__ __forceinline__ void load_lut(uint16_t *lds, const uint16_t *lut11p, int table, int lane) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(lut11p + (size_t)table * kPLut);
+#pragma unroll
+    for (int i = 0; i < kPLut * 2 / 16 / 64; ++i) reinterpret_cast<uint4 *>(lds)[i * 64 + lane] = src[i * 64 + lane];
+}
+
+// a code of more than kProgLutBits bits at the top of w (rare): canonical search (jpeg_decoder.py:712-722); len 0 = none
+__device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int &len, int &hv) {
+    len = 0; hv = 0;
+    for (int l = kProgLutBits + 1; l <= 16; ++l) {
+        const int dlt = (int)(w >> (32 - l)) - tab->first_code[l];
+        if (dlt >= 0 && dlt < tab->count[l]) { hv = tab->vals[tab->first_sym[l] + dlt]; len = l; return; }
+    }
+}
+
+// What a walk needs to know about the AC symbol that starts at the top bit of `w`, given its Huffman code's length and
+// value (len = 0: no code of <= kProgLutBits bits matches):
+//   bits 1..0   class: 0 = coefficient (size > 0), 1 = ZRL, 2 = end of band (EOBn), 3 = not in the table.
+//               ZRL_IS_COEF: a ZRL is class 0 with value 0 (the refining walk: "skip r zeros, take the next zero" for
+//               both, and a ZRL then places 0 into a coefficient that is 0)
+//   bits 5..2   zero run r (15 for ZRL)
+//   bits 10..6  bits consumed by the code and what belongs to it (value bits / the EOB run's extra bits)
+//   bits 31..16 class 0: the coefficient, extended (:1636-1646), shifted by Al and cut to int16 (:1225, :1248);
+//               class 2: the length of the end-of-band run, (1 << r) + extra bits (:1160-1166)
+template <bool ZRL_IS_COEF>
+__device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al) {
+    const int r = hv >> 4, s = hv & 15;
+    if (len == 0) return 3u;
+    if (s == 0 && r != 15) {
+        const uint32_t extra = r ? (w << len) >> (32 - r) : 0u;
+        return 2u | ((uint32_t)r << 2) | ((uint32_t)(len + r) << 6) | (((1u << r) + extra) << 16);
+    }
+    uint32_t val16 = 0;
+    if (s > 0) {
+        const uint32_t raw = (w << len) >> (32 - s);
+        const int val = (raw >> (s - 1)) ? (int)raw : (int)raw - ((1 << s) - 1);
+        val16 = (uint32_t)(uint16_t)(int16_t)(val << al);
+    }
+    return ((!ZRL_IS_COEF && s == 0) ? 1u : 0u) | ((uint32_t)r << 2) | ((uint32_t)(len + s) << 6) | (val16 << 16);
+}
+
+// ... and about a DC symbol (:1012-1029): bits 1..0 = 0, or 3 = not in the table / a size above 16; bits 11..6 the bits
+// consumed (code + size <= 32); bits 31..16 the difference, extended, modulo 2^16 (the predictor wraps to int16)
+__device__ __forceinline__ uint32_t dc_entry(uint32_t w, int len, int s) {
+    if (len == 0 || s > 16) return 3u;
+    uint32_t d16 = 0;
+    if (s > 0) {
+        const uint32_t raw = (uint32_t)(((uint64_t)w << len & 0xFFFFFFFFull) >> (32 - s));
+        const int val = (raw >> (s - 1)) ? (int)raw : (int)raw - ((1 << s) - 1);
+        d16 = (uint32_t)val & 0xFFFFu;
+    }
+    return ((uint32_t)(len + s) << 6) | (d16 << 16);
+}
+
+}  // namespace progstream
+}  // namespace mj

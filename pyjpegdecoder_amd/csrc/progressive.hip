@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     const bool is_dc = ss == 0 && !sequential;
     const int nsc = sc->n_comp;
     if (KIND != 2 && (KIND == 1) != (refining && !is_dc && !sequential)) return;
+    // rows_per_band < 0: the first scans and the refining AC scans are walked elsewhere (progressive_first.hip,
+    // progressive_refine.hip); what is left here is DC refinement and the sequential scans
+    if (!BANDED && rows_per_band < 0 && !sequential && !(is_dc && refining)) return;
     const bool ac_refining = KIND == 1 ? true : (KIND == 0 ? false : refining);      // in the AC branch below
 
     // ---- which part of the scan this launch does.  The scans of an image are pipelined over bands of `rows_per_band`

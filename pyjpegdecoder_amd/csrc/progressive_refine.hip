@@ -26,53 +26,11 @@
 //
 // ~35 instructions per coefficient symbol; blocks inside an end-of-band run cost ~40 in all.
 #include "mijpeg_internal.h"
+#include "prog_stream.h"
 
 namespace mj {
 
-namespace {
-
-constexpr int kRingDw = 256;              // stream ring per wave
-constexpr int kPLut = 1 << kProgLutBits;
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ uint64_t from_bit(int k) { return k >= 64 ? 0 : ~(uint64_t)0 << k; }          // bits k..63
-__device__ __forceinline__ uint64_t bit_range(int a, int b) { return from_bit(a) & ~from_bit(b); }        // bits a..b-1
-__device__ __forceinline__ int mbcnt(uint64_t m) {                                                       // bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-__constant__ uint8_t c_nat_of_zz_r[64] = {
-    0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
-   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
-   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
-   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-// What the walk needs to know about the symbol that starts at the top bit of `w`, given its Huffman code's length and
-// value (len = 0: no code of <= kProgLutBits bits matches):
-//   bits 1..0   class: 0 = coefficient (size > 0) or ZRL — "skip r zeros, take the next zero" for both, a ZRL places 0
-//                      into a coefficient that is 0 —, 2 = end of band (EOBn), 3 = not in the table
-//   bits 5..2   zero run r (15 for ZRL)
-//   bits 10..6  bits consumed by the code and what belongs to it (value bits / the EOB run's extra bits)
-//   bits 31..16 class 0: the new coefficient, extended (:1636-1646), shifted by Al and cut to int16 (:1225);
-//               class 2: the length of the end-of-band run, (1 << r) + extra bits (:1160-1166)
-__device__ __forceinline__ uint32_t symbol_entry(uint32_t w, int len, int hv, int al) {
-    const int r = hv >> 4, s = hv & 15;
-    if (len == 0) return 3u;
-    if (s == 0 && r != 15) {
-        const uint32_t extra = r ? (w << len) >> (32 - r) : 0u;
-        return 2u | ((uint32_t)r << 2) | ((uint32_t)(len + r) << 6) | (((1u << r) + extra) << 16);
-    }
-    uint32_t val16 = 0;
-    if (s > 0) {
-        const uint32_t raw = (w << len) >> (32 - s);
-        const int val = (raw >> (s - 1)) ? (int)raw : (int)raw - ((1 << s) - 1);
-        val16 = (uint32_t)(uint16_t)(int16_t)(val << al);
-    }
-    return 0u | ((uint32_t)r << 2) | ((uint32_t)(len + s) << 6) | (val16 << 16);
-}
-
-}  // namespace
+using namespace progstream;
 
 __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__restrict__ stream, const int32_t *__restrict__ seg_bits,
                                                             const DevProgSeg *__restrict__ segs, int n_segs,
@@ -94,37 +52,16 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
     uint16_t *lut = s_lut[wave];
     uint32_t *ring = s_ring[wave];
     const DevHuff *tab = huff + sc->ac_tab[0];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(lut11p + (size_t)sc->ac_tab[0] * kPLut);
-#pragma unroll
-        for (int i = 0; i < kPLut * 2 / 16 / 64; ++i) reinterpret_cast<uint4 *>(lut)[i * 64 + lane] = src[i * 64 + lane];
-    }
+    load_lut(lut, lut11p, sc->ac_tab[0], lane);
+    Stream st;
+    st.init(ring, stream, seg_bits, sg, lane);
 
-    // ---- the segment's stream: stage 0 wrote it at dword (begin >> 2) + segment number
-    const uint32_t *sw = stream + (sg->begin >> 2) + sg->stream_slot;
-    const int total_bits = seg_bits[sg->stream_slot];
-    const int n_dw = (total_bits + 31) >> 5;
-    auto chunk = [&](int d0) -> uint32_t { const int d = d0 + lane; return d < n_dw ? sw[d] : 0u; };    // zeros behind the end (:689-693)
-    int whi = 0;                              // dwords [whi - 256, whi) are in the ring; `pend` holds [whi, whi + 64)
-    uint32_t pend = chunk(0);
-    int bp = 0;                               // next bit
-    auto top_up = [&]() {                     // at least 128 dwords ahead of the next bit: a block takes 62 at most
-        while (whi - (bp >> 5) < 128) {
-            ring[(whi + lane) & (kRingDw - 1)] = pend;
-            whi += 64;
-            pend = chunk(whi);
-        }
-    };
-    top_up();
-
-    // ---- symbols of 64 consecutive bit offsets (see symbol_entry)
+    // ---- symbols of 64 consecutive bit offsets (see ac_entry)
     auto lookup64 = [&](int g, uint32_t &ve, uint32_t &vw) {
-        const int q = g + lane, d = q >> 5, sh = q & 31;
-        const uint32_t a = ring[d & (kRingDw - 1)], b = ring[(d + 1) & (kRingDw - 1)];
-        const uint32_t w = (uint32_t)((((uint64_t)a << 32 | b) << sh) >> 32);
+        const uint32_t w = st.bits_at(g + lane);
         const uint32_t e16 = lut[w >> (32 - kProgLutBits)];
         vw = w;
-        ve = symbol_entry(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
+        ve = ac_entry<true>(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
     };
     int gbase = 0;
     uint32_t ve0, vw0, ve1, vw1;              // offsets [gbase, gbase + 64) and [gbase + 64, gbase + 128)
@@ -139,7 +76,7 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
     const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
     const int first = c == 0 ? 0 : hmax * vmax + c - 1;
     const int smh = sc->mcu_count_h;
-    const int nz_nat = c_nat_of_zz_r[lane];
+    const int nz_nat = c_nat_of_zz_ps[lane];
     const int nat = tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;      // tr: blocks are kept [u][v] for the row-major stage 2
     // this lane's coefficient of the scan's blocks, one after the other in scan order (h, v are 1, 2 or 4: shifts)
     const int lh = h == 4 ? 2 : h - 1, lv = v == 4 ? 2 : v - 1;
@@ -156,7 +93,7 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
     int err = 0, eobrun = 0;
 
     auto one_block = [&](int cf, int16_t *p) __attribute__((always_inline)) {
-        top_up();
+        st.top_up();
         const uint64_t nz0 = __ballot(cf != 0);
         const uint64_t nzb = nz0 & band_from;              // history: non-zero coefficients from Ss on
         const int rank0 = mbcnt(nzb);                      // ... how many of them below this lane
@@ -164,8 +101,8 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
         int kend;                                          // corrections go to the history-non-zero lanes below kend
         bool dirty = false;
         if (eobrun > 0) {                                  // inside an end-of-band run: a bit for every non-zero coefficient of the band
-            vbase = bp;
-            bp += __builtin_popcountll(nzb & band);
+            vbase = st.bp;
+            st.bp += __builtin_popcountll(nzb & band);
             kend = se + 1;
             --eobrun;
         } else {
@@ -176,51 +113,50 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
             const int slot = ((zb >> lane) & 1) ? zrank : nzeros + lane - zrank;
             const uint32_t zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
             int k = ss, jz = 0, cnt = 0;                   // jz = zeros below k, cnt = history-non-zeros in [Ss, k)
-            while (k <= se) {
-                int off = bp - gbase;
-                if (off >= 64) {                           // next window of looked-up symbols
+            for (;;) {                                     // (Ss <= Se: a scan has at least one coefficient per block)
+                int off = st.bp - gbase;
+                if (__builtin_expect(off >= 64, 0)) {      // next window of looked-up symbols
                     if (off < 128) {
                         ve0 = ve1; vw0 = vw1; gbase += 64;
                     } else {
-                        gbase = bp;
+                        gbase = st.bp;
                         lookup64(gbase, ve0, vw0);
                     }
                     lookup64(gbase + 64, ve1, vw1);
-                    off = bp - gbase;
+                    off = st.bp - gbase;
                 }
                 uint32_t e = rdl(ve0, off);
-                if ((e & 3u) == 3u) {                      // a code longer than the LUT's index (rare) or no code at all
-                    const uint32_t w = rdl(vw0, off);
-                    int len = 0, hv = 0;
-                    for (int l = kProgLutBits + 1; l <= 16; ++l) {
-                        const int dlt = (int)(w >> (32 - l)) - tab->first_code[l];
-                        if (dlt >= 0 && dlt < tab->count[l]) { hv = tab->vals[tab->first_sym[l] + dlt]; len = l; break; }
+                if (__builtin_expect((e & 3u) != 0u, 0)) {
+                    if (e & 1u) {                          // a code longer than the LUT's index (rare) or no code at all
+                        const uint32_t w = rdl(vw0, off);
+                        int len, hv;
+                        long_code(w, tab, len, hv);
+                        e = ac_entry<true>(w, len, hv, al);
+                        if (len == 0) { err = MJ_ST_BAD_CODE; break; }
                     }
-                    if (len == 0) { err = MJ_ST_BAD_CODE; break; }
-                    e = symbol_entry(w, len, hv, al);
-                }
-                const int adv = (int)((e >> 6) & 31u);
-                if (e & 2u) {                              // end of band: this block's rest and eobrun - 1 further blocks (:1160-1166)
-                    eobrun = (int)(e >> 16);
-                    bp += adv;
-                    break;
+                    if (e & 2u) {                          // end of band: this block's rest and eobrun - 1 further blocks (:1160-1166)
+                        eobrun = (int)(e >> 16);
+                        st.bp += (int)((e >> 6) & 31u);
+                        break;
+                    }
                 }
                 const int jt = jz + (int)((e >> 2) & 15u);
-                if (jt >= nzeros) { err = MJ_ST_OVERRUN; break; }           // fewer zeros left than the run passes (:1190)
+                if (__builtin_expect(jt >= nzeros, 0)) { err = MJ_ST_OVERRUN; break; }   // fewer zeros left than the run passes (:1190)
                 const int pz = (int)rdl(zpos, jt);
                 const int cn = (int)rdl((uint32_t)rank0, pz);
-                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cf) : "s"((int)e >> 16), "s"(pz) : "m0");    // (:1225)
-                const int sbase = bp + adv - cnt;          // the symbol's corrections follow its value bits (:1202, :1231)
+                write_lane(cf, (int)e >> 16, pz);         // (:1225)
+                const int sbase = st.bp + (int)((e >> 6) & 31u) - cnt;      // the symbol's corrections follow its value bits (:1202, :1231)
                 vbase = lane >= k ? sbase : vbase;
-                bp += adv + (cn - cnt);
+                st.bp = sbase + cn;
                 cnt = cn; k = pz + 1; jz = jt + 1;
-                dirty = true;
+                if (k > se) break;
             }
+            dirty = true;
             kend = k;
             if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
-                const int sbase = bp - cnt;
+                const int sbase = st.bp - cnt;
                 vbase = lane >= k ? sbase : vbase;
-                bp += __builtin_popcountll(nzb & bit_range(k, se + 1));
+                st.bp += __builtin_popcountll(nzb & bit_range(k, se + 1));
                 kend = max(k, se + 1);
                 --eobrun;
             }
@@ -229,8 +165,7 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
         if (corr != 0) {
             if ((corr >> lane) & 1) {
                 const int bitpos = vbase + rank0;
-                const uint32_t dw = ring[(bitpos >> 5) & (kRingDw - 1)];
-                const int bit = (int)((dw >> (31 - (bitpos & 31))) & 1u);
+                const int bit = st.bit_at(bitpos);
                 if (spec) cf = (int)(int16_t)(cf + (cf < 0 ? -(bit << al) : (bit << al)));   // T.81 G.1.2.3
                 else cf = (int)(int16_t)(cf | (int)(int16_t)(bit << al));                    // the reference (:1114)
             }
@@ -263,10 +198,7 @@ __global__ __launch_bounds__(256) void k_progressive_refine(const uint32_t *__re
         }
     }
 
-    if (!err) {
-        if (bp > total_bits) err = MJ_ST_OVERRUN;                                  // bits were read from behind the end
-        else if (!sg->last && total_bits - bp >= 8) err = MJ_ST_DESYNC;            // a whole unread byte before the next restart marker
-    }
+    if (!err) err = st.end_status(sg->last != 0);
     if (err && lane == 0) atomicMax(status + sc->image, err);
 }
 
