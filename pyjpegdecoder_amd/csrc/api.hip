@@ -1047,30 +1047,32 @@ static int stage1_impl(mj_plan *p, void *stream) {
         // The scans are pipelined over bands of MCU rows: in launch number `step` a scan of dependency level L does band
         // step - L, so a refining scan follows one band behind what it refines instead of waiting for the whole scan.
         MJ_HIP(ctx, hipMemsetAsync(p->d_pstates, 0xFF, (size_t)p->n_psegs * sizeof(mj::DevProgState), s));
+        const bool fast = p->prog_refine_fast;
+        const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
+        if (fast)       // stage 0 for every segment: what progressive_fast.hip's walks read
+            MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
         if (p->prog_banded) {
-            for (int step = 0; step < p->prog_steps; ++step)
-                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs, (int)p->n_psegs, p->d_pscans, p->d_images,
-                                                        p->d_huff, p->d_coef, p->d_status, (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0,
-                                                        p->transposed ? 1 : 0, p->d_pstates, step, p->prog_rows_per_band));
+            for (int step = 0; step < p->prog_steps; ++step) {
+                if (fast)
+                    MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)p->n_psegs, p->d_pscans, p->d_images,
+                                                            p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates, step,
+                                                            p->prog_rows_per_band));
+                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs, (int)p->n_psegs, p->d_pscans, p->d_images, p->d_huff, p->d_coef,
+                                                        p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates, step, p->prog_rows_per_band));
+            }
         } else {        // one launch per dependency level over that level's segments (one band = the whole image)
-            const bool fast = p->prog_refine_fast;
-            if (fast)
-                MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
             for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {
                 const int64_t s0 = p->ordinal_seg_off[o], s1 = p->ordinal_seg_off[o + 1];
-                const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
                 if (!fast) {
                     MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + s0, (int)(s1 - s0), p->d_pscans, p->d_images, p->d_huff,
                                                             p->d_coef, p->d_status, spec, tr, p->d_pstates + s0, (int)o, 0));
                     continue;
                 }
-                const int64_t *ko = &p->ordinal_kind_off[o * 4];      // DC first | AC first | AC refining | the rest
-                MJ_HIP(ctx, mj::launch_progressive_first(s, p->d_stream, p->d_seg_bits, p->d_psegs + ko[0], (int)(ko[1] - ko[0]), (int)(ko[2] - ko[1]),
-                                                         p->d_pscans, p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status, tr));
-                MJ_HIP(ctx, mj::launch_progressive_refine(s, p->d_stream, p->d_seg_bits, p->d_psegs + ko[2], (int)(ko[3] - ko[2]), p->d_pscans,
-                                                          p->d_images, p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr));
-                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + ko[3], (int)(s1 - ko[3]), p->d_pscans, p->d_images, p->d_huff,
-                                                        p->d_coef, p->d_status, spec, tr, p->d_pstates + ko[3], (int)o, -1));
+                const int64_t r0 = p->ordinal_kind_off[o * 4 + 3];      // DC first | AC first | AC refining | the rest
+                MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs + s0, (int)(r0 - s0), p->d_pscans, p->d_images,
+                                                        p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates + s0, 0, 0));
+                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(s1 - r0), p->d_pscans, p->d_images, p->d_huff,
+                                                        p->d_coef, p->d_status, spec | 2, tr, p->d_pstates + r0, (int)o, -1));
             }
         }
         return MJ_OK;

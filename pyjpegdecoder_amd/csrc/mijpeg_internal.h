@@ -131,15 +131,13 @@ struct DevProgSeg {
 }  // namespace mj
 
 namespace mj {
-// the refining AC scans (progressive_refine.hip) read the stage-0 stream (destuff.hip) of the scans' segments — segment
+// the first scans and the refining AC scans (progressive_fast.hip) read the stage-0 stream (destuff.hip) of the scans' segments — segment
 // number DevProgSeg::stream_slot — and LUTs of kProgLutBits bits, (len << 8 | symbol) per entry, for every table
 constexpr int kProgLutBits = 11;
-hipError_t launch_progressive_refine(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
-                                     int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                     const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed);
-hipError_t launch_progressive_first(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
-                                    int n_dc, int n_ac, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
-                                    const uint16_t *lut11p, int16_t *coef, int32_t *status, int transposed);
+hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
+                                   int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
+                                   const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
+                                   DevProgState *states, int step, int rows_per_band);
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,

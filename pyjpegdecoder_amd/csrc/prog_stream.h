@@ -9,6 +9,8 @@ namespace progstream {
 
 constexpr int kRingDw = 256;              // stream ring per wave (dwords)
 constexpr int kPLut = 1 << kProgLutBits;
+constexpr int kProgDcLutBits = 9;         // DC tables (a dozen symbols) get by with 9 bits: three of them fit where one AC table does
+constexpr int kPDcLut = 1 << kProgDcLutBits;
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -42,13 +44,15 @@ struct Stream {
     int lane;
 
     __device__ __forceinline__ uint32_t chunk(int d0) const { const int d = d0 + lane; return d < n_dw ? sw[d] : 0u; }
-    __device__ __forceinline__ void init(uint32_t *ring_, const uint32_t *stream, const int32_t *seg_bits, const DevProgSeg *sg, int lane_) {
+    __device__ __forceinline__ void init(uint32_t *ring_, const uint32_t *stream, const int32_t *seg_bits, const DevProgSeg *sg, int lane_,
+                                         int bp0 = 0) {
         ring = ring_; lane = lane_;
         sw = stream + (sg->begin >> 2) + sg->stream_slot;       // stage 0 wrote it at dword (begin >> 2) + segment number
         total_bits = seg_bits[sg->stream_slot];
         n_dw = (total_bits + 31) >> 5;
-        whi = 0; bp = 0;
-        pend = chunk(0);
+        bp = bp0;
+        whi = (bp0 >> 5) & ~63;
+        pend = chunk(whi);
         top_up();
     }
     // at least 128 dwords ahead of the next bit; call it often enough that no more than ~100 are consumed in between
@@ -83,10 +87,20 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const uint16_t *lut11p, 
     for (int i = 0; i < kPLut * 2 / 16 / 64; ++i) reinterpret_cast<uint4 *>(lds)[i * 64 + lane] = src[i * 64 + lane];
 }
 
-// a code of more than kProgLutBits bits at the top of w (rare): canonical search (jpeg_decoder.py:712-722); len 0 = none
-__device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int &len, int &hv) {
+// the 9-bit LUT of a DC table from its 11-bit one: codes of 10 and 11 bits become misses (the long-code search finds them)
+__device__ __forceinline__ void load_dc_lut(uint16_t *lds, const uint16_t *lut11p, int table, int lane) {
+    const uint16_t *src = lut11p + (size_t)table * kPLut;
+#pragma unroll
+    for (int i = 0; i < kPDcLut / 64; ++i) {
+        const uint16_t e = src[(i * 64 + lane) << (kProgLutBits - kProgDcLutBits)];
+        lds[i * 64 + lane] = (e >> 8) <= kProgDcLutBits ? e : (uint16_t)0;
+    }
+}
+
+// a code of `from` or more bits at the top of w (rare): canonical search (jpeg_decoder.py:712-722); len 0 = none
+__device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int from, int &len, int &hv) {
     len = 0; hv = 0;
-    for (int l = kProgLutBits + 1; l <= 16; ++l) {
+    for (int l = from; l <= 16; ++l) {
         const int dlt = (int)(w >> (32 - l)) - tab->first_code[l];
         if (dlt >= 0 && dlt < tab->count[l]) { hv = tab->vals[tab->first_sym[l] + dlt]; len = l; return; }
     }

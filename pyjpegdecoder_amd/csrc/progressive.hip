@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                                                           int32_t *__restrict__ status, int spec_refine, int tr,
                                                           DevProgState *__restrict__ states, int step, int rows_per_band) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lut[];   // [4 waves][3 tables][kLutSize]
-    const bool spec = spec_refine != 0;
+    const bool spec = (spec_refine & 1) != 0;
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int seg_id = blockIdx.x * 4 + wave;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     const bool is_dc = ss == 0 && !sequential;
     const int nsc = sc->n_comp;
     if (KIND != 2 && (KIND == 1) != (refining && !is_dc && !sequential)) return;
-    // rows_per_band < 0: the first scans and the refining AC scans are walked elsewhere (progressive_first.hip,
-    // progressive_refine.hip); what is left here is DC refinement and the sequential scans
-    if (!BANDED && rows_per_band < 0 && !sequential && !(is_dc && refining)) return;
+    // spec_refine bit 1: the first scans and the refining AC scans are walked elsewhere (progressive_fast.hip); what is left
+    // here is DC refinement and the sequential scans
+    if ((spec_refine & 2) && !sequential && !(is_dc && refining)) return;
     const bool ac_refining = KIND == 1 ? true : (KIND == 0 ? false : refining);      // in the AC branch below
 
     // ---- which part of the scan this launch does.  The scans of an image are pipelined over bands of `rows_per_band`
@@ -383,7 +383,7 @@ hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, cons
     } else {        // every scan in one piece: `step` is the dependency level whose scans run
         hipLaunchKernelGGL((k_progressive_scan<false, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
                            scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
-        if (rows_per_band == 0)      // (-1: the refining AC scans are progressive_refine.hip's)
+        if (rows_per_band == 0)      // (-1: the refining AC scans are progressive_fast.hip's)
             hipLaunchKernelGGL((k_progressive_scan<false, 1>), dim3((unsigned)blocks), dim3(256), lds, stream, blob, segs, n_segs,
                                scans, images, huff, coef, status, spec_refine, transposed, states, step, 0);
     }

@@ -1,0 +1,520 @@
+// Stage 1 of progressive files on the stage-0 stream: one wavefront walks one restart segment of one scan.
+//
+// ---- the refining AC scans (Ah > 0, Ss > 0) — jpeg_decoder.py:1122-1298 with the correction queue of :1100-1115.
+// These scans are most of a progressive file's entropy-coded bytes (the last luma
+// scan alone is half of a libjpeg-default file) and they cannot be cut into independent pieces: how many correction
+// bits follow a symbol depends on which coefficients of the block earlier scans left non-zero.  What is left to
+// optimise is the serial chain per symbol; one wavefront walks one restart segment of one scan, and a lone
+// wavefront issues one instruction every ~5 cycles whatever the instruction is, so the chain is counted in
+// instructions.  progressive.hip's general walk spends ~170 of them per symbol (bit-buffer refills with the 0xFF
+// rule, an LDS round trip per Huffman symbol, a loop per skipped zero, a loop per 16 correction bits).  Here:
+//
+//   * stage 0 (destuff.hip) has already applied the byte rules: the segment is a big-endian dword stream, a bit
+//     position is one integer, and a 256-dword ring of it sits in LDS (refilled 64 dwords at a time, one global
+//     load in flight);
+//   * Huffman symbols are looked up 64 bit-offsets at a time: lane l decodes the symbol that WOULD start at bit
+//     gbase + l (two ring dwords, one LUT read) and packs what the walk needs — class, zero run, bits consumed by
+//     code and value, the value already extended and shifted — into one dword.  The walk picks its symbol with a
+//     v_readlane; a 64-bit window holds ~15 symbols of a final refinement scan, and the next window is looked up
+//     while this one is being consumed;
+//   * per block, the zero-history positions are turned into a table once (ds_permute: ordinal -> position), so
+//     "skip r zeros, then the next zero" (:1184-1215) is one v_readlane at ordinal jz + r, and the number of
+//     history-non-zero coefficients passed on the way — the correction bits to skip — is a second v_readlane into the
+//     prefix count of the non-zero mask.  The masks of the block's history do not change while the block is walked
+//     (a coefficient placed by this scan lies behind everything later symbols look at);
+//   * correction bits are not read when their symbol is decoded: every lane remembers where its bit will be
+//     (one v_cmp/v_cndmask per symbol) and the whole block's corrections are fetched from the ring and applied at
+//     once when the block ends; the new coefficients go into the lanes with v_writelane.
+//
+// ~35 instructions per coefficient symbol; blocks inside an end-of-band run cost ~40 in all.
+//
+// ---- the first scans of a band (Ah = 0): DC scans (:974-1029) and AC scans (:1122-1179, :1236-1250) only write.
+//   * AC: the block's new coefficients are collected in the lanes (lane = zig-zag index, v_writelane) together with a mask
+//     of the positions written, and stored once per block; blocks inside an end-of-band run are skipped untouched;
+//   * DC: the predictor chain (:1018-1020) is the serial part; the values of 64 consecutive blocks of the scan are
+//     collected in the lanes and stored together.  An interleaved scan uses one Huffman table per component, so each
+//     window of bit offsets is looked up in all of them and the walk takes the entry of the component whose turn it is.
+//   ~20 instructions per symbol.
+//
+// progressive.hip's general walk keeps the scans that are neither (DC refinement: one bit per block; sequential scans
+// of non-interleaved baseline files).
+//
+// ---- launches.  Scans of one image depend on each other (a refining scan needs what it refines), so they are grouped into
+// dependency levels.  Either one launch per level over that level's segments, or — BANDED — the scans of an image are
+// pipelined over bands of frame MCU rows: launch number `step` lets a scan of level L work on band step - L, so a
+// refining scan runs one band behind the scan it refines instead of waiting for all of it, and the serial chains of an
+// image's ten scans overlap.  Between two of its bands a scan keeps its bit position, end-of-band run and DC predictors in
+// a DevProgState.
+#include "mijpeg_internal.h"
+#include "prog_stream.h"
+
+namespace mj {
+
+using namespace progstream;
+
+namespace {
+
+// Everything a walk needs; wave-uniform
+struct Walk {
+    const DevProgSeg *sg;
+    const DevProgScan *sc;
+    const DevImage *im;
+    const DevHuff *huff;
+    int16_t *cbase;
+    int m_lo, m_hi;           // the scan MCUs this launch does
+    int ss, se, al, tr, lane;
+    bool spec;
+    // carried from band to band
+    int eobrun, pred0, pred1, pred2;
+    int err;
+};
+
+// ------------------------------------------------------------------------------------------------ DC, first scan (:974-1029)
+__device__ __forceinline__ void walk_dc_first(Walk &k, Stream &st, const uint16_t *lut /* [3][512] */) {
+    const DevProgScan *sc = k.sc;
+    const int lane = k.lane, al = k.al, nsc = sc->n_comp;
+    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu;
+    // blocks per MCU of each scan component (:980-1003): an interleaved scan covers the frame's MCUs, a single-component
+    // one (never of a subsampled-luma component: api.hip) one block per MCU
+    const int cA = sc->comp[0], cB = nsc > 1 ? sc->comp[1] : 0, cC = nsc > 2 ? sc->comp[2] : 0;
+    const int nA = (nsc > 1 && cA == 0) ? hmax * vmax : 1, nB = nsc > 1 ? ((cB == 0) ? hmax * vmax : 1) : 0;
+    const int nC = nsc > 2 ? ((cC == 0) ? hmax * vmax : 1) : 0;
+    const int bps = nA + nB + nC;
+    auto first_of = [&](int c) { return c == 0 ? 0 : hmax * vmax + c - 1; };      // a component's first block in the frame's MCU
+    uint32_t veA0, veB0 = 0, veC0 = 0, vw0, veA1, veB1 = 0, veC1 = 0, vw1;
+    auto lookup64 = [&](int g, uint32_t &va, uint32_t &vb, uint32_t &vc, uint32_t &vw) {
+        const uint32_t w = st.bits_at(g + lane);
+        const uint32_t i9 = w >> (32 - kProgDcLutBits);
+        vw = w;
+        const uint32_t ea = lut[i9];
+        va = dc_entry(w, (int)(ea >> 8), (int)(ea & 255u));
+        if (nsc > 1) { const uint32_t eb = lut[kPDcLut + i9]; vb = dc_entry(w, (int)(eb >> 8), (int)(eb & 255u)); }
+        if (nsc > 2) { const uint32_t ec = lut[2 * kPDcLut + i9]; vc = dc_entry(w, (int)(ec >> 8), (int)(ec & 255u)); }
+    };
+    int gbase = st.bp;
+    lookup64(gbase, veA0, veB0, veC0, vw0);
+    lookup64(gbase + 64, veA1, veB1, veC1, vw1);
+    int pred0 = k.pred0, pred1 = k.pred1, pred2 = k.pred2;
+    const int mcu0 = k.sg->mcu0;
+    const int t_lo = (k.m_lo - mcu0) * bps, t_hi = (k.m_hi - mcu0) * bps;      // blocks of the segment, in scan order
+    int vdc = 0;
+    int j = 0;                                                                // block of the MCU
+    int err = 0;
+    for (int t = t_lo; t < t_hi; ++t) {
+        if (((t - t_lo) & 15) == 0) st.top_up();
+        int off = st.bp - gbase;
+        if (__builtin_expect(off >= 64, 0)) {
+            if (off < 128) {
+                veA0 = veA1; veB0 = veB1; veC0 = veC1; vw0 = vw1; gbase += 64;
+            } else {
+                gbase = st.bp;
+                lookup64(gbase, veA0, veB0, veC0, vw0);
+            }
+            lookup64(gbase + 64, veA1, veB1, veC1, vw1);
+            off = st.bp - gbase;
+        }
+        const int ci = j < nA ? 0 : (j < nA + nB ? 1 : 2);                    // scan component of this block
+        uint32_t e = ci == 0 ? rdl(veA0, off) : (ci == 1 ? rdl(veB0, off) : rdl(veC0, off));
+        if (__builtin_expect((e & 3u) != 0u, 0)) {                            // a code longer than the LUT's index, or none
+            const uint32_t w = rdl(vw0, off);
+            int len, s;
+            long_code(w, k.huff + sc->dc_tab[ci], kProgDcLutBits + 1, len, s);
+            e = dc_entry(w, len, s);
+            if (e & 3u) { err = MJ_ST_BAD_CODE; break; }
+        }
+        st.bp += (int)((e >> 6) & 63u);
+        const int pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+        const int dcv = (int)(int16_t)((int)(e >> 16) + pred);              // (:1018-1020)
+        if (ci == 0) pred0 = dcv; else if (ci == 1) pred1 = dcv; else pred2 = dcv;
+        write_lane(vdc, (int)(int16_t)(dcv << al), (t - t_lo) & 63);        // (:1029)
+        if (++j == bps) j = 0;
+        if (((t - t_lo) & 63) == 63 || t + 1 == t_hi) {                      // 64 blocks' values at once
+            const int tl = t_lo + ((t - t_lo) & ~63) + lane;                  // this lane's block of the segment
+            if (tl <= t) {
+                const int mm = tl / bps, jj = tl - mm * bps;
+                const int cc = jj < nA ? cA : (jj < nA + nB ? cB : cC);
+                const int rr = jj < nA ? jj : (jj < nA + nB ? jj - nA : jj - nA - nB);
+                k.cbase[((int64_t)(mcu0 + mm) * bpm + first_of(cc) + rr) * 64] = (int16_t)vdc;
+            }
+        }
+    }
+    k.pred0 = pred0; k.pred1 = pred1; k.pred2 = pred2;
+    k.err = err;
+}
+
+// ------------------------------------------------------------------------- AC, first scan of the band (:1122-1179, :1236-1250)
+__device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_t *lut) {
+    const DevProgScan *sc = k.sc;
+    const int lane = k.lane, al = k.al, ss = k.ss, se = k.se;
+    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
+    const int ncf = k.im->ncomp;
+    const int c = sc->comp[0];
+    const DevHuff *tab = k.huff + sc->ac_tab[0];
+    const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
+    const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+    const int smh = sc->mcu_count_h;
+    const int nz_nat = c_nat_of_zz_ps[lane];
+    const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
+    const int lh = h == 4 ? 2 : h - 1, lv = v == 4 ? 2 : v - 1;               // h, v are 1, 2 or 4
+    int by = k.m_lo / smh, bx = k.m_lo - by * smh;
+    uint32_t ve0, vw0, ve1, vw1;
+    auto lookup64 = [&](int g, uint32_t &ve, uint32_t &vw) {
+        const uint32_t w = st.bits_at(g + lane);
+        const uint32_t e16 = lut[w >> (32 - kProgLutBits)];
+        vw = w;
+        ve = ac_entry<false>(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
+    };
+    int gbase = st.bp;
+    lookup64(gbase, ve0, vw0);
+    lookup64(gbase + 64, ve1, vw1);
+    int eobrun = k.eobrun, err = 0;
+    for (int m = k.m_lo; m < k.m_hi && !err; ++m) {
+        if (eobrun > 0) {                                  // the block lies in an end-of-band run: nothing of this band in it
+            --eobrun;
+        } else {
+            st.top_up();
+            int cf = 0;
+            uint64_t touched = 0;
+            int kk = ss;
+            for (;;) {
+                int off = st.bp - gbase;
+                if (__builtin_expect(off >= 64, 0)) {
+                    if (off < 128) {
+                        ve0 = ve1; vw0 = vw1; gbase += 64;
+                    } else {
+                        gbase = st.bp;
+                        lookup64(gbase, ve0, vw0);
+                    }
+                    lookup64(gbase + 64, ve1, vw1);
+                    off = st.bp - gbase;
+                }
+                uint32_t e = rdl(ve0, off);
+                if (__builtin_expect((e & 3u) != 0u, 0)) {
+                    if ((e & 3u) == 3u) {                  // a code longer than the LUT's index (rare) or no code at all
+                        const uint32_t w = rdl(vw0, off);
+                        int len, hv;
+                        long_code(w, tab, kProgLutBits + 1, len, hv);
+                        e = ac_entry<false>(w, len, hv, al);
+                        if (len == 0) { err = MJ_ST_BAD_CODE; break; }
+                    }
+                    if (e & 2u) {                          // end of band: the run counts this block (:1160-1166)
+                        eobrun = (int)(e >> 16) - 1;
+                        st.bp += (int)((e >> 6) & 31u);
+                        break;
+                    }
+                    if (e & 1u) {                          // ZRL: sixteen zeros (:1170)
+                        kk += 16;
+                        st.bp += (int)((e >> 6) & 31u);
+                        if (kk > se) break;
+                        continue;
+                    }
+                }
+                kk += (int)((e >> 2) & 15u);
+                if (__builtin_expect(kk > 63, 0)) { err = MJ_ST_OVERRUN; break; }
+                write_lane(cf, (int)e >> 16, kk);          // (:1248-1250)
+                touched |= (uint64_t)1 << kk;
+                st.bp += (int)((e >> 6) & 31u);
+                if (++kk > se) break;
+            }
+            if (touched != 0) {
+                const int mx = bx >> lh, my = by >> lv;
+                int16_t *p = k.cbase + ((int64_t)(my * fmx + mx) * bpm + first + ((by - (my << lv)) << lh) + (bx - (mx << lh))) * 64;
+                if ((touched >> lane) & 1) p[nat] = (int16_t)cf;
+            }
+        }
+        if (++bx == smh) { bx = 0; ++by; }
+    }
+    k.eobrun = eobrun;
+    k.err = err;
+}
+
+// -------------------------------------------------------------------------------------- AC, refining scan (:1122-1298, :1100-1115)
+__device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16_t *lut) {
+    const DevProgScan *sc = k.sc;
+    const int lane = k.lane, al = k.al, ss = k.ss, se = k.se;
+    const bool spec = k.spec;
+    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
+    const int ncf = k.im->ncomp;
+    const int c = sc->comp[0];
+    const DevHuff *tab = k.huff + sc->ac_tab[0];
+    int16_t *cbase = k.cbase;
+    const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
+    const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+    const int smh = sc->mcu_count_h;
+    const int nz_nat = c_nat_of_zz_ps[lane];
+    const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
+    // this lane's coefficient of the scan's blocks, one after the other in scan order (h, v are 1, 2 or 4: shifts)
+    const int lh = h == 4 ? 2 : h - 1, lv = v == 4 ? 2 : v - 1;
+    int nby = k.m_lo / smh, nbx = k.m_lo - nby * smh;
+    auto next_elem = [&]() -> int16_t * {
+        const int mx = nbx >> lh, my = nby >> lv;
+        int16_t *p = cbase + ((int64_t)(my * fmx + mx) * bpm + first + ((nby - (my << lv)) << lh) + (nbx - (mx << lh))) * 64 + nat;
+        if (++nbx == smh) { nbx = 0; ++nby; }
+        return p;
+    };
+    // ---- symbols of 64 consecutive bit offsets (see ac_entry)
+    auto lookup64 = [&](int g, uint32_t &ve, uint32_t &vw) {
+        const uint32_t w = st.bits_at(g + lane);
+        const uint32_t e16 = lut[w >> (32 - kProgLutBits)];
+        vw = w;
+        ve = ac_entry<true>(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
+    };
+    int gbase = st.bp;
+    uint32_t ve0, vw0, ve1, vw1;              // offsets [gbase, gbase + 64) and [gbase + 64, gbase + 128)
+    lookup64(gbase, ve0, vw0);
+    lookup64(gbase + 64, ve1, vw1);
+    const bool in_band = lane >= ss && lane <= se;
+    const uint64_t band_from = from_bit(ss), band = bit_range(ss, se + 1);
+    const int m_lo = k.m_lo, m_hi = k.m_hi;
+    int err = 0, eobrun = k.eobrun;
+
+    auto one_block = [&](int cf, int16_t *p) __attribute__((always_inline)) {
+        st.top_up();
+        const uint64_t nz0 = __ballot(cf != 0);
+        const uint64_t nzb = nz0 & band_from;              // history: non-zero coefficients from Ss on
+        const int rank0 = mbcnt(nzb);                      // ... how many of them below this lane
+        int vbase = 0;                                     // this lane's correction bit is bit vbase + rank0 of the stream
+        int kend;                                          // corrections go to the history-non-zero lanes below kend
+        bool dirty = false;
+        if (eobrun > 0) {                                  // inside an end-of-band run: a bit for every non-zero coefficient of the band
+            vbase = st.bp;
+            st.bp += __builtin_popcountll(nzb & band);
+            kend = se + 1;
+            --eobrun;
+        } else {
+            const uint64_t zb = ~nz0 & band_from;          // zero history
+            const int nzeros = __builtin_popcountll(zb);
+            const int zrank = mbcnt(zb);
+            // position of the j-th zero: lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
+            const int slot = ((zb >> lane) & 1) ? zrank : nzeros + lane - zrank;
+            const uint32_t zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
+            int k = ss, jz = 0, cnt = 0;                   // jz = zeros below k, cnt = history-non-zeros in [Ss, k)
+            for (;;) {                                     // (Ss <= Se: a scan has at least one coefficient per block)
+                // The run of plain coefficient symbols inside the current window, hand-scheduled: 27 instructions per symbol
+                // (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).  Leaves with
+                // code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not a plain coefficient
+                // (EOB, or not in the LUT);  3: the zero run passes the last zero.
+                // Wait states: v_readlane's lane select pz is VALU-written 9 instructions earlier (4 needed); SALU reads
+                // of VALU-written SGPRs are interlocked.
+                uint32_t e;
+                int code, t0, jt, pz, off;
+                int vt;
+                asm volatile(
+                    "Lsym%=:\n\t"
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
+                    "s_cmp_gt_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lwin%=\n\t"
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n\t"
+                    "s_and_b32 %[t0], %[e], 3\n\t"
+                    "s_cbranch_scc1 Lspec%=\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x40002\n\t"
+                    "s_add_u32 %[jt], %[jz], %[t0]\n\t"
+                    "s_cmp_ge_u32 %[jt], %[nzeros]\n\t"
+                    "s_cbranch_scc1 Lover%=\n\t"
+                    "v_readlane_b32 %[pz], %[zpos], %[jt]\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_add_u32 %[t0], %[t0], %[bp]\n\t"
+                    "s_sub_u32 %[t0], %[t0], %[cnt]\n\t"
+                    "v_mov_b32 %[vt], %[t0]\n\t"
+                    "v_cmp_le_u32 vcc, %[k], %[vlane]\n\t"
+                    "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
+                    "s_ashr_i32 %[e], %[e], 16\n\t"
+                    "s_mov_b32 m0, %[pz]\n\t"
+                    "v_writelane_b32 %[cf], %[e], m0\n\t"
+                    "v_readlane_b32 %[cnt], %[rank0], %[pz]\n\t"
+                    "s_add_u32 %[k], %[pz], 1\n\t"
+                    "s_add_u32 %[jz], %[jt], 1\n\t"
+                    "s_add_u32 %[bp], %[t0], %[cnt]\n\t"
+                    "s_cmp_le_u32 %[k], %[se]\n\t"
+                    "s_cbranch_scc1 Lsym%=\n\t"
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch Lend%=\n"
+                    "Lwin%=:\n\t"
+                    "s_mov_b32 %[code], 1\n\t"
+                    "s_branch Lend%=\n"
+                    "Lspec%=:\n\t"
+                    "s_mov_b32 %[code], 2\n\t"
+                    "s_branch Lend%=\n"
+                    "Lover%=:\n\t"
+                    "s_mov_b32 %[code], 3\n"
+                    "Lend%=:"
+                    : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [off] "=&s"(off), [vt] "=&v"(vt),
+                      [bp] "+s"(st.bp), [k] "+s"(k), [jz] "+s"(jz), [cnt] "+s"(cnt), [cf] "+v"(cf), [vbase] "+v"(vbase)
+                    : [gbase] "s"(gbase), [ve0] "v"(ve0), [zpos] "v"(zpos), [rank0] "v"(rank0), [vlane] "v"(lane), [se] "s"(se),
+                      [nzeros] "s"(nzeros)
+                    : "vcc", "scc", "m0");
+                if (code == 0) break;
+                if (code == 1) {                           // next window of looked-up symbols
+                    if (off < 128) {
+                        ve0 = ve1; vw0 = vw1; gbase += 64;
+                    } else {
+                        gbase = st.bp;
+                        lookup64(gbase, ve0, vw0);
+                    }
+                    lookup64(gbase + 64, ve1, vw1);
+                    continue;
+                }
+                if (code == 3) { err = MJ_ST_OVERRUN; break; }              // fewer zeros left than the run passes (:1190)
+                if (e & 1u) {                              // a code longer than the LUT's index (rare) or no code at all
+                    const uint32_t w = rdl(vw0, off);
+                    int len, hv;
+                    long_code(w, tab, kProgLutBits + 1, len, hv);
+                    e = ac_entry<true>(w, len, hv, al);
+                    if (len == 0) { err = MJ_ST_BAD_CODE; break; }
+                }
+                if (e & 2u) {                              // end of band: this block's rest and eobrun - 1 further blocks (:1160-1166)
+                    eobrun = (int)(e >> 16);
+                    st.bp += (int)((e >> 6) & 31u);
+                    break;
+                }
+                // (a long code's coefficient: the same step as above, once)
+                const int jt2 = jz + (int)((e >> 2) & 15u);
+                if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
+                const int pz2 = (int)rdl(zpos, jt2);
+                const int cn = (int)rdl((uint32_t)rank0, pz2);
+                write_lane(cf, (int)e >> 16, pz2);         // (:1225)
+                const int sbase = st.bp + (int)((e >> 6) & 31u) - cnt;      // the symbol's corrections follow its value bits (:1202, :1231)
+                vbase = lane >= k ? sbase : vbase;
+                st.bp = sbase + cn;
+                cnt = cn; k = pz2 + 1; jz = jt2 + 1;
+                if (k > se) break;
+            }
+            dirty = true;
+            kend = k;
+            if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
+                const int sbase = st.bp - cnt;
+                vbase = lane >= k ? sbase : vbase;
+                st.bp += __builtin_popcountll(nzb & bit_range(k, se + 1));
+                kend = max(k, se + 1);
+                --eobrun;
+            }
+        }
+        const uint64_t corr = nzb & ~from_bit(kend);
+        if (corr != 0) {
+            if ((corr >> lane) & 1) {
+                const int bitpos = vbase + rank0;
+                const int bit = st.bit_at(bitpos);
+                if (spec) cf = (int)(int16_t)(cf + (cf < 0 ? -(bit << al) : (bit << al)));   // T.81 G.1.2.3
+                else cf = (int)(int16_t)(cf | (int)(int16_t)(bit << al));                    // the reference (:1114)
+            }
+            dirty = true;
+        }
+        // only this scan's band is written back: other scans of the same dependency level may be updating other
+        // coefficients of the block at the same time
+        if (dirty && in_band) *p = (int16_t)cf;
+    };
+
+
+    // four blocks' coefficients in flight: a block is ~1 us of HBM latency away and takes less than that to walk
+    constexpr int D = 4;
+    int cfq[D];
+    int16_t *pq[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        pq[u] = cbase + nat;
+        cfq[u] = 0;
+        if (m_lo + u < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
+    }
+    for (int m = m_lo; m < m_hi && !err; m += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (m + u < m_hi && !err) {
+                const int cf = cfq[u];
+                int16_t *p = pq[u];
+                if (m + u + D < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
+                one_block(cf, p);
+            }
+        }
+    }
+    k.eobrun = eobrun;
+    k.err = err;
+}
+
+}  // namespace
+
+template <bool BANDED>
+__global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__restrict__ stream, const int32_t *__restrict__ seg_bits,
+                                                          const DevProgSeg *__restrict__ segs, int n_segs,
+                                                          const DevProgScan *__restrict__ scans, const DevImage *__restrict__ images,
+                                                          const DevHuff *__restrict__ huff, const uint16_t *__restrict__ lut11p,
+                                                          int16_t *__restrict__ coef, int32_t *__restrict__ status, int spec_refine, int tr,
+                                                          DevProgState *__restrict__ states, int step, int rows_per_band) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][kPLut];        // AC: one table of 11 bits; DC: up to three of 9 bits
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[4][kRingDw];
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int seg_id = blockIdx.x * 4 + wave;
+    if (seg_id >= n_segs) return;                              // wave-uniform; no workgroup barriers below
+    Walk k;
+    k.sg = segs + seg_id;
+    k.sc = scans + k.sg->scan;
+    const DevProgScan *sc = k.sc;
+    k.ss = sc->ss; k.se = sc->se; k.al = sc->al; k.tr = tr; k.lane = lane; k.spec = spec_refine != 0;
+    const bool sequential = k.ss == 0 && k.se == 63;
+    const bool is_dc = k.ss == 0;
+    if (sequential || (is_dc && sc->ah != 0)) return;          // progressive.hip's
+    k.im = images + sc->image;
+    k.huff = huff;
+    k.cbase = coef + k.im->block_off * 64;
+
+    // ---- which part of the scan this launch does
+    int b_lo = k.sg->mcu0, b_hi = k.sg->mcu0 + k.sg->n_mcu;
+    if (BANDED) {
+        const int band = step - sc->level;
+        if (band < 0) return;
+        const int v_scan = (sc->n_comp == 1 && k.im->ncomp > 1 && sc->comp[0] == 0) ? k.im->vmax : 1;   // block rows per frame MCU row
+        const int64_t mpb = (int64_t)sc->mcu_count_h * rows_per_band * v_scan;
+        const int64_t lo = (int64_t)band * mpb, hi = lo + mpb;
+        b_lo = (int)max((int64_t)b_lo, lo);
+        b_hi = (int)min((int64_t)b_hi, hi);
+        if (b_lo >= b_hi) return;
+    }
+    k.m_lo = b_lo; k.m_hi = b_hi;
+    const bool resume = BANDED && b_lo != k.sg->mcu0, finish = !BANDED || b_hi == k.sg->mcu0 + k.sg->n_mcu;
+    DevProgState *ps = states + seg_id;
+    int bp0 = 0;
+    k.eobrun = 0; k.pred0 = k.pred1 = k.pred2 = 0; k.err = 0;
+    if (resume) {
+        if (ps->err != 0 || ps->mcu_next != b_lo) return;      // the scan failed earlier (its status is set)
+        bp0 = ps->pos; k.eobrun = ps->eobrun; k.pred0 = ps->pred[0]; k.pred1 = ps->pred[1]; k.pred2 = ps->pred[2];
+    }
+
+    uint16_t *lut = s_lut[wave];
+    if (is_dc) {
+        for (int t = 0; t < sc->n_comp; ++t) load_dc_lut(lut + t * kPDcLut, lut11p, sc->dc_tab[t], lane);
+    } else {
+        load_lut(lut, lut11p, sc->ac_tab[0], lane);
+    }
+    Stream st;
+    st.init(s_ring[wave], stream, seg_bits, k.sg, lane, bp0);
+
+    if (is_dc) walk_dc_first(k, st, lut);
+    else if (sc->ah == 0) walk_ac_first(k, st, lut);
+    else walk_ac_refine(k, st, lut);
+
+    int err = k.err;
+    if (BANDED && !finish && lane == 0) {
+        ps->pos = st.bp; ps->eobrun = k.eobrun; ps->pred[0] = k.pred0; ps->pred[1] = k.pred1; ps->pred[2] = k.pred2;
+        ps->err = err; ps->mcu_next = b_hi;
+    }
+    if (!err && finish) err = st.end_status(k.sg->last != 0);
+    if (err && lane == 0) atomicMax(status + sc->image, err);
+}
+
+// rows_per_band > 0: launch number `step` of the band pipeline over all segments; otherwise the segments of one dependency level
+hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
+                                   int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
+                                   const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
+                                   DevProgState *states, int step, int rows_per_band) {
+    if (n_segs == 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_segs + 3) / 4));
+    if (rows_per_band > 0)
+        hipLaunchKernelGGL(k_progressive_fast<true>, grid, dim3(256), 0, stream, dstream, seg_bits, segs, n_segs, scans, images, huff,
+                           lut11p, coef, status, spec_refine, transposed, states, step, rows_per_band);
+    else
+        hipLaunchKernelGGL(k_progressive_fast<false>, grid, dim3(256), 0, stream, dstream, seg_bits, segs, n_segs, scans, images, huff,
+                           lut11p, coef, status, spec_refine, transposed, states, 0, 0);
+    return hipGetLastError();
+}
+
+}  // namespace mj
