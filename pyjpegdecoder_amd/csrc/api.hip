@@ -627,16 +627,22 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
           }
         }
         p->ordinal_seg_off[n_ord] = (int64_t)psegs.size();
-        {   // Band pipelining (see mj_plan_execute_stage1): ~34 bands over the tallest image, launches = bands + levels - 1.
-            // It shortens the critical path — a refining scan follows one band behind what it refines — which pays
-            // while the chip is mostly empty (measured: 256 x 1080p 433 -> 329 ms); with thousands of images the scalar
-            // units are the limit and all scans of all images at once only crowd them (1024 x 1080p: 454 -> 533 ms),
-            // so large batches keep one launch per dependency level.
+        {   // Band pipelining (see progressive_fast.hip): two frame MCU rows per band, launches = bands + levels - 1.  It
+            // shortens the critical path from the sum of the levels' longest scans to about the longest scan — a refining scan
+            // follows one band behind what it refines — and keeps all of an image's scans on the chip at once: faster than one
+            // launch per dependency level at every batch size measured (16 x 1080p: 146 -> 83 ms, 1024: 184 -> 145 ms,
+            // 8192: 728 -> 692 ms).  MJ_PROG_BANDS=0 (tests) keeps one launch per level.
             int max_rows = 1;
             for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
-            p->prog_banded = (int64_t)psegs.size() <= 4096;
+            p->prog_banded = true;
             if (const char *e = getenv("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
-            p->prog_rows_per_band = p->prog_banded ? std::max(1, (max_rows + 33) / 34) : max_rows;
+            p->prog_rows_per_band = p->prog_banded ? 2 : max_rows;
+            if (p->prog_banded) {
+                // every launch of the pipeline covers all segments, and more workgroups than the chip holds at once: the long
+                // walks go first (a launch lasts as long as its slowest wave; started last, the final luma refinement — half
+                // of a file's bytes — would begin when the short scans' waves leave)
+                std::stable_sort(psegs.begin(), psegs.end(), [](const mj::DevProgSeg &x, const mj::DevProgSeg &y) { return x.len > y.len; });
+            }
             if (const char *e = getenv("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
             p->prog_steps = n_bands + n_ord - 1;

@@ -1027,6 +1027,42 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
 
 
+@pytest.mark.parametrize("form", ["levels", "one_row_bands", "general_walk", "general_walk_levels"])
+def test_progressive_launch_forms(dec, dec_rm, form, monkeypatch):
+    """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
+    launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, two MCU rows per
+    band — is what every other progressive test runs; here the other combinations decode every progressive fixture in one
+    mixed batch, coefficient store included, plus larger random files with long EOB runs and restart intervals."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from oracle import oracle
+    from tools import synth
+    env = {"levels": {"MJ_PROG_BANDS": "0"}, "one_row_bands": {"MJ_PROG_ROWS": "1"}, "general_walk": {"MJ_PROG_FAST": "0"},
+           "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"}}[form]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    names = prog_names()
+    imgs, seams = dec.decode([load_golden(n)[0] for n in names], return_seams=True)
+    for n, img, seam in zip(names, imgs, seams):
+        vec = load_golden(n)[1]
+        assert np.array_equal(seam["coef"], vec["coef"]), (form, n)
+        assert np.array_equal(img, vec["rgb"]), (form, n)
+    files = []
+    for i, (w, h, ss, q, sigma, rows) in enumerate([(640, 360, 2, 85, 25.0, 0), (333, 211, 1, 95, 40.0, 2), (257, 129, 0, 40, 0.0, 0),
+                                                    (200, 300, 2, 70, 8.0, 1)]):
+        kw = dict(quality=q, subsampling=ss, progressive=True)
+        if rows:
+            kw["restart_marker_rows"] = rows
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(4100 + i, w, h, sigma)).save(b, "JPEG", **kw)
+        files.append(b.getvalue())
+    refs = [oracle.decode(f)["rgb"] for f in files]
+    for i, (img, ref) in enumerate(zip(dec.decode(files), refs)):
+        assert np.array_equal(img, ref), (form, i)
+    for i, (img, ref) in enumerate(zip(dec_rm.decode(files), refs)):
+        assert np.array_equal(np.swapaxes(img, 0, 1), ref), (form, i)
+
+
 # ---- round 2: boundary and fallbacks ---------------------------------------------------------------------------------
 def test_one_shot_entry_point_through_ctypes(dec):
     """`mj_decode_baseline_batch` is what INTEGRATION.md's reference-side stub binds: call it directly (no Plan wrapper)
