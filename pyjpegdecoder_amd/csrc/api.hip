@@ -172,6 +172,7 @@ struct mj_plan {
     mj::DevSegment *d_prog_dsegs = nullptr;  // d_psegs' byte ranges in the form stage 0 takes
     uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
     bool prog_refine_fast = false;
+    int64_t prog_rest_off = 0;               // banded: d_psegs[prog_rest_off..] are the segments of the scans progressive.hip walks
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
     std::vector<int64_t> ordinal_kind_off;  // [n_ordinals][4]: within a level, where the segments of each kind of scan start
     uint16_t *d_qt = nullptr;
@@ -641,7 +642,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 // every launch of the pipeline covers all segments, and more workgroups than the chip holds at once: the long
                 // walks go first (a launch lasts as long as its slowest wave; started last, the final luma refinement — half
                 // of a file's bytes — would begin when the short scans' waves leave)
-                std::stable_sort(psegs.begin(), psegs.end(), [](const mj::DevProgSeg &x, const mj::DevProgSeg &y) { return x.len > y.len; });
+                // (behind them the segments of the scans progressive.hip walks — DC refinement, sequential scans — so that its
+                // launches cover only those)
+                auto rest = [&](const mj::DevProgSeg &g) { return kind_of(b->scans[g.scan]) == 3; };
+                std::stable_sort(psegs.begin(), psegs.end(), [&](const mj::DevProgSeg &x, const mj::DevProgSeg &y) {
+                    return rest(x) != rest(y) ? rest(y) : x.len > y.len;
+                });
+                p->prog_rest_off = 0;
+                while (p->prog_rest_off < (int64_t)psegs.size() && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
             }
             if (const char *e = getenv("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
@@ -1060,11 +1068,13 @@ static int stage1_impl(mj_plan *p, void *stream) {
         if (p->prog_banded) {
             for (int step = 0; step < p->prog_steps; ++step) {
                 if (fast)
-                    MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)p->n_psegs, p->d_pscans, p->d_images,
+                    MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)p->prog_rest_off, p->d_pscans, p->d_images,
                                                             p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates, step,
                                                             p->prog_rows_per_band));
-                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs, (int)p->n_psegs, p->d_pscans, p->d_images, p->d_huff, p->d_coef,
-                                                        p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates, step, p->prog_rows_per_band));
+                const int64_t r0 = fast ? p->prog_rest_off : 0;
+                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(p->n_psegs - r0), p->d_pscans, p->d_images, p->d_huff,
+                                                        p->d_coef, p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates + r0, step,
+                                                        p->prog_rows_per_band));
             }
         } else {        // one launch per dependency level over that level's segments (one band = the whole image)
             for (size_t o = 0; o + 1 < p->ordinal_seg_off.size(); ++o) {

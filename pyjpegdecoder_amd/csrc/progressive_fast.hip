@@ -288,16 +288,18 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
             // position of the j-th zero: lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
             const int slot = ((zb >> lane) & 1) ? zrank : nzeros + lane - zrank;
             const uint32_t zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
-            int k = ss, jz = 0, cnt = 0;                   // jz = zeros below k, cnt = history-non-zeros in [Ss, k)
+            // ... and how many history-non-zero coefficients lie in front of it: the correction bits read up to there
+            const uint32_t ztab = (uint32_t)__builtin_amdgcn_ds_bpermute((int)zpos << 2, rank0);
+            int k = ss, jz = 0;                            // jz = zeros below k
+            int u = st.bp;                                 // the bit position without the correction bits read in this block
             for (;;) {                                     // (Ss <= Se: a scan has at least one coefficient per block)
-                // The run of plain coefficient symbols inside the current window, hand-scheduled: 27 instructions per symbol
-                // (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).  Leaves with
-                // code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not a plain coefficient
-                // (EOB, or not in the LUT);  3: the zero run passes the last zero.
-                // Wait states: v_readlane's lane select pz is VALU-written 9 instructions earlier (4 needed); SALU reads
-                // of VALU-written SGPRs are interlocked.
+                // The run of plain coefficient symbols inside the current window, hand-scheduled: 26 instructions per symbol,
+                // two v_readlane deep (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
+                // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not a plain
+                // coefficient (EOB, or not in the LUT);  3: the zero run passes the last zero.
+                // Wait states: no v_readlane takes its lane select from a VALU-written SGPR; SALU reads of those are interlocked.
                 uint32_t e;
-                int code, t0, jt, pz, off;
+                int code, t0, jt, pz, cn, off;
                 int vt;
                 asm volatile(
                     "Lsym%=:\n\t"
@@ -311,20 +313,19 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_add_u32 %[jt], %[jz], %[t0]\n\t"
                     "s_cmp_ge_u32 %[jt], %[nzeros]\n\t"
                     "s_cbranch_scc1 Lover%=\n\t"
+                    "v_readlane_b32 %[cn], %[ztab], %[jt]\n\t"
                     "v_readlane_b32 %[pz], %[zpos], %[jt]\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
-                    "s_add_u32 %[t0], %[t0], %[bp]\n\t"
-                    "s_sub_u32 %[t0], %[t0], %[cnt]\n\t"
-                    "v_mov_b32 %[vt], %[t0]\n\t"
+                    "s_add_u32 %[u], %[u], %[t0]\n\t"
+                    "s_add_u32 %[bp], %[u], %[cn]\n\t"
+                    "v_mov_b32 %[vt], %[u]\n\t"
                     "v_cmp_le_u32 vcc, %[k], %[vlane]\n\t"
                     "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
                     "s_ashr_i32 %[e], %[e], 16\n\t"
                     "s_mov_b32 m0, %[pz]\n\t"
                     "v_writelane_b32 %[cf], %[e], m0\n\t"
-                    "v_readlane_b32 %[cnt], %[rank0], %[pz]\n\t"
                     "s_add_u32 %[k], %[pz], 1\n\t"
                     "s_add_u32 %[jz], %[jt], 1\n\t"
-                    "s_add_u32 %[bp], %[t0], %[cnt]\n\t"
                     "s_cmp_le_u32 %[k], %[se]\n\t"
                     "s_cbranch_scc1 Lsym%=\n\t"
                     "s_mov_b32 %[code], 0\n\t"
@@ -338,9 +339,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "Lover%=:\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lend%=:"
-                    : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [off] "=&s"(off), [vt] "=&v"(vt),
-                      [bp] "+s"(st.bp), [k] "+s"(k), [jz] "+s"(jz), [cnt] "+s"(cnt), [cf] "+v"(cf), [vbase] "+v"(vbase)
-                    : [gbase] "s"(gbase), [ve0] "v"(ve0), [zpos] "v"(zpos), [rank0] "v"(rank0), [vlane] "v"(lane), [se] "s"(se),
+                    : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [cn] "=&s"(cn), [off] "=&s"(off),
+                      [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k] "+s"(k), [jz] "+s"(jz), [cf] "+v"(cf), [vbase] "+v"(vbase)
+                    : [gbase] "s"(gbase), [ve0] "v"(ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
                       [nzeros] "s"(nzeros)
                     : "vcc", "scc", "m0");
                 if (code == 0) break;
@@ -365,25 +366,24 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 if (e & 2u) {                              // end of band: this block's rest and eobrun - 1 further blocks (:1160-1166)
                     eobrun = (int)(e >> 16);
                     st.bp += (int)((e >> 6) & 31u);
+                    u += (int)((e >> 6) & 31u);
                     break;
                 }
                 // (a long code's coefficient: the same step as above, once)
                 const int jt2 = jz + (int)((e >> 2) & 15u);
                 if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
                 const int pz2 = (int)rdl(zpos, jt2);
-                const int cn = (int)rdl((uint32_t)rank0, pz2);
                 write_lane(cf, (int)e >> 16, pz2);         // (:1225)
-                const int sbase = st.bp + (int)((e >> 6) & 31u) - cnt;      // the symbol's corrections follow its value bits (:1202, :1231)
-                vbase = lane >= k ? sbase : vbase;
-                st.bp = sbase + cn;
-                cnt = cn; k = pz2 + 1; jz = jt2 + 1;
+                u += (int)((e >> 6) & 31u);                // the symbol's corrections follow its value bits (:1202, :1231)
+                vbase = lane >= k ? u : vbase;
+                st.bp = u + (int)rdl(ztab, jt2);
+                k = pz2 + 1; jz = jt2 + 1;
                 if (k > se) break;
             }
             dirty = true;
             kend = k;
             if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
-                const int sbase = st.bp - cnt;
-                vbase = lane >= k ? sbase : vbase;
+                vbase = lane >= k ? u : vbase;
                 st.bp += __builtin_popcountll(nzb & bit_range(k, se + 1));
                 kend = max(k, se + 1);
                 --eobrun;
