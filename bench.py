@@ -36,9 +36,11 @@ HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def sources_sha16() -> str:
-    """Fingerprint of the kernel sources: PMC summaries under profiles/ are only quoted for the build they came from."""
+    """Fingerprint of the sources of the kernels the roofline objects are about (stage 0, the lane-parallel stage 1, the fast
+    stage 2): PMC summaries under profiles/ are only quoted for the build they came from."""
     h = hashlib.sha256()
-    for f in sorted((ROOT / "pyjpegdecoder_amd" / "csrc").glob("*.h*")):
+    names = ("destuff.hip", "huffman_lanes.hip", "reconstruct_fast.hip", "mijpeg_internal.h", "upsample_taps.h")
+    for f in sorted((ROOT / "pyjpegdecoder_amd" / "csrc" / n) for n in names):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
