@@ -1329,6 +1329,7 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
             *stage1_ms = ms / iters;
 #ifdef MJ_DIAGNOSTIC
             mj::dbg_lanes_report();
+            mj::dbg_prog_report();
 #endif
         }
     }

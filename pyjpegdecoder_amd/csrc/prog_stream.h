@@ -69,6 +69,15 @@ struct Stream {
         const uint32_t a = ring[d & (kRingDw - 1)], b = ring[(d + 1) & (kRingDw - 1)];
         return (uint32_t)((((uint64_t)a << 32 | b) << sh) >> 32);
     }
+    // ... in two steps, so that the LDS reads can be left in flight: the two ring dwords around bit q, and what they hold from q on
+    __device__ __forceinline__ void raw_at(int q, uint32_t &a, uint32_t &b) const {
+        const int d = q >> 5;
+        a = ring[d & (kRingDw - 1)];
+        b = ring[(d + 1) & (kRingDw - 1)];
+    }
+    static __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b, int q) {
+        return (uint32_t)((((uint64_t)a << 32 | b) << (q & 31)) >> 32);
+    }
     // one bit (q per lane)
     __device__ __forceinline__ int bit_at(int q) const {
         return (int)((ring[(q >> 5) & (kRingDw - 1)] >> (31 - (q & 31))) & 1u);
@@ -144,6 +153,38 @@ __device__ __forceinline__ uint32_t dc_entry(uint32_t w, int len, int s) {
     }
     return ((uint32_t)(len + s) << 6) | (d16 << 16);
 }
+
+// The AC walks' look-ups, three windows of 64 bit offsets deep so that no LDS read is waited for: window 0
+// [gbase, gbase + 64) is ready (ve0 = ac_entry per offset, vw0 = the 32 stream bits from there), window 1 has its bits and
+// its LUT read in flight, window 2 its two ring reads.  advance() moves on by one window; the values it consumes were
+// requested a whole window (~15 symbols) earlier.
+template <bool ZRL_IS_COEF>
+struct AcWindows {
+    uint32_t ve0, vw0, w1, e1, a2, b2;
+    int gbase;
+    __device__ __forceinline__ void start(const Stream &st, const uint16_t *lut, int al, int lane, int g) {
+        gbase = g;
+        vw0 = st.bits_at(g + lane);
+        const uint32_t e0 = lut[vw0 >> (32 - kProgLutBits)];
+        ve0 = ac_entry<ZRL_IS_COEF>(vw0, (int)(e0 >> 8), (int)(e0 & 255u), al);
+        w1 = st.bits_at(g + 64 + lane);
+        e1 = lut[w1 >> (32 - kProgLutBits)];
+        st.raw_at(g + 128 + lane, a2, b2);
+    }
+    __device__ __forceinline__ void advance(const Stream &st, const uint16_t *lut, int al, int lane) {
+        gbase += 64;
+        ve0 = ac_entry<ZRL_IS_COEF>(w1, (int)(e1 >> 8), (int)(e1 & 255u), al);
+        vw0 = w1;
+        w1 = Stream::combine(a2, b2, gbase + 64 + lane);
+        e1 = lut[w1 >> (32 - kProgLutBits)];
+        st.raw_at(gbase + 128 + lane, a2, b2);
+    }
+    // the symbol at bit position bp lies `off` = bp - gbase >= 64 bits into the windows
+    __device__ __forceinline__ void move_to(const Stream &st, const uint16_t *lut, int al, int lane, int off) {
+        if (off < 128) advance(st, lut, al, lane);
+        else start(st, lut, al, lane, st.bp);
+    }
+};
 
 }  // namespace progstream
 }  // namespace mj

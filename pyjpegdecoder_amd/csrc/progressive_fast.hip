@@ -52,6 +52,25 @@ namespace mj {
 
 using namespace progstream;
 
+#ifdef MJ_DIAGNOSTIC   // separate diagnostic build only (make DIAG=1): where the final luma refinement's cycles go
+__device__ unsigned long long g_dbg_prog[8];
+void dbg_prog_report() {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_prog), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_prog), z, sizeof(z));
+    unsigned long long tot = 0;
+    for (int i = 0; i < 7; ++i) tot += h[i];
+    if (tot == 0) return;
+    static const char *nm[7] = {"block prologue", "symbol loop (asm)", "window look-ups", "EOB / long codes", "corrections + store", "blocks in EOB runs", "between blocks"};
+    fprintf(stderr, "[diag] refining walk of the Ah=1 luma scans, %llu waves: ", h[7]);
+    for (int i = 0; i < 7; ++i) fprintf(stderr, "%s %.1f%%  ", nm[i], 100.0 * (double)h[i] / (double)tot);
+    fprintf(stderr, "(%.1f Mcycles per wave)\n", (double)tot / (double)(h[7] ? h[7] : 1) / 1e6);
+}
+#define PSTAMP(i) do { if (dbg_on) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dacc[i] += s_ - dlast; dlast = s_; } } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 // Everything a walk needs; wave-uniform
@@ -157,16 +176,8 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
     const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
     const int lh = h == 4 ? 2 : h - 1, lv = v == 4 ? 2 : v - 1;               // h, v are 1, 2 or 4
     int by = k.m_lo / smh, bx = k.m_lo - by * smh;
-    uint32_t ve0, vw0, ve1, vw1;
-    auto lookup64 = [&](int g, uint32_t &ve, uint32_t &vw) {
-        const uint32_t w = st.bits_at(g + lane);
-        const uint32_t e16 = lut[w >> (32 - kProgLutBits)];
-        vw = w;
-        ve = ac_entry<false>(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
-    };
-    int gbase = st.bp;
-    lookup64(gbase, ve0, vw0);
-    lookup64(gbase + 64, ve1, vw1);
+    AcWindows<false> win;
+    win.start(st, lut, al, lane, st.bp);
     int eobrun = k.eobrun, err = 0;
     for (int m = k.m_lo; m < k.m_hi && !err; ++m) {
         if (eobrun > 0) {                                  // the block lies in an end-of-band run: nothing of this band in it
@@ -177,21 +188,15 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
             uint64_t touched = 0;
             int kk = ss;
             for (;;) {
-                int off = st.bp - gbase;
+                int off = st.bp - win.gbase;
                 if (__builtin_expect(off >= 64, 0)) {
-                    if (off < 128) {
-                        ve0 = ve1; vw0 = vw1; gbase += 64;
-                    } else {
-                        gbase = st.bp;
-                        lookup64(gbase, ve0, vw0);
-                    }
-                    lookup64(gbase + 64, ve1, vw1);
-                    off = st.bp - gbase;
+                    win.move_to(st, lut, al, lane, off);
+                    off = st.bp - win.gbase;
                 }
-                uint32_t e = rdl(ve0, off);
+                uint32_t e = rdl(win.ve0, off);
                 if (__builtin_expect((e & 3u) != 0u, 0)) {
                     if ((e & 3u) == 3u) {                  // a code longer than the LUT's index (rare) or no code at all
-                        const uint32_t w = rdl(vw0, off);
+                        const uint32_t w = rdl(win.vw0, off);
                         int len, hv;
                         long_code(w, tab, kProgLutBits + 1, len, hv);
                         e = ac_entry<false>(w, len, hv, al);
@@ -252,61 +257,89 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         if (++nbx == smh) { nbx = 0; ++nby; }
         return p;
     };
-    // ---- symbols of 64 consecutive bit offsets (see ac_entry)
-    auto lookup64 = [&](int g, uint32_t &ve, uint32_t &vw) {
-        const uint32_t w = st.bits_at(g + lane);
-        const uint32_t e16 = lut[w >> (32 - kProgLutBits)];
-        vw = w;
-        ve = ac_entry<true>(w, (int)(e16 >> 8), (int)(e16 & 255u), al);
-    };
-    int gbase = st.bp;
-    uint32_t ve0, vw0, ve1, vw1;              // offsets [gbase, gbase + 64) and [gbase + 64, gbase + 128)
-    lookup64(gbase, ve0, vw0);
-    lookup64(gbase + 64, ve1, vw1);
+    AcWindows<true> win;                      // symbols of 64 consecutive bit offsets (see ac_entry)
+    win.start(st, lut, al, lane, st.bp);
     const bool in_band = lane >= ss && lane <= se;
     const uint64_t band_from = from_bit(ss), band = bit_range(ss, se + 1);
     const int m_lo = k.m_lo, m_hi = k.m_hi;
     int err = 0, eobrun = k.eobrun;
+#ifdef MJ_DIAGNOSTIC
+    const bool dbg_on = sc->ah == 1 && c == 0;
+    uint64_t dacc[7] = {0, 0, 0, 0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
+#endif
 
-    auto one_block = [&](int cf, int16_t *p) __attribute__((always_inline)) {
-        st.top_up();
+    // What a block's walk needs from its history, worked out one block ahead (the two cross-lane permutes are LDS round trips)
+    struct Prep {
+        uint64_t nzb;         // history: non-zero coefficients from Ss on
+        int rank0;            // ... how many of them below this lane
+        int nzeros;           // zero-history positions from Ss on
+        uint32_t zpos;        // lane j: position of the j-th of them
+        uint32_t ztab;        // lane j: history-non-zero coefficients in front of it = correction bits read up to there
+    };
+    auto prepare = [&](int cf, bool in_eob_run) __attribute__((always_inline)) -> Prep {
+        Prep q;
         const uint64_t nz0 = __ballot(cf != 0);
-        const uint64_t nzb = nz0 & band_from;              // history: non-zero coefficients from Ss on
-        const int rank0 = mbcnt(nzb);                      // ... how many of them below this lane
+        q.nzb = nz0 & band_from;
+        q.rank0 = mbcnt(q.nzb);
+        q.nzeros = 0; q.zpos = 0; q.ztab = 0;
+        if (in_eob_run) return q;                          // a bit for every non-zero coefficient of the band: no zero runs to follow
+        const uint64_t zb = ~nz0 & band_from;
+        q.nzeros = __builtin_popcountll(zb);
+        const int zrank = mbcnt(zb);
+        // lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
+        const int slot = (cf == 0 && lane >= ss) ? zrank : q.nzeros + lane - zrank;
+        q.zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
+        q.ztab = (uint32_t)__builtin_amdgcn_ds_bpermute((int)q.zpos << 2, q.rank0);
+        return q;
+    };
+    auto one_block = [&](int cf, int16_t *p, const Prep &pr) __attribute__((always_inline)) {
+        PSTAMP(6);
+        st.top_up();
+        const uint64_t nzb = pr.nzb;
+        const int rank0 = pr.rank0;
         int vbase = 0;                                     // this lane's correction bit is bit vbase + rank0 of the stream
         int kend;                                          // corrections go to the history-non-zero lanes below kend
         bool dirty = false;
+#ifdef MJ_DIAGNOSTIC
+        bool dbg_eob = false;
+#endif
         if (eobrun > 0) {                                  // inside an end-of-band run: a bit for every non-zero coefficient of the band
             vbase = st.bp;
             st.bp += __builtin_popcountll(nzb & band);
             kend = se + 1;
             --eobrun;
+#ifdef MJ_DIAGNOSTIC
+            dbg_eob = true;
+#endif
         } else {
-            const uint64_t zb = ~nz0 & band_from;          // zero history
-            const int nzeros = __builtin_popcountll(zb);
-            const int zrank = mbcnt(zb);
-            // position of the j-th zero: lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
-            const int slot = ((zb >> lane) & 1) ? zrank : nzeros + lane - zrank;
-            const uint32_t zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
-            // ... and how many history-non-zero coefficients lie in front of it: the correction bits read up to there
-            const uint32_t ztab = (uint32_t)__builtin_amdgcn_ds_bpermute((int)zpos << 2, rank0);
+            const int nzeros = pr.nzeros;
+            const uint32_t zpos = pr.zpos, ztab = pr.ztab;
             int k = ss, jz = 0;                            // jz = zeros below k
             int u = st.bp;                                 // the bit position without the correction bits read in this block
+#ifdef MJ_DIAGNOSTIC
+            bool dbg_first = true;
+#endif
             for (;;) {                                     // (Ss <= Se: a scan has at least one coefficient per block)
-                // The run of plain coefficient symbols inside the current window, hand-scheduled: 26 instructions per symbol,
-                // two v_readlane deep (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
-                // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not a plain
-                // coefficient (EOB, or not in the LUT);  3: the zero run passes the last zero.
+                // The run of plain coefficient symbols inside the current window, hand-scheduled and software-pipelined: 28
+                // instructions per symbol, two v_readlane deep, the next symbol's entry in flight during this symbol's
+                // bookkeeping (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
+                // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not in the LUT;
+                // 3: the zero run passes the last zero;  4: end of band, run length in eobrun.
                 // Wait states: no v_readlane takes its lane select from a VALU-written SGPR; SALU reads of those are interlocked.
-                uint32_t e;
+                uint32_t e, e2;
                 int code, t0, jt, pz, cn, off;
                 int vt;
+                PSTAMP(dbg_first ? 0 : 3);
+#ifdef MJ_DIAGNOSTIC
+                dbg_first = false;
+#endif
                 asm volatile(
-                    "Lsym%=:\n\t"
+                    // prologue: the first symbol of the run
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "s_cmp_gt_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lwin%=\n\t"
-                    "v_readlane_b32 %[e], %[ve0], %[off]\n\t"
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    "Lsym%=:\n\t"
                     "s_and_b32 %[t0], %[e], 3\n\t"
                     "s_cbranch_scc1 Lspec%=\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x40002\n\t"
@@ -318,6 +351,10 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
                     "s_add_u32 %[u], %[u], %[t0]\n\t"
                     "s_add_u32 %[bp], %[u], %[cn]\n\t"
+                    // the next symbol's entry is requested before this symbol's bookkeeping (a window offset past 63 reads some
+                    // lane's entry, which is then not used)
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
+                    "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
                     "v_mov_b32 %[vt], %[u]\n\t"
                     "v_cmp_le_u32 vcc, %[k], %[vlane]\n\t"
                     "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
@@ -326,38 +363,50 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "v_writelane_b32 %[cf], %[e], m0\n\t"
                     "s_add_u32 %[k], %[pz], 1\n\t"
                     "s_add_u32 %[jz], %[jt], 1\n\t"
-                    "s_cmp_le_u32 %[k], %[se]\n\t"
-                    "s_cbranch_scc1 Lsym%=\n\t"
-                    "s_mov_b32 %[code], 0\n\t"
-                    "s_branch Lend%=\n"
+                    "s_mov_b32 %[e], %[e2]\n\t"
+                    "s_cmp_gt_u32 %[k], %[se]\n\t"
+                    "s_cbranch_scc1 Ldone%=\n\t"
+                    "s_cmp_le_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lsym%=\n"
                     "Lwin%=:\n\t"
                     "s_mov_b32 %[code], 1\n\t"
                     "s_branch Lend%=\n"
-                    "Lspec%=:\n\t"
+                    "Ldone%=:\n\t"
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch Lend%=\n"
+                    "Lspec%=:\n\t"                              // EOBn found in the LUT: the run's length, the bits of code and run
+                    "s_bitcmp1_b32 %[e], 0\n\t"
+                    "s_cbranch_scc1 Llong%=\n\t"
+                    "s_lshr_b32 %[eob], %[e], 16\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_add_u32 %[bp], %[bp], %[t0]\n\t"
+                    "s_add_u32 %[u], %[u], %[t0]\n\t"
+                    "s_mov_b32 %[code], 4\n\t"
+                    "s_branch Lend%=\n"
+                    "Llong%=:\n\t"
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lend%=\n"
                     "Lover%=:\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lend%=:"
-                    : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [cn] "=&s"(cn), [off] "=&s"(off),
-                      [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k] "+s"(k), [jz] "+s"(jz), [cf] "+v"(cf), [vbase] "+v"(vbase)
-                    : [gbase] "s"(gbase), [ve0] "v"(ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
+                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [cn] "=&s"(cn),
+                      [off] "=&s"(off), [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k] "+s"(k), [jz] "+s"(jz), [cf] "+v"(cf),
+                      [vbase] "+v"(vbase), [eob] "+s"(eobrun)
+                    : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
                       [nzeros] "s"(nzeros)
                     : "vcc", "scc", "m0");
-                if (code == 0) break;
+                PSTAMP(1);
+                if (code == 0 || code == 4) break;         // the band is done / end of band (:1160-1166)
                 if (code == 1) {                           // next window of looked-up symbols
-                    if (off < 128) {
-                        ve0 = ve1; vw0 = vw1; gbase += 64;
-                    } else {
-                        gbase = st.bp;
-                        lookup64(gbase, ve0, vw0);
-                    }
-                    lookup64(gbase + 64, ve1, vw1);
+                    win.move_to(st, lut, al, lane, off);
+#ifdef MJ_DIAGNOSTIC
+                    PSTAMP(2);
+#endif
                     continue;
                 }
                 if (code == 3) { err = MJ_ST_OVERRUN; break; }              // fewer zeros left than the run passes (:1190)
                 if (e & 1u) {                              // a code longer than the LUT's index (rare) or no code at all
-                    const uint32_t w = rdl(vw0, off);
+                    const uint32_t w = rdl(win.vw0, off);
                     int len, hv;
                     long_code(w, tab, kProgLutBits + 1, len, hv);
                     e = ac_entry<true>(w, len, hv, al);
@@ -380,6 +429,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 k = pz2 + 1; jz = jt2 + 1;
                 if (k > se) break;
             }
+            PSTAMP(3);
             dirty = true;
             kend = k;
             if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
@@ -402,6 +452,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         // only this scan's band is written back: other scans of the same dependency level may be updating other
         // coefficients of the block at the same time
         if (dirty && in_band) *p = (int16_t)cf;
+#ifdef MJ_DIAGNOSTIC
+        PSTAMP(dbg_eob ? 5 : 4);
+#endif
     };
 
 
@@ -422,12 +475,20 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 const int cf = cfq[u];
                 int16_t *p = pq[u];
                 if (m + u + D < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
-                one_block(cf, p);
+                // (working the next block's tables out one block ahead, to hide the permutes' latency, was slower: the tables
+                // of two blocks alive at once cost scalar registers the symbol loop's surroundings need)
+                one_block(cf, p, prepare(cf, eobrun > 0));
             }
         }
     }
     k.eobrun = eobrun;
     k.err = err;
+#ifdef MJ_DIAGNOSTIC
+    if (dbg_on && lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_dbg_prog[i], (unsigned long long)dacc[i]);
+        atomicAdd(&g_dbg_prog[7], 1ull);
+    }
+#endif
 }
 
 }  // namespace

@@ -8,6 +8,9 @@ from tools import synth
 from pyjpegdecoder_amd import _binding as B
 from pyjpegdecoder_amd.batch import prepare_batch
 W, H, nd = 1920, 1080, 8
+if os.environ.get("MJ_PROBE_LIB"):      # e.g. pyjpegdecoder_amd/libmijpeg_diag.so: its stage timing prints the refining walk's phase shares
+    from pathlib import Path
+    B.LIB_PATH = Path(os.environ["MJ_PROBE_LIB"]).resolve()
 raws = []
 for i in range(nd):
     b = io.BytesIO(); Image.fromarray(synth.synth_rgb(500000 + i, W, H)).save(b, "JPEG", quality=85, subsampling=2, progressive=True); raws.append(b.getvalue())
@@ -23,6 +26,8 @@ for n in [int(a) for a in sys.argv[1:]] or [1024]:
     for _ in range(2): plan.execute(0, d_rgb.data_ptr())
     plan.sync(); dt = (time.perf_counter() - t) / 2
     ok = not plan.read(rgb=False)["status"].any()
+    if os.environ.get("MJ_PROBE_LIB"):
+        print("stage times", plan.time_stages(1, d_rgb.data_ptr()), flush=True)
     print(f"{n} x 1080p progressive: {dt*1e3:.1f} ms per batch = {n*W*H/1e6/dt:.0f} MP/s  status ok {ok}", flush=True)
     plan.close(); del d_rgb, d_blob
     torch.cuda.empty_cache()
