@@ -43,7 +43,7 @@ struct Stream {
     int bp;               // next bit
     int lane;
 
-    __device__ __forceinline__ uint32_t chunk(int d0) const { const int d = d0 + lane; return d < n_dw ? sw[d] : 0u; }
+    __device__ __forceinline__ uint32_t chunk(int d0) const { const int d = d0 + lane; return (uint32_t)d < (uint32_t)n_dw ? sw[d] : 0u; }
     __device__ __forceinline__ void init(uint32_t *ring_, const uint32_t *stream, const int32_t *seg_bits, const DevProgSeg *sg, int lane_,
                                          int bp0 = 0) {
         ring = ring_; lane = lane_;

@@ -784,6 +784,45 @@ def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
                 os.environ.pop("MJ_HUFFMAN", None)
 
 
+def test_damaged_progressive_streams_both_walks_agree(dec, monkeypatch):
+    """Random byte damage inside the scans of progressive files: the stream walks (progressive_fast.hip) and the general
+    walk (progressive.hip) implement the same reader — zeros behind a segment's end, the same overrun / desync / bad-code
+    rules — so they must fail on the same files and, where the damage still decodes, leave the same pixels."""
+    from pyjpegdecoder_amd import JpegError, parse_jpeg
+    rng = np.random.default_rng(4321)
+    names = prog_names()
+    for name in names[:6]:
+        raw, vec = load_golden(name)
+        scans = parse_jpeg(raw).scans
+        damaged = []
+        for _ in range(20):
+            b = bytearray(raw)
+            for _ in range(int(rng.integers(1, 4))):
+                sc = scans[int(rng.integers(0, len(scans)))]
+                lo, hi = int(sc.entropy_start), int(sc.entropy_end)
+                if hi > lo:
+                    b[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
+            damaged.append(bytes(b))
+        outcomes = {}
+        for walk in ("stream", "general"):
+            if walk == "general":
+                monkeypatch.setenv("MJ_PROG_FAST", "0")
+            else:
+                monkeypatch.delenv("MJ_PROG_FAST", raising=False)
+            res = []
+            for f in damaged:
+                try:
+                    res.append(dec.decode([f])[0])
+                except JpegError:
+                    res.append(None)
+            outcomes[walk] = res
+            assert np.array_equal(dec.decode([raw])[0], vec["rgb"]), (name, walk)       # the decoder is still healthy
+        for i, (a, b) in enumerate(zip(outcomes["stream"], outcomes["general"])):
+            assert (a is None) == (b is None), (name, i)
+            if a is not None:
+                assert np.array_equal(a, b), (name, i)
+
+
 def test_reference_repository_example_progressive_file(dec):
     """4160x2340 4:2:0 progressive with DRI redefined between scans: the two truncations whose
     decoded images the reference repository ships as PNGs, and the whole file against the oracle."""
