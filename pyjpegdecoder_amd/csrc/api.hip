@@ -171,8 +171,9 @@ struct mj_plan {
     // the refining AC scans read the stage-0 stream of the scans' segments (progressive_refine.hip)
     mj::DevSegment *d_prog_dsegs = nullptr;  // d_psegs' byte ranges in the form stage 0 takes
     uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
-    bool prog_refine_fast = false;
+    bool prog_fast = false;
     int64_t prog_rest_off = 0;               // banded: d_psegs[prog_rest_off..] are the segments of the scans progressive.hip walks
+    // (one launch per dependency level only — MJ_PROG_BANDS=0; the band pipeline orders d_psegs by length instead)
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
     std::vector<int64_t> ordinal_kind_off;  // [n_ordinals][4]: within a level, where the segments of each kind of scan start
     uint16_t *d_qt = nullptr;
@@ -911,9 +912,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->n_psegs = (int64_t)psegs.size();
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
             // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_first.hip, progressive_refine.hip)
-            p->prog_refine_fast = true;
-            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_refine_fast = atoi(e) != 0;
-            if (p->prog_refine_fast) {
+            p->prog_fast = true;
+            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = atoi(e) != 0;
+            if (p->prog_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
                 // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if
                 // they are numbered in blob order — psegs is ordered by dependency level, so each one records its number
@@ -1061,7 +1062,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
         // The scans are pipelined over bands of MCU rows: in launch number `step` a scan of dependency level L does band
         // step - L, so a refining scan follows one band behind what it refines instead of waiting for the whole scan.
         MJ_HIP(ctx, hipMemsetAsync(p->d_pstates, 0xFF, (size_t)p->n_psegs * sizeof(mj::DevProgState), s));
-        const bool fast = p->prog_refine_fast;
+        const bool fast = p->prog_fast;
         const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
         if (fast)       // stage 0 for every segment: what progressive_fast.hip's walks read
             MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
