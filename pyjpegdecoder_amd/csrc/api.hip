@@ -1313,9 +1313,13 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
     if (!p || iters <= 0) return MJ_ERR_INVALID;
     mj_context *ctx = p->ctx;
     hipStream_t s = ctx->stream;
-    hipEvent_t e0, e1;
-    MJ_HIP(ctx, hipEventCreate(&e0));
-    MJ_HIP(ctx, hipEventCreate(&e1));
+    struct Events {           // destroyed on every way out, the error returns of MJ_HIP included
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    MJ_HIP(ctx, hipEventCreate(&ev.a));
+    MJ_HIP(ctx, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     int rc = MJ_OK;
     float ms = 0.f;
     if (stage1_ms) {
@@ -1357,8 +1361,6 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
         }
 #endif
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return rc;
 }
 
