@@ -272,6 +272,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     struct Prep {
         uint64_t nzb;         // history: non-zero coefficients from Ss on
         int rank0;            // ... how many of them below this lane
+        int nband;            // ... how many of them in the band [Ss, Se]
         int nzeros;           // zero-history positions from Ss on
         uint32_t zpos;        // lane j: position of the j-th of them
         uint32_t ztab;        // lane j: history-non-zero coefficients in front of it = correction bits read up to there
@@ -281,6 +282,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         const uint64_t nz0 = __ballot(cf != 0);
         q.nzb = nz0 & band_from;
         q.rank0 = mbcnt(q.nzb);
+        q.nband = __builtin_popcountll(q.nzb & band);
         q.nzeros = 0; q.zpos = 0; q.ztab = 0;
         if (in_eob_run) return q;                          // a bit for every non-zero coefficient of the band: no zero runs to follow
         const uint64_t zb = ~nz0 & band_from;
@@ -297,6 +299,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         st.top_up();
         const uint64_t nzb = pr.nzb;
         const int rank0 = pr.rank0;
+        const bool hist = cf != 0 && lane >= ss;           // this lane's coefficient is history-non-zero (the walk only writes zero ones)
         int vbase = 0;                                     // this lane's correction bit is bit vbase + rank0 of the stream
         int kend;                                          // corrections go to the history-non-zero lanes below kend
         bool dirty = false;
@@ -305,7 +308,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
 #endif
         if (eobrun > 0) {                                  // inside an end-of-band run: a bit for every non-zero coefficient of the band
             vbase = st.bp;
-            st.bp += __builtin_popcountll(nzb & band);
+            st.bp += pr.nband;
             kend = se + 1;
             --eobrun;
 #ifdef MJ_DIAGNOSTIC
@@ -434,14 +437,15 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
             kend = k;
             if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
                 vbase = lane >= k ? u : vbase;
-                st.bp += __builtin_popcountll(nzb & bit_range(k, se + 1));
+                // st.bp - u corrections have been read for [Ss, k): the band's other history-non-zero coefficients follow
+                if (k <= se) st.bp = u + pr.nband;
                 kend = max(k, se + 1);
                 --eobrun;
             }
         }
         const uint64_t corr = nzb & ~from_bit(kend);
         if (corr != 0) {
-            if ((corr >> lane) & 1) {
+            if (hist && lane < kend) {
                 const int bitpos = vbase + rank0;
                 const int bit = st.bit_at(bitpos);
                 if (spec) cf = (int)(int16_t)(cf + (cf < 0 ? -(bit << al) : (bit << al)));   // T.81 G.1.2.3
