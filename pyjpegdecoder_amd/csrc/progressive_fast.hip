@@ -188,34 +188,87 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
             uint64_t touched = 0;
             int kk = ss;
             for (;;) {
-                int off = st.bp - win.gbase;
-                if (__builtin_expect(off >= 64, 0)) {
-                    win.move_to(st, lut, al, lane, off);
-                    off = st.bp - win.gbase;
+                // The run of coefficient symbols inside the current window, hand-scheduled like the refining walk's: 20
+                // instructions per symbol, the next symbol's entry in flight during this one's placement.  Leaves with code
+                // 0: kk > Se;  1: the next symbol starts behind the window;  2: ZRL, or entry not in the LUT;
+                // 3: position past 63;  4: end of band, eobrun set (the run counts this block, :1160-1166).
+                uint32_t e, e2;
+                int code, t0, off;
+                asm volatile(
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
+                    "s_cmp_gt_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lfwin%=\n\t"
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    "Lfsym%=:\n\t"
+                    "s_and_b32 %[t0], %[e], 3\n\t"
+                    "s_cbranch_scc1 Lfspec%=\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x40002\n\t"
+                    "s_add_u32 %[kk], %[kk], %[t0]\n\t"
+                    "s_cmp_gt_u32 %[kk], 63\n\t"
+                    "s_cbranch_scc1 Lfover%=\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_add_u32 %[bp], %[bp], %[t0]\n\t"
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
+                    "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
+                    "s_ashr_i32 %[e], %[e], 16\n\t"
+                    "s_mov_b32 m0, %[kk]\n\t"
+                    "v_writelane_b32 %[cf], %[e], m0\n\t"           // (:1248-1250)
+                    "s_bitset1_b64 %[touched], %[kk]\n\t"
+                    "s_add_u32 %[kk], %[kk], 1\n\t"
+                    "s_mov_b32 %[e], %[e2]\n\t"
+                    "s_cmp_gt_u32 %[kk], %[se]\n\t"
+                    "s_cbranch_scc1 Lfdone%=\n\t"
+                    "s_cmp_le_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lfsym%=\n"
+                    "Lfwin%=:\n\t"
+                    "s_mov_b32 %[code], 1\n\t"
+                    "s_branch Lfend%=\n"
+                    "Lfdone%=:\n\t"
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch Lfend%=\n"
+                    "Lfspec%=:\n\t"
+                    "s_cmp_eq_u32 %[t0], 2\n\t"                    // EOBn found in the LUT
+                    "s_cbranch_scc0 Lfother%=\n\t"
+                    "s_lshr_b32 %[eob], %[e], 16\n\t"
+                    "s_sub_u32 %[eob], %[eob], 1\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_add_u32 %[bp], %[bp], %[t0]\n\t"
+                    "s_mov_b32 %[code], 4\n\t"
+                    "s_branch Lfend%=\n"
+                    "Lfother%=:\n\t"
+                    "s_mov_b32 %[code], 2\n\t"
+                    "s_branch Lfend%=\n"
+                    "Lfover%=:\n\t"
+                    "s_mov_b32 %[code], 3\n"
+                    "Lfend%=:"
+                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [bp] "+s"(st.bp), [kk] "+s"(kk),
+                      [touched] "+s"(touched), [cf] "+v"(cf), [eob] "+s"(eobrun)
+                    : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [se] "s"(se)
+                    : "vcc", "scc", "m0");
+                if (code == 0 || code == 4) break;
+                if (code == 1) { win.move_to(st, lut, al, lane, off); continue; }
+                if (code == 3) { err = MJ_ST_OVERRUN; break; }
+                if ((e & 3u) == 3u) {                      // a code longer than the LUT's index (rare) or no code at all
+                    const uint32_t w = rdl(win.vw0, off);
+                    int len, hv;
+                    long_code(w, tab, kProgLutBits + 1, len, hv);
+                    e = ac_entry<false>(w, len, hv, al);
+                    if (len == 0) { err = MJ_ST_BAD_CODE; break; }
                 }
-                uint32_t e = rdl(win.ve0, off);
-                if (__builtin_expect((e & 3u) != 0u, 0)) {
-                    if ((e & 3u) == 3u) {                  // a code longer than the LUT's index (rare) or no code at all
-                        const uint32_t w = rdl(win.vw0, off);
-                        int len, hv;
-                        long_code(w, tab, kProgLutBits + 1, len, hv);
-                        e = ac_entry<false>(w, len, hv, al);
-                        if (len == 0) { err = MJ_ST_BAD_CODE; break; }
-                    }
-                    if (e & 2u) {                          // end of band: the run counts this block (:1160-1166)
-                        eobrun = (int)(e >> 16) - 1;
-                        st.bp += (int)((e >> 6) & 31u);
-                        break;
-                    }
-                    if (e & 1u) {                          // ZRL: sixteen zeros (:1170)
-                        kk += 16;
-                        st.bp += (int)((e >> 6) & 31u);
-                        if (kk > se) break;
-                        continue;
-                    }
+                if (e & 2u) {                              // end of band: the run counts this block (:1160-1166)
+                    eobrun = (int)(e >> 16) - 1;
+                    st.bp += (int)((e >> 6) & 31u);
+                    break;
                 }
+                if (e & 1u) {                              // ZRL: sixteen zeros (:1170)
+                    kk += 16;
+                    st.bp += (int)((e >> 6) & 31u);
+                    if (kk > se) break;
+                    continue;
+                }
+                // (a long code's coefficient)
                 kk += (int)((e >> 2) & 15u);
-                if (__builtin_expect(kk > 63, 0)) { err = MJ_ST_OVERRUN; break; }
+                if (kk > 63) { err = MJ_ST_OVERRUN; break; }
                 write_lane(cf, (int)e >> 16, kk);          // (:1248-1250)
                 touched |= (uint64_t)1 << kk;
                 st.bp += (int)((e >> 6) & 31u);
