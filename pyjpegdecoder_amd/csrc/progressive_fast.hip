@@ -179,10 +179,20 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
     AcWindows<false> win;
     win.start(st, lut, al, lane, st.bp);
     int eobrun = k.eobrun, err = 0;
-    for (int m = k.m_lo; m < k.m_hi && !err; ++m) {
-        if (eobrun > 0) {                                  // the block lies in an end-of-band run: nothing of this band in it
-            --eobrun;
-        } else {
+    // first block of block row `by` (the part of a block's number that only changes with the row)
+    auto row_base = [&](int y) { const int my = y >> lv; return my * fmx * bpm + first + ((y - (my << lv)) << lh); };
+    int rbase = row_base(by);
+    for (int m = k.m_lo; m < k.m_hi && !err;) {
+        if (eobrun > 0) {                                  // blocks inside an end-of-band run hold nothing of this band: skipped in one step
+            const int n = min(eobrun, k.m_hi - m);
+            eobrun -= n; m += n; bx += n;
+            if (bx >= smh) {
+                do { bx -= smh; ++by; } while (bx >= smh);
+                rbase = row_base(by);
+            }
+            continue;
+        }
+        {
             st.top_up();
             int cf = 0;
             uint64_t touched = 0;
@@ -275,12 +285,13 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                 if (++kk > se) break;
             }
             if (touched != 0) {
-                const int mx = bx >> lh, my = by >> lv;
-                int16_t *p = k.cbase + ((int64_t)(my * fmx + mx) * bpm + first + ((by - (my << lv)) << lh) + (bx - (mx << lh))) * 64;
+                const int mx = bx >> lh;
+                int16_t *p = k.cbase + (int64_t)(rbase + mx * bpm + (bx - (mx << lh))) * 64;
                 if ((touched >> lane) & 1) p[nat] = (int16_t)cf;
             }
         }
-        if (++bx == smh) { bx = 0; ++by; }
+        ++m;
+        if (++bx == smh) { bx = 0; ++by; rbase = row_base(by); }
     }
     k.eobrun = eobrun;
     k.err = err;
