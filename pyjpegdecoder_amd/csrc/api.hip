@@ -168,7 +168,7 @@ struct mj_plan {
     int64_t n_psegs = 0;
     int prog_rows_per_band = 2, prog_steps = 0;
     bool prog_banded = false;
-    // the refining AC scans read the stage-0 stream of the scans' segments (progressive_refine.hip)
+    // the first scans and the refining AC scans read the stage-0 stream of the scans' segments (progressive_fast.hip)
     mj::DevSegment *d_prog_dsegs = nullptr;  // d_psegs' byte ranges in the form stage 0 takes
     uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
     bool prog_fast = false;
@@ -911,7 +911,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
             p->n_psegs = (int64_t)psegs.size();
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
-            // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_first.hip, progressive_refine.hip)
+            // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_fast.hip)
             p->prog_fast = true;
             if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = atoi(e) != 0;
             if (p->prog_fast) {

@@ -125,7 +125,7 @@ struct DevProgSeg {
     int32_t scan;         // index into the DevProgScan array
     int32_t mcu0, n_mcu;  // in units of the scan's own MCUs
     int32_t last;
-    int32_t stream_slot;  // the segment's number in stage 0's stream buffer (progressive_refine.hip), blob order
+    int32_t stream_slot;  // the segment's number in stage 0's stream buffer (progressive_fast.hip), blob order
 };
 
 }  // namespace mj

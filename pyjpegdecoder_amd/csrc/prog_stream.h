@@ -1,6 +1,6 @@
-// What the progressive stage-1 kernels that work on the stage-0 stream share (progressive_refine.hip,
-// progressive_first.hip): the per-wave ring of the segment's stream in LDS, and the packed description of the symbol
-// that would start at a given bit.  See progressive_refine.hip for the design.
+// What the progressive stage-1 walks on the stage-0 stream share (progressive_fast.hip): the per-wave ring of the
+// segment's stream in LDS, the packed description of the symbol that would start at a given bit, and the windows of
+// looked-up symbols.  See progressive_fast.hip for the design.
 #pragma once
 #include "mijpeg_internal.h"
 
