@@ -123,6 +123,10 @@ struct mj_plan {
     mj::DevImage *d_images = nullptr;
     mj::DevHuff *d_huff = nullptr;
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
+    // resolved 13-bit AC tables of the lane form's fast variant (huffman_lanes13.hip), when the batch's tables fit LDS that way
+    uint32_t *d_lut13 = nullptr;        // [n_ac13][8192]
+    int n_ac13 = 0, n_dc13 = 0;
+    uint64_t ac_slot_pk = 0, dc_slot_pk = 0, dc_tab_pk = 0;
     // batches with more tables than LDS holds (files with their own optimised tables): per workgroup, the tables its
     // units of work use — one list for the lane kernel's launch, one for the counting rounds (256 chunks per workgroup)
     int32_t *d_wg_tabs_lanes = nullptr, *d_wg_tabs_count = nullptr;
@@ -389,7 +393,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -721,6 +725,79 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 }
             }
             if ((rc = upload(ctx, &p->d_lut11, l11.data(), l11.size())) != MJ_OK) return rc;
+            // the fast variant of the lane form (huffman_lanes13.hip): 13-bit AC tables whose entries are finished symbols
+            // — bits consumed, step of the write position, EXTENDed coefficient (jpeg_decoder.py:834-866, :1636-1646) —
+            // wherever code + value bits fit the index; every table must have one role and the lot must fit LDS
+            {
+                int n_ac = 0, n_dc = 0;
+                uint64_t ac_pk = 0, dc_pk = 0, dct_pk = 0;
+                bool ok13 = b->n_huff <= 8 && !both_roles && !prog;
+                for (int t = 0; t < b->n_huff && ok13; ++t) {
+                    if (role[t] == 2) ac_pk |= (uint64_t)n_ac++ << (8 * t);
+                    else if (role[t] == 1) { dc_pk |= (uint64_t)n_dc << (8 * t); dct_pk |= (uint64_t)t << (8 * n_dc); ++n_dc; }
+                }
+                const char *f13 = getenv("MJ_HUFFMAN");
+                if (f13 && !strcmp(f13, "lanes11")) ok13 = false;
+                if (ok13 && mj::lanes13_fits(n_ac, n_dc)) {
+                    const int AB = 13, AS = 1 << AB, SLOT = mj::kLanes13SlotBytes / 4;
+                    std::vector<uint32_t> l13((size_t)n_ac * SLOT, 0xFFFFFFFFu);
+                    for (int t = 0; t < b->n_huff && ok13; ++t) {
+                        if (role[t] != 2) continue;
+                        uint32_t *tab = l13.data() + (size_t)((ac_pk >> (8 * t)) & 0xFF) * SLOT;
+                        // second-level tables behind the main one: 8 entries for the three bits that follow a 13-bit prefix of
+                        // codes of 14..16 bits; table 0 = "no such code" (where every other unset main entry points as well)
+                        int n_sub = 1;
+                        for (int i = 0; i < 8; ++i) tab[AS + i] = 0x8000u;
+                        int code = 0, k = 0;
+                        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
+                            for (uint32_t f = 0; f < count; ++f)
+                                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
+                        };
+                        for (int l = 1; l <= 16; ++l) {
+                            code <<= 1;
+                            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                                if (code >= (1 << l)) continue;
+                                const int hv = b->huff[t].vals[k], run = hv >> 4, size = hv & 15;
+                                const uint32_t adv = hv == 0 ? 127u : 2u * (uint32_t)(run + 1);
+                                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | (adv << 16) | 0x8000u | (uint32_t)l;     // value bits taken arithmetically
+                                if (l > AB) {
+                                    const uint32_t prefix = (uint32_t)code >> (l - AB);
+                                    uint32_t &m = tab[prefix];
+                                    if (m == 0xFFFFFFFFu) {                       // first long code under this prefix: a new table
+                                        if (n_sub >= mj::kLanes13SubTables) { ok13 = false; break; }
+                                        for (int j = 0; j < 8; ++j) tab[AS + n_sub * 8 + j] = 0xFFFFFFFFu;
+                                        m = ((uint32_t)(AS * 4 + n_sub * 32) << 16) | 0x8000u;
+                                        ++n_sub;
+                                    }
+                                    if ((m & 0xFFu) != 0) continue;               // a shorter code owns the prefix (over-subscribed table)
+                                    uint32_t *sub = tab + ((m >> 16) / 4);
+                                    put(sub, ((uint32_t)code << (16 - l)) & 7u, 1u << (16 - l), open_entry);
+                                } else if (hv == 0 || l + size <= AB) {
+                                    const int n = hv == 0 ? 0 : size, rest = AB - l - n;
+                                    for (uint32_t vb = 0; vb < (1u << n); ++vb) {
+                                        // bin_twos_complement (:1636-1646): leading 1 = the value itself, leading 0 = value - (2^n - 1)
+                                        const int val = n == 0 ? 0 : ((vb >> (n - 1)) ? (int)vb : (int)vb - ((1 << n) - 1));
+                                        put(tab, (((uint32_t)code << n) | vb) << rest, 1u << rest,
+                                            ((uint32_t)(uint16_t)(int16_t)val << 16) | (adv << 8) | (uint32_t)(l + n));
+                                    }
+                                } else {
+                                    put(tab, (uint32_t)code << (AB - l), 1u << (AB - l), open_entry);
+                                }
+                            }
+                            if (!ok13) break;
+                        }
+                        for (int i = 0; i < AS; ++i)
+                            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0x8000u;          // no such code: the empty second-level table
+                        for (int i = AS; i < SLOT; ++i)
+                            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x8000u;
+                    }
+                    if (!ok13) goto no_lanes13;
+                    if ((rc = upload(ctx, &p->d_lut13, l13.data(), l13.size())) != MJ_OK) return rc;
+                    p->n_ac13 = n_ac; p->n_dc13 = n_dc;
+                    p->ac_slot_pk = ac_pk; p->dc_slot_pk = dc_pk; p->dc_tab_pk = dct_pk;
+                }
+            no_lanes13:;
+            }
             {   // huffman_sync.hip wants every table in the unified format (DC tables: run 0, size = the symbol)
                 std::vector<uint16_t> lu = l11;
                 for (int t = 0; t < b->n_huff; ++t) {
@@ -1122,12 +1199,22 @@ static int stage1_impl(mj_plan *p, void *stream) {
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,
                                                in, p->d_status));
-            MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
-                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes, p->wg_slots_lanes));
+            if (p->d_lut13)
+                MJ_HIP(ctx, mj::launch_huffman_lanes13(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
+                                                       p->d_lut13, p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk,
+                                                       p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs));
+            else
+                MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
+                                                     p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, p->d_vsegs, p->d_wg_tabs_lanes, p->wg_slots_lanes));
             return MJ_OK;
         }
-        MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
-                                             p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes, p->wg_slots_lanes));
+        if (p->d_lut13)
+            MJ_HIP(ctx, mj::launch_huffman_lanes13(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
+                                                   p->d_lut13, p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk,
+                                                   p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr));
+        else
+            MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
+                                                 p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes, p->wg_slots_lanes));
     } else
         MJ_HIP(ctx, mj::launch_huffman(s, p->d_blob, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_coef,
                                        p->d_status, p->lut_slots, p->transposed ? 1 : 0));

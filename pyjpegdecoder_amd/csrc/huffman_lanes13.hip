@@ -1,0 +1,536 @@
+// Stage 1, lane-parallel form with RESOLVED 13-bit tables — baseline Huffman entropy decode, one restart segment per lane.
+//
+// Same contract and output as huffman_lanes.hip (the 11-bit form: its header describes the lock-step, the per-lane bit
+// reader on stage 0's stream and the LDS block rows, all of which are kept).  What changes is the AC symbol step, the
+// only thing that matters: the kernel is bound by the number of instructions on each wave's serial path.
+//   * The AC table of a component is a 13-bit LUT of 32-bit entries that carry the FINISHED symbol whenever code and
+//     value bits together fit the index (99.6 % of the symbols of the benchmark's files; jpeg_decoder.py:834-866 and
+//     bin_twos_complement :1636-1646 are evaluated when the table is built):
+//         byte 0      bits consumed (code + value bits)
+//         byte 1      how far the write position moves: 2 * (run + 1) bytes; end of block = 127 (odd: lands outside
+//                     the row whatever the position); bit 7 = entry not resolved
+//         bits 31:16  the coefficient, EXTENDed, ready for ds_write_b16_d16_hi
+//     Not resolved (code <= 13 bits but code + value > 13): byte 0 = code length, byte 2 = 2 * (run + 1), byte 3 =
+//     31 - size; the value bits are taken arithmetically, under the lanes' exec mask.  Codes longer than 13 bits or
+//     absent (byte 0 = 0): the loop hands those lanes to the canonical search (jpeg_decoder.py:366-377 semantics), rare.
+//   * The symbol step is hand-written (inline asm): LUT address from the top of the bit buffer (2 instructions), ds_read,
+//     position += byte 1 (SDWA), buffer <<= byte 0 (the 64-bit shift reads its 6 low bits), count -= byte 0 (SDWA),
+//     v_cmpx narrows exec to the lanes still inside their block, ds_write_b16_d16_hi, a second v_cmpx drops the lanes
+//     that have just written coefficient 63.  Finished lanes are simply off (exec), so nothing is selected or clamped:
+//     12 instructions per symbol including the "not resolved" test, against 44 in the 11-bit form.
+//   * "index >= 64 after a run ends the block and its value bits stay unread" (:849, :855-856) is not tested per symbol:
+//     a resolved entry that overshoots has consumed its value bits; the lane is found after the block by the parity of
+//     its final position (end of block is the only odd step) and is put back on the right bit — damaged files only.
+//   * The flush moves 16 bytes per lane (8 blocks per store instruction) instead of 4.
+// Used when the batch's distinct tables fit LDS in this format (<= 3 AC tables of 32 KiB + <= 4 DC tables of 4 KiB: every
+// batch of files with the standard tables); other batches keep the 11-bit form with its per-workgroup table lists.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "mijpeg_internal.h"
+
+namespace mj {
+
+namespace {
+
+constexpr int kABits = 13;                   // AC LUT index bits
+constexpr int kASize = 1 << kABits;
+constexpr int kASlotBytes = kLanes13SlotBytes;   // main table + second-level tables of one AC table
+constexpr int kDBits = kLaneLutBits;         // DC LUTs: the 11-bit (len << 8 | symbol) tables of the other lane form
+constexpr int kDSize = 1 << kDBits;
+constexpr int kRow = 33;                     // dwords per lane block in LDS (32 + 1 pad)
+
+__constant__ uint8_t c_zz_of_nat_13[64] = {
+    0,  1,  5,  6, 14, 15, 27, 28,  2,  4,  7, 13, 16, 26, 29, 42,
+    3,  8, 12, 17, 25, 30, 41, 43,  9, 11, 18, 24, 31, 40, 44, 53,
+   10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+   21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+typedef uint32_t __attribute__((address_space(3))) *lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const unsigned char __attribute__((address_space(3))) *)p;
+}
+
+// canonical search over code lengths l0..16 (jpeg_decoder.py:366-377 semantics); (len << 8) | symbol, or -1
+__device__ __noinline__ int canon_code(const DevHuff *t, uint32_t p16, int l0) {
+    int r = -1;
+#pragma unroll 1
+    for (int l = l0; l <= 16; ++l) {
+        const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
+        if (r < 0 && d >= 0 && d < t->count[l]) r = (l << 8) | t->vals[t->first_sym[l] + d];
+    }
+    return r;
+}
+
+__device__ __forceinline__ int extend13(uint32_t raw, int n) {   // bin_twos_complement (:1636-1646); n = 0 -> 0
+    const int half = (1 << n) >> 1;
+    return (int)raw - (((int)raw < half) ? ((1 << n) - 1) : 0);
+}
+
+}  // namespace
+
+#ifdef MJ_X_STAMP
+__device__ unsigned long long g_dbg13[16];
+#endif
+__global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__restrict__ stream,   // stage 0's output
+                                                           const int32_t *__restrict__ seg_bits,
+                                                           const DevSegment *__restrict__ segs, int64_t n_segs,
+                                                           const DevImage *__restrict__ images,
+                                                           const DevHuff *__restrict__ huff,
+                                                           const uint16_t *__restrict__ lut11,   // [n_huff][kDSize]: DC tables are read from here
+                                                           const uint32_t *__restrict__ lut13,   // [n_ac][kASize]
+                                                           int n_ac, int n_dc,
+                                                           uint64_t ac_slot_pk,   // byte t = LDS slot of table t as an AC table
+                                                           uint64_t dc_slot_pk,   // byte t = LDS slot of table t as a DC table
+                                                           uint64_t dc_tab_pk,    // byte s = table index held by DC slot s
+                                                           int16_t *__restrict__ coef, int32_t *__restrict__ status, int lpw, int tr,
+                                                           const DevVSeg *__restrict__ vsegs /* or null */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][kASize]
+    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * kASlotBytes);          // [n_dc][kDSize]
+    const int lpw2 = (lpw + 7) & ~7;                                                             // the flush moves blocks eight at a time
+    const int wstride = (lpw2 * kRow + 3) & ~3;                                                  // dwords per wave, 16-byte multiple
+    unsigned char *rows0 = smem + (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2;
+    uint32_t *s_blk = reinterpret_cast<uint32_t *>(rows0) + wave * wstride;
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4) + wave * lpw2;
+
+    for (int i = tid; i < n_ac * (kASlotBytes / 16); i += (int)blockDim.x)
+        reinterpret_cast<uint4 *>(s_ac)[i] = reinterpret_cast<const uint4 *>(lut13)[i];
+    for (int s = 0; s < n_dc; ++s) {
+        const int t = (int)((dc_tab_pk >> (8 * s)) & 0xFF);
+        for (int i = tid; i < kDSize / 8; i += (int)blockDim.x)
+            reinterpret_cast<uint4 *>(s_dc + s * kDSize)[i] = reinterpret_cast<const uint4 *>(lut11 + (size_t)t * kDSize)[i];
+    }
+    for (int i = tid; i < nw * wstride; i += (int)blockDim.x) reinterpret_cast<uint32_t *>(rows0)[i] = 0;
+    __syncthreads();
+
+    const int64_t seg_id = ((int64_t)blockIdx.x * nw + wave) * lpw + lane;
+    const bool have = lane < lpw && seg_id < n_segs;
+    DevSegment sg = segs[(have && !vsegs) ? seg_id : 0];
+    DevVSeg vs{};
+    if (vsegs) {
+        vs = vsegs[have ? seg_id : 0];
+        sg.image = vs.image; sg.mcu0 = vs.mcu0; sg.n_mcu = vs.n_mcu; sg.last = vs.last == 1;
+    }
+    const DevImage *im = images + sg.image;
+    const int bpm = __builtin_amdgcn_readfirstlane(im->blocks_per_mcu);     // one sampling layout per plan
+    const uint64_t comp_pk = *reinterpret_cast<const uint64_t *>(im->blk_comp);
+    const uint64_t comp_pk_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(comp_pk >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)comp_pk);
+    // per-lane table numbers per component: index in the batch (for the canonical search) and LDS slot
+    int dcG[3], acG[3];
+    {
+        int seen = 0;
+        for (int b = 0; b < 8 && b < im->blocks_per_mcu; ++b) {
+            const int c = im->blk_comp[b];
+            if (!((seen >> c) & 1)) {
+                seen |= 1 << c;
+                const int dt = im->tab_index[im->blk_dc_slot[b]], at = im->tab_index[im->blk_ac_slot[b]];
+                if (c == 0) { dcG[0] = dt; acG[0] = at; } else if (c == 1) { dcG[1] = dt; acG[1] = at; } else { dcG[2] = dt; acG[2] = at; }
+            }
+        }
+        if (!(seen & 2)) { dcG[1] = dcG[0]; acG[1] = acG[0]; }
+        if (!(seen & 4)) { dcG[2] = dcG[0]; acG[2] = acG[0]; }
+    }
+    int dcS[3], acS[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dcS[c] = (int)((dc_slot_pk >> (8 * dcG[c])) & 0xFF);
+        acS[c] = (int)((ac_slot_pk >> (8 * acG[c])) & 0xFF);
+    }
+    const int n_mcu = have ? sg.n_mcu : 0;
+    int max_mcu = n_mcu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_mcu = max(max_mcu, __shfl_xor(max_mcu, o));
+    max_mcu = __builtin_amdgcn_readfirstlane(max_mcu);
+
+    // ---- per-lane bit reader: bb = bit buffer (next bit = bit 63), bc = its fill, voff = byte offset of the next dword
+    // of the stream, nxtw = that dword (loaded one step before it can be needed)
+    const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
+    const uint32_t bit_sh = vsegs ? (uint32_t)vs.bit0 & 31u : 0u;
+    const uint32_t voff0 = !have ? 0u : (vsegs ? vs.voff0 + ((uint32_t)vs.bit0 >> 5) * 4u : (uint32_t)(((sg.begin >> 2) + seg_id) * 4));
+    const int nbits = !have ? 0 : (vsegs ? vs.bit_end - vs.bit0 : seg_bits[seg_id]);
+    uint64_t bb;
+    uint32_t bc, voff, nxtw;
+    auto seek = [&](uint32_t consumed_bits) {       // position the reader `consumed_bits` behind the (virtual) segment's first bit
+        const uint32_t ab = bit_sh + consumed_bits;
+        const uint32_t o = voff0 + (ab >> 5) * 4u, sh = ab & 31u;
+        const uint32_t d0 = *reinterpret_cast<const uint32_t *>(streamb + o), d1 = *reinterpret_cast<const uint32_t *>(streamb + o + 4);
+        bb = (((uint64_t)d0 << 32) | d1) << sh;
+        bc = 64u - sh;
+        voff = o + 8;
+        nxtw = *reinterpret_cast<const uint32_t *>(streamb + voff);
+    };
+    seek(0);
+    auto consumed = [&]() { return (int)((voff - voff0) * 8u) - (int)bc - (int)bit_sh; };
+    const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
+    if (lane < lpw2) s_base[lane] = (uint64_t)out_off;
+    int pred0 = vs.pred[0], pred1 = vs.pred[1], pred2 = vs.pred[2];        // zero for a restart segment (:900)
+    int err = 0;
+    uint32_t *myblk = s_blk + (lane < lpw2 ? lane : 0) * kRow;
+    int16_t *myblk16 = reinterpret_cast<int16_t *>(myblk);
+    const uint32_t mybase = lds_addr(myblk);
+    const uint32_t lastB = mybase + 126u, storeB = mybase + 127u;
+    const uint32_t ac_base = lds_addr(s_ac);
+    const uint32_t c7f = 0x7FFFFFFFu;
+
+    // flush geometry: lane (slot, part) moves the 8 coefficients of natural positions 8*part .. 8*part+7 of block
+    // slot + 8*it — 16 bytes; they are read from their zig-zag slots, so the block lands in HBM in the natural [v][u]
+    // order stage 2 wants ([u][v] when the plan is transposed)
+    const int fslot = lane >> 3, fpart = lane & 7;
+    uint32_t fa[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int nat = fpart * 8 + u;
+        fa[u] = lds_addr(s_blk + fslot * kRow) + 2u * c_zz_of_nat_13[tr ? ((nat & 7) << 3 | nat >> 3) : nat];
+    }
+    const uint64_t full_mask = lpw >= 64 ? ~0ull : (1ull << lpw) - 1;
+
+#ifdef MJ_X_STAMP
+    uint32_t dbg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_iter = 0;
+    uint64_t dbg_in = 0;
+    uint64_t dbg_ac = 0, dbg_fl = 0;
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int m = 0; m < max_mcu; ++m) {
+        const bool in_mcu = m < n_mcu;
+        for (int b = 0; b < bpm; ++b) {
+            const int comp = (int)((comp_pk_u >> (8 * b)) & 0xFF);          // wave-uniform
+            const int dcs = comp == 0 ? dcS[0] : (comp == 1 ? dcS[1] : dcS[2]);
+            const int acs = comp == 0 ? acS[0] : (comp == 1 ? acS[1] : acS[2]);
+            const int dcg = comp == 0 ? dcG[0] : (comp == 1 ? dcG[1] : dcG[2]);
+            const int acg = comp == 0 ? acG[0] : (comp == 1 ? acG[1] : acG[2]);
+            const bool act = in_mcu && err == 0;
+
+            // ---- DC (:810-820): one symbol per lane, straight-line
+            {
+                const bool want = bc <= 32u;
+                const uint32_t t = want ? nxtw : 0u;
+                bb |= (uint64_t)t << ((32u - bc) & 63u);
+                const uint32_t inc = want ? 4u : 0u;
+                voff += inc;
+                bc += inc * 8u;
+                if (want) nxtw = *reinterpret_cast<const uint32_t *>(streamb + voff);
+            }
+            uint32_t pB;
+            {
+                const uint32_t p16 = (uint32_t)(bb >> 48);
+                const int e = s_dc[dcs * kDSize + (p16 >> (16 - kDBits))];
+                int len = e >> 8, s = e & 0xFF;
+                if (__builtin_amdgcn_ballot_w64(act && len == 0) != 0) {                              // code longer than 11 bits: rare
+                    if (act && len == 0) {
+                        const int r = canon_code(huff + dcg, p16, kDBits + 1);
+                        len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF;
+                    }
+                }
+                const bool bad = act && s > 16;
+                err = bad ? MJ_ST_BAD_CODE : err;
+                const bool ok = act && !bad;
+                const int ln = ok ? len : 0, sz = ok ? s : 0;
+                const uint32_t hw = (uint32_t)(bb >> 32) << ln;             // ln + sz <= 32 <= bc
+                const uint32_t rawv = (hw >> 1) >> (31 - sz);
+                bb <<= ln + sz;
+                bc -= (uint32_t)(ln + sz);
+                const int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
+                const int dcv = (int)(int16_t)(extend13(rawv, sz) + pred);
+                pred0 = (ok && comp == 0) ? dcv : pred0;
+                pred1 = (ok && comp == 1) ? dcv : pred1;
+                pred2 = (ok && comp == 2) ? dcv : pred2;
+                myblk16[ok ? 0 : 64] = (int16_t)dcv;                           // 64 = the row's pad slot, never flushed
+                pB = ok ? mybase : lastB;                                      // position of the last coefficient written; lastB = lane is done
+            }
+            // ---- AC (:833-866): until every lane is at its end of block.  See the header for the entry formats.
+            const uint32_t lutb = ac_base + (uint32_t)acs * kASlotBytes;
+            uint32_t e_last = 0;
+#ifdef MJ_X_STAMP
+            const uint64_t dbg_a0 = __builtin_amdgcn_s_memtime();
+#endif
+            for (;;) {
+                uint64_t pend, nx = nxtw, tmp64;
+                uint32_t t0, t1, t2, t3, t4;
+#ifdef MJ_X_STAMP
+                const uint64_t dbg_i0 = __builtin_amdgcn_s_memtime();
+#endif
+                // One symbol of the lanes in exec, entry already in %[e] and known to be resolved in every one of them
+#define MJ_STEP13 \
+    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+    "v_lshlrev_b64 v[2:3], %[e], v[2:3]\n\t"                                                                    \
+    "v_sub_u32_sdwa %[bc], %[bc], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_cmpx_gt_u32 %[storeB], %[pB]\n\t"                                                                        \
+    "ds_write_b16_d16_hi %[pB], %[e]\n\t"                                                                       \
+    "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
+#ifdef MJ_X_STAMPASM
+#define MJ_ST(k) "s_memtime s[54:55]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s56, s54, s52\n\ts_mov_b32 s52, s54\n\tv_add_u32 %[d" #k "], s56, %[d" #k "]\n\t"
+#else
+#define MJ_ST(k)
+#endif
+#define MJ_LOOK13 \
+    "v_bfe_u32 %[t0], v3, 19, 13\n\t"                   \
+    "v_lshl_add_u32 %[t0], %[t0], 2, %[lutb]\n\t"       \
+    "ds_read_b32 %[e], %[t0]\n\t"                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                          \
+    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"
+                asm volatile(
+                    "s_mov_b64 s[40:41], exec\n\t"
+#ifdef MJ_X_STAMPASM
+                    "s_memtime s[52:53]\n\ts_waitcnt lgkmcnt(0)\n\t"
+#endif
+                    "s_mov_b64 %[pend], 0\n\t"
+                    "v_cmpx_gt_u32 %[lastB], %[pB]\n"
+                    "L_loop%=:\n\t"
+                    "s_cbranch_execz L_done%=\n\t"
+                    // refill: lanes whose buffer is at most half full take the next dword and ask for the one after it
+                    MJ_ST(0)
+                    "s_waitcnt vmcnt(0)\n\t"
+                    MJ_ST(1)
+#ifdef MJ_X_STAMPASM
+                    "v_add_u32 %[di], 1, %[di]\n\t"
+#endif
+                    "v_cmp_ge_u32 vcc, 32, %[bc]\n\t"
+                    "s_and_saveexec_b64 s[42:43], vcc\n\t"
+                    "v_sub_u32 %[t0], 32, %[bc]\n\t"
+                    "v_lshlrev_b64 v[4:5], %[t0], v[6:7]\n\t"
+                    "v_or_b32 v3, v3, v5\n\t"
+                    "v_mov_b32 v2, v4\n\t"
+                    "v_add_u32 %[bc], 32, %[bc]\n\t"
+                    "v_add_u32 %[voff], 4, %[voff]\n\t"
+#ifndef MJ_X_NOLOAD
+                    "global_load_dword v6, %[voff], %[sbase]\n\t"
+#endif
+                    "s_mov_b64 exec, s[42:43]\n\t"
+                    MJ_ST(2)
+                    // first symbol
+                    MJ_LOOK13
+                    MJ_ST(3)
+                    "s_cbranch_vccnz L_h1%=\n\t"
+                    MJ_STEP13
+                    MJ_ST(4)
+                    // second symbol (a resolved symbol is at most 13 bits: 32 - 13 are left at least)
+                    MJ_LOOK13
+                    MJ_ST(5)
+                    "s_cbranch_vccnz L_h2%=\n\t"
+                    MJ_STEP13
+                    "s_branch L_loop%=\n"
+                    "L_h2%=:\n\t"                              // second symbol not resolved in some lanes: they sit this step out
+                    "s_mov_b64 s[44:45], vcc\n\t"
+                    "s_andn2_b64 exec, exec, vcc\n\t"
+                    MJ_STEP13
+                    "s_or_b64 exec, exec, s[44:45]\n\t"
+                    MJ_ST(6)
+                    "s_branch L_loop%=\n"
+                    "L_h1%=:\n\t"                              // first symbol not resolved in some lanes
+                    "s_mov_b64 s[44:45], vcc\n\t"
+                    "s_andn2_b64 exec, exec, vcc\n\t"
+                    MJ_STEP13
+                    "s_mov_b64 s[48:49], exec\n\t"
+                    "s_mov_b64 exec, s[44:45]\n\t"
+                    "v_and_b32 %[t1], 0xff, %[e]\n\t"          // code length; 0 = longer than 13 bits: second-level table
+                    "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"
+                    "s_cbranch_vccz L_arith%=\n\t"
+                    "s_and_saveexec_b64 s[50:51], vcc\n\t"
+                    "v_bfe_u32 %[t0], v3, 16, 3\n\t"          // the three bits behind the 13 of the index
+                    "v_lshlrev_b32 %[t0], 2, %[t0]\n\t"
+                    "v_add_u32_sdwa %[t0], %[t0], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                    "v_add_u32 %[t0], %[t0], %[lutb]\n\t"
+                    "ds_read_b32 %[e], %[t0]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_and_b32 %[t1], 0xff, %[e]\n\t"
+                    "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"          // no code of 14..16 bits either
+                    "s_mov_b64 exec, s[50:51]\n\t"
+#ifndef MJ_X_NORARE
+                    "s_cbranch_vccnz L_rare%=\n"
+#endif
+                    "L_arith%=:\n\t"
+                    "v_lshlrev_b32 %[t2], %[t1], v3\n\t"       // value bits on top
+                    "v_lshrrev_b32 %[t3], 1, %[t2]\n\t"
+                    "v_lshrrev_b32_sdwa %[t3], %[e], %[t3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"   // raw
+                    "v_lshrrev_b32_sdwa %[t4], %[e], %[c7f] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"  // 2^size - 1
+                    "v_cmp_le_i32 vcc, 0, %[t2]\n\t"           // leading value bit 0: value = raw - (2^size - 1)  (:1636-1646)
+                    "v_cndmask_b32 %[t2], 0, %[t4], vcc\n\t"
+                    "v_sub_u32 %[t3], %[t3], %[t2]\n\t"        // the coefficient
+                    "v_bcnt_u32_b32 %[t4], %[t4], %[t1]\n\t"   // code + value bits
+                    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                    "v_cmp_gt_u32 vcc, %[storeB], %[pB]\n\t"   // past the block: the value bits stay unread (:855-856)
+                    "v_cndmask_b32 %[t4], %[t1], %[t4], vcc\n\t"
+                    "v_lshlrev_b64 v[2:3], %[t4], v[2:3]\n\t"
+                    "v_sub_u32 %[bc], %[bc], %[t4]\n\t"
+                    "v_cmpx_gt_u32 %[storeB], %[pB]\n\t"
+                    "ds_write_b16 %[pB], %[t3]\n\t"
+                    "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
+                    "s_or_b64 exec, exec, s[48:49]\n\t"
+                    MJ_ST(7)
+                    "s_branch L_loop%=\n"                      // (those lanes may have used up to 28 bits: refill before the next symbol)
+                    "L_rare%=:\n\t"
+                    "s_mov_b64 %[pend], s[44:45]\n"
+                    "L_done%=:\n\t"
+                    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, s[40:41]\n\t"
+                    : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last), [voff] "+v"(voff),
+                      [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [pend] "=&s"(pend)
+#ifdef MJ_X_STAMPASM
+                      , [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_d[7]), [di] "+v"(dbg_iter)
+#endif
+                    : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f)
+                    : "memory", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s48", "s49", "s50", "s51"
+#ifdef MJ_X_STAMPASM
+                      , "s52", "s53", "s54", "s55", "s56"
+#endif
+                    );
+#undef MJ_STEP13
+#undef MJ_LOOK13
+                nxtw = (uint32_t)nx;
+#ifdef MJ_X_STAMP
+                dbg_in += __builtin_amdgcn_s_memtime() - dbg_i0;
+#endif
+                if (pend == 0) break;
+                // rare: a code longer than 13 bits (or none at all) in some lane: every lane whose entry was not resolved in
+                // that step (`pend`; they have not moved) takes the canonical search
+                if ((pend >> lane) & 1) {
+                    const uint32_t hi = (uint32_t)(bb >> 32);
+                    const int r = canon_code(huff + acg, hi >> 16, 1);        // (none: the tables cover every code there is)
+                    if (r < 0) {
+                        err = MJ_ST_BAD_CODE;
+                        pB = lastB;
+                    } else {
+                        const int ln = r >> 8, hv = r & 0xFF;
+                        const uint32_t nB = pB + (hv == 0 ? 127u : 2u * (uint32_t)((hv >> 4) + 1));
+                        const bool inblk = nB < storeB;
+                        const int n = inblk ? (hv & 15) : 0;
+                        const int tot = ln + n;                                   // <= 31 <= bc (first symbol after a refill)
+                        const uint32_t raw = __builtin_amdgcn_ubfe(hi, (uint32_t)(32 - tot), (uint32_t)n);
+                        if (inblk) myblk16[(nB - mybase) >> 1] = (int16_t)extend13(raw, n);
+                        bb <<= tot;
+                        bc -= (uint32_t)tot;
+                        pB = nB;
+                    }
+                    e_last = 0x8000u;                                              // (not a resolved entry: no correction below)
+                }
+            }
+            // a resolved entry that overshot the block has consumed its value bits, which the reference leaves unread
+            // (:855-856): its final position is even (only the end-of-block symbol moves by an odd amount) and past the row
+            {
+                const bool ovf = act && pB > lastB && !(pB & 1u) && !(e_last & 0x8000u);
+                if (__builtin_amdgcn_ballot_w64(ovf) != 0) {
+                    if (ovf) {
+                        const int at = consumed() - (int)(e_last & 0xFFu);            // where that symbol began
+                        seek((uint32_t)at);
+                        const int r = canon_code(huff + acg, (uint32_t)(bb >> 48), 1);
+                        seek((uint32_t)(at + (r < 0 ? 0 : r >> 8)));
+                    }
+                }
+            }
+            // a segment that consumed more bits than it has is corrupt (it has been reading its neighbour's bytes)
+            err = (act && err == 0 && consumed() > nbits) ? MJ_ST_OVERRUN : err;
+#ifdef MJ_X_STAMP
+            const uint64_t dbg_a1 = __builtin_amdgcn_s_memtime();
+            dbg_ac += dbg_a1 - dbg_a0;
+#endif
+            // ---- round of blocks done: LDS -> HBM, eight blocks (8 x 128 bytes) per store instruction, and clear
+            const uint64_t act_mask = __ballot(in_mcu);
+            const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
+            unsigned char *dst0 = reinterpret_cast<unsigned char *>(coef) + blk_byte + fpart * 16;
+            for (int it = 0; it * 8 < lpw; ++it) {
+                if (((act_mask >> (8 * it)) & 0xFF) == 0) continue;      // uniform
+                const uint32_t ro = (uint32_t)it * (8u * kRow * 4u);
+                auto rd = [&](int u) { return (uint32_t)*(const uint16_t __attribute__((address_space(3))) *)(uintptr_t)(fa[u] + ro); };
+                uint4 v;
+                v.x = rd(0) | (rd(1) << 16);
+                v.y = rd(2) | (rd(3) << 16);
+                v.z = rd(4) | (rd(5) << 16);
+                v.w = rd(6) | (rd(7) << 16);
+                const int o = it * 8 + fslot;
+#ifdef MJ_X_NOSTORE
+                if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
+#else
+                if ((act_mask >> o) & 1) *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
+#endif
+            }
+            (void)full_mask;
+            for (int i = lane; i < wstride / 4; i += 64) reinterpret_cast<uint4 *>(s_blk)[i] = make_uint4(0, 0, 0, 0);
+#ifdef MJ_X_STAMP
+            dbg_fl += __builtin_amdgcn_s_memtime() - dbg_a1;
+#endif
+        }
+    }
+#ifdef MJ_X_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg13[8 + i], (unsigned long long)dbg_d[i]);
+        atomicAdd(&g_dbg13[6], (unsigned long long)dbg_in);
+        atomicAdd(&g_dbg13[1], (unsigned long long)dbg_iter);
+        atomicAdd(&g_dbg13[2], (unsigned long long)dbg_ac);
+        atomicAdd(&g_dbg13[3], (unsigned long long)dbg_fl);
+        atomicAdd(&g_dbg13[4], (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
+        atomicAdd(&g_dbg13[5], 1ull);
+    }
+#endif
+
+    if (have) {
+        const int left = nbits - consumed();
+        if (!err && vsegs && vs.last == 0 && left != 0) err = MJ_ST_DESYNC;     // a virtual segment ends exactly where the next starts
+        if (!err && (vsegs ? vs.last == 2 : !sg.last) && left >= 8) err = MJ_ST_DESYNC;
+        if (err) atomicMax(status + sg.image, err);
+    }
+}
+
+// LDS bytes of a launch with `nw` waves of `lpw` lanes
+static size_t lds13(int n_ac, int n_dc, int nw, int lpw) {
+    const int lpw2 = (lpw + 7) & ~7, wstride = (lpw2 * kRow + 3) & ~3;
+    return (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8;
+}
+
+bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8) <= 160 * 1024; }
+
+hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
+                                  const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
+                                  int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk,
+                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs) {
+    if (n_segs == 0) return hipSuccess;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    // tuning hooks (tools/stage_probe.py): waves per workgroup, lanes per wave
+    int env_nw = -1, env_lpw = -1;
+    if (const char *e = getenv("MJ_LANES_WAVES")) { env_nw = atoi(e); if (env_nw < 1 || env_nw > 16) env_nw = -1; }
+    if (const char *e = getenv("MJ_LANES_PER_WAVE")) { env_lpw = atoi(e); if (env_lpw < 1 || env_lpw > 64) env_lpw = -1; }
+    // One workgroup per CU (the tables take most of its LDS), all workgroups resident at once and equally loaded: the
+    // segments a CU gets are spread over `nw` waves (the kernel is bound by instruction issue and LDS latency: about three
+    // waves per SIMD keep a SIMD busy, more lanes per wave cost lock-step waiting).
+    const int64_t per_cu = (n_segs + cus - 1) / cus;
+    int nw = env_nw > 0 ? env_nw : (int)std::min<int64_t>(12, std::max<int64_t>(1, (per_cu + 15) / 16));
+    auto fit_of = [&](int w) { int f = 64; while (f > 1 && lds13(n_ac, n_dc, w, f) > 160 * 1024) --f; return f; };
+    int fit = fit_of(nw);
+    const int64_t rounds = (per_cu + (int64_t)nw * fit - 1) / ((int64_t)nw * fit);
+    const int64_t per_wg = (per_cu + rounds - 1) / rounds;
+    int lpw = env_lpw > 0 ? std::min(env_lpw, fit) : (int)std::min<int64_t>(fit, std::max<int64_t>(1, (per_wg + nw - 1) / nw));
+    const int64_t blocks = (n_segs + (int64_t)nw * lpw - 1) / ((int64_t)nw * lpw);
+    const size_t lds = lds13(n_ac, n_dc, nw, lpw);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes13), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
+                       lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs);
+#ifdef MJ_X_STAMP
+    if (getenv("MJ_X_REPORT")) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[16], z[16] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg13), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg13), z, sizeof(z));
+        const double it = (double)(h[1] ? h[1] : 1);
+        fprintf(stderr, "[lanes13 nw=%d lpw=%d] waves %llu: per wave: total %.0f cyc, AC loop %.0f, flush+clear %.0f, %.0f iterations; per iteration: loop-back/other %.0f, vm wait %.0f, refill %.0f, look1 %.0f, step1 %.0f, look2 %.0f, h2 %.0f, h1 %.0f; inside the asm statement %.0f per wave\n",
+                nw, lpw, h[5], (double)h[4] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], it / h[5], h[8] / it, h[9] / it, h[10] / it, h[11] / it, h[12] / it, h[13] / it, h[14] / it, h[15] / it, (double)h[6] / h[5]);
+    }
+#endif
+    return hipGetLastError();
+}
+
+}  // namespace mj

@@ -182,6 +182,15 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
                                 const DevImage *images, const DevHuff *huff, const uint16_t *lut11, int n_huff,
                                 int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs = nullptr,
                                 const int32_t *wg_tabs = nullptr, int wg_slots = 0);   // wg_tabs: [workgroups][kMaxWgTables]
+// the same with resolved 13-bit AC tables (huffman_lanes13.hip); lut13: [n_ac][kLanes13SlotBytes / 4]: 8192 finished symbols + second-level tables for codes of 14..16 bits, lut11 supplies the DC
+// tables; byte t of ac_slot_pk / dc_slot_pk = LDS slot of table t in that role, byte s of dc_tab_pk = table of DC slot s
+constexpr int kLanes13SubTables = 144;                              // second-level tables per AC table (8 entries each)
+constexpr int kLanes13SlotBytes = 8192 * 4 + kLanes13SubTables * 32;  // one AC table in that form
+bool lanes13_fits(int n_ac, int n_dc);
+hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
+                                  const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
+                                  int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk,
+                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs);
 // how that launch groups its units of work: lanes per wavefront (a workgroup = 4 waves = 4 x this many consecutive units)
 int lanes_per_wave(int64_t n_segs, int n_slots);
 

@@ -1,0 +1,107 @@
+// Micro-benchmark (round 3): cycles per Huffman symbol step of the lane-parallel stage 1, by formulation, lanes per wave and
+// waves per SIMD.   hipcc --offload-arch=gfx950 -O3 -o /tmp/step_probe tools/step_probe.hip && /tmp/step_probe
+// Every variant runs ITERS x 8 symbol steps on a 13-bit LUT in LDS (entries: 5 bits consumed, no movement, value 7) with the
+// bit buffer kept busy by an OR of a per-lane constant; each wave stamps s_memtime around its loop.  Printed: shader cycles
+// per symbol step per wave (median over waves), i.e. what one wave's serial path costs at that occupancy.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#include <algorithm>
+
+#define LOOK \
+    "v_bfe_u32 %[t0], v3, 20, 12\n\t"             \
+    "v_lshl_add_u32 %[t0], %[t0], 2, %[lutb]\n\t" \
+    "ds_read_b32 %[e], %[t0]\n\t"                 \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define FLAG "v_cmp_gt_i16 vcc, 0, %[e]\n\ts_cbranch_vccnz 9f\n\t"
+#define CORE \
+    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+    "v_lshlrev_b64 v[2:3], %[e], v[2:3]\n\t"                                                                    \
+    "v_sub_u32_sdwa %[bc], %[bc], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_or_b32 v2, v2, %[k]\n\t"
+#define CMPX1 "v_cmpx_gt_u32 %[storeB], %[pB]\n\t"
+#define CMPX2 "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
+#define WR "ds_write_b16_d16_hi %[pB], %[e]\n\t"
+// exec narrowed through vcc and the scalar unit instead of v_cmpx
+#define SCMP1 "v_cmp_gt_u32 vcc, %[storeB], %[pB]\n\ts_and_b64 exec, exec, vcc\n\t"
+#define SCMP2 "v_cmp_gt_u32 vcc, %[lastB], %[pB]\n\ts_and_b64 exec, exec, vcc\n\t"
+// no exec at all: clamp the position (v_min) and let finished lanes write their pad slot
+#define CLAMP "v_min_u32 %[pB], %[pB], %[storeB]\n\t"
+
+enum V { V_FULL, V_NOFLAG, V_NOCMPX, V_CHAIN, V_SCMP, V_CLAMP, V_ONECMPX, V_LOOKONLY, V_NOLDSWR, N_V };
+static const char *kNames[] = {"look + flag + core + cmpx + write + cmpx (the kernel's step)", "  without the flag test", "  without the two v_cmpx",
+                               "  look + core + write only (dependent chain)", "  exec through v_cmp + s_and_b64 instead of v_cmpx",
+                               "  v_min clamp instead of exec (no cmpx)", "  one v_cmpx (after the write)", "  look only (LDS round trip + 2 VALU)",
+                               "  full step without the LDS write"};
+
+template <int VAR>
+__global__ __launch_bounds__(256) void k(uint64_t *out, int iters, int lanes) {
+    __shared__ uint32_t lut[4096 + 64 * 33];
+    for (int i = threadIdx.x; i < 4096; i += 256) lut[i] = (7u << 16) | (0u << 8) | 5u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    uint64_t bb = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1);
+    uint32_t bc = 1u << 30, e = 0, t0;
+    const uint32_t lutb = (uint32_t)(uintptr_t)(uint32_t __attribute__((address_space(3))) *)lut;
+    uint32_t pB = lutb + 4096 * 4 + lane * 132 + (threadIdx.x >> 6) * 0;   // rows behind the table (one wave's worth is enough: values are never read)
+    const uint32_t storeB = lane < lanes ? 0xFFFFFFF0u : 0u, lastB = storeB;
+    const uint32_t kk = 0x01234567u * (lane + 3) | 1u;
+    __builtin_amdgcn_s_barrier();
+    uint64_t t_0, t_1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_0)::"memory");
+#define STEP_ASM(body) \
+    asm volatile("s_mov_b64 s[40:41], exec\n\tv_cmpx_gt_u32 %[lastB], %[pB]\n\t" body body body body body body body body "9:\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[40:41]\n\t" \
+                 : "+{v[2:3]}"(bb), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e), [t0] "=&v"(t0)                                                   \
+                 : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "v"(lutb), [k] "v"(kk)                                                         \
+                 : "memory", "vcc", "s40", "s41")
+    for (int it = 0; it < iters; ++it) {
+        if (VAR == V_FULL) STEP_ASM(LOOK FLAG CORE CMPX1 WR CMPX2);
+        if (VAR == V_NOFLAG) STEP_ASM(LOOK CORE CMPX1 WR CMPX2);
+        if (VAR == V_NOCMPX) STEP_ASM(LOOK FLAG CORE WR);
+        if (VAR == V_CHAIN) STEP_ASM(LOOK CORE WR);
+        if (VAR == V_SCMP) STEP_ASM(LOOK FLAG CORE SCMP1 WR SCMP2);
+        if (VAR == V_CLAMP) STEP_ASM(LOOK FLAG CORE CLAMP WR);
+        if (VAR == V_ONECMPX) STEP_ASM(LOOK FLAG CORE WR CMPX2);
+        if (VAR == V_LOOKONLY) STEP_ASM(LOOK "v_xor_b32 v3, v3, %[e]\n\t");
+        if (VAR == V_NOLDSWR) STEP_ASM(LOOK FLAG CORE CMPX1 CMPX2);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_1)::"memory");
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (lane == 0) { out[2 * gw] = t_1 - t_0; out[2 * gw + 1] = bb ^ bc ^ pB ^ e; }
+}
+
+template <int VAR>
+static void run(uint64_t *d, std::vector<uint64_t> &h) {
+    const int iters = 2000;
+    for (int lanes : {64, 17}) {
+        printf("%-62s %2d lanes", kNames[VAR], lanes);
+        for (int wps = 1; wps <= 4; ++wps) {
+            const int blocks = 256 * wps;
+            k<VAR><<<blocks, 256>>>(d, iters, lanes);
+            k<VAR><<<blocks, 256>>>(d, iters, lanes);
+            hipDeviceSynchronize();
+            hipMemcpy(h.data(), d, blocks * 4 * 16, hipMemcpyDeviceToHost);
+            std::vector<uint64_t> cyc(blocks * 4);
+            for (int i = 0; i < blocks * 4; ++i) cyc[i] = h[2 * i];
+            std::sort(cyc.begin(), cyc.end());
+            printf("  w%d: %6.1f", wps, (double)cyc[cyc.size() / 2] / ((double)iters * 8));
+        }
+        printf("\n");
+    }
+}
+
+template <int VAR>
+static void run_all(uint64_t *d, std::vector<uint64_t> &h) {
+    run<VAR>(d, h);
+    if constexpr (VAR + 1 < N_V) run_all<VAR + 1>(d, h);
+}
+
+int main() {
+    uint64_t *d;
+    hipMalloc(&d, 2048 * 4 * 16);
+    std::vector<uint64_t> h(2048 * 4 * 2);
+    printf("# tools/step_probe.hip: shader cycles per symbol step per wave; wN = N waves per SIMD\n");
+    run_all<0>(d, h);
+    return 0;
+}
