@@ -759,17 +759,17 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                                 if (code >= (1 << l)) continue;
                                 const int hv = b->huff[t].vals[k], run = hv >> 4, size = hv & 15;
                                 const uint32_t adv = hv == 0 ? 127u : 2u * (uint32_t)(run + 1);
-                                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | (adv << 16) | 0x8000u | (uint32_t)l;     // value bits taken arithmetically
+                                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | ((uint32_t)l << 16) | 0x8000u | ((hv == 0 ? 0u : (uint32_t)(run + 1)) << 8);   // value bits taken arithmetically
                                 if (l > AB) {
                                     const uint32_t prefix = (uint32_t)code >> (l - AB);
                                     uint32_t &m = tab[prefix];
                                     if (m == 0xFFFFFFFFu) {                       // first long code under this prefix: a new table
                                         if (n_sub >= mj::kLanes13SubTables) { ok13 = false; break; }
                                         for (int j = 0; j < 8; ++j) tab[AS + n_sub * 8 + j] = 0xFFFFFFFFu;
-                                        m = ((uint32_t)(AS * 4 + n_sub * 32) << 16) | 0x8000u;
+                                        m = ((uint32_t)(AS * 4 + n_sub * 32) << 16) | 0xC000u;
                                         ++n_sub;
                                     }
-                                    if ((m & 0xFFu) != 0) continue;               // a shorter code owns the prefix (over-subscribed table)
+                                    if ((m & 0xC0FFu) != 0xC000u) continue;       // a shorter code owns the prefix (over-subscribed table)
                                     uint32_t *sub = tab + ((m >> 16) / 4);
                                     put(sub, ((uint32_t)code << (16 - l)) & 7u, 1u << (16 - l), open_entry);
                                 } else if (hv == 0 || l + size <= AB) {
@@ -787,7 +787,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                             if (!ok13) break;
                         }
                         for (int i = 0; i < AS; ++i)
-                            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0x8000u;          // no such code: the empty second-level table
+                            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0xC000u;          // no such code: the empty second-level table
                         for (int i = AS; i < SLOT; ++i)
                             if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x8000u;
                     }

@@ -246,53 +246,41 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
             }
             // ---- AC (:833-866): until every lane is at its end of block.  See the header for the entry formats.
             const uint32_t lutb = ac_base + (uint32_t)acs * kASlotBytes;
-            uint32_t e_last = 0;
+            uint32_t e_last = 0xFFu;                 // the lane's latest entry; 0xFF = "nothing a correction below could use"
 #ifdef MJ_X_STAMP
             const uint64_t dbg_a0 = __builtin_amdgcn_s_memtime();
 #endif
             for (;;) {
                 uint64_t pend, nx = nxtw, tmp64;
-                uint32_t t0, t1, t2, t3, t4;
+                uint32_t t0, t1, t2, t3, t4, t5, t6, ew;
 #ifdef MJ_X_STAMP
                 const uint64_t dbg_i0 = __builtin_amdgcn_s_memtime();
 #endif
-                // One symbol of the lanes in exec, entry already in %[e] and known to be resolved in every one of them
-#define MJ_STEP13 \
-    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-    "v_lshlrev_b64 v[2:3], %[e], v[2:3]\n\t"                                                                    \
-    "v_sub_u32_sdwa %[bc], %[bc], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-    "v_cmpx_gt_u32 %[storeB], %[pB]\n\t"                                                                        \
-    "ds_write_b16_d16_hi %[pB], %[e]\n\t"                                                                       \
-    "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
-#ifdef MJ_X_STAMPASM
-#define MJ_ST(k) "s_memtime s[54:55]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s56, s54, s52\n\ts_mov_b32 s52, s54\n\tv_add_u32 %[d" #k "], s56, %[d" #k "]\n\t"
-#else
-#define MJ_ST(k)
-#endif
+                // LUT address from the 13 bits on top of the buffer, and the read
 #define MJ_LOOK13 \
     "v_bfe_u32 %[t0], v3, 19, 13\n\t"                   \
     "v_lshl_add_u32 %[t0], %[t0], 2, %[lutb]\n\t"       \
-    "ds_read_b32 %[e], %[t0]\n\t"                       \
-    "s_waitcnt lgkmcnt(0)\n\t"                          \
-    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"
+    "ds_read_b32 %[e], %[t0]\n\t"
+                // the entry applied: position, buffer, count; exec keeps the lanes that are still inside their block AFTER this
+                // symbol — they are also the ones that store it (a lane whose symbol lands on coefficient 63 leaves here and
+                // stores it after the loop; an entry that is not resolved moves its lane out by 128+ and consumes nothing)
+#define MJ_CORE13 \
+    "v_mov_b32 %[ew], %[e]\n\t"                                                                                  \
+    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+    "v_lshlrev_b64 v[2:3], %[e], v[2:3]\n\t"                                                                    \
+    "v_sub_u32_sdwa %[bc], %[bc], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
+#define MJ_WRITE13 "ds_write_b16_d16_hi %[pB], %[ew]\n\t"
                 asm volatile(
                     "s_mov_b64 s[40:41], exec\n\t"
-#ifdef MJ_X_STAMPASM
-                    "s_memtime s[52:53]\n\ts_waitcnt lgkmcnt(0)\n\t"
-#endif
                     "s_mov_b64 %[pend], 0\n\t"
                     "v_cmpx_gt_u32 %[lastB], %[pB]\n"
                     "L_loop%=:\n\t"
                     "s_cbranch_execz L_done%=\n\t"
                     // refill: lanes whose buffer is at most half full take the next dword and ask for the one after it
-                    MJ_ST(0)
                     "s_waitcnt vmcnt(0)\n\t"
-                    MJ_ST(1)
-#ifdef MJ_X_STAMPASM
-                    "v_add_u32 %[di], 1, %[di]\n\t"
-#endif
-                    "v_cmp_ge_u32 vcc, 32, %[bc]\n\t"
-                    "s_and_saveexec_b64 s[42:43], vcc\n\t"
+                    "s_mov_b64 s[42:43], exec\n\t"
+                    "v_cmpx_ge_u32 32, %[bc]\n\t"
                     "v_sub_u32 %[t0], 32, %[bc]\n\t"
                     "v_lshlrev_b64 v[4:5], %[t0], v[6:7]\n\t"
                     "v_or_b32 v3, v3, v5\n\t"
@@ -303,118 +291,123 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     "global_load_dword v6, %[voff], %[sbase]\n\t"
 #endif
                     "s_mov_b64 exec, s[42:43]\n\t"
-                    MJ_ST(2)
                     // first symbol
                     MJ_LOOK13
-                    MJ_ST(3)
-                    "s_cbranch_vccnz L_h1%=\n\t"
-                    MJ_STEP13
-                    MJ_ST(4)
-                    // second symbol (a resolved symbol is at most 13 bits: 32 - 13 are left at least)
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    MJ_CORE13
+                    // second symbol (a resolved symbol is at most 13 bits: 32 - 13 are left at least); the first one's
+                    // store goes out behind the second one's read
                     MJ_LOOK13
-                    MJ_ST(5)
-                    "s_cbranch_vccnz L_h2%=\n\t"
-                    MJ_STEP13
-                    "s_branch L_loop%=\n"
-                    "L_h2%=:\n\t"                              // second symbol not resolved in some lanes: they sit this step out
-                    "s_mov_b64 s[44:45], vcc\n\t"
-                    "s_andn2_b64 exec, exec, vcc\n\t"
-                    MJ_STEP13
-                    "s_or_b64 exec, exec, s[44:45]\n\t"
-                    MJ_ST(6)
-                    "s_branch L_loop%=\n"
-                    "L_h1%=:\n\t"                              // first symbol not resolved in some lanes
-                    "s_mov_b64 s[44:45], vcc\n\t"
-                    "s_andn2_b64 exec, exec, vcc\n\t"
-                    MJ_STEP13
-                    "s_mov_b64 s[48:49], exec\n\t"
+                    MJ_WRITE13
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    MJ_CORE13
+                    MJ_WRITE13
+                    // any entry that was not resolved?  (every lane of the wave is looked at: lanes that are done keep a clean entry)
+                    "s_mov_b64 s[44:45], exec\n\t"
+                    "s_mov_b64 exec, s[40:41]\n\t"
+                    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"
                     "s_mov_b64 exec, s[44:45]\n\t"
-                    "v_and_b32 %[t1], 0xff, %[e]\n\t"          // code length; 0 = longer than 13 bits: second-level table
-                    "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"
+                    "s_cbranch_vccz L_loop%=\n\t"
+                    // ---- entries that are not resolved (0.4 % of the symbols): the lanes of vcc.  Byte 1 = 0x80 | 0x40 if the
+                    // code is longer than 13 bits (then the high word is where its second-level table starts) | run + 1
+                    // (0 = end of block); byte 2 = code length (0 = no such code); byte 3 = 31 - size
+                    "s_mov_b64 s[46:47], vcc\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "v_mov_b32 %[t5], %[e]\n\t"
+                    "v_sub_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"   // back where it was
+                    "v_mov_b32 %[e], 0xff\n\t"
+                    "v_cmpx_le_u32 31, %[bc]\n\t"              // bits for the longest symbol?  else again after the next refill
+                    "s_andn2_b64 s[46:47], s[46:47], exec\n\t" // ... those lanes simply go on
+                    "s_cbranch_execz L_hend%=\n\t"
+                    "v_and_b32 %[t1], 0x4000, %[t5]\n\t"
+                    "v_cmp_ne_u32 vcc, 0, %[t1]\n\t"
                     "s_cbranch_vccz L_arith%=\n\t"
                     "s_and_saveexec_b64 s[50:51], vcc\n\t"
                     "v_bfe_u32 %[t0], v3, 16, 3\n\t"          // the three bits behind the 13 of the index
                     "v_lshlrev_b32 %[t0], 2, %[t0]\n\t"
-                    "v_add_u32_sdwa %[t0], %[t0], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                    "v_add_u32_sdwa %[t0], %[t0], %[t5] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
                     "v_add_u32 %[t0], %[t0], %[lutb]\n\t"
-                    "ds_read_b32 %[e], %[t0]\n\t"
+                    "ds_read_b32 %[t5], %[t0]\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
-                    "v_and_b32 %[t1], 0xff, %[e]\n\t"
-                    "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"          // no code of 14..16 bits either
-                    "s_mov_b64 exec, s[50:51]\n\t"
-#ifndef MJ_X_NORARE
-                    "s_cbranch_vccnz L_rare%=\n"
-#endif
+                    "s_mov_b64 exec, s[50:51]\n"
                     "L_arith%=:\n\t"
+                    "v_bfe_u32 %[t1], %[t5], 16, 8\n\t"        // code length
+                    "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"
+#ifndef MJ_X_NORARE
+                    "s_cbranch_vccnz L_rare%=\n\t"             // no such code (a damaged file): the canonical search says so
+#endif
+                    "v_bfe_u32 %[t6], %[t5], 8, 5\n\t"         // run + 1, 0 = end of block
+                    "v_lshlrev_b32 %[t6], 1, %[t6]\n\t"
+                    "v_cmp_eq_u32 vcc, 0, %[t6]\n\t"
+                    "v_mov_b32 %[t2], 0x7f\n\t"
+                    "v_cndmask_b32_e64 %[t6], %[t6], %[t2], vcc\n\t"
                     "v_lshlrev_b32 %[t2], %[t1], v3\n\t"       // value bits on top
                     "v_lshrrev_b32 %[t3], 1, %[t2]\n\t"
-                    "v_lshrrev_b32_sdwa %[t3], %[e], %[t3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"   // raw
-                    "v_lshrrev_b32_sdwa %[t4], %[e], %[c7f] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"  // 2^size - 1
+                    "v_lshrrev_b32_sdwa %[t3], %[t5], %[t3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"   // raw
+                    "v_lshrrev_b32_sdwa %[t4], %[t5], %[c7f] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"  // 2^size - 1
                     "v_cmp_le_i32 vcc, 0, %[t2]\n\t"           // leading value bit 0: value = raw - (2^size - 1)  (:1636-1646)
-                    "v_cndmask_b32 %[t2], 0, %[t4], vcc\n\t"
+                    "v_cndmask_b32_e64 %[t2], 0, %[t4], vcc\n\t"
                     "v_sub_u32 %[t3], %[t3], %[t2]\n\t"        // the coefficient
                     "v_bcnt_u32_b32 %[t4], %[t4], %[t1]\n\t"   // code + value bits
-                    "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                    "v_add_u32 %[pB], %[pB], %[t6]\n\t"
                     "v_cmp_gt_u32 vcc, %[storeB], %[pB]\n\t"   // past the block: the value bits stay unread (:855-856)
-                    "v_cndmask_b32 %[t4], %[t1], %[t4], vcc\n\t"
+                    "v_cndmask_b32_e64 %[t4], %[t1], %[t4], vcc\n\t"
                     "v_lshlrev_b64 v[2:3], %[t4], v[2:3]\n\t"
                     "v_sub_u32 %[bc], %[bc], %[t4]\n\t"
                     "v_cmpx_gt_u32 %[storeB], %[pB]\n\t"
                     "ds_write_b16 %[pB], %[t3]\n\t"
-                    "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
-                    "s_or_b64 exec, exec, s[48:49]\n\t"
-                    MJ_ST(7)
-                    "s_branch L_loop%=\n"                      // (those lanes may have used up to 28 bits: refill before the next symbol)
+                    "v_cmpx_gt_u32 %[lastB], %[pB]\n"
+                    "L_hend%=:\n\t"
+                    "s_or_b64 exec, exec, s[44:45]\n\t"
+                    "s_or_b64 exec, exec, s[46:47]\n\t"
+                    "s_branch L_loop%=\n"
                     "L_rare%=:\n\t"
-                    "s_mov_b64 %[pend], s[44:45]\n"
+                    "s_mov_b64 %[pend], exec\n"
                     "L_done%=:\n\t"
                     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, s[40:41]\n\t"
                     : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last), [voff] "+v"(voff),
-                      [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [pend] "=&s"(pend)
-#ifdef MJ_X_STAMPASM
-                      , [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_d[7]), [di] "+v"(dbg_iter)
-#endif
+                      [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+                      [ew] "=&v"(ew), [pend] "=&s"(pend)
                     : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f)
-                    : "memory", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s48", "s49", "s50", "s51"
-#ifdef MJ_X_STAMPASM
-                      , "s52", "s53", "s54", "s55", "s56"
-#endif
-                    );
-#undef MJ_STEP13
+                    : "memory", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51");
 #undef MJ_LOOK13
+#undef MJ_CORE13
+#undef MJ_WRITE13
                 nxtw = (uint32_t)nx;
 #ifdef MJ_X_STAMP
                 dbg_in += __builtin_amdgcn_s_memtime() - dbg_i0;
 #endif
                 if (pend == 0) break;
-                // rare: a code longer than 13 bits (or none at all) in some lane: every lane whose entry was not resolved in
-                // that step (`pend`; they have not moved) takes the canonical search
+                // rare: no code at all in some lane (a damaged file); the lanes of `pend` — back at their positions, nothing
+                // consumed — take the canonical search (jpeg_decoder.py:366-377 semantics), which says so or decodes the symbol
                 if ((pend >> lane) & 1) {
                     const uint32_t hi = (uint32_t)(bb >> 32);
-                    const int r = canon_code(huff + acg, hi >> 16, 1);        // (none: the tables cover every code there is)
+                    const int r = canon_code(huff + acg, hi >> 16, 1);
                     if (r < 0) {
                         err = MJ_ST_BAD_CODE;
-                        pB = lastB;
+                        pB = lastB + 1u;                                          // done (and nothing to correct below)
                     } else {
                         const int ln = r >> 8, hv = r & 0xFF;
                         const uint32_t nB = pB + (hv == 0 ? 127u : 2u * (uint32_t)((hv >> 4) + 1));
                         const bool inblk = nB < storeB;
                         const int n = inblk ? (hv & 15) : 0;
-                        const int tot = ln + n;                                   // <= 31 <= bc (first symbol after a refill)
+                        const int tot = ln + n;                                   // <= 31 <= bc
                         const uint32_t raw = __builtin_amdgcn_ubfe(hi, (uint32_t)(32 - tot), (uint32_t)n);
                         if (inblk) myblk16[(nB - mybase) >> 1] = (int16_t)extend13(raw, n);
                         bb <<= tot;
                         bc -= (uint32_t)tot;
                         pB = nB;
                     }
-                    e_last = 0x8000u;                                              // (not a resolved entry: no correction below)
                 }
             }
-            // a resolved entry that overshot the block has consumed its value bits, which the reference leaves unread
-            // (:855-856): its final position is even (only the end-of-block symbol moves by an odd amount) and past the row
             {
-                const bool ovf = act && pB > lastB && !(pB & 1u) && !(e_last & 0x8000u);
+                const bool resolved = act && (e_last & 0xFFu) != 0xFFu;       // the lane's last symbol came straight out of a resolved entry
+                // ... onto coefficient 63: the loop left the store to us (its lanes leave before they store)
+                if (resolved && pB == lastB) myblk16[63] = (int16_t)(e_last >> 16);
+                // ... past the block: the entry has consumed its value bits, which the reference leaves unread (:855-856).  The
+                // final position is even then (only the end-of-block symbol moves by an odd amount).  Damaged files only.
+                const bool ovf = resolved && pB > lastB && !(pB & 1u);
                 if (__builtin_amdgcn_ballot_w64(ovf) != 0) {
                     if (ovf) {
                         const int at = consumed() - (int)(e_last & 0xFFu);            // where that symbol began
