@@ -41,6 +41,7 @@ constexpr int kASlotBytes = kLanes13SlotBytes;   // main table + second-level ta
 constexpr int kDBits = kLaneLutBits;         // DC LUTs: the 11-bit (len << 8 | symbol) tables of the other lane form
 constexpr int kDSize = 1 << kDBits;
 constexpr int kRow = 33;                     // dwords per lane block in LDS (32 + 1 pad)
+constexpr int kRing = 128;                   // bytes of stream per lane in LDS
 
 __constant__ uint8_t c_zz_of_nat_13[64] = {
     0,  1,  5,  6, 14, 15, 27, 28,  2,  4,  7, 13, 16, 26, 29, 42,
@@ -49,6 +50,7 @@ __constant__ uint8_t c_zz_of_nat_13[64] = {
    21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 typedef uint32_t __attribute__((address_space(3))) *lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const unsigned char __attribute__((address_space(3))) *)p;
 }
@@ -98,6 +100,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     unsigned char *rows0 = smem + (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2;
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(rows0) + wave * wstride;
     uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4) + wave * lpw2;
+    // per-lane window on the lane's stream: kRing bytes, the stream's bytes at their offsets modulo kRing (see the bit reader)
+    unsigned char *rings0 = smem + (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8 + 127) & ~(size_t)127);
 
     for (int i = tid; i < n_ac * (kASlotBytes / 16); i += (int)blockDim.x)
         reinterpret_cast<uint4 *>(s_ac)[i] = reinterpret_cast<const uint4 *>(lut13)[i];
@@ -150,13 +154,28 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     max_mcu = __builtin_amdgcn_readfirstlane(max_mcu);
 
     // ---- per-lane bit reader: bb = bit buffer (next bit = bit 63), bc = its fill, voff = byte offset of the next dword
-    // of the stream, nxtw = that dword (loaded one step before it can be needed)
+    // of the stream, nxtw = that dword (read one step before it can be needed).  The dwords come from the lane's window in
+    // LDS — the kRing bytes of its stream up to byte pf, each at its stream offset modulo kRing — which the lane keeps
+    // topped up 16 bytes at a time, well ahead of the reader: a load from the stream itself in the symbol loop would put
+    // an L2 round trip (every lane walks cache lines of its own, 270 of them per CU: L1 does not hold them) on the serial
+    // path of every iteration, and its wait would also wait for the previous block's coefficient stores (vmcnt is in order).
     const unsigned char *streamb = reinterpret_cast<const unsigned char *>(stream);
     const uint32_t bit_sh = vsegs ? (uint32_t)vs.bit0 & 31u : 0u;
     const uint32_t voff0 = !have ? 0u : (vsegs ? vs.voff0 + ((uint32_t)vs.bit0 >> 5) * 4u : (uint32_t)(((sg.begin >> 2) + seg_id) * 4));
     const int nbits = !have ? 0 : (vsegs ? vs.bit_end - vs.bit0 : seg_bits[seg_id]);
+    const uint32_t ringbase = lds_addr(rings0 + (size_t)(wave * lpw2 + (lane < lpw2 ? lane : 0)) * kRing);
+    const uint64_t ring_lanes = lpw2 >= 64 ? ~0ull : (1ull << lpw2) - 1;      // lanes that own a window
+    auto ring_u32 = [&](uint32_t off) { return *(const uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ringbase + (off & (kRing - 4))); };
     uint64_t bb;
     uint32_t bc, voff, nxtw;
+    uint32_t pf = voff0 & ~15u;                      // the window holds the stream's bytes [pf - kRing, pf)
+    auto top_up = [&](uint32_t want_ahead) {         // synchronous: at start, and should a lane ever run low (it does not: the loop keeps ahead)
+        while (lane < lpw2 && (int)(pf - voff) < (int)want_ahead) {
+            const u32x4 c = *reinterpret_cast<const u32x4 *>(streamb + pf);
+            *(u32x4 __attribute__((address_space(3))) *)(uintptr_t)(ringbase + (pf & (kRing - 16))) = c;
+            pf += 16;
+        }
+    };
     auto seek = [&](uint32_t consumed_bits) {       // position the reader `consumed_bits` behind the (virtual) segment's first bit
         const uint32_t ab = bit_sh + consumed_bits;
         const uint32_t o = voff0 + (ab >> 5) * 4u, sh = ab & 31u;
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
         nxtw = *reinterpret_cast<const uint32_t *>(streamb + voff);
     };
     seek(0);
+    top_up(kRing - 16);
     auto consumed = [&]() { return (int)((voff - voff0) * 8u) - (int)bc - (int)bit_sh; };
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
     if (lane < lpw2) s_base[lane] = (uint64_t)out_off;
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     const uint32_t mybase = lds_addr(myblk);
     const uint32_t lastB = mybase + 126u, storeB = mybase + 127u;
     const uint32_t ac_base = lds_addr(s_ac);
-    const uint32_t c7f = 0x7FFFFFFFu;
+    const uint32_t c7f = 0x7FFFFFFFu, c124 = kRing - 4, c112 = kRing - 16;
 
     // flush geometry: lane (slot, part) moves the 8 coefficients of natural positions 8*part .. 8*part+7 of block
     // slot + 8*it — 16 bytes; they are read from their zig-zag slots, so the block lands in HBM in the natural [v][u]
@@ -215,7 +235,10 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 const uint32_t inc = want ? 4u : 0u;
                 voff += inc;
                 bc += inc * 8u;
-                if (want) nxtw = *reinterpret_cast<const uint32_t *>(streamb + voff);
+                if (want) nxtw = ring_u32(voff);
+                // (the loop below reads at most 4 bytes per iteration and brings in 16 per two: a lane cannot run its window dry,
+                // but nothing is lost by looking)
+                if (__builtin_amdgcn_ballot_w64(lane < lpw2 && (int)(pf - voff) < 24) != 0) top_up(64);
             }
             uint32_t pB;
             {
@@ -253,6 +276,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
             for (;;) {
                 uint64_t pend, nx = nxtw, tmp64;
                 uint32_t t0, t1, t2, t3, t4, t5, t6, ew;
+                u32x4 chunk;
 #ifdef MJ_X_STAMP
                 const uint64_t dbg_i0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -271,46 +295,68 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     "v_sub_u32_sdwa %[bc], %[bc], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
     "v_cmpx_gt_u32 %[lastB], %[pB]\n\t"
 #define MJ_WRITE13 "ds_write_b16_d16_hi %[pB], %[ew]\n\t"
+                // refill: lanes whose buffer is at most half full take the next dword and read the one after it from their window
+#define MJ_REFILL13 \
+    "s_mov_b64 s[42:43], exec\n\t"                        \
+    "v_cmpx_ge_u32 32, %[bc]\n\t"                         \
+    "v_sub_u32 %[t0], 32, %[bc]\n\t"                      \
+    "v_lshlrev_b64 v[4:5], %[t0], v[6:7]\n\t"             \
+    "v_or_b32 v3, v3, v5\n\t"                             \
+    "v_mov_b32 v2, v4\n\t"                                \
+    "v_add_u32 %[bc], 32, %[bc]\n\t"                      \
+    "v_add_u32 %[voff], 4, %[voff]\n\t"                   \
+    "v_and_or_b32 %[t0], %[voff], %[c124], %[ring]\n\t"   \
+    "ds_read_b32 v6, %[t0]\n\t"                           \
+    "s_mov_b64 exec, s[42:43]\n\t"
+                // two symbols of the lanes in exec (a resolved symbol is at most 13 bits: after a refill there are bits for
+                // two); the first one's store goes out behind the second one's read
+#define MJ_PAIR13 \
+    MJ_LOOK13 "s_waitcnt lgkmcnt(0)\n\t" MJ_CORE13 MJ_LOOK13 MJ_WRITE13 "s_waitcnt lgkmcnt(1)\n\t" MJ_CORE13 MJ_WRITE13
+                // any entry that was not resolved?  (every lane of the wave is looked at: lanes that are done keep a clean entry)
+#define MJ_CHECK13 \
+    "s_mov_b64 s[44:45], exec\n\t"        \
+    "s_mov_b64 exec, s[40:41]\n\t"        \
+    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"       \
+    "s_mov_b64 exec, s[44:45]\n\t"
+                // the window's upkeep, once per two iterations and for every lane that owns one: the 16 bytes asked for last
+                // time go into the window, the next 16 are asked for if they fit (they overwrite what lies kRing behind them)
+#define MJ_WINDOW_IN13 \
+    "s_waitcnt vmcnt(0)\n\t"                              \
+    "s_mov_b64 exec, s[52:53]\n\t"                        \
+    "v_and_or_b32 %[t0], %[pf], %[c112], %[ring]\n\t"     \
+    "ds_write_b128 %[t0], v[8:11]\n\t"                    \
+    "v_add_u32 %[pf], 16, %[pf]\n\t"
                 asm volatile(
                     "s_mov_b64 s[40:41], exec\n\t"
                     "s_mov_b64 %[pend], 0\n\t"
+                    "s_mov_b64 s[52:53], 0\n\t"                // lanes with 16 bytes on their way
                     "v_cmpx_gt_u32 %[lastB], %[pB]\n"
                     "L_loop%=:\n\t"
                     "s_cbranch_execz L_done%=\n\t"
-                    // refill: lanes whose buffer is at most half full take the next dword and ask for the one after it
-                    "s_waitcnt vmcnt(0)\n\t"
                     "s_mov_b64 s[42:43], exec\n\t"
-                    "v_cmpx_ge_u32 32, %[bc]\n\t"
-                    "v_sub_u32 %[t0], 32, %[bc]\n\t"
-                    "v_lshlrev_b64 v[4:5], %[t0], v[6:7]\n\t"
-                    "v_or_b32 v3, v3, v5\n\t"
-                    "v_mov_b32 v2, v4\n\t"
-                    "v_add_u32 %[bc], 32, %[bc]\n\t"
-                    "v_add_u32 %[voff], 4, %[voff]\n\t"
-#ifndef MJ_X_NOLOAD
-                    "global_load_dword v6, %[voff], %[sbase]\n\t"
-#endif
+                    MJ_WINDOW_IN13
+                    "s_mov_b64 exec, %[rl]\n\t"
+                    "v_sub_u32 %[t0], %[pf], %[voff]\n\t"
+                    "v_cmpx_ge_u32 112, %[t0]\n\t"
+                    "global_load_dwordx4 v[8:11], %[pf], %[sbase]\n\t"
+                    "s_mov_b64 s[52:53], exec\n\t"
                     "s_mov_b64 exec, s[42:43]\n\t"
-                    // first symbol
-                    MJ_LOOK13
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    MJ_CORE13
-                    // second symbol (a resolved symbol is at most 13 bits: 32 - 13 are left at least); the first one's
-                    // store goes out behind the second one's read
-                    MJ_LOOK13
-                    MJ_WRITE13
-                    "s_waitcnt lgkmcnt(1)\n\t"
-                    MJ_CORE13
-                    MJ_WRITE13
-                    // any entry that was not resolved?  (every lane of the wave is looked at: lanes that are done keep a clean entry)
-                    "s_mov_b64 s[44:45], exec\n\t"
-                    "s_mov_b64 exec, s[40:41]\n\t"
-                    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"
-                    "s_mov_b64 exec, s[44:45]\n\t"
+                    MJ_REFILL13
+                    MJ_PAIR13
+                    MJ_CHECK13
+                    "s_mov_b32 s54, 0\n\t"
+                    "s_cbranch_vccnz L_open%=\n"
+                    "L_mid%=:\n\t"
+                    "s_cbranch_execz L_done%=\n\t"
+                    MJ_REFILL13
+                    MJ_PAIR13
+                    MJ_CHECK13
                     "s_cbranch_vccz L_loop%=\n\t"
+                    "s_mov_b32 s54, 1\n"
                     // ---- entries that are not resolved (0.4 % of the symbols): the lanes of vcc.  Byte 1 = 0x80 | 0x40 if the
                     // code is longer than 13 bits (then the high word is where its second-level table starts) | run + 1
                     // (0 = end of block); byte 2 = code length (0 = no such code); byte 3 = 31 - size
+                    "L_open%=:\n\t"
                     "s_mov_b64 s[46:47], vcc\n\t"
                     "s_mov_b64 exec, vcc\n\t"
                     "v_mov_b32 %[t5], %[e]\n\t"
@@ -333,9 +379,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     "L_arith%=:\n\t"
                     "v_bfe_u32 %[t1], %[t5], 16, 8\n\t"        // code length
                     "v_cmp_eq_u32 vcc, 0, %[t1]\n\t"
-#ifndef MJ_X_NORARE
                     "s_cbranch_vccnz L_rare%=\n\t"             // no such code (a damaged file): the canonical search says so
-#endif
                     "v_bfe_u32 %[t6], %[t5], 8, 5\n\t"         // run + 1, 0 = end of block
                     "v_lshlrev_b32 %[t6], 1, %[t6]\n\t"
                     "v_cmp_eq_u32 vcc, 0, %[t6]\n\t"
@@ -360,17 +404,26 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     "L_hend%=:\n\t"
                     "s_or_b64 exec, exec, s[44:45]\n\t"
                     "s_or_b64 exec, exec, s[46:47]\n\t"
+                    "s_cmp_eq_u32 s54, 0\n\t"
+                    "s_cbranch_scc1 L_mid%=\n\t"
                     "s_branch L_loop%=\n"
                     "L_rare%=:\n\t"
                     "s_mov_b64 %[pend], exec\n"
                     "L_done%=:\n\t"
-                    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                    MJ_WINDOW_IN13
+                    "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, s[40:41]\n\t"
-                    : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last), [voff] "+v"(voff),
+                    : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), "=&{v[8:11]}"(chunk), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last),
+                      [voff] "+v"(voff), [pf] "+v"(pf),
                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
                       [ew] "=&v"(ew), [pend] "=&s"(pend)
-                    : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f)
-                    : "memory", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51");
+                    : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
+                      [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [rl] "s"(ring_lanes)
+                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54");
+#undef MJ_REFILL13
+#undef MJ_PAIR13
+#undef MJ_CHECK13
+#undef MJ_WINDOW_IN13
 #undef MJ_LOOK13
 #undef MJ_CORE13
 #undef MJ_WRITE13
@@ -414,6 +467,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                         seek((uint32_t)at);
                         const int r = canon_code(huff + acg, (uint32_t)(bb >> 48), 1);
                         seek((uint32_t)(at + (r < 0 ? 0 : r >> 8)));
+                        pf = voff & ~15u;                                             // (the window again, from there)
+                        top_up(kRing - 16);
                     }
                 }
             }
@@ -473,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 // LDS bytes of a launch with `nw` waves of `lpw` lanes
 static size_t lds13(int n_ac, int n_dc, int nw, int lpw) {
     const int lpw2 = (lpw + 7) & ~7, wstride = (lpw2 * kRow + 3) & ~3;
-    return (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8;
+    return (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8 + 127) & ~(size_t)127) + (size_t)nw * lpw2 * kRing;
 }
 
 bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8) <= 160 * 1024; }
