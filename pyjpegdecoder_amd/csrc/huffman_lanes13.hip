@@ -95,13 +95,15 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     const int nw = (int)(blockDim.x >> 6);
     uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][kASize]
     uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * kASlotBytes);          // [n_dc][kDSize]
-    const int lpw2 = (lpw + 7) & ~7;                                                             // the flush moves blocks eight at a time
+    // (the flush moves blocks eight at a time and may read up to seven rows and positions past a wave's last: the next wave's,
+    // or the slack behind the last wave's — never stored)
+    const int lpw2 = lpw;
     const int wstride = (lpw2 * kRow + 3) & ~3;                                                  // dwords per wave, 16-byte multiple
     unsigned char *rows0 = smem + (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2;
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(rows0) + wave * wstride;
-    uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4) + wave * lpw2;
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4 + 8 * kRow * 4) + wave * lpw2;
     // per-lane window on the lane's stream: kRing bytes, the stream's bytes at their offsets modulo kRing (see the bit reader)
-    unsigned char *rings0 = smem + (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8 + 127) & ~(size_t)127);
+    unsigned char *rings0 = smem + (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127);
 
     for (int i = tid; i < n_ac * (kASlotBytes / 16); i += (int)blockDim.x)
         reinterpret_cast<uint4 *>(s_ac)[i] = reinterpret_cast<const uint4 *>(lut13)[i];
@@ -168,10 +170,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     auto ring_u32 = [&](uint32_t off) { return *(const uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ringbase + (off & (kRing - 4))); };
     uint64_t bb;
     uint32_t bc, voff, nxtw;
-    uint32_t pf = voff0 & ~15u;                      // the window holds the stream's bytes [pf - kRing, pf)
+    // (voff and pf carry a per-lane rotation of the window, `rot`, on top of the stream offset: the lanes of a wave read and
+    // fill their windows at similar offsets, which without it are the same LDS banks for all of them)
+    const uint32_t rot = (uint32_t)(lane & 7) * 16u;
+    uint32_t pf = (voff0 & ~15u) + rot;              // the window holds the stream's bytes [pf - kRing, pf) (minus rot)
     auto top_up = [&](uint32_t want_ahead) {         // synchronous: at start, and should a lane ever run low (it does not: the loop keeps ahead)
         while (lane < lpw2 && (int)(pf - voff) < (int)want_ahead) {
-            const u32x4 c = *reinterpret_cast<const u32x4 *>(streamb + pf);
+            const u32x4 c = *reinterpret_cast<const u32x4 *>(streamb + (pf - rot));
             *(u32x4 __attribute__((address_space(3))) *)(uintptr_t)(ringbase + (pf & (kRing - 16))) = c;
             pf += 16;
         }
@@ -182,12 +187,12 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
         const uint32_t d0 = *reinterpret_cast<const uint32_t *>(streamb + o), d1 = *reinterpret_cast<const uint32_t *>(streamb + o + 4);
         bb = (((uint64_t)d0 << 32) | d1) << sh;
         bc = 64u - sh;
-        voff = o + 8;
-        nxtw = *reinterpret_cast<const uint32_t *>(streamb + voff);
+        voff = o + 8 + rot;
+        nxtw = *reinterpret_cast<const uint32_t *>(streamb + o + 8);
     };
     seek(0);
     top_up(kRing - 16);
-    auto consumed = [&]() { return (int)((voff - voff0) * 8u) - (int)bc - (int)bit_sh; };
+    auto consumed = [&]() { return (int)((voff - rot - voff0) * 8u) - (int)bc - (int)bit_sh; };
     const int64_t out_off = (im->block_off + (int64_t)sg.mcu0 * bpm) * 128;
     if (lane < lpw2) s_base[lane] = (uint64_t)out_off;
     int pred0 = vs.pred[0], pred1 = vs.pred[1], pred2 = vs.pred[2];        // zero for a restart segment (:900)
@@ -212,8 +217,9 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     const uint64_t full_mask = lpw >= 64 ? ~0ull : (1ull << lpw) - 1;
 
 #ifdef MJ_X_STAMP
-    uint32_t dbg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_iter = 0;
+    uint32_t dbg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_iter = 0, dbg_w[3] = {0, 0, 0};
     uint64_t dbg_in = 0;
+    uint32_t dbg_sym = 0, dbg_flag = 0;
     uint64_t dbg_ac = 0, dbg_fl = 0;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -288,7 +294,12 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 // the entry applied: position, buffer, count; exec keeps the lanes that are still inside their block AFTER this
                 // symbol — they are also the ones that store it (a lane whose symbol lands on coefficient 63 leaves here and
                 // stores it after the loop; an entry that is not resolved moves its lane out by 128+ and consumes nothing)
-#define MJ_CORE13 \
+#ifdef MJ_X_STAMP
+#define MJ_CNT13
+#else
+#define MJ_CNT13
+#endif
+#define MJ_CORE13 MJ_CNT13 \
     "v_mov_b32 %[ew], %[e]\n\t"                                                                                  \
     "v_add_u32_sdwa %[pB], %[pB], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
     "v_lshlrev_b64 v[2:3], %[e], v[2:3]\n\t"                                                                    \
@@ -313,11 +324,6 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 #define MJ_PAIR13 \
     MJ_LOOK13 "s_waitcnt lgkmcnt(0)\n\t" MJ_CORE13 MJ_LOOK13 MJ_WRITE13 "s_waitcnt lgkmcnt(1)\n\t" MJ_CORE13 MJ_WRITE13
                 // any entry that was not resolved?  (every lane of the wave is looked at: lanes that are done keep a clean entry)
-#define MJ_CHECK13 \
-    "s_mov_b64 s[44:45], exec\n\t"        \
-    "s_mov_b64 exec, s[40:41]\n\t"        \
-    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"       \
-    "s_mov_b64 exec, s[44:45]\n\t"
                 // the window's upkeep, once per two iterations and for every lane that owns one: the 16 bytes asked for last
                 // time go into the window, the next 16 are asked for if they fit (they overwrite what lies kRing behind them)
 #define MJ_WINDOW_IN13 \
@@ -326,33 +332,64 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     "v_and_or_b32 %[t0], %[pf], %[c112], %[ring]\n\t"     \
     "ds_write_b128 %[t0], v[8:11]\n\t"                    \
     "v_add_u32 %[pf], 16, %[pf]\n\t"
+#ifdef MJ_X_STAMP
+#define MJ_T(k) "s_memtime s[58:59]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s57, s58, s60\n\ts_mov_b32 s60, s58\n\ts_add_u32 s" #k ", s" #k ", s57\n\t"
+#else
+#define MJ_T(k)
+#endif
                 asm volatile(
                     "s_mov_b64 s[40:41], exec\n\t"
+#ifdef MJ_X_STAMP
+                    "s_mov_b32 s62, 0\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s64, 0\n\ts_mov_b32 s65, 0\n\ts_mov_b32 s66, 0\n\ts_mov_b32 s67, 0\n\ts_mov_b32 s68, 0\n\ts_mov_b32 s69, 0\n\ts_mov_b32 s70, 0\n\ts_mov_b32 s71, 0\n\t"
+                    "s_memtime s[60:61]\n\ts_waitcnt lgkmcnt(0)\n\t"
+#endif
                     "s_mov_b64 %[pend], 0\n\t"
                     "s_mov_b64 s[52:53], 0\n\t"                // lanes with 16 bytes on their way
+#ifdef MJ_X_STAMP
+                    "s_mov_b32 s55, 0\n\t"
+#endif
                     "v_cmpx_gt_u32 %[lastB], %[pB]\n"
+                    // One turn of the loop = the window's upkeep and the look for entries that were not resolved, both on every
+                    // lane of the wave, then two refill + two-symbol rounds of the lanes still inside their block
                     "L_loop%=:\n\t"
-                    "s_cbranch_execz L_done%=\n\t"
-                    "s_mov_b64 s[42:43], exec\n\t"
-                    MJ_WINDOW_IN13
+                    MJ_T(62)
+                    "s_mov_b64 s[44:45], exec\n\t"             // the lanes that go on
                     "s_mov_b64 exec, %[rl]\n\t"
+                    "v_cmp_gt_i16 vcc, 0, %[e]\n\t"            // (lanes that are done keep a clean entry)
+                    "s_cbranch_vccnz L_open%=\n"
+                    "L_back%=:\n\t"
+                    "s_cmp_eq_u64 s[44:45], 0\n\t"
+                    "s_cbranch_scc1 L_done%=\n\t"
+                    "s_cmp_eq_u64 s[52:53], 0\n\t"             // nothing on its way (first turn): no wait — it would wait for the
+                    "s_cbranch_scc1 L_ask%=\n\t"               // previous block's coefficient stores as well
+                    MJ_T(69)
+                    "s_waitcnt vmcnt(0)\n\t"
+                    MJ_T(70)
+                    MJ_WINDOW_IN13
+                    "s_mov_b64 exec, %[rl]\n"
+                    MJ_T(71)
+                    "L_ask%=:\n\t"
                     "v_sub_u32 %[t0], %[pf], %[voff]\n\t"
                     "v_cmpx_ge_u32 112, %[t0]\n\t"
-                    "global_load_dwordx4 v[8:11], %[pf], %[sbase]\n\t"
+                    "v_sub_u32 %[t0], %[pf], %[rot]\n\t"
+                    "global_load_dwordx4 v[8:11], %[t0], %[sbase]\n\t"
                     "s_mov_b64 s[52:53], exec\n\t"
-                    "s_mov_b64 exec, s[42:43]\n\t"
+                    "s_mov_b64 exec, s[44:45]\n\t"
+                    MJ_T(63)
+                    MJ_REFILL13
+                    MJ_T(64)
+#ifdef MJ_X_STAMP
+                    MJ_LOOK13 "s_waitcnt lgkmcnt(0)\n\t" MJ_T(65) MJ_CORE13 MJ_LOOK13 MJ_WRITE13 "s_waitcnt lgkmcnt(1)\n\t" MJ_T(66) MJ_CORE13 MJ_WRITE13 MJ_T(67)
+#else
+                    MJ_PAIR13
+#endif
                     MJ_REFILL13
                     MJ_PAIR13
-                    MJ_CHECK13
-                    "s_mov_b32 s54, 0\n\t"
-                    "s_cbranch_vccnz L_open%=\n"
-                    "L_mid%=:\n\t"
-                    "s_cbranch_execz L_done%=\n\t"
-                    MJ_REFILL13
-                    MJ_PAIR13
-                    MJ_CHECK13
-                    "s_cbranch_vccz L_loop%=\n\t"
-                    "s_mov_b32 s54, 1\n"
+                    MJ_T(68)
+#ifdef MJ_X_STAMP
+                    "s_add_u32 s55, s55, 1\n\t"
+#endif
+                    "s_branch L_loop%=\n"
                     // ---- entries that are not resolved (0.4 % of the symbols): the lanes of vcc.  Byte 1 = 0x80 | 0x40 if the
                     // code is longer than 13 bits (then the high word is where its second-level table starts) | run + 1
                     // (0 = end of block); byte 2 = code length (0 = no such code); byte 3 = 31 - size
@@ -402,27 +439,34 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     "ds_write_b16 %[pB], %[t3]\n\t"
                     "v_cmpx_gt_u32 %[lastB], %[pB]\n"
                     "L_hend%=:\n\t"
-                    "s_or_b64 exec, exec, s[44:45]\n\t"
-                    "s_or_b64 exec, exec, s[46:47]\n\t"
-                    "s_cmp_eq_u32 s54, 0\n\t"
-                    "s_cbranch_scc1 L_mid%=\n\t"
-                    "s_branch L_loop%=\n"
+                    "s_or_b64 s[44:45], s[44:45], exec\n\t"
+                    "s_or_b64 s[44:45], s[44:45], s[46:47]\n\t"
+                    "s_mov_b64 exec, %[rl]\n\t"
+                    "s_branch L_back%=\n"
                     "L_rare%=:\n\t"
                     "s_mov_b64 %[pend], exec\n"
                     "L_done%=:\n\t"
                     MJ_WINDOW_IN13
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, s[40:41]\n\t"
+#ifdef MJ_X_STAMP
+                    "v_add_u32 %[di], s55, %[di]\n\t"
+                    "v_add_u32 %[d0], s62, %[d0]\n\tv_add_u32 %[d1], s63, %[d1]\n\tv_add_u32 %[d2], s64, %[d2]\n\tv_add_u32 %[d3], s65, %[d3]\n\t"
+                    "v_add_u32 %[d4], s66, %[d4]\n\tv_add_u32 %[d5], s67, %[d5]\n\tv_add_u32 %[d6], s68, %[d6]\n\t"
+                    "v_add_u32 %[d7], s69, %[d7]\n\tv_add_u32 %[d8], s70, %[d8]\n\tv_add_u32 %[d9], s71, %[d9]\n\t"
+#endif
                     : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), "=&{v[8:11]}"(chunk), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last),
                       [voff] "+v"(voff), [pf] "+v"(pf),
                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
                       [ew] "=&v"(ew), [pend] "=&s"(pend)
+#ifdef MJ_X_STAMP
+                      , [di] "+v"(dbg_iter), [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_w[0]), [d8] "+v"(dbg_w[1]), [d9] "+v"(dbg_w[2])
+#endif
                     : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
-                      [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [rl] "s"(ring_lanes)
-                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54");
+                      [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [rl] "s"(ring_lanes), [rot] "v"(rot)
+                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71");
 #undef MJ_REFILL13
 #undef MJ_PAIR13
-#undef MJ_CHECK13
 #undef MJ_WINDOW_IN13
 #undef MJ_LOOK13
 #undef MJ_CORE13
@@ -430,6 +474,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 nxtw = (uint32_t)nx;
 #ifdef MJ_X_STAMP
                 dbg_in += __builtin_amdgcn_s_memtime() - dbg_i0;
+                dbg_d[7] += 1;
 #endif
                 if (pend == 0) break;
                 // rare: no code at all in some lane (a damaged file); the lanes of `pend` — back at their positions, nothing
@@ -437,6 +482,9 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 if ((pend >> lane) & 1) {
                     const uint32_t hi = (uint32_t)(bb >> 32);
                     const int r = canon_code(huff + acg, hi >> 16, 1);
+#ifdef MJ_X_STAMP
+                    if (blockIdx.x < 4 && m < 30) printf("rare: lane %d m %d b %d hi %08x r %x bc %u pB-mybase %d e_last %x\n", lane, m, b, hi, r, bc, (int)(pB - mybase), e_last);
+#endif
                     if (r < 0) {
                         err = MJ_ST_BAD_CODE;
                         pB = lastB + 1u;                                          // done (and nothing to correct below)
@@ -507,9 +555,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     }
 #ifdef MJ_X_STAMP
     if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg13[8 + i], (unsigned long long)dbg_d[i]);
         atomicAdd(&g_dbg13[6], (unsigned long long)dbg_in);
         atomicAdd(&g_dbg13[1], (unsigned long long)dbg_iter);
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_dbg13[9 + i], (unsigned long long)dbg_d[i]);
+        atomicAdd(&g_dbg13[8], (unsigned long long)dbg_d[7]);
+        atomicAdd(&g_dbg13[0], (unsigned long long)dbg_w[0]); atomicAdd(&g_dbg13[7], (unsigned long long)dbg_w[1]);
+    }
+    if (lane == 0) {
         atomicAdd(&g_dbg13[2], (unsigned long long)dbg_ac);
         atomicAdd(&g_dbg13[3], (unsigned long long)dbg_fl);
         atomicAdd(&g_dbg13[4], (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
@@ -527,8 +579,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 
 // LDS bytes of a launch with `nw` waves of `lpw` lanes
 static size_t lds13(int n_ac, int n_dc, int nw, int lpw) {
-    const int lpw2 = (lpw + 7) & ~7, wstride = (lpw2 * kRow + 3) & ~3;
-    return (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + (size_t)nw * lpw2 * 8 + 127) & ~(size_t)127) + (size_t)nw * lpw2 * kRing;
+    const int lpw2 = lpw, wstride = (lpw2 * kRow + 3) & ~3;
+    return (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127) + (size_t)nw * lpw2 * kRing;
 }
 
 bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8) <= 160 * 1024; }
@@ -573,9 +625,11 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
         unsigned long long h[16], z[16] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg13), sizeof(h));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg13), z, sizeof(z));
-        const double it = (double)(h[1] ? h[1] : 1);
-        fprintf(stderr, "[lanes13 nw=%d lpw=%d] waves %llu: per wave: total %.0f cyc, AC loop %.0f, flush+clear %.0f, %.0f iterations; per iteration: loop-back/other %.0f, vm wait %.0f, refill %.0f, look1 %.0f, step1 %.0f, look2 %.0f, h2 %.0f, h1 %.0f; inside the asm statement %.0f per wave\n",
-                nw, lpw, h[5], (double)h[4] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], it / h[5], h[8] / it, h[9] / it, h[10] / it, h[11] / it, h[12] / it, h[13] / it, h[14] / it, h[15] / it, (double)h[6] / h[5]);
+        const double w = (double)h[5], turns = (double)(h[1] ? h[1] : 1);
+        fprintf(stderr, "[lanes13 nw=%d lpw=%d] waves %llu: per wave: total %.0f cyc, DC etc. %.0f, AC loop %.0f of which in the asm %.0f, flush+clear %.0f; %.0f turns of the loop in %.0f asm runs; "
+                        "per turn: loop back %.0f, look for open entries + window %.0f, refill %.0f, look1 %.0f, core1+look2 %.0f, core2+write %.0f, second round %.0f; of the window: up to the wait %.0f, the wait %.0f\n",
+                nw, lpw, h[5], h[4] / w, ((double)h[4] - h[2] - h[3]) / w, h[2] / w, h[6] / w, h[3] / w, h[1] / w, h[8] / w,
+                h[9] / turns, h[10] / turns, h[11] / turns, h[12] / turns, h[13] / turns, h[14] / turns, h[15] / turns, h[0] / turns, h[7] / turns);
     }
 #endif
     return hipGetLastError();
