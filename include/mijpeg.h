@@ -223,6 +223,12 @@ int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, u
  * stream, measured with HIP events recorded on that stream. */
 int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms);
 
+/* Diagnostic of the fast stage 2 (reference :1561-1573): of the blocks the plan's latest stage-2 execute WITH seam outputs
+ * (MJ_FLAG_KEEP_IDCT / MJ_FLAG_KEEP_PLANES) put through the IDCT, counts[0] = all of them, counts[1] = how many the fp32
+ * first level could not decide (they went to the fp64 level), counts[2] = how many of those went on to the exact-order
+ * routine.  Waits for that execute. */
+int mj_plan_idct_levels(mj_plan *plan, uint64_t counts[3]);
+
 /* ---- host-side helper (no GPU needed) -------------------------------------------------------------- */
 /* The IDCT table as the library builds it: 4096 doubles laid out [u*8+v][x*8+y], the transpose of the
  * reference's InverseDCT.idct_table (:1541-1553).  Lets CPU tests pin it bit-for-bit. */

@@ -27,7 +27,7 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES = 0, 1, 2, 3, 16
 MJ_HOST_DECLINED = 1
@@ -121,6 +121,7 @@ def load_library():
     L.mj_host_idct_table.restype = None
     L.mj_host_assemble.argtypes = [ctypes.POINTER(HostJobC)]
     L.mj_plan_stage1_form.argtypes = [vp]
+    L.mj_plan_idct_levels.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 
@@ -221,6 +222,12 @@ class Plan:
         c, r, p, d = (ctypes.c_void_p() for _ in range(4))
         self.ctx.check(self.ctx.lib.mj_plan_device_buffers(self.handle, ctypes.byref(c), ctypes.byref(r), ctypes.byref(p), ctypes.byref(d)))
         return {"coef": c.value, "rgb": r.value, "planes": p.value, "idct": d.value}
+
+    def idct_levels(self):
+        """(blocks, sent on by the fp32 level, sent on by the fp64 level) of the latest stage-2 execute with seam outputs."""
+        c = (ctypes.c_uint64 * 3)()
+        self.ctx.check(self.ctx.lib.mj_plan_idct_levels(self.handle, c))
+        return int(c[0]), int(c[1]), int(c[2])
 
     def time_stages(self, iters: int = 10, rgb_device: int = 0):
         s1, s2 = ctypes.c_float(), ctypes.c_float()

@@ -1248,6 +1248,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.debug = 0;
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
+    if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(ctx->d_dump + mj::kStage2DumpBytes - 64, 0, 64, s));     // mj_plan_idct_levels
     if (a.exact_only) {
         MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
     } else {
@@ -1394,6 +1395,14 @@ int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, u
     if (rc == MJ_OK) rc = mj_plan_read(p, rgb_out, nullptr, nullptr, nullptr, nullptr);
     mj_plan_destroy(p);
     return rc;
+}
+
+int mj_plan_idct_levels(mj_plan *p, uint64_t counts[3]) {
+    if (!p || !counts) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
+    MJ_HIP(ctx, hipMemcpy(counts, ctx->d_dump + mj::kStage2DumpBytes - 64, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MJ_OK;
 }
 
 int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms) {

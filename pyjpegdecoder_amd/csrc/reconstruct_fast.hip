@@ -512,10 +512,11 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
             uint32_t rb[8];
             float err = 0.0f;
 #pragma unroll
-            for (int y = 0; y < 8; ++y) {
-                const float rr = t[y] + magic;
-                err = __builtin_fmaxf(err, __builtin_fabsf(t[y] - (rr - magic)));
-                rb[y] = __builtin_bit_cast(uint32_t, rr);
+            for (int y = 0; y < 8; y += 2) {
+                const float r0 = t[y] + magic, r1 = t[y + 1] + magic;
+                err = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t[y] - (r0 - magic)), __builtin_fabsf(t[y + 1] - (r1 - magic))), err);   // v_max3_f32
+                rb[y] = __builtin_bit_cast(uint32_t, r0);
+                rb[y + 1] = __builtin_bit_cast(uint32_t, r1);
             }
             uint4 ow;
             ow.x = __builtin_amdgcn_perm(rb[1], rb[0], 0x05040100u);
@@ -535,6 +536,16 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                 flagged = flagged && !dconly;
             }
             if (real) store_row(k, b, ow);
+            if constexpr (SEAMS) {          // how the levels are used (mj_plan_idct_levels; seam-output kernels only: the tests' path)
+                uint64_t fb = __ballot(flagged);
+                fb |= fb >> 4; fb |= fb >> 2; fb |= fb >> 1; fb &= 0x0101010101010101ull;       // one bit per block with a flagged row
+                const uint64_t rb8 = __ballot(real && j == 0);
+                if (lane == 0) {
+                    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(a.dump + kStage2DumpBytes - 64);
+                    atomicAdd(cnt, (unsigned long long)__builtin_popcountll(rb8));
+                    if (fb) atomicAdd(cnt + 1, (unsigned long long)__builtin_popcountll(fb));
+                }
+            }
             // ---- level 2 (about one round in eight on noisy images): the groups whose block failed do it again in fp64
             if (__ballot(flagged) != 0) {
 #ifdef MJ_DIAGNOSTIC
@@ -563,6 +574,10 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                     o[y] = (int)(int16_t)((int)(int16_t)(int)rr + shift);
                 }
                 const uint64_t sb = __ballot(mine && errd > (0.5 - 9.5367431640625e-07));
+                if constexpr (SEAMS) {
+                    const uint64_t s3 = __ballot(mine && j == 0 && ((sb >> (lane & 56)) & 0xFF) != 0);
+                    if (lane == 0 && s3) atomicAdd(reinterpret_cast<unsigned long long *>(a.dump + kStage2DumpBytes - 64) + 2, (unsigned long long)__builtin_popcountll(s3));
+                }
                 uint4 ow2;
                 ow2.x = (uint32_t)(o[0] & 0xFFFF) | ((uint32_t)o[1] << 16);
                 ow2.y = (uint32_t)(o[2] & 0xFFFF) | ((uint32_t)o[3] << 16);
@@ -668,7 +683,23 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                     auto pairB = [&](int i) { return f32x2{(float)((i & 1) ? hi16(bw2[i >> 1]) : lo16(bw2[i >> 1])), (float)((i & 1) ? hi16(rw2[i >> 1]) : lo16(rw2[i >> 1]))}; };
                     // largest |Cb-128|, |Cr-128| among the source samples (an upsampled value lies between its sources)
                     // and largest |remainder| of the green term: both decide, once per lane, whether fp32 was exact
-                    float crange = 0.0f, tie125 = 1.0f;
+                    float crange = 0.0f;
+                    // |Cb - 128| = 125 somewhere in the run is the B tie (below).  An upsampled value lies between its sources, so
+                    // it is ruled out once for the whole run on the packed int16 source samples: all of them inside (-125, 125),
+                    // all above 125 or all below -125
+                    bool tie125;
+                    {
+                        typedef short s16x2 __attribute__((ext_vector_type(2)));
+                        auto pmax = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); };
+                        auto pmin = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); };
+                        uint32_t mx = pmax(pmax(bw[0], bw[1]), pmax(bw[2], bw[3])), mn = pmin(pmin(bw[0], bw[1]), pmin(bw[2], bw[3]));
+                        if constexpr (HS > 1) {
+                            mx = pmax(mx, pmax(pmax(bw2[0], bw2[1]), pmax(bw2[2], bw2[3])));
+                            mn = pmin(mn, pmin(pmin(bw2[0], bw2[1]), pmin(bw2[2], bw2[3])));
+                        }
+                        const int hi_ = max(lo16(mx), hi16(mx)), lo_ = min(lo16(mn), hi16(mn));
+                        tie125 = !((hi_ < 125 && lo_ > -125) || lo_ > 125 || hi_ < -125);
+                    }
                     constexpr float MAGIC = 12582912.0f;                       // 1.5 * 2^23: x + MAGIC rounds x to an integer
 #pragma unroll
                     for (int by = 0; by < G::MH / 8; ++by) {
@@ -733,8 +764,6 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                             const float Gf = Ym - qm;
                             const float rem = __builtin_fmaf(-50000.0f, qm - MAGIC, N);
                             remmax = __builtin_fmaxf(__builtin_fabsf(rem), remmax);
-                            // |cb| = 125 somewhere in the run -> the B tie: the whole run goes the float64 way
-                            tie125 = __builtin_fminf(tie125, __builtin_fabsf(__builtin_fabsf(C.x) - 125.0f));
                             const int o0 = 3 * y, o1 = 3 * y + 1, o2 = 3 * y + 2;
                             ob[o0 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(br2.y, o0 & 3, ob[o0 >> 2]);
                             ob[o1 >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(Gf, o1 & 3, ob[o1 >> 2]);
@@ -742,7 +771,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                         }
                         rg |= remmax >= 24998.5f ? (1 << by) : 0;      // this half of the column has a pixel whose green must be redone
                     }
-                    slow |= crange >= 250.0f || tie125 == 0.0f;
+                    slow |= crange >= 250.0f || tie125;
                 } else {
                     const uint4 yw = *reinterpret_cast<const uint4 *>(mt + (px & 7) * 8);
                     const uint32_t ywd[4] = {yw.x, yw.y, yw.z, yw.w};

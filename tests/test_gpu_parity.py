@@ -1250,3 +1250,137 @@ def test_config4_sharded_queue_two_ranks_on_one_gpu():
     assert line["config"]["images_all_gpus"] == 50 and line["config"]["images_per_gpu"] == 25
     assert line["parity"].startswith("bit-exact")
     assert abs(line["value"] - 50 * 1920 * 1080 / 1e6 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]      # whole job / time per pass
+
+
+def _idct_blocks_through_stage2(dec, blocks_xy, layout, cols=2048):
+    """Dequantised int16 blocks [n,8,8] ([x,y]) as the coefficients of a greyscale image with an all-ones quantisation table
+    through Plan.execute_stage2; returns the IDCT seam [n,8,8] and the level counts."""
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd._parse import ZZ_GRID
+    import ctypes
+    n = blocks_xy.shape[0]
+    rows = -(-n // cols)
+    zz = np.zeros((rows * cols, 64), dtype=np.int16)
+    for x in range(8):
+        for y in range(8):
+            zz[:n, ZZ_GRID[y, x]] = blocks_xy[:, x, y]
+    d = (B.ImageDescC * 1)()
+    d[0].width, d[0].height, d[0].ncomp = 8 * cols, 8 * rows, 1
+    d[0].hs[0] = d[0].vs[0] = 1
+    d[0].mcu_count_h, d[0].mcu_count_v = cols, rows
+    d[0].n_segments = 1
+    qt = np.ones((1, 64), dtype=np.uint16)
+    bc = B.BatchC()
+    bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
+    bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
+    bc.n_qt = 1; bc.qt = qt.ctypes.data
+    bc.layout = B.MJ_LAYOUT_ROWMAJOR if layout == "rowmajor" else B.MJ_LAYOUT_XMAJOR
+    bc.flags = B.MJ_FLAG_KEEP_IDCT
+    plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
+    try:
+        plan.write_coef(zz)
+        plan.execute_stage2()
+        plan.sync()
+        out = plan.read(rgb=False, idct=True)
+        levels = plan.idct_levels()
+    finally:
+        plan.close()
+    return out["idct"].reshape(rows * cols, 8, 8)[:n], levels
+
+
+@pytest.mark.parametrize("layout", ["xmajor", "rowmajor"])
+def test_idct_random_blocks_attack_the_fp32_bound(dec, layout):
+    """The fast stage 2 accepts an fp32 IDCT sample when it is at least 2.0e-7 * A + 1e-6 away from a half-integer (A = sum
+    of |dequantised coefficient|; DESIGN.md section 3 argues the bound).  This drives more than a million arbitrary int16
+    blocks through Plan.execute_stage2 against oracle.idct_xy (jpeg_decoder.py:1561-1573 restated): dense uniform, heavy
+    tailed, one and two coefficients up to the int16 limit, and the golden exact-tie blocks perturbed and scaled — every
+    sample must be the reference's, and the number of blocks each level passed on is printed."""
+    from oracle import oracle
+    rng = np.random.default_rng(20261003 + (layout == "rowmajor"))
+    n = 131072
+    fams = {}
+    fams["dense uniform +-1000"] = rng.integers(-1000, 1001, size=(n, 8, 8))
+    lap = rng.laplace(0.0, 40.0, size=(n, 8, 8))
+    lap[rng.random((n, 8, 8)) < 0.01] *= 40                                   # a few very large ones
+    fams["heavy tailed"] = np.clip(np.rint(lap), -12000, 12000)
+    one = np.zeros((n, 8, 8))
+    idx = rng.integers(0, 64, size=n)
+    one.reshape(n, 64)[np.arange(n), idx] = rng.integers(-32767, 32768, size=n)
+    two = one.copy() // 2
+    idx2 = rng.integers(0, 64, size=n)
+    two.reshape(n, 64)[np.arange(n), idx2] += rng.integers(-16000, 16001, size=n)
+    fams["one coefficient up to the int16 limit"] = one
+    fams["two coefficients"] = two
+    g = np.load(GOLDEN / "idct_blocks.npz")["blocks"].astype(np.int64)          # exact ties of the reference (F6/F7)
+    tie = g[rng.integers(0, g.shape[0], size=n)].copy()
+    tie[:, 0, 0] += 8 * rng.integers(-100, 101, size=n)                        # ~ integer shift of every sample: still next to the tie
+    pert = rng.random(n) < 0.5
+    k = rng.integers(1, 64, size=n)
+    tie.reshape(n, 64)[np.arange(n)[pert], k[pert]] += rng.integers(-2, 3, size=int(pert.sum()))
+    fams["golden tie blocks shifted and perturbed"] = tie
+    scaled = g[rng.integers(0, g.shape[0], size=n)] * rng.choice([3, 5, 7, 9, 11, 25, 101], size=n)[:, None, None]
+    fams["golden tie blocks scaled by odd factors"] = np.clip(scaled, -32767, 32767)
+    mixed = np.clip(np.rint(rng.laplace(0.0, 12.0, size=(n, 8, 8))), -2000, 2000)
+    mixed[:, 4:, :] = 0; mixed[:, :, 4:] = 0                                   # low-frequency blocks: where real files live
+    mixed += tie * (rng.random(n) < 0.3)[:, None, None]
+    fams["low-frequency noise, a third of them on top of a tie block"] = mixed
+    total = 0
+    for name, blocks in fams.items():
+        blocks = blocks.astype(np.int16)
+        got, (nb, l2, l3) = _idct_blocks_through_stage2(dec, blocks, layout)
+        want = oracle.idct_xy(blocks)
+        bad = np.flatnonzero((got != want).any(axis=(1, 2)))
+        print(f"[{layout}] {name}: {blocks.shape[0]} blocks, {l2} to the fp64 level ({100.0 * l2 / max(nb, 1):.2f} %), {l3} to the exact-order routine")
+        assert bad.size == 0, f"{name}: {bad.size} blocks differ, first {bad[0]}: {blocks[bad[0]].tolist()}"
+        total += blocks.shape[0]
+    assert total >= 900000
+
+
+def test_colour_lattice_around_the_green_patch_threshold(dec):
+    """YCbCr -> RGB (jpeg_decoder.py:1689-1700) on a lattice chosen against the fast path's decisions: every (Cb, Cr) in
+    [-260, 260]^2 whose green numerator 17207 cb + 35707 cr leaves a remainder within 2 of +-25000 (the patch threshold of
+    reconstruct_fast.hip), plus |c| in {124..126, 249..251} against everything, each with several Y.  4:4:4 DC-only blocks
+    (every sample of a block = the wanted value); compared with the oracle's float64 expression."""
+    from pyjpegdecoder_amd import _binding as B
+    from oracle import oracle
+    import ctypes
+    cb, cr = np.meshgrid(np.arange(-260, 261), np.arange(-260, 261), indexing="ij")
+    nnum = 17207 * cb + 35707 * cr
+    rem = np.abs(((nnum + 25000) % 50000) - 25000)                            # distance of the remainder from 0 ... 25000
+    near = rem >= 24998
+    edge = np.isin(np.abs(cb), [124, 125, 126, 249, 250, 251]) | np.isin(np.abs(cr), [124, 125, 126, 249, 250, 251])
+    sel = near | edge
+    cbs, crs = cb[sel], cr[sel]
+    ys = np.array([0, 1, 17, 128, 200, 254, 255, 300, -20])
+    ycc = np.stack([np.repeat(ys, cbs.size), np.tile(cbs + 128, ys.size), np.tile(crs + 128, ys.size)], axis=1).astype(np.int32)
+    n = ycc.shape[0]
+    cols = 1024
+    rows = -(-n // cols)
+    coef = np.zeros((rows * cols, 3, 64), dtype=np.int16)
+    coef[:n, :, 0] = (ycc - 128) * 8
+    d = (B.ImageDescC * 1)()
+    d[0].width, d[0].height, d[0].ncomp = 8 * cols, 8 * rows, 3
+    for c in range(3):
+        d[0].hs[c] = d[0].vs[c] = 1
+    d[0].mcu_count_h, d[0].mcu_count_v = cols, rows
+    d[0].n_segments = 1
+    qt = np.ones((1, 64), dtype=np.uint16)
+    bc = B.BatchC()
+    bc.n_images = 1; bc.images = ctypes.cast(d, ctypes.POINTER(B.ImageDescC))
+    bc.blob = None; bc.blob_mem = B.MJ_MEM_NONE
+    bc.n_qt = 1; bc.qt = qt.ctypes.data
+    bc.layout = B.MJ_LAYOUT_XMAJOR
+    plan = B.Plan(dec.ctx, bc, {"n_images": 1, "keep": (d, qt)})
+    try:
+        plan.write_coef(coef.reshape(-1, 64))
+        plan.execute_stage2()
+        plan.sync()
+        rgb = plan.read(rgb=True)["rgb"]
+    finally:
+        plan.close()
+    img = np.asarray(rgb, dtype=np.uint8).reshape(8 * cols, 8 * rows, 3)          # x-major
+    got = img[::8, ::8].transpose(1, 0, 2).reshape(rows * cols, 3)[:n]            # block (row r, col c) = index r * cols + c
+    want = oracle.ycbcr_to_rgb(ycc.reshape(-1, 1, 3).astype(np.int16)).reshape(-1, 3)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    print(f"colour lattice: {n} (Y, Cb, Cr) triples, {int(near.sum())} chroma pairs at the green threshold, {int(edge.sum())} at the B/R edges")
+    assert bad.size == 0, f"{bad.size} differ, first: ycc {ycc[bad[0]].tolist()} got {got[bad[0]].tolist()} want {want[bad[0]].tolist()}"
