@@ -215,6 +215,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
         fa[u] = lds_addr(s_blk + fslot * kRow) + 2u * c_zz_of_nat_13[tr ? ((nat & 7) << 3 | nat >> 3) : nat];
     }
     const uint64_t full_mask = lpw >= 64 ? ~0ull : (1ull << lpw) - 1;
+    const uint32_t fb_addr = lds_addr(s_base + fslot);
 
 #ifdef MJ_X_STAMP
     uint32_t dbg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_iter = 0, dbg_w[3] = {0, 0, 0};
@@ -530,6 +531,44 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
             const uint64_t act_mask = __ballot(in_mcu);
             const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
             unsigned char *dst0 = reinterpret_cast<unsigned char *>(coef) + blk_byte + fpart * 16;
+            if (act_mask == full_mask) {
+                // every lane of the wave has a block (all but a segment's last rounds): by hand — per eight blocks eight 16-bit
+                // reads and four packs (a d16 load clears the other half of its register on this chip), the block's address from
+                // LDS, one 16-byte store per lane
+                u32x4 fd, fh;
+                uint64_t fad;
+#define MJ_FLUSH8(it) \
+    "s_sub_u32 s42, %[lpw], " #it "*8\n\t"                                   \
+    "v_cmpx_gt_u32 s42, %[fslot]\n\t"                                      \
+    "ds_read_u16 v10, %[fa0] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v16, %[fa1] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v11, %[fa2] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v17, %[fa3] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v12, %[fa4] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v18, %[fa5] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v13, %[fa6] offset:" #it "*1056\n\t"                      \
+    "ds_read_u16 v19, %[fa7] offset:" #it "*1056\n\t"                      \
+    "ds_read_b64 v[14:15], %[fb] offset:" #it "*64\n\t"                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                             \
+    "v_lshl_or_b32 v10, v16, 16, v10\n\t"                                  \
+    "v_lshl_or_b32 v11, v17, 16, v11\n\t"                                  \
+    "v_lshl_or_b32 v12, v18, 16, v12\n\t"                                  \
+    "v_lshl_or_b32 v13, v19, 16, v13\n\t"                                  \
+    "v_lshl_add_u64 v[14:15], v[14:15], 0, %[dst]\n\t"                     \
+    "global_store_dwordx4 v[14:15], v[10:13], off\n\t"
+#define MJ_FLUSH_MORE(it) "s_cmp_le_u32 %[lpw], " #it "*8\n\ts_cbranch_scc1 L_fend%=\n\t" MJ_FLUSH8(it)
+                asm volatile(
+                    "s_mov_b64 s[40:41], exec\n\t"
+                    MJ_FLUSH8(0) MJ_FLUSH_MORE(1) MJ_FLUSH_MORE(2) MJ_FLUSH_MORE(3) MJ_FLUSH_MORE(4) MJ_FLUSH_MORE(5) MJ_FLUSH_MORE(6) MJ_FLUSH_MORE(7)
+                    "L_fend%=:\n\t"
+                    "s_mov_b64 exec, s[40:41]\n\t"
+                    : "=&{v[10:13]}"(fd), "=&{v[14:15]}"(fad), "=&{v[16:19]}"(fh)
+                    : [lpw] "s"(lpw), [fslot] "v"(fslot), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]), [fa3] "v"(fa[3]), [fa4] "v"(fa[4]),
+                      [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7]), [fb] "v"(fb_addr), [dst] "v"((uint64_t)(uintptr_t)dst0)
+                    : "memory", "vcc", "scc", "s40", "s41", "s42");
+#undef MJ_FLUSH8
+#undef MJ_FLUSH_MORE
+            } else
             for (int it = 0; it * 8 < lpw; ++it) {
                 if (((act_mask >> (8 * it)) & 0xFF) == 0) continue;      // uniform
                 const uint32_t ro = (uint32_t)it * (8u * kRow * 4u);
@@ -540,13 +579,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 v.z = rd(4) | (rd(5) << 16);
                 v.w = rd(6) | (rd(7) << 16);
                 const int o = it * 8 + fslot;
-#ifdef MJ_X_NOSTORE
-                if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
-#else
                 if ((act_mask >> o) & 1) *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
-#endif
             }
-            (void)full_mask;
             for (int i = lane; i < wstride / 4; i += 64) reinterpret_cast<uint4 *>(s_blk)[i] = make_uint4(0, 0, 0, 0);
 #ifdef MJ_X_STAMP
             dbg_fl += __builtin_amdgcn_s_memtime() - dbg_a1;
