@@ -124,6 +124,8 @@ struct mj_plan {
     mj::DevHuff *d_huff = nullptr;
     uint16_t *d_lut11 = nullptr;        // [n_huff][2048] primary LUTs of the lane-parallel stage-1 kernel
     // resolved 13-bit AC tables of the lane form's fast variant (huffman_lanes13.hip), when the batch's tables fit LDS that way
+    int32_t *d_by_length = nullptr;     // restart segments, longest first (how the lane form deals them out to its waves)
+    int seg_order_mode = 0;
     uint32_t *d_lut13 = nullptr;        // [n_ac13][8192]
     int n_ac13 = 0, n_dc13 = 0;
     uint64_t ac_slot_pk = 0, dc_slot_pk = 0, dc_tab_pk = 0;
@@ -393,7 +395,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -978,6 +980,23 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 p->use_sync = true;
             }
         }
+        if (p->use_lanes && !p->use_sync && p->d_lut13 && jobs.empty() && segs.size() > 1) {
+            // the lane form deals restart segments out by length (huffman_lanes13.hip); MJ_SEG_ORDER = blob | binned | striped (tests, measurements)
+            const char *e = getenv("MJ_SEG_ORDER");
+            // (measured, 1024 x 1080p: files of mixed content 7.5 ms in blob order, 7.9 binned, 6.65 striped; files of one kind
+            // 4.01 / 4.13 — so segments of similar length stay in blob order)
+            int64_t sum_len = 0;
+            int32_t top_len = 0;
+            for (const auto &g : segs) { sum_len += g.len; top_len = std::max(top_len, g.len); }
+            const bool spread = (int64_t)top_len * 4 * (int64_t)segs.size() > 5 * sum_len;             // longest > 1.25 x mean
+            p->seg_order_mode = (e && !strcmp(e, "blob")) ? 0 : ((e && !strcmp(e, "binned")) ? 1 : ((e && !strcmp(e, "striped")) || spread ? 2 : 0));
+            if (p->seg_order_mode) {
+                std::vector<int32_t> ord(segs.size());
+                for (size_t i = 0; i < segs.size(); ++i) ord[i] = (int32_t)i;
+                std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return segs[x].len > segs[y].len; });
+                if ((rc = upload(ctx, &p->d_by_length, ord.data(), ord.size())) != MJ_OK) return rc;
+            }
+        }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
         if (!jobs.empty()) {
             if (prog) return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT is for baseline batches");
@@ -1211,7 +1230,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
         if (p->d_lut13)
             MJ_HIP(ctx, mj::launch_huffman_lanes13(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                                    p->d_lut13, p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk,
-                                                   p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr));
+                                                   p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_by_length, p->seg_order_mode));
         else
             MJ_HIP(ctx, mj::launch_huffman_lanes(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11,
                                                  p->n_huff, p->d_coef, p->d_status, p->transposed ? 1 : 0, nullptr, p->d_wg_tabs_lanes, p->wg_slots_lanes));

@@ -88,7 +88,9 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                                                            uint64_t dc_slot_pk,   // byte t = LDS slot of table t as a DC table
                                                            uint64_t dc_tab_pk,    // byte s = table index held by DC slot s
                                                            int16_t *__restrict__ coef, int32_t *__restrict__ status, int lpw, int tr,
-                                                           const DevVSeg *__restrict__ vsegs /* or null */) {
+                                                           const DevVSeg *__restrict__ vsegs /* or null */,
+                                                           const int32_t *__restrict__ by_length /* or null: segment numbers, longest first */,
+                                                           int order_mode /* 1 = a wave takes neighbours of that list, 2 = one of every stride */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,7 +117,15 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     for (int i = tid; i < nw * wstride; i += (int)blockDim.x) reinterpret_cast<uint32_t *>(rows0)[i] = 0;
     __syncthreads();
 
-    const int64_t seg_id = ((int64_t)blockIdx.x * nw + wave) * lpw + lane;
+    // Which segment a lane takes.  Without a length list: the segments in blob order.  With one (restart segments whose
+    // lengths the host knows), mode 2 deals the list out one segment per wave and round, so that the long ones sit in
+    // different waves, each beside short ones: a wave is as slow as the lock-step of its lanes, and a lane with a long
+    // segment mostly sets its wave's pace alone.  Mode 1 (neighbours of the list share a wave) is there to be measured.
+    int64_t seg_id = ((int64_t)blockIdx.x * nw + wave) * lpw + lane;
+    if (by_length) {
+        const int64_t n_waves = (int64_t)gridDim.x * nw, rank = order_mode == 2 ? (int64_t)lane * n_waves + ((int64_t)blockIdx.x * nw + wave) : seg_id;
+        seg_id = (lane < lpw && rank < n_segs) ? by_length[rank] : n_segs;
+    }
     const bool have = lane < lpw && seg_id < n_segs;
     DevSegment sg = segs[(have && !vsegs) ? seg_id : 0];
     DevVSeg vs{};
@@ -622,7 +632,7 @@ bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >=
 hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                   const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                                   int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk,
-                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs) {
+                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs, const int32_t *by_length, int order_mode) {
     if (n_segs == 0) return hipSuccess;
     static int cus = 0;
     if (cus == 0) {
@@ -652,7 +662,7 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
-                       lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs);
+                       lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs, by_length, order_mode);
 #ifdef MJ_X_STAMP
     if (getenv("MJ_X_REPORT")) {
         (void)hipStreamSynchronize(stream);

@@ -190,7 +190,8 @@ bool lanes13_fits(int n_ac, int n_dc);
 hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                   const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                                   int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk,
-                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs);
+                                  int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs,
+                                  const int32_t *by_length = nullptr, int order_mode = 0);   // by_length: segment numbers, longest first
 // how that launch groups its units of work: lanes per wavefront (a workgroup = 4 waves = 4 x this many consecutive units)
 int lanes_per_wave(int64_t n_segs, int n_slots);
 

@@ -393,3 +393,49 @@ long mjenc_synth_batch(int n, uint64_t seed0, int W, int H, float noise_sigma, i
     free(bufs); free(sizes);
     return bad ? -1 : (long)off;
 }
+
+/* Heterogeneous batch (bench.py `mixed_content`): file i draws, from its seed, a JPEG quality in {50, 60, 75, 85, 90, 95},
+ * two noise levels out of {0, 5, 12, 40, 80} and a split row: the rows above it carry the first noise level, those below
+ * the second — so the MCU rows (= restart segments) of one file, and the files among themselves, differ several-fold
+ * in bits.  Same outputs as mjenc_synth_batch. */
+long mjenc_synth_mixed_batch(int n, uint64_t seed0, int W, int H, int subsamp, int restart_interval, uint8_t *blob, size_t cap,
+                             uint64_t *offsets) {
+    static const int kQ[6] = {50, 60, 75, 85, 90, 95};
+    static const float kS[5] = {0.0f, 5.0f, 12.0f, 40.0f, 80.0f};
+    size_t stride = (size_t)W * H * 3 + 65536;
+    long *sizes = (long *)malloc(sizeof(long) * (size_t)n);
+    uint8_t **bufs = (uint8_t **)calloc((size_t)n, sizeof(uint8_t *));
+    int bad = 0;
+    if (!gauss_ready) gauss_init();
+    if (!fd_ready) fd_init();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        uint64_t h = (seed0 + (uint64_t)i) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        const int q = kQ[h % 6];
+        const float sa = kS[(h >> 8) % 5], sb = kS[(h >> 16) % 5];
+        const int split = (int)((h >> 24) % (uint64_t)(H + 1));
+        uint8_t *rgb = (uint8_t *)malloc((size_t)W * H * 3), *rgb2 = (uint8_t *)malloc((size_t)W * H * 3);
+        uint8_t *tmp = (uint8_t *)malloc(stride * 3);              /* quality 95 on sigma 80: well above 1 byte per pixel */
+        mjenc_synth_rgb(seed0 + (uint64_t)i, W, H, sa, rgb);
+        mjenc_synth_rgb(seed0 + (uint64_t)i, W, H, sb, rgb2);
+        memcpy(rgb + (size_t)split * W * 3, rgb2 + (size_t)split * W * 3, (size_t)(H - split) * W * 3);
+        long sz = mjenc_encode_rgb(rgb, W, H, q, subsamp, restart_interval, tmp, stride * 3);
+        free(rgb); free(rgb2);
+        if (sz < 0) { free(tmp); tmp = NULL; }
+        else tmp = (uint8_t *)realloc(tmp, (size_t)sz);
+        sizes[i] = sz; bufs[i] = tmp;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        offsets[i] = off;
+        if (sizes[i] < 0 || off + (size_t)sizes[i] > cap) { bad = 1; break; }
+        memcpy(blob + off, bufs[i], (size_t)sizes[i]);
+        off += (size_t)sizes[i];
+    }
+    offsets[n] = off;
+    for (int i = 0; i < n; i++) free(bufs[i]);
+    free(bufs); free(sizes);
+    return bad ? -1 : (long)off;
+}
+

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warm", type=int, default=15, help="untimed executes before the timed ones (clock ramp)")
+    ap.add_argument("--mixed", action="store_true", help="the heterogeneous family of bench.py's mixed_content instead of the homogeneous one")
     ap.add_argument("exps", nargs="*", default=[""])
     args = ap.parse_args()
     import numpy as np
@@ -34,7 +35,10 @@ def main():
     from pyjpegdecoder_amd.batch import prepare_batch
     from tools import synth
     dev = torch.device("cuda", 0)
-    blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, args.ri)
+    if args.mixed:
+        blob, offs = synth.synth_mixed_batch(args.distinct, 900000, args.width, args.height, args.subsampling, args.ri)
+    else:
+        blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, args.ri)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(args.distinct)]
     files = [raws[i % args.distinct] for i in range(args.batch)]
     layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR

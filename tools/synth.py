@@ -43,6 +43,9 @@ def _load():
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_size_t,
                                           ctypes.POINTER(ctypes.c_uint64)]
         lib.mjenc_synth_batch.restype = ctypes.c_long
+        lib.mjenc_synth_mixed_batch.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        lib.mjenc_synth_mixed_batch.restype = ctypes.c_long
         _lib = lib
     return _lib
 
@@ -89,6 +92,19 @@ def synth_batch(n: int, seed0: int, width: int, height: int, quality: int = 85, 
                                       offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
     if total < 0:
         raise RuntimeError("jpegenc: batch encode failed")
+    return blob[:total].copy(), offs
+
+
+def synth_mixed_batch(n: int, seed0: int, width: int, height: int, subsampling: str = "420", restart_interval: int = 0):
+    """n files of mixed content (tools/jpegenc.c: quality 50..95, noise 0..80 above / below a random split row), encoded on
+    all host cores.  Returns (blob uint8[total], offsets uint64[n+1])."""
+    cap = n * (3 * width * height + 65536)
+    blob = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    total = _load().mjenc_synth_mixed_batch(n, seed0, width, height, SUBSAMPLING[subsampling], restart_interval, _u8p(blob), cap,
+                                            offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    if total < 0:
+        raise RuntimeError("jpegenc: mixed batch encode failed")
     return blob[:total].copy(), offs
 
 
