@@ -36,11 +36,11 @@ HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def sources_sha16() -> str:
-    """Fingerprint of the sources of the kernels the roofline objects are about (stage 0, the lane-parallel stage 1, the fast
-    stage 2): PMC summaries under profiles/ are only quoted for the build they came from."""
+    """Fingerprint of every source of libmijpeg.so (kernels, launch geometry, headers): PMC summaries under profiles/ are
+    only quoted for the build they came from."""
     h = hashlib.sha256()
-    names = ("destuff.hip", "huffman_lanes.hip", "reconstruct_fast.hip", "mijpeg_internal.h", "upsample_taps.h")
-    for f in sorted((ROOT / "pyjpegdecoder_amd" / "csrc" / n) for n in names):
+    d = ROOT / "pyjpegdecoder_amd" / "csrc"
+    for f in sorted(list(d.glob("*.hip")) + list(d.glob("*.h")) + list(d.glob("*.cpp")) + [ROOT / "include" / "mijpeg.h"]):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
@@ -161,12 +161,80 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             ok = ok and np.array_equal(host[i * per:(i + 1) * per].reshape(W, H, 3), oracle.decode(files[i])["rgb"])
     finally:
         plan.close()
+    # algorithmic bytes of the scan walks: the entropy-coded bytes once, plus for every scan the coefficients it covers —
+    # 2 B x (Se - Ss + 1) per block of its components, written by a first scan, read and written by a refining one
+    from pyjpegdecoder_amd import parse_jpeg
+    scan_bytes = 0
+    p0 = parse_jpeg(raws[0])
+    comp_blocks = {cid: (c.horizontal_sampling * c.vertical_sampling) * (BLOCKS_PER_IMAGE // 6) for cid, c in p0.color_components.items()}
+    for sc in p0.scans:
+        per_block = 2 * (sc.spectral_end - sc.spectral_start + 1) * (2 if sc.bit_high else 1)
+        scan_bytes += per_block * sum(comp_blocks[c] for c in sc.component_ids)
+    ent = int(sum(map(len, raws)) // n_distinct)
+    s1_bytes = n_images * (ent + scan_bytes)
+    roof = {"kernel": "k_destuff_pieces + k_progressive_fast + k_progressive_scan (all launches of stage 1)", "bound": "hbm",
+            "achieved": round(s1_bytes / (s1 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(s1_bytes / (s1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_step": int(s1_bytes), "stage1_ms": round(s1, 3),
+            "note": "entropy bytes + per scan 2 B x (Se-Ss+1) per covered block (x2 for refining scans: read-modify-write); "
+                    "serial-walk (instruction issue) bound, quoted against HBM as SURVEY 8d asks; launches per step and their "
+                    "average durations: profiles/r03_progressive_kernel_stats.csv"}
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
-            "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3),
+            "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3), "roofline": roof,
             "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
                         "scan-by-scan entropy decode + the ordinary stage 2 (BASELINE configs[4])",
             "entropy_bytes_per_image": int(sum(map(len, raws)) // n_distinct),
             "parity": "bit-exact vs oracle (images 0 and 1)" if ok else "MISMATCH"}
+
+
+def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 1024, n_distinct: int = 256):
+    """The headline workload on files of MIXED content (tools/jpegenc.c mjenc_synth_mixed_batch: quality 50..95, noise 0..80
+    above / below a random split row: restart segments differ several-fold in bits): one lane walks one restart segment, so
+    the stage-1 launch lasts as long as the longest segment's walk.  Parity of the smallest and the largest file vs the oracle."""
+    import numpy as np
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import synth
+    blob, offs = synth.synth_mixed_batch(n_distinct, 900000, W, H, "420", 120)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n_distinct)]
+    files = [raws[i % n_distinct] for i in range(n_images)]
+    prep = prepare_batch(files, layout, 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n_images})
+    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for _ in range(3):
+            plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        s1, s2 = plan.time_stages(5, d_rgb.data_ptr())
+        ok = not plan.read(rgb=False)["status"].any()
+        per = W * H * 3
+        sizes = [len(r) for r in raws]
+        for i in (int(np.argmin(sizes)), int(np.argmax(sizes))):
+            got = d_rgb[i * per:(i + 1) * per].cpu().numpy()
+            want = oracle.decode(raws[i])["rgb"]
+            got = got.reshape(want.shape) if layout == B.MJ_LAYOUT_XMAJOR else np.swapaxes(got.reshape(H, W, 3), 0, 1)
+            ok = ok and np.array_equal(got, want)
+        seg_len = np.asarray(prep.seg_end, dtype=np.int64) - np.asarray(prep.seg_begin, dtype=np.int64)
+    finally:
+        plan.close()
+    return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 3),
+            "stage01_ms": round(s1, 3), "stage2_ms": round(s2, 3), "vs_headline_ms_per_step": round(dt * 1e3 / headline_ms, 3),
+            "workload": f"{n_images} x 1920x1080 4:2:0 baseline JPEG, DRI=120, {n_distinct} distinct files of mixed content "
+                        "(quality 50..95, noise sigma 0..80 above / below a random split row)",
+            "file_bytes": {"min": int(min(sizes)), "mean": int(sum(sizes) // len(sizes)), "max": int(max(sizes))},
+            "restart_segment_bytes": {"mean": int(seg_len.mean()), "max": int(seg_len.max())},
+            "parity": "bit-exact vs oracle (smallest and largest file)" if ok else "MISMATCH",
+            "note": "stage 1 = one restart segment per lane: its launch lasts as long as the longest segment's serial walk, whatever "
+                    "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3)"}
 
 
 class DeviceImageQueue:
@@ -426,8 +494,8 @@ def main():
                     "device_copy_gbs": copy_gbs, "frac_of_device_copy": round(gbs / copy_gbs, 4) if copy_gbs else None,
                     "note": note}
 
-        form = {B.MJ_FORM_WAVE: "k_huffman", B.MJ_FORM_LANES: "k_destuff + k_huffman_lanes",
-                B.MJ_FORM_SYNC: "k_destuff + k_sync_count + k_build_vsegs + k_huffman_lanes"}.get(plan.stage1_form() & 15, "stage 1")
+        form = {B.MJ_FORM_WAVE: "k_huffman", B.MJ_FORM_LANES: "k_destuff + k_huffman_lanes13",
+                B.MJ_FORM_SYNC: "k_destuff + k_sync_count + k_build_vsegs + k_huffman_lanes13"}.get(plan.stage1_form() & 15, "stage 1")
         r1 = roof(f"{form} (stage 0+1: byte-drop pass + Huffman decode; k_scan_markers too with --segment gpu)", s1_bytes, s1_ms,
                   "entropy bytes read + 128 B/block coefficients written; serial-decode (instruction issue) bound, quoted against HBM as SURVEY §8d asks",
                   "stage1")
@@ -444,6 +512,10 @@ def main():
             except Exception as exc:
                 line["pipelined"] = {"error": repr(exc)}
             plan.close()
+        try:
+            line["mixed_content"] = mixed_content_side(ctx, dev, torch, layout, line["ms_per_step"])
+        except Exception as exc:
+            line["mixed_content"] = {"error": repr(exc)}
         if not args.no_progressive:
             try:
                 line["progressive"] = progressive_side(ctx, dev, torch)

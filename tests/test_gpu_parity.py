@@ -1384,3 +1384,41 @@ def test_colour_lattice_around_the_green_patch_threshold(dec):
     bad = np.flatnonzero((got != want).any(axis=1))
     print(f"colour lattice: {n} (Y, Cb, Cr) triples, {int(near.sum())} chroma pairs at the green threshold, {int(edge.sum())} at the B/R edges")
     assert bad.size == 0, f"{bad.size} differ, first: ycc {ycc[bad[0]].tolist()} got {got[bad[0]].tolist()} want {want[bad[0]].tolist()}"
+
+
+@pytest.mark.parametrize("order", ["striped", "binned", "blob"])
+def test_mixed_content_batch_at_size(dec, order, monkeypatch):
+    """1024 x 1080p DRI files of MIXED content (bench.py's `mixed_content`: quality 50..95, noise 0..80 above / below a random
+    split row, so restart segments differ several-fold in bits), through the lane form with its segments dealt out by length
+    in each of the three orders (MJ_SEG_ORDER): four files — the smallest, the largest, two others — against the oracle;
+    every replica against its first instance."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, nd, n = 1920, 1080, 64, 1024
+    blob, offs = synth.synth_mixed_batch(nd, 424200, W, H, "420", 120)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(nd)]
+    files = [raws[i % nd] for i in range(n)]
+    monkeypatch.setenv("MJ_SEG_ORDER", order)
+    dev = torch.device("cuda", 0)
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+    try:
+        assert plan.stage1_form() & 15 == B.MJ_FORM_LANES
+        d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        plan.execute(0, d_rgb.data_ptr())
+        plan.sync()
+        assert not plan.read(rgb=False)["status"].any()
+        per = W * H * 3
+        imgs = d_rgb.view(n, per)
+        sizes = [len(r) for r in raws]
+        for i in sorted({int(np.argmin(sizes)), int(np.argmax(sizes)), 1, nd - 1}):
+            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), oracle.decode(raws[i])["rgb"]), i
+        first = imgs[:nd]
+        for k in range(1, n // nd):
+            assert torch.equal(imgs[k * nd:(k + 1) * nd], first), k
+    finally:
+        plan.close()
