@@ -287,8 +287,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic images per GPU (tiled to the workload's size)")
     ap.add_argument("--total-images", type=int, default=0,
                     help="BASELINE configs[3]: ONE job of this many images sharded over the ranks, per-GPU image queue (strong scaling)")
-    ap.add_argument("--queue-batch", type=int, default=417, help="images per plan in the per-GPU queue (--total-images)")
-    ap.add_argument("--queue-depth", type=int, default=3, help="plans in flight at once in the per-GPU queue, one stream each")
+    ap.add_argument("--queue-batch", type=int, default=1250,
+                    help="images per plan in the per-GPU queue (--total-images): stage 1 lasts as long as one restart segment's walk "
+                         "whatever the plan holds, up to ~1400 1080p images, so plans are as large as the share allows")
+    ap.add_argument("--queue-depth", type=int, default=2, help="plans in flight at once in the per-GPU queue, one stream each")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--segment", default="host", choices=["host", "gpu"],
                     help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
@@ -305,6 +307,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:        # every rank writes its own synthetic files with an OpenMP team: an equal share of the host's cores each
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))      # (torch.distributed.run presets 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np

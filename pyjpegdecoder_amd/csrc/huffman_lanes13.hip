@@ -41,7 +41,6 @@ constexpr int kASlotBytes = kLanes13SlotBytes;   // main table + second-level ta
 constexpr int kDBits = kLaneLutBits;         // DC LUTs: the 11-bit (len << 8 | symbol) tables of the other lane form
 constexpr int kDSize = 1 << kDBits;
 constexpr int kRow = 33;                     // dwords per lane block in LDS (32 + 1 pad)
-constexpr int kRing = 128;                   // bytes of stream per lane in LDS
 
 __constant__ uint8_t c_zz_of_nat_13[64] = {
     0,  1,  5,  6, 14, 15, 27, 28,  2,  4,  7, 13, 16, 26, 29, 42,
@@ -90,7 +89,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                                                            int16_t *__restrict__ coef, int32_t *__restrict__ status, int lpw, int tr,
                                                            const DevVSeg *__restrict__ vsegs /* or null */,
                                                            const int32_t *__restrict__ by_length /* or null: segment numbers, longest first */,
-                                                           int order_mode /* 1 = a wave takes neighbours of that list, 2 = one of every stride */) {
+                                                           int order_mode /* 1 = a wave takes neighbours of that list, 2 = one of every stride */,
+                                                           int kRing /* bytes of stream per lane in LDS: 128, or 64 to fit more lanes */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     const uint32_t mybase = lds_addr(myblk);
     const uint32_t lastB = mybase + 126u, storeB = mybase + 127u;
     const uint32_t ac_base = lds_addr(s_ac);
-    const uint32_t c7f = 0x7FFFFFFFu, c124 = kRing - 4, c112 = kRing - 16;
+    const uint32_t c7f = 0x7FFFFFFFu, c124 = (uint32_t)kRing - 4, c112 = (uint32_t)kRing - 16;
 
     // flush geometry: lane (slot, part) moves the 8 coefficients of natural positions 8*part .. 8*part+7 of block
     // slot + 8*it — 16 bytes; they are read from their zig-zag slots, so the block lands in HBM in the natural [v][u]
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 if (want) nxtw = ring_u32(voff);
                 // (the loop below reads at most 4 bytes per iteration and brings in 16 per two: a lane cannot run its window dry,
                 // but nothing is lost by looking)
-                if (__builtin_amdgcn_ballot_w64(lane < lpw2 && (int)(pf - voff) < 24) != 0) top_up(64);
+                if (__builtin_amdgcn_ballot_w64(lane < lpw2 && (int)(pf - voff) < 24) != 0) top_up(48);
             }
             uint32_t pB;
             {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     MJ_T(71)
                     "L_ask%=:\n\t"
                     "v_sub_u32 %[t0], %[pf], %[voff]\n\t"
-                    "v_cmpx_ge_u32 112, %[t0]\n\t"
+                    "v_cmpx_ge_u32 %[c112], %[t0]\n\t"
                     "v_sub_u32 %[t0], %[pf], %[rot]\n\t"
                     "global_load_dwordx4 v[8:11], %[t0], %[sbase]\n\t"
                     "s_mov_b64 s[52:53], exec\n\t"
@@ -622,12 +622,12 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 }
 
 // LDS bytes of a launch with `nw` waves of `lpw` lanes
-static size_t lds13(int n_ac, int n_dc, int nw, int lpw) {
+static size_t lds13(int n_ac, int n_dc, int nw, int lpw, int kRing = 128) {
     const int lpw2 = lpw, wstride = (lpw2 * kRow + 3) & ~3;
     return (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127) + (size_t)nw * lpw2 * kRing;
 }
 
-bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8) <= 160 * 1024; }
+bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8, 64) <= 160 * 1024; }
 
 hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, int64_t n_segs,
                                   const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
@@ -649,20 +649,28 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
     // waves per SIMD keep a SIMD busy, more lanes per wave cost lock-step waiting).
     const int64_t per_cu = (n_segs + cus - 1) / cus;
     int nw = env_nw > 0 ? env_nw : (int)std::min<int64_t>(12, std::max<int64_t>(1, (per_cu + 15) / 16));
-    auto fit_of = [&](int w) { int f = 64; while (f > 1 && lds13(n_ac, n_dc, w, f) > 160 * 1024) --f; return f; };
-    int fit = fit_of(nw);
-    const int64_t rounds = (per_cu + (int64_t)nw * fit - 1) / ((int64_t)nw * fit);
-    const int64_t per_wg = (per_cu + rounds - 1) / rounds;
-    int lpw = env_lpw > 0 ? std::min(env_lpw, fit) : (int)std::min<int64_t>(fit, std::max<int64_t>(1, (per_wg + nw - 1) / nw));
-    const int64_t blocks = (n_segs + (int64_t)nw * lpw - 1) / ((int64_t)nw * lpw);
-    const size_t lds = lds13(n_ac, n_dc, nw, lpw);
+    // 128 bytes of stream window per lane when every segment then has its lane at once, else 64 (a third more lanes per CU:
+    // a second round of workgroups would take as long again as the first)
+    int ring = 128, fit = 0, lpw = 0;
+    int64_t blocks = 0;
+    for (;; ring = 64) {
+        auto fit_of = [&](int w) { int f = 64; while (f > 1 && lds13(n_ac, n_dc, w, f, ring) > 160 * 1024) --f; return f; };
+        fit = fit_of(nw);
+        const int64_t rounds = (per_cu + (int64_t)nw * fit - 1) / ((int64_t)nw * fit);
+        const int64_t per_wg = (per_cu + rounds - 1) / rounds;
+        lpw = env_lpw > 0 ? std::min(env_lpw, fit) : (int)std::min<int64_t>(fit, std::max<int64_t>(1, (per_wg + nw - 1) / nw));
+        blocks = (n_segs + (int64_t)nw * lpw - 1) / ((int64_t)nw * lpw);
+        if (rounds == 1 || ring == 64) break;
+    }
+    if (const char *e = getenv("MJ_LANES_RING")) { const int v = atoi(e); if ((v == 64 || v == 128) && lds13(n_ac, n_dc, nw, lpw, v) <= 160 * 1024) ring = v; }
+    const size_t lds = lds13(n_ac, n_dc, nw, lpw, ring);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes13), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
-                       lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs, by_length, order_mode);
+                       lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs, by_length, order_mode, ring);
 #ifdef MJ_X_STAMP
     if (getenv("MJ_X_REPORT")) {
         (void)hipStreamSynchronize(stream);

@@ -1422,3 +1422,18 @@ def test_mixed_content_batch_at_size(dec, order, monkeypatch):
             assert torch.equal(imgs[k * nd:(k + 1) * nd], first), k
     finally:
         plan.close()
+
+
+def test_config4_one_ranks_share_at_size():
+    """BASELINE configs[3], one GPU's part at its stated size: 1 250 of the job's 10 000 1080p files through `bench.py
+    --total-images 1250` (the per-GPU image queue with its default plan size), first and last image against the oracle."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--total-images", "1250", "--distinct", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["images_per_gpu"] == 1250
+    assert line["parity"].startswith("bit-exact"), line["parity"]
+    assert line["value"] > 0
