@@ -585,21 +585,26 @@ class BatchDecoder:
             try:
                 plan.sync()
                 status = plan.read(rgb=False)["status"]
-                if ((status == B.MJ_ST_TAIL) | (status == B.MJ_ST_UNCONVERGED)).any():
-                    return None                                   # something behind a scan / rounds not settled: redo the batch the long way
+                again = np.flatnonzero((status == B.MJ_ST_TAIL) | (status == B.MJ_ST_UNCONVERGED))
+                status = status.copy()
+                status[again] = 0                                 # something behind a scan / rounds not settled: those files again, below
                 raise_for_status(status)
                 out, off = [], 0
                 for (w, h, nc) in prep.shapes:
                     n = w * h * nc
                     out.append(d_rgb[off:off + n].view(self._shape(w, h, nc)))
                     off += n
-                return out
+                return out, again
             finally:
                 plan.close()
 
         def collect(job):
-            done = finish(job[0])
-            return done if done is not None else self.decode_device(job[1])
+            out, again = finish(job[0])
+            if again.size:                                        # only the files concerned take the long way (host parse)
+                redo = self.decode_device([job[1][int(i)] for i in again])
+                for i, img in zip(again, redo):
+                    out[int(i)] = img
+            return out
 
         for files in batches:
             files = list(files)

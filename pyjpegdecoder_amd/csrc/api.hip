@@ -638,8 +638,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         {   // Band pipelining (see progressive_fast.hip): two frame MCU rows per band, launches = bands + levels - 1.  It
             // shortens the critical path from the sum of the levels' longest scans to about the longest scan — a refining scan
             // follows one band behind what it refines — and keeps all of an image's scans on the chip at once: faster than one
-            // launch per dependency level at every batch size measured (16 x 1080p: 146 -> 83 ms, 1024: 184 -> 145 ms,
-            // 8192: 728 -> 692 ms).  MJ_PROG_BANDS=0 (tests) keeps one launch per level.
+            // launch per dependency level at every batch size measured (profiles/r02d_progressive_sweep.txt: 16 x 1080p
+            // 146 -> 80.5 ms, 1024: 184 -> 93 ms, 8192: 728 -> 510 ms with the ordering and the loops of progressive_fast.hip).
+            // MJ_PROG_BANDS=0 keeps one launch per level.  (MJ_PROG_BANDS, MJ_PROG_ROWS, MJ_PROG_FAST, MJ_SYNC_ROUNDS,
+            // MJ_SYNC_CHUNK, MJ_HUFFMAN, MJ_SEG_ORDER and the MJ_LANES_* variables are hooks of the test-suite and of
+            // tools/stage_probe.py: read once, at plan creation or launch; mj_plan_stage1_form() reports the form in effect.)
             int max_rows = 1;
             for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
             p->prog_banded = true;
@@ -1008,8 +1011,12 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->n_psegs = (int64_t)psegs.size();
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
             // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_fast.hip)
-            p->prog_fast = true;
-            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = atoi(e) != 0;
+            // (a plan none of whose scans they take — non-interleaved baseline files, DC refinement only — needs neither the
+            // stage-0 stream nor its pass per execute)
+            p->prog_fast = false;
+            for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
+                p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
+            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
             if (p->prog_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
                 // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if

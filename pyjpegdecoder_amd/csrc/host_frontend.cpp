@@ -87,8 +87,11 @@ bool parse_headers(const uint8_t *raw, int64_t n, FileHeader &o) {
                 TableRef t;
                 t.bits = data + q + 1;
                 int total = 0;
-                for (int l = 0; l < 16; ++l) total += t.bits[l];
-                if (total > 256 || q + 17 + total > size) return false;
+                long kraft = 0;                                        // codes used so far, in units of 2^-16
+                for (int l = 0; l < 16; ++l) { total += t.bits[l]; kraft += (long)t.bits[l] << (15 - l); }
+                // (an over-subscribed table: the Python parser raises CorruptedJpeg for it — declined here, so that both
+                // front ends give such a file the same answer)
+                if (total > 256 || kraft > (1L << 16) || q + 17 + total > size) return false;
                 t.vals = data + q + 17;
                 t.n_vals = total;
                 huff[data[q]] = t;

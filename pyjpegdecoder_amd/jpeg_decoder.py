@@ -194,7 +194,28 @@ class JpegDecoder():
         img = np.swapaxes(self.image_array, 0, 1)
         Image.fromarray(img).show()
 
-    def save(self, path) -> None:
-        """Lossless save of the decoded image (the reference's save dialog, :1490-1532, minus the GUI)."""
+    def save(self, path=None):
+        """Lossless save of the decoded image — the reference's save dialog (:1490-1532) minus the dialog: `path` stands for
+        what the user would have picked (default: the source file's folder and stem, ".png").  As there, an existing file is
+        never overwritten (" (1)", " (2)", ... is put behind the stem) and a suffix Pillow cannot write falls back to PNG.
+        Returns the path written."""
+        from pathlib import Path
         from PIL import Image
-        Image.fromarray(np.swapaxes(self.image_array, 0, 1)).save(path)
+        target = Path(path) if path is not None else self.file_path.with_suffix(".png")
+        picture = Image.fromarray(np.swapaxes(self.image_array, 0, 1))
+
+        def free_name(q: Path) -> Path:
+            stem, n = q.stem, 0
+            while q.exists():
+                n += 1
+                q = q.with_stem(f"{stem} ({n})")
+            return q
+
+        target = free_name(target)
+        try:
+            picture.save(target)
+        except ValueError:                          # no writer for that suffix
+            target = free_name(target.with_suffix(".png"))
+            picture.save(target, format="png")
+        self._say(f"Decoded image was saved to '{target}'")
+        return target

@@ -299,6 +299,17 @@ def test_jpegdecoder_class_surface(tmp_path):
         assert set(d.handlers) == {b"\xFF\xC4", b"\xFF\xDB", b"\xFF\xDD", b"\xFF\xC0", b"\xFF\xC2", b"\xFF\xDA", b"\xFF\xD9"}
     with pytest.raises(AttributeError):
         JpegDecoder(str(f), verbose=True)     # the reference needs a Path too (`file.name`, :41)
+    # save (:1490-1532): lossless round trip, never over an existing file, PNG when the suffix has no writer
+    from PIL import Image
+    first = d.save()
+    assert first == f.with_suffix(".png") and first.exists()
+    assert np.array_equal(np.swapaxes(np.asarray(Image.open(first)), 0, 1), d.image_array)
+    second = d.save(first)
+    assert second.name == f"{f.stem} (1).png" and np.array_equal(np.asarray(Image.open(second)), np.asarray(Image.open(first)))
+    third = d.save(tmp_path / "picture.nosuchformat")
+    assert third == tmp_path / "picture.png" and Image.open(third).format == "PNG"
+    bmp = d.save(tmp_path / "picture.bmp")
+    assert np.array_equal(np.swapaxes(np.asarray(Image.open(bmp)), 0, 1), d.image_array)
 
 
 def test_corrupt_streams_raise_like_the_reference(dec):

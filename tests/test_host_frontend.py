@@ -188,3 +188,26 @@ def test_split_keeps_what_it_can():
     for g in groups:
         sub = [files[i] for i in g]
         _same(prepare_batch_native(sub), _py(sub))
+
+
+def test_oversubscribed_huffman_table_gets_the_same_answer_from_both_front_ends():
+    """A DHT whose code lengths claim more codes than exist (Kraft sum > 1): the Python parser raises CorruptedJpeg
+    (_parse.parse_huffman_segment: the reference would build colliding keys and fail later, :718-719); the native front
+    end must not build a first-fit LUT for such a file on its own — it declines, so the batch takes the Python path and the
+    same exception."""
+    from pyjpegdecoder_amd import CorruptedJpeg
+    raw = bytearray(synth.synth_jpeg(5, 64, 48, 85, "420", 0))
+    at = raw.index(b"\xFF\xC4")                     # first DHT: BITS[16] start 5 bytes in
+    bits = at + 5
+    raw[bits + 1] += 3                              # three more 2-bit codes than the table had: over-subscribed ...
+    # (keep the segment's length consistent: take the three extra symbols from the longest lengths)
+    taken = 0
+    for l in range(15, 1, -1):
+        while raw[bits + l] > 0 and taken < 3:
+            raw[bits + l] -= 1
+            taken += 1
+    assert taken == 3
+    raw = bytes(raw)
+    with pytest.raises(CorruptedJpeg):
+        parse_jpeg(raw, headers_only=True)
+    assert prepare_batch_native([raw]) is None
