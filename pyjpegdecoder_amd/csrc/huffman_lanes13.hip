@@ -1,28 +1,34 @@
 // Stage 1, lane-parallel form with RESOLVED 13-bit tables — baseline Huffman entropy decode, one restart segment per lane.
 //
-// Same contract and output as huffman_lanes.hip (the 11-bit form: its header describes the lock-step, the per-lane bit
-// reader on stage 0's stream and the LDS block rows, all of which are kept).  What changes is the AC symbol step, the
-// only thing that matters: the kernel is bound by the number of instructions on each wave's serial path.
+// Same contract and output as huffman_lanes.hip (the 11-bit form: its header describes the lock-step at block granularity and
+// the LDS block rows, both kept).  What changes is everything on a wave's serial path, the only thing that matters here:
+// the launch lasts as long as one segment's walk.
 //   * The AC table of a component is a 13-bit LUT of 32-bit entries that carry the FINISHED symbol whenever code and
 //     value bits together fit the index (99.6 % of the symbols of the benchmark's files; jpeg_decoder.py:834-866 and
-//     bin_twos_complement :1636-1646 are evaluated when the table is built):
+//     bin_twos_complement :1636-1646 are evaluated when the table is built, api.hip):
 //         byte 0      bits consumed (code + value bits)
-//         byte 1      how far the write position moves: 2 * (run + 1) bytes; end of block = 127 (odd: lands outside
-//                     the row whatever the position); bit 7 = entry not resolved
+//         byte 1      how far the write position moves: 2 * (run + 1) bytes; end of block = 127 (odd, and past the row
+//                     wherever the position is)
 //         bits 31:16  the coefficient, EXTENDed, ready for ds_write_b16_d16_hi
-//     Not resolved (code <= 13 bits but code + value > 13): byte 0 = code length, byte 2 = 2 * (run + 1), byte 3 =
-//     31 - size; the value bits are taken arithmetically, under the lanes' exec mask.  Codes longer than 13 bits or
-//     absent (byte 0 = 0): the loop hands those lanes to the canonical search (jpeg_decoder.py:366-377 semantics), rare.
-//   * The symbol step is hand-written (inline asm): LUT address from the top of the bit buffer (2 instructions), ds_read,
-//     position += byte 1 (SDWA), buffer <<= byte 0 (the 64-bit shift reads its 6 low bits), count -= byte 0 (SDWA),
-//     v_cmpx narrows exec to the lanes still inside their block, ds_write_b16_d16_hi, a second v_cmpx drops the lanes
-//     that have just written coefficient 63.  Finished lanes are simply off (exec), so nothing is selected or clamped:
-//     12 instructions per symbol including the "not resolved" test, against 44 in the 11-bit form.
-//   * "index >= 64 after a run ends the block and its value bits stay unread" (:849, :855-856) is not tested per symbol:
-//     a resolved entry that overshoots has consumed its value bits; the lane is found after the block by the parity of
-//     its final position (end of block is the only odd step) and is put back on the right bit — damaged files only.
-//   * The flush moves 16 bytes per lane (8 blocks per store instruction) instead of 4.
-// Used when the batch's distinct tables fit LDS in this format (<= 3 AC tables of 32 KiB + <= 4 DC tables of 4 KiB: every
+//     Not resolved (bit 15): byte 0 = 0 — nothing is consumed and the position leaves the row by 128 or more —, byte 1 =
+//     0x80 | run + 1 (0 = end of block), byte 2 = code length, byte 3 = 31 - size for a code of <= 13 bits whose value bits
+//     do not fit; byte 1 = 0xC0 and the high word = where the 8-entry second-level table of its 13-bit prefix starts, for
+//     codes of 14..16 bits (entries of the same kind; code length 0 = no such code: the canonical search,
+//     jpeg_decoder.py:366-377 semantics, reports it).
+//   * The symbol step is hand-written (inline asm, the 64-bit bit buffer in fixed registers): LUT address from the top of
+//     the buffer (v_bfe, v_lshl_add), ds_read_b32, position += byte 1 (SDWA), buffer <<= byte 0 (v_lshlrev_b64 reads its 6
+//     low bits of the entry as it is), count -= byte 0 (SDWA), one v_cmpx that keeps the lanes still inside their block —
+//     the lanes that store this symbol —, and the store straight from the entry's high half, issued behind the NEXT symbol's
+//     LUT read.  Finished lanes are simply off (exec): nothing is selected or clamped.  10 instructions per symbol against
+//     44 in the 11-bit form.  What the step does not test is put right later: a symbol that lands on coefficient 63 is
+//     stored after the loop (its lane left before the store, the entry is still in its register); an entry that overshoots
+//     the block has consumed value bits the reference leaves unread (:849, :855-856) — found after the block by the parity
+//     of the final position, damaged files only; entries that are not resolved are looked for once per turn of the loop
+//     (four refills, eight symbols) on every lane at once, and their lanes take an arithmetic step.
+//   * The stream is read through a per-lane window in LDS, topped up 16 or 32 bytes per turn one turn ahead: a refill of the
+//     bit buffer is a ds_read_b32, no vector-memory wait sits in the loop except the window's own, a turn old.
+//   * The flush moves 16 bytes per lane (8 blocks per store instruction), by hand for full rounds.
+// Used when the batch's distinct tables fit LDS in this format (<= 3 AC tables of 37 KiB + <= 4 DC tables of 4 KiB: every
 // batch of files with the standard tables); other batches keep the 11-bit form with its per-workgroup table lists.
 #include <stdio.h>
 #include <stdlib.h>
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     const uint32_t mybase = lds_addr(myblk);
     const uint32_t lastB = mybase + 126u, storeB = mybase + 127u;
     const uint32_t ac_base = lds_addr(s_ac);
-    const uint32_t c7f = 0x7FFFFFFFu, c124 = (uint32_t)kRing - 4, c112 = (uint32_t)kRing - 16;
+    const uint32_t c7f = 0x7FFFFFFFu, c124 = (uint32_t)kRing - 4, c112 = (uint32_t)kRing - 16, c96 = (uint32_t)kRing - 32;
 
     // flush geometry: lane (slot, part) moves the 8 coefficients of natural positions 8*part .. 8*part+7 of block
     // slot + 8*it — 16 bytes; they are read from their zig-zag slots, so the block lands in HBM in the natural [v][u]
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
             for (;;) {
                 uint64_t pend, nx = nxtw, tmp64;
                 uint32_t t0, t1, t2, t3, t4, t5, t6, ew;
-                u32x4 chunk;
+                u32x4 chunk, chunk2;
 #ifdef MJ_X_STAMP
                 const uint64_t dbg_i0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -342,9 +348,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
     "s_mov_b64 exec, s[52:53]\n\t"                        \
     "v_and_or_b32 %[t0], %[pf], %[c112], %[ring]\n\t"     \
     "ds_write_b128 %[t0], v[8:11]\n\t"                    \
+    "v_add_u32 %[pf], 16, %[pf]\n\t"                      \
+    "s_mov_b64 exec, s[56:57]\n\t"                        \
+    "v_and_or_b32 %[t0], %[pf], %[c112], %[ring]\n\t"     \
+    "ds_write_b128 %[t0], v[12:15]\n\t"                   \
     "v_add_u32 %[pf], 16, %[pf]\n\t"
 #ifdef MJ_X_STAMP
-#define MJ_T(k) "s_memtime s[58:59]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s57, s58, s60\n\ts_mov_b32 s60, s58\n\ts_add_u32 s" #k ", s" #k ", s57\n\t"
+#define MJ_T(k) "s_memtime s[58:59]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s72, s58, s60\n\ts_mov_b32 s60, s58\n\ts_add_u32 s" #k ", s" #k ", s72\n\t"
 #else
 #define MJ_T(k)
 #endif
@@ -356,12 +366,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 #endif
                     "s_mov_b64 %[pend], 0\n\t"
                     "s_mov_b64 s[52:53], 0\n\t"                // lanes with 16 bytes on their way
+                    "s_mov_b64 s[56:57], 0\n\t"                // ... and with 16 more behind those
 #ifdef MJ_X_STAMP
                     "s_mov_b32 s55, 0\n\t"
 #endif
                     "v_cmpx_gt_u32 %[lastB], %[pB]\n"
                     // One turn of the loop = the window's upkeep and the look for entries that were not resolved, both on every
-                    // lane of the wave, then two refill + two-symbol rounds of the lanes still inside their block
+                    // lane of the wave, then four refill + two-symbol rounds of the lanes still inside their block
                     "L_loop%=:\n\t"
                     MJ_T(62)
                     "s_mov_b64 s[44:45], exec\n\t"             // the lanes that go on
@@ -381,10 +392,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     MJ_T(71)
                     "L_ask%=:\n\t"
                     "v_sub_u32 %[t0], %[pf], %[voff]\n\t"
-                    "v_cmpx_ge_u32 %[c112], %[t0]\n\t"
-                    "v_sub_u32 %[t0], %[pf], %[rot]\n\t"
-                    "global_load_dwordx4 v[8:11], %[t0], %[sbase]\n\t"
+                    "v_cmpx_ge_u32 %[c112], %[t0]\n\t"       // room for 16 bytes (they overwrite what lies a window behind them)
+                    "v_sub_u32 %[t1], %[pf], %[rot]\n\t"
+                    "global_load_dwordx4 v[8:11], %[t1], %[sbase]\n\t"
                     "s_mov_b64 s[52:53], exec\n\t"
+                    "v_cmpx_ge_u32 %[c96], %[t0]\n\t"        // ... and for 16 more
+                    "global_load_dwordx4 v[12:15], %[t1], %[sbase] offset:16\n\t"
+                    "s_mov_b64 s[56:57], exec\n\t"
                     "s_mov_b64 exec, s[44:45]\n\t"
                     MJ_T(63)
                     MJ_REFILL13
@@ -394,6 +408,13 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 #else
                     MJ_PAIR13
 #endif
+                    "s_cbranch_execz L_loop%=\n\t"
+                    MJ_REFILL13
+                    MJ_PAIR13
+                    "s_cbranch_execz L_loop%=\n\t"
+                    MJ_REFILL13
+                    MJ_PAIR13
+                    "s_cbranch_execz L_loop%=\n\t"
                     MJ_REFILL13
                     MJ_PAIR13
                     MJ_T(68)
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                     "v_add_u32 %[d4], s66, %[d4]\n\tv_add_u32 %[d5], s67, %[d5]\n\tv_add_u32 %[d6], s68, %[d6]\n\t"
                     "v_add_u32 %[d7], s69, %[d7]\n\tv_add_u32 %[d8], s70, %[d8]\n\tv_add_u32 %[d9], s71, %[d9]\n\t"
 #endif
-                    : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), "=&{v[8:11]}"(chunk), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last),
+                    : "+{v[2:3]}"(bb), "+{v[6:7]}"(nx), "=&{v[4:5]}"(tmp64), "=&{v[8:11]}"(chunk), "=&{v[12:15]}"(chunk2), [bc] "+v"(bc), [pB] "+v"(pB), [e] "+v"(e_last),
                       [voff] "+v"(voff), [pf] "+v"(pf),
                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
                       [ew] "=&v"(ew), [pend] "=&s"(pend)
@@ -474,8 +495,8 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                       , [di] "+v"(dbg_iter), [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_w[0]), [d8] "+v"(dbg_w[1]), [d9] "+v"(dbg_w[2])
 #endif
                     : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
-                      [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [rl] "s"(ring_lanes), [rot] "v"(rot)
-                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71");
+                      [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [c96] "v"(c96), [rl] "s"(ring_lanes), [rot] "v"(rot)
+                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72");
 #undef MJ_REFILL13
 #undef MJ_PAIR13
 #undef MJ_WINDOW_IN13
