@@ -408,15 +408,17 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 #else
                     MJ_PAIR13
 #endif
-                    "s_cbranch_execz L_loop%=\n\t"
-                    MJ_REFILL13
-                    MJ_PAIR13
-                    "s_cbranch_execz L_loop%=\n\t"
-                    MJ_REFILL13
-                    MJ_PAIR13
-                    "s_cbranch_execz L_loop%=\n\t"
-                    MJ_REFILL13
-                    MJ_PAIR13
+#define MJ_ROUND13 "s_cbranch_execz L_loop%=\n\t" MJ_REFILL13 MJ_PAIR13
+#ifndef MJ_X_ROUNDS
+#define MJ_X_ROUNDS 6
+#endif
+                    MJ_ROUND13 MJ_ROUND13 MJ_ROUND13
+#if MJ_X_ROUNDS >= 6
+                    MJ_ROUND13 MJ_ROUND13
+#endif
+#if MJ_X_ROUNDS >= 8
+                    MJ_ROUND13 MJ_ROUND13
+#endif
                     MJ_T(68)
 #ifdef MJ_X_STAMP
                     "s_add_u32 s55, s55, 1\n\t"
