@@ -1448,3 +1448,73 @@ def test_config4_one_ranks_share_at_size():
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["images_per_gpu"] == 1250
     assert line["parity"].startswith("bit-exact"), line["parity"]
     assert line["value"] > 0
+
+
+def _craft_grey_stream(width, blocks):
+    """A greyscale baseline file of `width` x 8 whose entropy-coded data is written here symbol by symbol: `blocks` = per block
+    the list of AC (run, size, value-bits or None) symbols after a zero DC difference; value-bits None = the symbol's value
+    bits are NOT written (what follows a run past index 63, jpeg_decoder.py:855-856)."""
+    from pyjpegdecoder_amd import parse_jpeg
+    from tools import synth
+    base = synth.synth_jpeg(3, width, 8, 85, "grey", 0)
+    p = parse_jpeg(base)
+    sc = p.scans[0]
+
+    def codes(t):
+        out, code, k = {}, 0, 0
+        for l in range(1, 17):
+            code <<= 1
+            for _ in range(int(t.bits[l - 1])):
+                out[int(t.vals[k])] = (code, l)
+                k += 1
+                code += 1
+        return out
+    dc, ac = codes(sc.huffman[0x00]), codes(sc.huffman[0x10])
+    bits = []
+
+    def put(value, n):
+        bits.extend((value >> (n - 1 - i)) & 1 for i in range(n))
+    for syms in blocks:
+        put(*dc[0])
+        for run, size, vbits in syms:
+            put(*ac[(run << 4) | size])
+            if vbits is not None and size:
+                put(vbits, size)
+    while len(bits) % 8:
+        bits.append(1)
+    data = bytearray()
+    for i in range(0, len(bits), 8):
+        b = int("".join(map(str, bits[i:i + 8])), 2)
+        data.append(b)
+        if b == 0xFF:
+            data.append(0x00)
+    return base[:sc.entropy_start] + bytes(data) + b"\xFF\xD9"
+
+
+@pytest.mark.parametrize("form", ["lanes", "lanes11", "wave", "sync"])
+def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch):
+    """The reference ends a block when a run carries the index to 64 or beyond and leaves that symbol's value bits unread
+    (jpeg_decoder.py:849, :855-856); a symbol that lands exactly on index 63 ends it too, after its value.  Hand-written
+    streams drive both through every stage-1 form — for the resolved-table lane form that is its after-the-loop store of
+    coefficient 63 and its parity-of-the-position correction, through a resolved entry, an entry whose value bits are taken
+    arithmetically and a code from a second-level table — against the oracle."""
+    from oracle import oracle
+    one = (0, 1, 1)                                   # run 0, size 1, value +1
+    blocks = [
+        [one] * 62 + [(1, 1, None)],                  # 62 coefficients, then run 1: index 64 -> over, value bit unread (resolved entry)
+        [one] * 62 + [(1, 10, None)],                 # ... through a 16-bit code (second-level table) whose 10 value bits stay unread
+        [one] * 60 + [(3, 4, None)],                  # index 61 + 3 = 64
+        [one] * 60 + [(2, 9, 0x1FF)],                 # index 61 + 2 = 63: the last coefficient, value bits read (arithmetic entry)
+        [one] * 63,                                   # coefficient 63 straight from a resolved entry
+        [(0, 2, 3), (0, 0, None)],                    # an ordinary block behind them: value 3, end of block
+        [(15, 0, None)] * 3 + [(14, 1, 0)],           # three ZRLs, then run 14: index 1 + 48 + 14 = 63, value -1
+        [(15, 0, None)] * 3 + [(15, 1, None)],        # ... run 15: index 64, over
+        [(0, 3, 5), (0, 0, None)],
+    ]
+    raw = _craft_grey_stream(8 * len(blocks), blocks)
+    ref = oracle.decode(raw)
+    assert ref["coef"][4, 63] == 1 and ref["coef"][3, 63] == 511 and ref["coef"][6, 63] == -1 and ref["coef"][8, 1] == 5
+    monkeypatch.setenv("MJ_HUFFMAN", form)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"])
+    assert np.array_equal(img, ref["rgb"])

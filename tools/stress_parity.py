@@ -57,7 +57,7 @@ for seg in ("host", "gpu"):
         total += check(f"decode        segment={seg} layout={layout}", dec.decode(files), layout == "rowmajor")
         total += check(f"decode_device segment={seg} layout={layout}", dec.decode_device(files), layout == "rowmajor")
         dec.close()
-for form in ("wave", "lanes", "sync"):
+for form in ("wave", "lanes", "lanes11", "sync"):
     os.environ["MJ_HUFFMAN"] = form
     dec = BatchDecoder(0, segment="host")
     total += check(f"decode        stage-1 form forced: {form}", dec.decode(files))
