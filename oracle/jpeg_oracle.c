@@ -115,11 +115,11 @@ void orc_idct_xy(const int16_t *blk, const double *T, int16_t *out_xy) {
  * sum(n_i * v_i)/15 can never be a half-integer (15 is odd), so the float64 result of griddata
  * (accurate to ~1e-14) rounds the same way as this exact form.
  */
-void orc_upsample(const int16_t *in, int n_in, const int8_t *W /* [n_out][n_in] numerators; a row sums to its denominator */,
+void orc_upsample(const int16_t *in, int n_in, const int16_t *W /* [n_out][n_in] numerators; a row sums to its denominator */,
                   int n_out, int16_t *out) {
     for (int o = 0; o < n_out; o++) {
-        long acc = 0, den = 0;              /* 15 for the x2 operators, 31 for 8x8 -> 32x8 (4:1:1): odd either way */
-        const int8_t *w = W + (size_t)o * n_in;
+        long acc = 0, den = 0;              /* a product of (8n - 1)s — 15, 31, 15 * 23 ... — odd in every case */
+        const int16_t *w = W + (size_t)o * n_in;
         for (int k = 0; k < n_in; k++) { acc += (long)w[k] * in[k]; den += w[k]; }
         out[o] = (int16_t)nearbyint((double)acc / (double)den);
     }
@@ -293,7 +293,7 @@ int orc_entropy_decode_baseline(const uint8_t *file, int64_t file_size, int64_t 
  * rgb_out: uint8 [width][height][3] (or [width][height] for greyscale), golden G6.
  */
 int orc_reconstruct_baseline(const OrcScan *sc, const int16_t *coef, const int16_t *qt_xy, const double *T,
-                             const int8_t *const *W_up, int16_t *idct_out, int16_t *planes_out,
+                             const int16_t *const *W_up, int16_t *idct_out, int16_t *planes_out,
                              uint8_t *rgb_out) {
     int hmax = 1, vmax = 1;
     for (int c = 0; c < sc->ncomp; c++) { if (sc->hs[c] > hmax) hmax = sc->hs[c]; if (sc->vs[c] > vmax) vmax = sc->vs[c]; }

@@ -110,16 +110,62 @@ def dequant_idct(coef_zz: np.ndarray, qt_xy: np.ndarray):
     return deq.reshape(-1, 8, 8), out.reshape(-1, 8, 8)
 
 
+def operator_from_diagonals(src_shape, dst_shape, diag: np.ndarray) -> np.ndarray:
+    """The upsample operator of ResizeGrid (:1588-1626) for ANY pair of shapes, as int16 numerators [n_out][n_in] over
+    D = dx * dy (dx = dst_w - 1 where the width changes, else 1; dy likewise): griddata interpolates linearly inside the
+    triangles of scipy's Delaunay triangulation of the SOURCE grid, and on a regular grid every triangle is half of a unit
+    cell — so an output sample at (x (sw-1)/(dw-1), y (sh-1)/(dh-1)) takes barycentric weights of the three corners of the
+    half it falls in.  Which diagonal cuts a cell is Qhull's choice; `diag[cx, cy]` (0: the diagonal through corner (0,0),
+    1: the other one) is captured from the reference per source shape (tests/golden/upsample_diagonals.npz,
+    tools/make_layout_goldens.py — which also checks this function against the operator captured for every pair of
+    sampling factors 1..4)."""
+    (sw, sh), (dw, dh) = src_shape, dst_shape
+    dx = dw - 1 if sw != dw else 1
+    dy = dh - 1 if sh != dh else 1
+    D = dx * dy
+    W = np.zeros((dw * dh, sw * sh), dtype=np.int16)
+    for x in range(dw):
+        cx, rx = (x, 0) if sw == dw else divmod(x * (sw - 1), dx)
+        for y in range(dh):
+            cy, ry = (y, 0) if sh == dh else divmod(y * (sh - 1), dy)
+            FX, FY = rx * dy, ry * dx
+            x1, y1 = min(cx + 1, sw - 1), min(cy + 1, sh - 1)
+            kind = int(diag[min(cx, sw - 2), min(cy, sh - 2)]) if (rx and ry) else 0
+            if kind == 0:
+                if FX >= FY:
+                    n = [((cx, cy), D - FX), ((x1, cy), FX - FY), ((x1, y1), FY)]
+                else:
+                    n = [((cx, cy), D - FY), ((cx, y1), FY - FX), ((x1, y1), FX)]
+            else:
+                if FX + FY <= D:
+                    n = [((cx, cy), D - FX - FY), ((x1, cy), FX), ((cx, y1), FY)]
+                else:
+                    n = [((x1, y1), FX + FY - D), ((x1, cy), D - FY), ((cx, y1), D - FX)]
+            row = W[x * dh + y]
+            for (px, py), w in n:
+                row[px * sh + py] += w
+    return W
+
+
+_DIAG = None
+
+
 def load_W(src_shape, dst_shape) -> np.ndarray:
-    """Upsample operator captured from the reference's ResizeGrid (int8 numerators over 15)."""
+    """Upsample operator of the reference's ResizeGrid as integer numerators (a row sums to its denominator): the
+    matrices captured in round 1 for the common layouts, operator_from_diagonals for every other pair of shapes."""
+    global _DIAG
     f = _GOLDEN / f"upsample_W_{src_shape[0]}x{src_shape[1]}_{dst_shape[0]}x{dst_shape[1]}.npy"
-    return np.load(f)
+    if f.exists():
+        return np.load(f).astype(np.int16)
+    if _DIAG is None:
+        _DIAG = dict(np.load(_GOLDEN / "upsample_diagonals.npz"))
+    return operator_from_diagonals(tuple(src_shape), tuple(dst_shape), _DIAG[f"{src_shape[0]}x{src_shape[1]}"])
 
 
 def upsample(block: np.ndarray, dst_shape) -> np.ndarray:
     """ResizeGrid.__call__ (:1588-1626) for int16 [sw,sh] -> [dw,dh]."""
     block = np.ascontiguousarray(block, dtype=np.int16)
-    W = np.ascontiguousarray(load_W(block.shape, dst_shape), dtype=np.int8)
+    W = np.ascontiguousarray(load_W(block.shape, dst_shape), dtype=np.int16)
     out = np.empty(dst_shape, dtype=np.int16)
     lib().orc_upsample(_p(block), block.size, _p(W), out.size, _p(out))
     return out
@@ -196,7 +242,7 @@ def reconstruct(parsed, coef: np.ndarray, scan=None, want_idct: bool = False):
         for i, cid in enumerate(scan.component_ids):
             c = parsed.color_components[cid]
             if tuple(c.shape) != tuple(parsed.sample_shape):
-                Wm = np.ascontiguousarray(load_W(c.shape, parsed.sample_shape), dtype=np.int8)
+                Wm = np.ascontiguousarray(load_W(c.shape, parsed.sample_shape), dtype=np.int16)
                 keep.append(Wm)
                 ups[i] = Wm.ctypes.data
     coef = np.ascontiguousarray(coef, dtype=np.int16)

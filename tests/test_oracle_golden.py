@@ -37,6 +37,37 @@ def test_upsample_operator_shape():
         assert (W.sum(1) == 15).all() and ((W != 0).sum(1) <= 3).all() and W.min() >= 0
 
 
+def test_operator_from_diagonals_equals_the_matrices_captured_in_round_1():
+    """Every other pair of shapes gets its operator from the captured cell diagonals (tools/make_layout_goldens.py checks
+    the formula against griddata for all 84 pairs of factors 1..4 when it writes them); here: the formula reproduces the four
+    dense matrices captured earlier, up to the common denominator."""
+    diag = np.load(GOLDEN / "upsample_diagonals.npz")
+    assert sorted(diag.files) == sorted(f"{8 * h}x{8 * v}" for h in range(1, 5) for v in range(1, 5))
+    for dst in [(16, 16), (16, 8), (8, 16), (32, 8)]:
+        W1 = np.load(GOLDEN / f"upsample_W_8x8_{dst[0]}x{dst[1]}.npy").astype(np.int64)
+        Wf = oracle.operator_from_diagonals((8, 8), dst, diag["8x8"]).astype(np.int64)
+        assert np.array_equal(Wf * W1.sum(1)[:, None], W1 * Wf.sum(1)[:, None])
+    W = oracle.load_W((16, 8), (32, 24))          # a pair only the formula serves: numerators over 31 * 23
+    assert W.shape == (32 * 24, 128) and (W.sum(1) == 31 * 23).all() and ((W != 0).sum(1) <= 3).all() and W.min() >= 0
+
+
+def odd_layout_names():
+    g = np.load(GOLDEN / "odd_layouts.npz")
+    return sorted({k.rsplit(".", 1)[0] for k in g.files})
+
+
+@pytest.mark.parametrize("name", odd_layout_names())
+def test_unusual_sampling_layouts_every_seam(name):
+    """Files with sampling factors outside the common layouts (4:1:0, 1x4, factors of 3, chroma factors above one, luma below
+    the chroma resolution, fourteen blocks per MCU), decoded by the reference (tools/make_layout_goldens.py): coefficients,
+    the planes before the colour conversion and the image."""
+    g = np.load(GOLDEN / "odd_layouts.npz")
+    o = oracle.decode(g[name + ".jpg"].tobytes())
+    assert np.array_equal(o["coef"], g[name + ".coef"])
+    assert np.array_equal(o["planes"], g[name + ".planes"])
+    assert np.array_equal(o["rgb"], g[name + ".rgb"])
+
+
 def test_ycbcr_to_rgb_known_answers_including_ties():
     g = np.load(GOLDEN / "ycc_rgb.npz")
     assert np.array_equal(oracle.ycbcr_to_rgb(g["ycc"]), g["rgb"])
