@@ -110,6 +110,7 @@ struct mj_plan {
     bool uniform = false;
     // row-major plans run the fast stage 2 on the transposed problem: blocks and tables are then stored [u][v]
     bool transposed = false;
+    bool generic = false;              // a sampling layout outside the common ones: wave form of stage 1, k_reconstruct_generic
     uint8_t *d_rgb_tmp = nullptr;  // planar layouts: the interleaved image stage 2 writes before the components are separated
     int64_t max_pixels = 0;        // largest width*height of the batch
     int32_t mcus_per_image = 0;
@@ -272,6 +273,20 @@ bool sampling_class(const mj_image_desc &d, int &hmax, int &vmax) {
     return ((hmax == 1 || hmax == 2) && (vmax == 1 || vmax == 2)) || (hmax == 4 && vmax == 1);
 }
 
+// Any other three-component layout with factors 1..4 (4:1:0, 1x4, factors of 3, chroma above 1x1, luma below the chroma
+// resolution ...): decoded by the wave form of stage 1 and k_reconstruct_generic.  The reference takes them all (:205-240).
+bool generic_sampling(const mj_image_desc &d, int &hmax, int &vmax) {
+    if (d.ncomp != 3) return false;
+    hmax = vmax = 1;
+    int blocks = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (d.hs[c] < 1 || d.hs[c] > 4 || d.vs[c] < 1 || d.vs[c] > 4) return false;
+        hmax = std::max(hmax, (int)d.hs[c]); vmax = std::max(vmax, (int)d.vs[c]);
+        blocks += d.hs[c] * d.vs[c];
+    }
+    return blocks <= mj::kMaxBlocksPerMcu;
+}
+
 template <typename T>
 int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
     MJ_HIP(ctx, ctx->cache.get((void **)dst, n * sizeof(T) + pad_bytes + 16));
@@ -417,7 +432,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     p->n_images = b->n_images;
     p->layout = b->layout;
     p->flags = b->flags;
-    p->transposed = (b->layout & 1) == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY);
+    for (int i = 0; i < b->n_images; ++i) { int h_, v_; if (!sampling_class(b->images[i], h_, v_)) p->generic = true; }
+    // (the generic stage 2, like the exact-order one, writes either orientation itself: no transposed store)
+    p->transposed = (b->layout & 1) == MJ_LAYOUT_ROWMAJOR && !(p->flags & MJ_FLAG_EXACT_ONLY) && !p->generic;
     struct Guard { mj_plan *p; mj_context *c; ~Guard() { c->cur = nullptr; if (p) mj_plan_destroy(p); } } guard{p, ctx};
     if (!ctx->free_arenas.empty()) { p->arena = ctx->free_arenas.back(); ctx->free_arenas.pop_back(); }
     else if (hipHostMalloc((void **)&p->arena.base, (size_t)8 << 20, hipHostMallocDefault) == hipSuccess) p->arena.cap = (size_t)8 << 20;
@@ -447,12 +464,18 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         int hmax, vmax;
         if (d.width <= 0 || d.height <= 0 || d.width > 65535 || d.height > 65535)
             return fail(ctx, MJ_ERR_INVALID, "image %d: bad dimensions %dx%d", i, d.width, d.height);
-        if (!sampling_class(d, hmax, vmax))
+        const bool common = sampling_class(d, hmax, vmax);
+        if (!common && !generic_sampling(d, hmax, vmax))
             return fail(ctx, MJ_ERR_UNSUPPORTED,
                         "image %d: sampling layout not supported by the MI355X path (ncomp=%d, Y %dx%d, Cb %dx%d, Cr %dx%d); "
-                        "supported: greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1", i, d.ncomp, d.hs[0], d.vs[0], d.hs[1], d.vs[1], d.hs[2], d.vs[2]);
+                        "supported: one component, or three with factors 1..4 and at most %d blocks per MCU", i, d.ncomp, d.hs[0], d.vs[0],
+                        d.hs[1], d.vs[1], d.hs[2], d.vs[2], mj::kMaxBlocksPerMcu);
+        if (!common && prog)
+            return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: scan-by-scan files (progressive, one scan per component) are decoded in the common "
+                        "sampling layouts only (greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1)", i);
         if (i == 0) { p->hmax = hmax; p->vmax = vmax; p->ncomp = d.ncomp; }
-        else if (hmax != p->hmax || vmax != p->vmax || d.ncomp != p->ncomp)
+        else if (hmax != p->hmax || vmax != p->vmax || d.ncomp != p->ncomp || common == p->generic ||
+                 (p->generic && (memcmp(d.hs, b->images[0].hs, sizeof(d.hs)) || memcmp(d.vs, b->images[0].vs, sizeof(d.vs)))))
             return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: a plan holds one sampling layout; split the batch by layout", i);
         const int mw = d.ncomp == 1 ? 8 : 8 * hmax, mh = d.ncomp == 1 ? 8 : 8 * vmax;
         if (d.mcu_count_h != (d.width + mw - 1) / mw || d.mcu_count_v != (d.height + mh - 1) / mh)
@@ -462,6 +485,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         p->max_pixels = std::max(p->max_pixels, (int64_t)d.width * d.height);
         im.hmax = hmax; im.vmax = vmax;
         im.blocks_per_mcu = d.ncomp == 1 ? 1 : hmax * vmax + 2;
+        im.generic = common ? 0 : 1;
+        if (!common) im.blocks_per_mcu = d.hs[0] * d.vs[0] + d.hs[1] * d.vs[1] + d.hs[2] * d.vs[2];
         im.mcu_count_h = d.mcu_count_h; im.mcu_count_v = d.mcu_count_v;
         im.restart_interval = d.restart_interval;
         const int64_t mcus = (int64_t)d.mcu_count_h * d.mcu_count_v;
@@ -482,7 +507,10 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 dslot = slot_of(d.dc_sel[c]);
                 aslot = slot_of(d.ac_sel[c]);
             }
-            const int rep = d.ncomp == 1 ? 1 : (c == 0 ? hmax * vmax : 1);
+            const int rep = d.ncomp == 1 ? 1 : (common ? (c == 0 ? hmax * vmax : 1) : d.hs[c] * d.vs[c]);
+            im.comp_h[c] = (uint8_t)(d.ncomp == 1 ? 1 : (common ? (c == 0 ? hmax : 1) : d.hs[c]));
+            im.comp_v[c] = (uint8_t)(d.ncomp == 1 ? 1 : (common ? (c == 0 ? vmax : 1) : d.vs[c]));
+            im.comp_first[c] = (uint8_t)nb;
             for (int r = 0; r < rep; ++r, ++nb) {
                 im.blk_comp[nb] = (uint8_t)c; im.blk_dc_slot[nb] = (uint8_t)dslot; im.blk_ac_slot[nb] = (uint8_t)aslot;
             }
@@ -682,7 +710,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 qn[(size_t)t * 64 + (p->transposed ? ((n & 7) << 3 | n >> 3) : n)] = b->qt[(size_t)t * 64 + z];
             }
         if ((rc = upload(ctx, &p->d_qt, qn.data(), qn.size())) != MJ_OK) return rc;
-        const int tm = mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp, p->transposed);
+        const int tm = p->generic ? 1 : mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp, p->transposed);
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
             // strips run down the MCU columns of the image the kernel sees (the transposed one for row-major plans)
@@ -706,7 +734,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             std::vector<uint16_t> l11((size_t)b->n_huff * LS, 0);
             // how each table is used: bit 0 = as a DC table, bit 1 = as an AC table (the two LUT formats differ)
             for (const mj::DevImage &im : imgs)
-                for (int k2 = 0; k2 < im.blocks_per_mcu && k2 < 8; ++k2) {
+                for (int k2 = 0; k2 < im.blocks_per_mcu && k2 < mj::kMaxBlocksPerMcu; ++k2) {
                     role[im.tab_index[im.blk_dc_slot[k2]]] |= 1;
                     role[im.tab_index[im.blk_ac_slot[k2]]] |= 2;
                 }
@@ -875,7 +903,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 p->wg_slots_lanes = cap;
             }
         }
-        const bool lanes_ok = ordered && (!many_tabs || many_ok_dri) && !both_roles && !prog &&
+        const bool lanes_ok = ordered && (!many_tabs || many_ok_dri) && !both_roles && !prog && !p->generic &&
                               (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
         p->use_lanes = lanes_ok && (int64_t)segs.size() >= 1024;       // measured crossover with the wave form: ~1000 segments
         if (force && !strcmp(force, "wave")) p->use_lanes = false;
@@ -922,7 +950,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         const bool few_segs = !segs.empty() && (int64_t)segs.size() < 20000 && total_len / (int64_t)segs.size() >= 2048 && est_chunks >= 64;
         // (with many tables the synchronisation form needs its own two workgroup shapes to get by with their table lists;
         // its lane launch runs over chunks, so the restart-segment shape checked above does not matter for it)
-        const bool sync_shape_ok = ordered && !both_roles && !prog && (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
+        const bool sync_shape_ok = ordered && !both_roles && !prog && !p->generic && (uint64_t)b->blob_len + 4 * (uint64_t)segs.size() + 4096 < (1ull << 32);
         bool want_sync = !(b->flags & MJ_FLAG_NO_SYNC) && (many_tabs ? sync_shape_ok : lanes_ok) && (jobs.empty() || one_seg_each) && dc_fits &&
                          ((force && !strcmp(force, "sync")) || (!force && (long_segs || few_segs)));
         if (want_sync && many_tabs) {
@@ -1278,7 +1306,9 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(ctx->d_dump + mj::kStage2DumpBytes - 64, 0, 64, s));     // mj_plan_idct_levels
-    if (a.exact_only) {
+    if (p->generic) {
+        MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
+    } else if (a.exact_only) {
         MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
     } else {
         // row-major plans: the same kernel on the transposed problem, whose x-major output IS the row-major image

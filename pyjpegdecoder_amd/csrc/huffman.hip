@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
 
     const int bpm = im->blocks_per_mcu;
     const int n_mcu = sg->n_mcu;
-    // per-block tables packed into scalars: 8 blocks x 8 bits each
-    const uint64_t comp_pk = *reinterpret_cast<const uint64_t *>(im->blk_comp);
-    const uint64_t dc_pk = *reinterpret_cast<const uint64_t *>(im->blk_dc_slot);
-    const uint64_t ac_pk = *reinterpret_cast<const uint64_t *>(im->blk_ac_slot);
+    // per-block tables packed into scalars: 8 blocks x 8 bits each, twice (unusual sampling layouts have up to 16 blocks per MCU)
+    const uint64_t comp_pk0 = reinterpret_cast<const uint64_t *>(im->blk_comp)[0], comp_pk1 = reinterpret_cast<const uint64_t *>(im->blk_comp)[1];
+    const uint64_t dc_pk0 = reinterpret_cast<const uint64_t *>(im->blk_dc_slot)[0], dc_pk1 = reinterpret_cast<const uint64_t *>(im->blk_dc_slot)[1];
+    const uint64_t ac_pk0 = reinterpret_cast<const uint64_t *>(im->blk_ac_slot)[0], ac_pk1 = reinterpret_cast<const uint64_t *>(im->blk_ac_slot)[1];
 
     // tr: the plan keeps blocks transposed ([u][v]) for the row-major stage 2
     const int nat0 = c_nat_of_zz[lane], nat = tr ? ((nat0 & 7) << 3 | nat0 >> 3) : nat0;
@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256) void k_huffman(const uint8_t *__restrict__ blo
 
     for (int m = 0; m < n_mcu; ++m) {
         for (int b = 0; b < bpm; ++b) {
-            const int comp = (int)((comp_pk >> (8 * b)) & 0xFF);
-            const int dslot = (int)((dc_pk >> (8 * b)) & 0xFF);
-            const int aslot = (int)((ac_pk >> (8 * b)) & 0xFF);
+            const int sh8 = 8 * (b & 7);
+            const int comp = (int)(((b < 8 ? comp_pk0 : comp_pk1) >> sh8) & 0xFF);
+            const int dslot = (int)(((b < 8 ? dc_pk0 : dc_pk1) >> sh8) & 0xFF);
+            const int aslot = (int)(((b < 8 ? ac_pk0 : ac_pk1) >> sh8) & 0xFF);
             const uint16_t *dc_lut = my_lut + dslot * kLutSize;
             const uint16_t *ac_lut = my_lut + aslot * kLutSize;
             const DevHuff *dc_tab = huff + im->tab_index[dslot];

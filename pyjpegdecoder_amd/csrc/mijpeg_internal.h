@@ -10,7 +10,7 @@ namespace mj {
 constexpr int kWave = 64;               // CDNA4 wavefront
 constexpr int kLutBits = 9;             // primary Huffman LUT: codes up to 9 bits resolve in one LDS read
 constexpr int kLutSize = 1 << kLutBits;
-constexpr int kMaxBlocksPerMcu = 6;     // 4:2:0 = 4 Y + Cb + Cr; every supported layout has <= 6
+constexpr int kMaxBlocksPerMcu = 16;    // the common layouts have <= 6 (4:2:0 = 4 Y + Cb + Cr); T.81 allows 10 per interleaved scan, the reference does not check (:774-785)
 constexpr int kMaxTabsPerImage = 6;     // DC+AC for up to three components
 
 // One Huffman table on the device.  `lut` is staged into LDS by the stage-1 kernel; the long-code
@@ -35,10 +35,15 @@ struct DevImage {
     int32_t n_tabs;                   // distinct Huffman tables of this image (<= kMaxTabsPerImage)
     int32_t tab_index[kMaxTabsPerImage];   // indices into the batch's DevHuff array
     // for each block of an MCU, in decode order (jpeg_decoder.py:774, :805):
-    uint8_t blk_comp[8];              // component 0..2
-    uint8_t blk_dc_slot[8];           // slot (0..n_tabs-1) of its DC table in the wave's LDS copy
-    uint8_t blk_ac_slot[8];
+    // (the common layouts have at most 6 blocks per MCU and the lane / synchronisation forms read the first 8 entries as one
+    // 64-bit word; layouts with more blocks — kMaxBlocksPerMcu — are decoded by the wave form and k_reconstruct_generic)
+    uint8_t blk_comp[kMaxBlocksPerMcu];     // component 0..2
+    uint8_t blk_dc_slot[kMaxBlocksPerMcu];  // slot (0..n_tabs-1) of its DC table in the wave's LDS copy
+    uint8_t blk_ac_slot[kMaxBlocksPerMcu];
     int32_t qt_index[3];              // per component, into the batch's quantisation tables
+    uint8_t comp_h[4], comp_v[4];     // sampling factors per component (jpeg_decoder.py:205-207)
+    uint8_t comp_first[4];            // first block of the component inside an MCU
+    int32_t generic;                  // 1 = a layout outside the common ones: any factors 1..4 per component
     int32_t pad0;
     int64_t block_off;                // first coefficient block of this image in the packed coef array
     int64_t mcu_off;                  // first MCU of this image in the batch-wide MCU numbering
@@ -221,6 +226,8 @@ struct ReconArgs {
     int32_t mcus_per_image;
 };
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);
+// any sampling factors 1..4 per component (DevImage::generic): reconstruct.hip
+hipError_t launch_reconstruct_generic(hipStream_t stream, const ReconArgs &a);
 // fast form: strips of fast_tile_mcus() MCUs in column-major MCU order.  transposed = the kernel runs on the transposed
 // image (blocks and tables stored [u][v]), so its x-major output is the row-major image (MJ_LAYOUT_ROWMAJOR)
 int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);

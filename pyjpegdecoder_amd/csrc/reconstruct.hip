@@ -280,6 +280,129 @@ static hipError_t launch_t(hipStream_t stream, const ReconArgs &a) {
     return hipGetLastError();
 }
 
+// ---- any sampling factors 1..4 per component (three components): the layouts outside the common five.
+// The reference upsamples every component whose MCU shape differs from the largest one (:882-883) through ResizeGrid
+// (:1588-1626) — scipy's griddata on a Delaunay triangulation of the source grid.  On a regular grid each triangle is half of
+// a unit cell, so output sample (x, y) of an (8 hmax x 8 vmax) MCU lies at source position (x (sw-1)/(dw-1), y (sh-1)/(dh-1))
+// and takes the barycentric weights of the three corners of the half-cell it falls in; which diagonal cuts a cell is
+// captured from the reference (UP_DIAG, tools/make_layout_goldens.py: the formula reproduces griddata's operator for all 84
+// pairs of factors).  Weights are integers over D = (dw-1)(dh-1) (a factor 1 where the dimension does not change): D is odd,
+// sum(n_i v_i) / D is never a half-integer, and the float64 result of the reference rounds the way the integers do.
+// One MCU per wavefront pass, exact-order IDCT (the reference's summation order), integer colour: correct first, it is the
+// path of rare files.  Luma may be the upsampled component (Y 1x1 under 2x2 chroma).
+__device__ __forceinline__ int generic_sample(const int16_t *plane, int sw, int sh, int dw, int dh, int hi, int vi, int x, int y) {
+    if (sw == dw && sh == dh) return plane[x * sh + y];
+    const int dxx = sw == dw ? 1 : dw - 1, dyy = sh == dh ? 1 : dh - 1;
+    int cx = x, rx = 0, cy = y, ry = 0;
+    if (sw != dw) { const int ax = x * (sw - 1); cx = ax / dxx; rx = ax - cx * dxx; }
+    if (sh != dh) { const int ay = y * (sh - 1); cy = ay / dyy; ry = ay - cy * dyy; }
+    const int D = dxx * dyy, FX = rx * dyy, FY = ry * dxx;
+    const int x1 = min(cx + 1, sw - 1), y1 = min(cy + 1, sh - 1);
+    const int v00 = plane[cx * sh + cy], v10 = plane[x1 * sh + cy], v01 = plane[cx * sh + y1], v11 = plane[x1 * sh + y1];
+    const bool anti = rx != 0 && ry != 0 && ((UP_DIAG[(hi - 1) * 4 + (vi - 1)][min(cx, sw - 2)] >> min(cy, sh - 2)) & 1u);
+    int s;
+    if (!anti) s = FX >= FY ? (D - FX) * v00 + (FX - FY) * v10 + FY * v11 : (D - FY) * v00 + (FY - FX) * v01 + FX * v11;
+    else s = FX + FY <= D ? (D - FX - FY) * v00 + FX * v10 + FY * v01 : (FX + FY - D) * v11 + (D - FY) * v10 + (D - FX) * v01;
+    // round(s / D), never a tie: floor((2s + D) / 2D) with a bias that keeps the dividend positive (|s| < 961 * 2^15)
+    return (int)(int16_t)((int)((unsigned)(2 * s + D + 2 * D * 65536) / (unsigned)(2 * D)) - 65536);
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void k_reconstruct_generic(ReconArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_tt = reinterpret_cast<double *>(smem);                                  // 32 KiB
+    int16_t *s_mcu_all = reinterpret_cast<int16_t *>(smem + 64 * 64 * sizeof(double));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    int16_t *s_mcu = s_mcu_all + wave * (kMaxBlocksPerMcu * 64);                      // component planes, one after the other
+    for (int i = tid; i < 64 * 64; i += 256) s_tt[i] = a.idct_tt[i];
+    __syncthreads();
+    const int src_of_lane = (lane & 7) * 8 + (lane >> 3);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < a.total_mcus; g += n_waves) {
+        int img, m;
+        if (a.uniform_geometry) {
+            img = (int)(g / a.mcus_per_image);
+            m = (int)(g - (int64_t)img * a.mcus_per_image);
+        } else {
+            int lo = 0, hi = a.n_images;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (a.mcu_prefix[mid] <= g) lo = mid; else hi = mid;
+            }
+            img = lo;
+            m = (int)(g - a.mcu_prefix[img]);
+        }
+        const DevImage *im = a.images + img;
+        const int W = im->width, H = im->height, bpm = im->blocks_per_mcu;
+        const int MW = 8 * im->hmax, MH = 8 * im->vmax;
+        const int mcu_y = m / im->mcu_count_h, mcu_x = m - mcu_y * im->mcu_count_h;
+        const int64_t blk0 = im->block_off + (int64_t)m * bpm;
+        __builtin_amdgcn_wave_barrier();   // the previous pass has read its planes
+        for (int b = 0; b < bpm; ++b) {
+            const int comp = im->blk_comp[b];
+            const int q = a.qt[im->qt_index[comp] * 64 + src_of_lane];
+            const int dn = (int)(int16_t)(a.coef[(blk0 + b) * 64 + src_of_lane] * q);      // int16 * int16 -> int16 (:869)
+            const uint64_t mask = __ballot(dn != 0);
+            double r[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) r[v] = 0.0;
+#pragma unroll 1
+            for (int u = 0; u < 8; ++u) {                // running sums r[v] over u in order (NumPy's pairwise sum)
+                const uint32_t rowbits = (uint32_t)(mask >> (u * 8)) & 0xFFu;
+                if (rowbits == 0) continue;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    if ((rowbits >> v) & 1) {
+                        const int c = __builtin_amdgcn_readlane(dn, u * 8 + v);
+                        const double p = (double)c * s_tt[(u * 8 + v) * 64 + lane];
+                        r[v] = r[v] + p;
+                    }
+                }
+            }
+            const double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            const int val = (int)(int16_t)((int)(int16_t)(int)__builtin_rint(s) + 128);   // :1573
+            // block `rep` of its component sits at (8 bx, 8 by) of the component's MCU, block_y, block_x = divmod(rep, h) (:875)
+            const int rep = b - im->comp_first[comp], hc = im->comp_h[comp], sh = 8 * im->comp_v[comp];
+            const int by = rep / hc, bx = rep - by * hc;
+            s_mcu[im->comp_first[comp] * 64 + (bx * 8 + (lane >> 3)) * sh + by * 8 + (lane & 7)] = (int16_t)val;
+            if (a.idct_out) a.idct_out[(blk0 + b) * 64 + lane] = (int16_t)val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int npix = MW * MH;
+        for (int p = lane; p < npix; p += 64) {
+            int x, y;
+            if (LAYOUT == MJ_LAYOUT_XMAJOR) { x = p / MH; y = p - x * MH; }
+            else                            { y = p / MW; x = p - y * MW; }
+            const int gx = mcu_x * MW + x, gy = mcu_y * MH + y;
+            if (gx >= W || gy >= H) continue;
+            int v3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v3[c] = generic_sample(s_mcu + im->comp_first[c] * 64, 8 * im->comp_h[c], 8 * im->comp_v[c], MW, MH, im->comp_h[c], im->comp_v[c], x, y);
+            if (a.planes) {
+                int16_t *pl = a.planes + (im->pix_off + (int64_t)gx * H + gy) * 3;
+                pl[0] = (int16_t)v3[0]; pl[1] = (int16_t)v3[1]; pl[2] = (int16_t)v3[2];
+            }
+            int R, Gc, B;
+            ycc_to_rgb(v3[0], v3[1], v3[2], R, Gc, B);
+            unsigned char *dst = a.rgb + im->rgb_off + (LAYOUT == MJ_LAYOUT_XMAJOR ? ((int64_t)gx * H + gy) : ((int64_t)gy * W + gx)) * 3;
+            dst[0] = (unsigned char)R; dst[1] = (unsigned char)Gc; dst[2] = (unsigned char)B;
+        }
+    }
+}
+
+hipError_t launch_reconstruct_generic(hipStream_t stream, const ReconArgs &a) {
+    const size_t lds = 64 * 64 * sizeof(double) + (size_t)4 * kMaxBlocksPerMcu * 64 * sizeof(int16_t);
+    const int64_t want = (a.total_mcus + 3) / 4, cap = 256 * 4;
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    if (blocks == 0) return hipSuccess;
+    if (a.layout == MJ_LAYOUT_XMAJOR) hipLaunchKernelGGL((k_reconstruct_generic<MJ_LAYOUT_XMAJOR>), dim3(blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k_reconstruct_generic<MJ_LAYOUT_ROWMAJOR>), dim3(blocks), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp) {
     if (ncomp == 1) return launch_t<1, 1, 1>(stream, a);
     if (hmax == 1 && vmax == 1) return launch_t<1, 1, 3>(stream, a);

@@ -1518,3 +1518,51 @@ def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch):
     (img,), (seam,) = dec.decode([raw], return_seams=True)
     assert np.array_equal(seam["coef"], ref["coef"])
     assert np.array_equal(img, ref["rgb"])
+
+
+# ---- sampling layouts outside the common ones (any factors 1..4 per component) ----------------------------------------
+def _odd_layout_names():
+    g = np.load(GOLDEN / "odd_layouts.npz")
+    return sorted({k.rsplit(".", 1)[0] for k in g.files})
+
+
+@pytest.mark.parametrize("name", _odd_layout_names())
+def test_unusual_sampling_layouts_against_the_reference(dec, dec_rm, name):
+    """4:1:0, 1x4, factors of 3, chroma factors above one, luma below the chroma resolution, fourteen blocks per MCU — files the
+    reference decoded (tools/make_layout_goldens.py): coefficients, planes and image bit for bit, both orientations."""
+    g = np.load(GOLDEN / "odd_layouts.npz")
+    raw = g[name + ".jpg"].tobytes()
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], g[name + ".coef"])
+    assert np.array_equal(seam["planes"], g[name + ".planes"])
+    assert np.array_equal(img, g[name + ".rgb"])
+    (img_rm,) = dec_rm.decode([raw])
+    assert np.array_equal(img_rm, g[name + ".rgb"].transpose(1, 0, 2))
+
+
+def test_unusual_sampling_layouts_random_files_against_the_oracle(dec):
+    """Every combination class again on random crafted files (tools/craft_jpeg.py), batched by layout, with and without
+    restart markers and with the GPU marker scan, against the oracle (itself pinned on the twelve reference-decoded files)."""
+    from oracle import oracle
+    from pyjpegdecoder_amd import BatchDecoder
+    from tools.craft_jpeg import craft_baseline
+    rng = np.random.default_rng(7)
+    files = []
+    for i in range(40):
+        f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
+        while sum(h * v for h, v in f) > 16:
+            f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
+        w, h = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        files.append(craft_baseline(w, h, f, seed=1000 + i, restart_interval=int(rng.integers(0, 4)), density=float(rng.uniform(0.05, 0.6)),
+                                    max_size=int(rng.integers(1, 8)), dc_size=int(rng.integers(1, 8))))
+    want = [oracle.decode(f)["rgb"] for f in files]
+    got = dec.decode(files)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), i
+    d2 = BatchDecoder(device=0, segment="gpu")
+    try:
+        got2 = d2.decode(files)
+    finally:
+        d2.close()
+    for i, (a, b) in enumerate(zip(got2, want)):
+        assert np.array_equal(a, b), i
