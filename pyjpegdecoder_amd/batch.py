@@ -36,13 +36,12 @@ def check_supported(p: ParsedJpeg) -> ScanInfo:
                 raise CorruptedJpeg("Progressive JPEG images cannot contain more than 1 bit for each value on a refining scan.")
             if sc.spectral_start > 0 and len(sc.component_ids) > 1:
                 raise CorruptedJpeg("An AC progressive scan can only have a single color component.")
-            if sc.spectral_start == 0 and 1 < len(sc.component_ids) < len(p.color_components):
-                raise UnsupportedJpeg("Interleaved scans of a subset of the components are not supported by the MI355X path.")
             if sc.spectral_start == 0 and len(sc.component_ids) == 1 and len(p.color_components) > 1:
                 c = p.color_components[sc.component_ids[0]]
                 if c.horizontal_sampling > 1 or c.vertical_sampling > 1:
                     raise UnsupportedJpeg("Single-component DC scan of a component with sampling > 1 "
-                                          "(the reference misplaces these blocks) is not supported.")
+                                          "(the reference steps such a scan's blocks by the component's MCU size, "
+                                          "jpeg_decoder.py:993-994, and runs off its array: IndexError) is not supported.")
         return p.scans[0]
     if p.scan_mode != "baseline_dct":
         raise UnsupportedJpeg("Encoding mode not supported. Only 'Baseline DCT' and 'Progressive DCT' are supported.")

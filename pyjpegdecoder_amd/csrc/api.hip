@@ -470,9 +470,15 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                         "image %d: sampling layout not supported by the MI355X path (ncomp=%d, Y %dx%d, Cb %dx%d, Cr %dx%d); "
                         "supported: one component, or three with factors 1..4 and at most %d blocks per MCU", i, d.ncomp, d.hs[0], d.vs[0],
                         d.hs[1], d.vs[1], d.hs[2], d.vs[2], mj::kMaxBlocksPerMcu);
-        if (!common && prog)
-            return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: scan-by-scan files (progressive, one scan per component) are decoded in the common "
-                        "sampling layouts only (greyscale, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1)", i);
+        if (!common && prog) {
+            // the reference's final pass (:1319-1362) resizes every 8x8 block of a component to the full MCU shape and stores it
+            // into ratio x ratio blocks: that only fits when the component is 1x1 — or is not resized at all
+            for (int c = 0; c < 3; ++c)
+                if (!((d.hs[c] == 1 && d.vs[c] == 1) || (d.hs[c] == hmax && d.vs[c] == vmax)))
+                    return fail(ctx, MJ_ERR_UNSUPPORTED, "image %d: scan-by-scan files need every component at 1x1 or at the full resolution "
+                                "(the reference's final pass cannot place the blocks of a %dx%d component under %dx%d: ValueError)", i,
+                                d.hs[c], d.vs[c], hmax, vmax);
+        }
         if (i == 0) { p->hmax = hmax; p->vmax = vmax; p->ncomp = d.ncomp; }
         else if (hmax != p->hmax || vmax != p->vmax || d.ncomp != p->ncomp || common == p->generic ||
                  (p->generic && (memcmp(d.hs, b->images[0].hs, sizeof(d.hs)) || memcmp(d.vs, b->images[0].vs, sizeof(d.vs)))))
@@ -609,13 +615,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // geometry the kernel relies on
             int want_h, want_v;
             if (sd.n_comp > 1) {
-                if (sd.n_comp != d.ncomp) return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: interleaved scans of a subset of the components are not supported", k);
+                // (an interleaved DC scan may cover a subset of the components: its MCUs are still the frame's, :591-594, :610-611)
                 want_h = im.mcu_count_h; want_v = im.mcu_count_v;
             } else {
                 const int c = sd.comp[0];
-                const int h = (d.ncomp > 1 && c == 0) ? im.hmax : 1, v = (d.ncomp > 1 && c == 0) ? im.vmax : 1;
+                const int h = im.comp_h[c], v = im.comp_v[c];
                 if (sd.ss == 0 && (h > 1 || v > 1))
-                    return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: single-component DC scan of a component with sampling > 1 (the reference misplaces these)", k);
+                    return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: single-component DC scan of a component with sampling > 1 (the reference steps "
+                                "its blocks by the component's MCU size, :993-994, and runs off its array: IndexError)", k);
                 const int cw = (d.width * h + im.hmax - 1) / im.hmax, ch = (d.height * v + im.vmax - 1) / im.vmax;   // ceil(W / ratio)
                 want_h = (cw + 7) / 8; want_v = (ch + 7) / 8;
                 if (d.ncomp == 1) { want_h = (d.width + 7) / 8; want_v = (d.height + 7) / 8; }
@@ -1045,6 +1052,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
                 p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
             if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
+            if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
             if (p->prog_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
                 // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if

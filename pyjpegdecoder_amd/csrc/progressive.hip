@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     } else if (sequential) {
         if (band != 0) return;                       // the whole scan at once (baseline scans of separate components depend on nothing)
     } else {
-        const int v_scan = (nsc == 1 && im->ncomp > 1 && sc->comp[0] == 0) ? im->vmax : 1;   // block rows per frame MCU row
+        const int v_scan = nsc == 1 ? im->comp_v[sc->comp[0]] : 1;   // block rows per frame MCU row
         const int64_t mpb = (int64_t)sc->mcu_count_h * rows_per_band * v_scan;
         const int64_t lo = (int64_t)band * mpb, hi = lo + mpb;
         b_lo = (int)max((int64_t)b_lo, lo);
@@ -141,12 +141,10 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     }
 
     // frame geometry (interleaved block order of the coefficient store)
-    const int hmax = im->hmax, vmax = im->vmax, bpm = im->blocks_per_mcu, fmx = im->mcu_count_h;
-    const int ncf = im->ncomp;
+    const int bpm = im->blocks_per_mcu, fmx = im->mcu_count_h;
     int16_t *cbase = coef + im->block_off * 64;
     auto block_ptr = [&](int c, int bx, int by) -> int16_t * {
-        const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
-        const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+        const int h = im->comp_h[c], v = im->comp_v[c], first = im->comp_first[c];   // (a lone component: 1 x 1, block 0)
         const int mx = bx / h, my = by / v;
         return cbase + ((int64_t)(my * fmx + mx) * bpm + first + (by - my * v) * h + (bx - mx * h)) * 64;
     };
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
             // One bit per block (:1038), blocks in scan order: lane i takes the i-th block of a group of 64, so the
             // read-modify-write of 64 DC values is one load and one store instead of 64 dependent round trips.
             int bps = 0;                                   // blocks per MCU of this scan
-            for (int i = 0; i < nsc; ++i) { const int c = sc->comp[i]; bps += (nsc > 1 && c == 0) ? hmax * vmax : 1; }
+            for (int i = 0; i < nsc; ++i) { const int c = sc->comp[i]; bps += nsc > 1 ? im->comp_h[c] * im->comp_v[c] : 1; }
             const int total = (m_hi - sg->mcu0) * bps;
             for (int t0 = (m_lo - sg->mcu0) * bps; t0 < total; t0 += 64) {
                 const int n = min(64, total - t0);
@@ -217,12 +215,12 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
                     int j = t % bps, c = 0, r = 0;
                     for (int i = 0; i < nsc; ++i) {               // which scan component / block of the MCU
                         const int ci = sc->comp[i];
-                        const int cnt = (nsc > 1 && ci == 0) ? hmax * vmax : 1;
+                        const int cnt = nsc > 1 ? im->comp_h[ci] * im->comp_v[ci] : 1;
                         if (j < cnt) { c = ci; r = j; break; }
                         j -= cnt;
                     }
                     const int mcy = m / smh, mcx = m - mcy * smh;
-                    const int h = (nsc > 1 && c == 0) ? hmax : 1, v = (nsc > 1 && c == 0) ? vmax : 1;
+                    const int h = nsc > 1 ? im->comp_h[c] : 1, v = nsc > 1 ? im->comp_v[c] : 1;
                     int16_t *p = block_ptr(c, mcx * h + r % h, mcy * v + r / h);
                     const int nlo = min(32, n);
                     const int bit = lane < 32 ? (w0 >> (nlo - 1 - lane)) & 1 : (w1 >> (n - 32 - 1 - (lane - 32))) & 1;
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
             const int mcy = m / smh, mcx = m - mcy * smh;
             for (int i = 0; i < nsc && !err; ++i) {
                 const int c = sc->comp[i];
-                const int h = (nsc > 1 && c == 0) ? hmax : 1, v = (nsc > 1 && c == 0) ? vmax : 1;
+                const int h = nsc > 1 ? im->comp_h[c] : 1, v = nsc > 1 ? im->comp_v[c] : 1;
                 for (int r = 0; r < h * v; ++r) {
                     const int bx = mcx * h + r % h, by = mcy * v + r / h;
                     int16_t *p = block_ptr(c, bx, by);

@@ -92,14 +92,15 @@ struct Walk {
 __device__ __forceinline__ void walk_dc_first(Walk &k, Stream &st, const uint16_t *lut /* [3][512] */) {
     const DevProgScan *sc = k.sc;
     const int lane = k.lane, al = k.al, nsc = sc->n_comp;
-    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu;
+    const int bpm = k.im->blocks_per_mcu;
+    const DevImage *im = k.im;
     // blocks per MCU of each scan component (:980-1003): an interleaved scan covers the frame's MCUs, a single-component
     // one (never of a subsampled-luma component: api.hip) one block per MCU
     const int cA = sc->comp[0], cB = nsc > 1 ? sc->comp[1] : 0, cC = nsc > 2 ? sc->comp[2] : 0;
-    const int nA = (nsc > 1 && cA == 0) ? hmax * vmax : 1, nB = nsc > 1 ? ((cB == 0) ? hmax * vmax : 1) : 0;
-    const int nC = nsc > 2 ? ((cC == 0) ? hmax * vmax : 1) : 0;
+    const int nA = nsc > 1 ? im->comp_h[cA] * im->comp_v[cA] : 1, nB = nsc > 1 ? im->comp_h[cB] * im->comp_v[cB] : 0;
+    const int nC = nsc > 2 ? im->comp_h[cC] * im->comp_v[cC] : 0;
     const int bps = nA + nB + nC;
-    auto first_of = [&](int c) { return c == 0 ? 0 : hmax * vmax + c - 1; };      // a component's first block in the frame's MCU
+    auto first_of = [&](int c) { return (int)im->comp_first[c]; };      // a component's first block in the frame's MCU
     uint32_t veA0, veB0 = 0, veC0 = 0, vw0, veA1, veB1 = 0, veC1 = 0, vw1;
     auto lookup64 = [&](int g, uint32_t &va, uint32_t &vb, uint32_t &vc, uint32_t &vw) {
         const uint32_t w = st.bits_at(g + lane);
@@ -165,12 +166,10 @@ __device__ __forceinline__ void walk_dc_first(Walk &k, Stream &st, const uint16_
 __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_t *lut) {
     const DevProgScan *sc = k.sc;
     const int lane = k.lane, al = k.al, ss = k.ss, se = k.se;
-    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
-    const int ncf = k.im->ncomp;
+    const int bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
     const int c = sc->comp[0];
     const DevHuff *tab = k.huff + sc->ac_tab[0];
-    const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
-    const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+    const int h = k.im->comp_h[c], v = k.im->comp_v[c], first = k.im->comp_first[c];   // (h, v: 1, 2 or 4 here — api.hip sends other factors to the general walk)
     const int smh = sc->mcu_count_h;
     const int nz_nat = c_nat_of_zz_ps[lane];
     const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
@@ -302,13 +301,11 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     const DevProgScan *sc = k.sc;
     const int lane = k.lane, al = k.al, ss = k.ss, se = k.se;
     const bool spec = k.spec;
-    const int hmax = k.im->hmax, vmax = k.im->vmax, bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
-    const int ncf = k.im->ncomp;
+    const int bpm = k.im->blocks_per_mcu, fmx = k.im->mcu_count_h;
     const int c = sc->comp[0];
     const DevHuff *tab = k.huff + sc->ac_tab[0];
     int16_t *cbase = k.cbase;
-    const int h = (ncf > 1 && c == 0) ? hmax : 1, v = (ncf > 1 && c == 0) ? vmax : 1;
-    const int first = c == 0 ? 0 : hmax * vmax + c - 1;
+    const int h = k.im->comp_h[c], v = k.im->comp_v[c], first = k.im->comp_first[c];   // (h, v: 1, 2 or 4 here — api.hip sends other factors to the general walk)
     const int smh = sc->mcu_count_h;
     const int nz_nat = c_nat_of_zz_ps[lane];
     const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
@@ -591,7 +588,7 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     if (BANDED) {
         const int band = step - sc->level;
         if (band < 0) return;
-        const int v_scan = (sc->n_comp == 1 && k.im->ncomp > 1 && sc->comp[0] == 0) ? k.im->vmax : 1;   // block rows per frame MCU row
+        const int v_scan = sc->n_comp == 1 ? k.im->comp_v[sc->comp[0]] : 1;   // block rows per frame MCU row
         const int64_t mpb = (int64_t)sc->mcu_count_h * rows_per_band * v_scan;
         const int64_t lo = (int64_t)band * mpb, hi = lo + mpb;
         b_lo = (int)max((int64_t)b_lo, lo);

@@ -68,6 +68,24 @@ def test_unusual_sampling_layouts_every_seam(name):
     assert np.array_equal(o["rgb"], g[name + ".rgb"])
 
 
+def crafted_progressive_names():
+    g = np.load(GOLDEN / "crafted_progressive.npz")
+    return sorted({k.rsplit(".", 1)[0] for k in g.files})
+
+
+@pytest.mark.parametrize("name", crafted_progressive_names())
+def test_crafted_progressive_scripts_every_seam(name):
+    """Progressive files written scan by scan (tools/craft_jpeg.py) with scripts no encoder at hand produces — interleaved DC
+    scans over a subset of the components, several bands and refinement levels, end-of-band runs over hundreds of blocks, 4:1:0
+    and other unusual layouts — as the reference decoded them (tools/make_layout_goldens.py): coefficient store after the last
+    scan, planes, image."""
+    g = np.load(GOLDEN / "crafted_progressive.npz")
+    o = oracle.decode(g[name + ".jpg"].tobytes())
+    assert np.array_equal(o["coef"], g[name + ".coef"])
+    assert np.array_equal(o["planes"], g[name + ".planes"])
+    assert np.array_equal(o["rgb"], g[name + ".rgb"])
+
+
 def test_ycbcr_to_rgb_known_answers_including_ties():
     g = np.load(GOLDEN / "ycc_rgb.npz")
     assert np.array_equal(oracle.ycbcr_to_rgb(g["ycc"]), g["rgb"])

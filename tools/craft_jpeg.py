@@ -159,3 +159,193 @@ def craft_baseline(width: int, height: int, factors, seed: int = 0, restart_inte
     out += w.out
     out += b"\xFF\xD9"
     return bytes(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Progressive files, scan by scan.  Nothing is transformed: every scan's symbols are drawn at random, subject only to what
+# a decoder has seen so far (a refining scan sends a correction bit for every coefficient earlier scans left non-zero and
+# may place +-1 where they left zero), so any scan script is possible — DC scans over a subset of the components,
+# arbitrary bands, several refinement levels, long end-of-band runs, restart intervals.  The symbol order of the
+# refining scans follows T.81 G.1.2.3 / figure G.7 (zero runs count zero-history coefficients only; corrections follow
+# the symbol that passes them; an end-of-band run carries the corrections of everything it skips).
+
+def _ac_prog_table(seed: int):
+    """A Huffman table holding every (run, size) symbol a progressive AC scan can use (sizes 0..10; size 0 = EOBn / ZRL), code
+    lengths from 3 to 14 bits so that LUT hits, long codes and second-level tables all occur."""
+    rng = np.random.default_rng(seed)
+    syms = [(r << 4) | s for s in range(0, 11) for r in range(16)]
+    likely = [0x00, 0x01, 0x11, 0x02, 0x21, 0x10, 0xF0, 0x31, 0x41, 0x12, 0x03, 0x20]
+    rest = [s for s in syms if s not in likely]
+    rng.shuffle(rest)
+    order = likely + rest
+    counts = {3: 2, 4: 2, 5: 4, 6: 6, 7: 10, 8: 16, 9: 24, 10: 32, 12: 40, 14: 40}
+    assert sum(counts.values()) == len(order) == 176
+    bits = bytes(counts.get(l, 0) for l in range(1, 17))
+    return bits, bytes(order)
+
+
+DEFAULT_SCRIPT = [   # libjpeg's default for three components: (components, Ss, Se, Ah, Al)
+    ((0, 1, 2), 0, 0, 0, 1), ((0,), 1, 5, 0, 2), ((2,), 1, 63, 0, 1), ((1,), 1, 63, 0, 1), ((0,), 6, 63, 0, 2),
+    ((0,), 1, 63, 2, 1), ((0, 1, 2), 0, 0, 1, 0), ((2,), 1, 63, 1, 0), ((1,), 1, 63, 1, 0), ((0,), 1, 63, 1, 0),
+]
+
+
+def craft_progressive(width: int, height: int, factors, seed: int = 0, script=None, restart_interval: int = 0,
+                      density: float = 0.2, new_density: float = 0.08, empty_block: float = 0.3, max_size: int = 4, dc_size: int = 4) -> bytes:
+    factors = [tuple(f) for f in factors]
+    ncomp = len(factors)
+    assert ncomp in (1, 3)
+    script = script or (DEFAULT_SCRIPT if ncomp == 3 else [((0,), 0, 0, 0, 1), ((0,), 1, 63, 0, 1), ((0,), 0, 0, 1, 0), ((0,), 1, 63, 1, 0)])
+    rng = np.random.default_rng(seed)
+    hmax = max(h for h, _ in factors) if ncomp > 1 else 1
+    vmax = max(v for _, v in factors) if ncomp > 1 else 1
+    mcw, mch = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    ac_bits, ac_vals = _ac_prog_table(seed)
+    ac_codes = _codes(ac_bits, ac_vals)
+    out = bytearray(b"\xFF\xD8")
+    out += _seg(0xDB, b"\x00" + _T["STD_QT_LUMA_ZZ"])
+    out += _seg(0xDB, b"\x01" + _T["STD_QT_CHROMA_ZZ"])
+    sof = bytes([8]) + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([ncomp])
+    for c, (h, v) in enumerate(factors):
+        sof += bytes([c + 1, (h << 4) | v, 0 if c == 0 else 1])
+    out += _seg(0xC2, sof)
+    out += _seg(0xC4, b"\x00" + _T["STD_DC_LUMA_BITS"] + _T["STD_DC_LUMA_VALS"])
+    out += _seg(0xC4, b"\x01" + _T["STD_DC_CHROMA_BITS"] + _T["STD_DC_CHROMA_VALS"])
+    out += _seg(0xC4, b"\x10" + ac_bits + ac_vals)
+    out += _seg(0xC4, b"\x11" + ac_bits + ac_vals)
+    if restart_interval:
+        out += _seg(0xDD, restart_interval.to_bytes(2, "big"))
+    # what a decoder holds so far: non-zero flags per component, [block row][block column][zig-zag index], padded to whole MCUs
+    fh = [(h, v) if ncomp > 1 else (1, 1) for h, v in factors]
+    nz = [np.zeros((mch * v, mcw * h, 64), dtype=bool) for h, v in fh]
+
+    for comps, ss, se, ah, al in script:
+        # (table selectors: DC table 0 / 1 and AC table 0 / 1 for luma / the others)
+        sos = bytes([len(comps)]) + b"".join(bytes([c + 1, ((0 if c == 0 else 1) << 4) | (0 if c == 0 else 1)]) for c in comps)
+        sos += bytes([ss, se, (ah << 4) | al])
+        out += _seg(0xDA, sos)
+        w = _Bits()
+        rst = [0]
+
+        def restart_marker():
+            w.flush()
+            w.out.extend(bytes([0xFF, 0xD0 + (rst[0] & 7)]))
+            rst[0] += 1
+
+        if ss == 0:                                                    # ---- DC scan
+            assert se == 0
+            if len(comps) > 1:
+                n_mcu = mcw * mch
+            else:
+                h, v = fh[comps[0]]
+                bwn = -(-(width * h) // (hmax * 8)) if ncomp > 1 else -(-width // 8)
+                bhn = -(-(height * v) // (vmax * 8)) if ncomp > 1 else -(-height // 8)
+                n_mcu = bwn * bhn
+            for m in range(n_mcu):
+                for c in comps:
+                    h, v = fh[c]
+                    rep = h * v if len(comps) > 1 else 1
+                    for _ in range(rep):
+                        if ah == 0:
+                            s = int(rng.integers(0, dc_size + 1))
+                            w.put(*_DC[0 if c == 0 else 1][s])
+                            if s:
+                                w.put(int(rng.integers(0, 1 << s)), s)
+                        else:
+                            w.put(int(rng.integers(0, 2)), 1)
+                if restart_interval and (m + 1) % restart_interval == 0 and m + 1 != n_mcu:
+                    restart_marker()
+            w.flush()
+            out += w.out
+            continue
+        # ---- AC scan of one component, its own block raster (:612-619)
+        assert len(comps) == 1
+        c = comps[0]
+        h, v = fh[c]
+        bwn = -(-(width * h) // (hmax * 8)) if ncomp > 1 else -(-width // 8)
+        bhn = -(-(height * v) // (vmax * 8)) if ncomp > 1 else -(-height // 8)
+        n_mcu = bwn * bhn
+        codes = ac_codes
+        eobrun = [0]
+        be = []                                                        # correction bits waiting behind the end-of-band run
+
+        def emit_eobrun():
+            if eobrun[0] > 0:
+                nb = eobrun[0].bit_length() - 1
+                w.put(*codes[nb << 4])
+                if nb:
+                    w.put(eobrun[0] & ((1 << nb) - 1), nb)
+                eobrun[0] = 0
+            for b in be:
+                w.put(b, 1)
+            be.clear()
+
+        for m in range(n_mcu):
+            by, bx = divmod(m, bwn)
+            flags = nz[c][by, bx]
+            if ah == 0:                                                # first scan of the band
+                r = 0
+                if rng.random() >= empty_block:
+                    for k in range(ss, se + 1):
+                        if rng.random() >= density * np.exp(-(k - ss) / 24.0):
+                            r += 1
+                            continue
+                        emit_eobrun()
+                        while r > 15:
+                            w.put(*codes[0xF0])
+                            r -= 16
+                        s = int(rng.integers(1, max_size + 1))
+                        w.put(*codes[(r << 4) | s])
+                        w.put(int(rng.integers(0, 1 << s)), s)
+                        flags[k] = True
+                        r = 0
+                else:
+                    r = se - ss + 1
+                if r > 0:
+                    eobrun[0] += 1
+                    if eobrun[0] == 0x7FFF:
+                        emit_eobrun()
+            else:                                                      # refining scan
+                kinds = np.zeros(64, dtype=np.int8)                    # 0 stays zero, 1 history, 2 new
+                kinds[flags] = 1
+                if rng.random() >= empty_block:
+                    new = (~flags) & (rng.random(64) < new_density)
+                    kinds[new] = 2
+                band = range(ss, se + 1)
+                eob_at = max([k for k in band if kinds[k] == 2], default=-1)
+                r, br = 0, []
+                for k in band:
+                    if kinds[k] == 0:
+                        r += 1
+                        continue
+                    while r > 15 and k <= eob_at:
+                        emit_eobrun()
+                        w.put(*codes[0xF0])
+                        r -= 16
+                        for b in br:
+                            w.put(b, 1)
+                        br = []
+                    if kinds[k] == 1:
+                        br.append(int(rng.integers(0, 2)))
+                        continue
+                    emit_eobrun()
+                    w.put(*codes[(r << 4) | 1])
+                    w.put(int(rng.integers(0, 2)), 1)
+                    for b in br:
+                        w.put(b, 1)
+                    br = []
+                    r = 0
+                    flags[k] = True
+                if r > 0 or br:
+                    eobrun[0] += 1
+                    be.extend(br)
+                    if eobrun[0] == 0x7FFF or len(be) > 900:
+                        emit_eobrun()
+            if restart_interval and (m + 1) % restart_interval == 0 and m + 1 != n_mcu:
+                emit_eobrun()
+                restart_marker()
+        emit_eobrun()
+        w.flush()
+        out += w.out
+    out += b"\xFF\xD9"
+    return bytes(out)
