@@ -1545,16 +1545,9 @@ def test_unusual_sampling_layouts_random_files_against_the_oracle(dec):
     restart markers and with the GPU marker scan, against the oracle (itself pinned on the twelve reference-decoded files)."""
     from oracle import oracle
     from pyjpegdecoder_amd import BatchDecoder
-    from tools.craft_jpeg import craft_baseline
+    from tools.craft_jpeg import random_baseline
     rng = np.random.default_rng(7)
-    files = []
-    for i in range(40):
-        f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
-        while sum(h * v for h, v in f) > 16:
-            f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
-        w, h = int(rng.integers(1, 120)), int(rng.integers(1, 120))
-        files.append(craft_baseline(w, h, f, seed=1000 + i, restart_interval=int(rng.integers(0, 4)), density=float(rng.uniform(0.05, 0.6)),
-                                    max_size=int(rng.integers(1, 8)), dc_size=int(rng.integers(1, 8))))
+    files = [random_baseline(rng, 1000 + i) for i in range(40)]
     want = [oracle.decode(f)["rgb"] for f in files]
     got = dec.decode(files)
     for i, (a, b) in enumerate(zip(got, want)):
@@ -1591,52 +1584,12 @@ def test_crafted_progressive_scripts_against_the_reference(dec, name, fast, monk
 def test_crafted_progressive_random_scripts_against_the_oracle(dec):
     """Random scan scripts (bands cut at random, DC components grouped at random, successive approximation two or three levels
     deep, with and without restart intervals), random layouts the reference can finish (every component 1x1 or at the full
-    resolution), batched: against the oracle."""
+    resolution), batched: against the oracle (tools/craft_jpeg.random_progressive; the reference agrees with the oracle on
+    every one of these files — checked where the reference lives, tools/crosscheck_reference.py --crafted)."""
     from oracle import oracle
-    from tools.craft_jpeg import craft_progressive
+    from tools.craft_jpeg import random_progressive
     rng = np.random.default_rng(11)
-    files = []
-    for i in range(36):
-        H, V = int(rng.integers(1, 5)), int(rng.integers(1, 5))
-        while H * V + 2 > 16:
-            H, V = int(rng.integers(1, 5)), int(rng.integers(1, 5))
-        kind = int(rng.integers(0, 4))
-        factors = [((H, V), (1, 1), (1, 1)), ((1, 1), (H, V), (H, V)), ((H, V), (H, V), (1, 1)), ((1, 1),)][kind]
-        if sum(h * v for h, v in factors) > 16:
-            factors = ((H, V), (1, 1), (1, 1))
-        nc = len(factors)
-        script = []
-        # DC: the components in random groups (a lone component must be 1x1: the reference cannot do the other kind), Al = a
-        a = int(rng.integers(0, 3))
-        lone_ok = [c for c in range(nc) if factors[c] == (1, 1) or nc == 1]
-        comps = list(range(nc))
-        groups = [tuple(comps)]
-        if nc == 3 and rng.random() < 0.6:
-            c = int(rng.choice(lone_ok)) if lone_ok else None
-            if c is not None:
-                groups = [tuple(x for x in comps if x != c), (c,)]
-                if rng.random() < 0.5:
-                    groups.reverse()
-        dc_first = [(g_, 0, 0, 0, a) for g_ in groups]
-        dc_ref = [[(g_, 0, 0, lvl + 1, lvl) for g_ in groups] for lvl in range(a - 1, -1, -1)]
-        ac = {c: [] for c in comps}
-        for c in comps:
-            al = int(rng.integers(0, 3))
-            cuts = sorted(set([1, 64] + [int(x) for x in rng.integers(2, 64, size=int(rng.integers(0, 3)))]))
-            bands = [(cuts[j], cuts[j + 1] - 1) for j in range(len(cuts) - 1)]
-            ac[c].append([((c,), lo, hi, 0, al) for lo, hi in bands])
-            for lvl in range(al - 1, -1, -1):
-                cuts = sorted(set([1, 64] + [int(x) for x in rng.integers(2, 64, size=int(rng.integers(0, 2)))]))
-                ac[c].append([((c,), cuts[j], cuts[j + 1] - 1, lvl + 1, lvl) for j in range(len(cuts) - 1)])
-        script += dc_first
-        stages = [dc_ref] + [ac[c] for c in comps]          # lists of stages; stages of one list stay in order
-        while any(stages):
-            j = int(rng.choice([k for k, s_ in enumerate(stages) if s_]))
-            script += stages[j].pop(0)
-        files.append(craft_progressive(int(rng.integers(1, 90)), int(rng.integers(1, 90)), factors, seed=3000 + i, script=script,
-                                       restart_interval=int(rng.choice([0, 0, 1, 3, 7])), density=float(rng.uniform(0.05, 0.4)),
-                                       new_density=float(rng.uniform(0.02, 0.25)), empty_block=float(rng.uniform(0.0, 0.95)),
-                                       max_size=int(rng.integers(1, 7)), dc_size=int(rng.integers(1, 7))))
+    files = [random_progressive(rng, 3000 + i) for i in range(36)]
     want = [oracle.decode(f) for f in files]
     got, seams = dec.decode(files, return_seams=True)
     for i in range(len(files)):

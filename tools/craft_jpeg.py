@@ -349,3 +349,61 @@ def craft_progressive(width: int, height: int, factors, seed: int = 0, script=No
         out += w.out
     out += b"\xFF\xD9"
     return bytes(out)
+
+
+# ---- random files of both kinds (tests, tools/stress_crafted.py, tools/crosscheck_reference.py --crafted) ----------------
+def random_baseline(rng, seed: int) -> bytes:
+    """Any factors 1..4 per component (at most 16 blocks per MCU), 1..119 pixels a side, with and without restart intervals."""
+    f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
+    while sum(h * v for h, v in f) > 16:
+        f = [(int(rng.integers(1, 5)), int(rng.integers(1, 5))) for _ in range(3)]
+    w, h = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+    return craft_baseline(w, h, f, seed=seed, restart_interval=int(rng.integers(0, 4)), density=float(rng.uniform(0.05, 0.6)),
+                          max_size=int(rng.integers(1, 8)), dc_size=int(rng.integers(1, 8)))
+
+
+def random_script(rng, factors):
+    """A scan script for `factors`: the DC components in random groups (a component on its own must be 1x1: the reference
+    cannot walk the other kind), bands cut at random, successive approximation up to three levels deep, the scans of the
+    components interleaved at random (every scan behind the ones it refines)."""
+    nc = len(factors)
+    comps = list(range(nc))
+    a = int(rng.integers(0, 3))
+    lone_ok = [c for c in comps if factors[c] == (1, 1) or nc == 1]
+    groups = [tuple(comps)]
+    if nc == 3 and lone_ok and rng.random() < 0.6:
+        c = int(rng.choice(lone_ok))
+        groups = [tuple(x for x in comps if x != c), (c,)]
+        if rng.random() < 0.5:
+            groups.reverse()
+    script = [(g, 0, 0, 0, a) for g in groups]
+    dc_ref = [[(g, 0, 0, lvl + 1, lvl) for g in groups] for lvl in range(a - 1, -1, -1)]
+    ac = {c: [] for c in comps}
+    for c in comps:
+        al = int(rng.integers(0, 3))
+        cuts = sorted(set([1, 64] + [int(x) for x in rng.integers(2, 64, size=int(rng.integers(0, 3)))]))
+        ac[c].append([((c,), cuts[j], cuts[j + 1] - 1, 0, al) for j in range(len(cuts) - 1)])
+        for lvl in range(al - 1, -1, -1):
+            cuts = sorted(set([1, 64] + [int(x) for x in rng.integers(2, 64, size=int(rng.integers(0, 2)))]))
+            ac[c].append([((c,), cuts[j], cuts[j + 1] - 1, lvl + 1, lvl) for j in range(len(cuts) - 1)])
+    stages = [dc_ref] + [ac[c] for c in comps]          # lists of stages; the stages of one list stay in order
+    while any(stages):
+        j = int(rng.choice([k for k, s_ in enumerate(stages) if s_]))
+        script += stages[j].pop(0)
+    return script
+
+
+def random_progressive(rng, seed: int) -> bytes:
+    """A random layout the reference can finish (every component 1x1 or at the full resolution, or greyscale), a random
+    script, 1..89 pixels a side."""
+    H, V = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    while H * V + 2 > 16:                                       # (16 blocks per MCU is what the MI355X path holds; T.81 allows 10)
+        H, V = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    kind = int(rng.integers(0, 4))
+    factors = [((H, V), (1, 1), (1, 1)), ((1, 1), (H, V), (H, V)), ((H, V), (H, V), (1, 1)), ((1, 1),)][kind]
+    if sum(h * v for h, v in factors) > 16:
+        factors = ((H, V), (1, 1), (1, 1))
+    return craft_progressive(int(rng.integers(1, 90)), int(rng.integers(1, 90)), factors, seed=seed, script=random_script(rng, factors),
+                             restart_interval=int(rng.choice([0, 0, 1, 3, 7])), density=float(rng.uniform(0.05, 0.4)),
+                             new_density=float(rng.uniform(0.02, 0.25)), empty_block=float(rng.uniform(0.0, 0.95)),
+                             max_size=int(rng.integers(1, 7)), dc_size=int(rng.integers(1, 7)))

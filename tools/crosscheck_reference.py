@@ -4,7 +4,11 @@ oracle/ — final image and zig-zag coefficients must be identical.  tests/golde
 this is the same comparison on as many random files as one cares to wait for (the reference does ~0.04 MP/s).
 Not part of the test suite and of no use on the GPU box (/root/reference does not exist there).
 
-    python tools/crosscheck_reference.py [n_files] [seed] [processes]
+    python tools/crosscheck_reference.py [n_files] [seed] [processes] [--crafted]
+
+--crafted: the files of tools/craft_jpeg.py instead — baseline files with any sampling factors 1..4 per component,
+progressive files with random scan scripts (DC scans over subsets of the components, random bands and refinement levels) in
+every layout the reference can finish.
 """
 import contextlib
 import io
@@ -19,12 +23,21 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+CRAFTED = "--crafted" in sys.argv
+
+
 def one(args):
     i, seed = args
     from tools import make_goldens as mg          # imports the reference
     from tools import synth
     from oracle import oracle
     rng = np.random.default_rng([seed, i])
+    if CRAFTED:
+        from tools.craft_jpeg import random_baseline, random_progressive
+        prog = bool(rng.integers(0, 2))
+        raw = (random_progressive if prog else random_baseline)(rng, int(rng.integers(0, 1 << 30)))
+        desc = f"crafted {'progressive' if prog else 'baseline'} #{i}, {len(raw)} bytes"
+        return compare(i, desc, raw, prog, mg, oracle)
     w, h = int(rng.integers(1, 97)), int(rng.integers(1, 97))
     q = int(rng.choice([10, 40, 75, 85, 95, 100]))
     noise = float(rng.choice([0.0, 8.0, 30.0, 90.0]))
@@ -45,6 +58,10 @@ def one(args):
         raw = b.getvalue()
         desc = f"progressive {w}x{h} q{q} sub{sub} noise{noise}"
         prog = True
+    return compare(i, desc, raw, prog, mg, oracle)
+
+
+def compare(i, desc, raw, prog, mg, oracle):
     with tempfile.TemporaryDirectory() as d:
         path = Path(d) / "f.jpg"
         path.write_bytes(raw)
@@ -67,9 +84,10 @@ def one(args):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    procs = int(sys.argv[3]) if len(sys.argv) > 3 else min(8, os.cpu_count() or 1)
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(argv[0]) if len(argv) > 0 else 200
+    seed = int(argv[1]) if len(argv) > 1 else 1
+    procs = int(argv[2]) if len(argv) > 2 else min(8, os.cpu_count() or 1)
     from multiprocessing import Pool
     with Pool(procs) as pool:
         res = pool.map(one, [(i, seed) for i in range(n)], chunksize=4)
