@@ -28,6 +28,17 @@ def check_supported(p: ParsedJpeg) -> ScanInfo:
     if not p.scans:
         raise CorruptedJpeg("No scan found in the file.")
     if p.scan_mode == "progressive_dct":
+        comps = list(p.color_components.values())
+        if len(comps) > 1:
+            hmax = max(c.horizontal_sampling for c in comps)
+            vmax = max(c.vertical_sampling for c in comps)
+            for c in comps:
+                h, v = c.horizontal_sampling, c.vertical_sampling
+                if (h, v) != (1, 1) and (h, v) != (hmax, vmax):
+                    # the reference's final pass resizes every 8x8 block to the full MCU shape and stores it into a
+                    # ratio x ratio region (jpeg_decoder.py:1345-1358): a shape mismatch for such a component (ValueError)
+                    raise UnsupportedJpeg(f"Progressive files need every component at 1x1 or at the full resolution "
+                                          f"(a {h}x{v} component under {hmax}x{vmax} is not supported).")
         for sc in p.scans:
             # the reference's own checks (jpeg_decoder.py:917-934, :966-967)
             if sc.spectral_start == 0 and sc.spectral_end != 0 or sc.spectral_start > sc.spectral_end:

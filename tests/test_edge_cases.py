@@ -73,3 +73,31 @@ def test_max_dimension_geometry():
     p = parse_jpeg(bytes(big))
     assert (p.image_width, p.image_height) == (65535, 65535)
     assert p.scans[0].mcu_count_h == 8192 and p.scans[0].mcu_count == 8192 * 8192
+
+
+def test_scan_structures_the_reference_cannot_decode_are_refused_on_the_host():
+    """What stays refused after round 3, and why: the reference itself fails on these files (tools/craft_jpeg.py writes them;
+    /root/reference run on them where it lives: IndexError / ValueError).  Everything else the crafter can write is decoded
+    (tests/test_gpu_parity.py: the crafted files)."""
+    from tools.craft_jpeg import craft_progressive
+    y420 = ((2, 2), (1, 1), (1, 1))
+    # a single-component DC scan of a subsampled component: :993-994 step its blocks by the component's MCU size -> IndexError
+    raw = craft_progressive(40, 40, y420, seed=8, script=[((0,), 0, 0, 0, 0), ((1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 0)])
+    with pytest.raises(UnsupportedJpeg):
+        check_supported(parse_jpeg(raw))
+    # a component between 1x1 and the full resolution in a progressive file: the final pass (:1345-1358) cannot place its blocks
+    raw = craft_progressive(40, 40, ((2, 2), (2, 1), (1, 1)), seed=12)
+    with pytest.raises(UnsupportedJpeg):
+        check_supported(parse_jpeg(raw))
+    # ... while these are taken: DC scans interleaved over a subset of the components, and a lone 1x1 component
+    raw = craft_progressive(50, 37, y420, seed=5, script=[((0, 1), 0, 0, 0, 0), ((2,), 0, 0, 0, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0),
+                                                          ((2,), 1, 63, 0, 0)])
+    p = parse_jpeg(raw)
+    check_supported(p)
+    prep = prepare_batch([raw])
+    assert prep.n_scans == 5 and prep.scans[0].n_comp == 2 and prep.scans[1].n_comp == 1
+    assert (prep.scans[0].mcu_count_h, prep.scans[0].mcu_count_v) == (4, 3)       # the frame's MCUs (:591-594, :610-611)
+    assert (prep.scans[1].mcu_count_h, prep.scans[1].mcu_count_v) == (4, 3)       # Cr alone: ceil(ceil(50/2)/8) x ceil(ceil(37/2)/8)
+    # unusual sampling factors (4:1:0, luma below the chroma resolution) in a progressive file
+    for factors in (((4, 2), (1, 1), (1, 1)), ((1, 1), (2, 2), (2, 2))):
+        check_supported(parse_jpeg(craft_progressive(40, 40, factors, seed=3)))

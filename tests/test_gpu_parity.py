@@ -1538,6 +1538,31 @@ def test_unusual_sampling_layouts_against_the_reference(dec, dec_rm, name):
     assert np.array_equal(img, g[name + ".rgb"])
     (img_rm,) = dec_rm.decode([raw])
     assert np.array_equal(img_rm, g[name + ".rgb"].transpose(1, 0, 2))
+    from oracle import oracle
+    assert np.array_equal(seam["idct"], oracle.decode(raw, want_idct=True)["idct"])     # the :872 seam, against the (pinned) oracle
+
+
+def test_unusual_layouts_through_the_class_surface_and_planar_output(tmp_path):
+    """The drop-in class on a 4:1:0 baseline file and on a crafted progressive one (subset DC scans); planar output of the generic
+    stage 2."""
+    from pyjpegdecoder_amd import BatchDecoder, JpegDecoder
+    g = np.load(GOLDEN / "odd_layouts.npz")
+    f = tmp_path / "y4x2.jpg"
+    f.write_bytes(g["y4x2.jpg"].tobytes())
+    d = JpegDecoder(f)
+    assert np.array_equal(d.image_array, g["y4x2.rgb"]) and d.scan_mode == "baseline_dct"
+    assert tuple(d.sample_shape) == (32, 16) and (d.mcu_width, d.mcu_height) == (32, 16)
+    gp = np.load(GOLDEN / "crafted_progressive.npz")
+    f2 = tmp_path / "subset.jpg"
+    f2.write_bytes(gp["dc_y_cr_refined.jpg"].tobytes())
+    d2 = JpegDecoder(f2)
+    assert np.array_equal(d2.image_array, gp["dc_y_cr_refined.rgb"]) and d2.scan_mode == "progressive_dct" and d2.scan_amount == 10
+    dp = BatchDecoder(device=0, layout="planar_rowmajor")
+    try:
+        (pl,) = dp.decode([g["y2x2_c1x2_2x1.jpg"].tobytes()])
+    finally:
+        dp.close()
+    assert np.array_equal(pl, g["y2x2_c1x2_2x1.rgb"].transpose(2, 1, 0))
 
 
 def test_unusual_sampling_layouts_random_files_against_the_oracle(dec):
