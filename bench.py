@@ -178,7 +178,7 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             "algorithmic_bytes_per_step": int(s1_bytes), "stage1_ms": round(s1, 3),
             "note": "entropy bytes + per scan 2 B x (Se-Ss+1) per covered block (x2 for refining scans: read-modify-write); "
                     "serial-walk (instruction issue) bound, quoted against HBM as SURVEY 8d asks; launches per step and their "
-                    "average durations: profiles/r03_progressive_kernel_stats.csv"}
+                    "average durations: profiles/r03c_progressive_kernel_stats.csv"}
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
             "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3), "roofline": roof,
             "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
@@ -319,10 +319,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        # the Gloo transport announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries ONE JSON line
+        # and nothing else, so file descriptor 1 points at stderr while the process group comes up (and whenever it talks)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
