@@ -91,6 +91,13 @@ def load_library():
         raise BackendError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C pyjpegdecoder_amd/csrc`). There is no CPU fallback.")
+    # PyTorch's ROCm wheels bundle their own HIP / HSA runtime under the same soname as /opt/rocm's.  Whichever is loaded first
+    # serves the whole process: torch's first, and this library binds to it; /opt/rocm's first (through this library), and a
+    # later `import torch` finds "No HIP GPUs are available".  So torch — which the device-tensor API needs anyway — goes first.
+    try:
+        import torch  # noqa: F401
+    except Exception:      # no PyTorch: the host-array API works on /opt/rocm's runtime alone
+        pass
     try:
         L = ctypes.CDLL(str(LIB_PATH))
     except OSError as exc:
