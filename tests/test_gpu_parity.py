@@ -1620,3 +1620,20 @@ def test_crafted_progressive_random_scripts_against_the_oracle(dec):
     for i in range(len(files)):
         assert np.array_equal(seams[i]["coef"], want[i]["coef"]), i
         assert np.array_equal(got[i], want[i]["rgb"]), i
+
+
+def test_library_first_then_torch_in_a_fresh_process():
+    """PyTorch's ROCm wheels bundle a HIP runtime under the soname of /opt/rocm's; whichever loads first serves the process, and
+    torch finds "No HIP GPUs" behind /opt/rocm's.  The binding therefore imports torch before it loads libmijpeg.so — a program
+    that creates a decoder first and touches torch.cuda afterwards must work (a fresh process: this one has torch loaded long since)."""
+    import subprocess
+    import sys
+    code = ("from pyjpegdecoder_amd import BatchDecoder\n"
+            "d = BatchDecoder(0)\n"
+            "import torch\n"
+            "t = torch.arange(4, device='cuda') + 1\n"
+            "assert t.sum().item() == 10\n"
+            "d.close()\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
