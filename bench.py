@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric (megapixels/s decoded on 1080p 4:2:0 baseline batches) on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]          N > 1: starts the N ranks itself (torch.distributed.run as a child)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (the same ranks, launcher outside)
 
 Default workload = BASELINE configs[2]: per GPU a batch of 1024 synthetic 1920x1080 4:2:0 baseline JPEGs with DRI
 restart markers, on-GPU Huffman + IDCT.  A "step" = one pass of the hot path (stage 0+1 Huffman decode, stage 2
@@ -237,6 +237,47 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
                     "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3)"}
 
 
+def visible_gpus() -> int:
+    """GPUs of this node, counted without initialising HIP (the launcher must stay a process that never touched the GPU): the
+    KFD topology lists one node per agent, CPUs with simd_count 0.  Honours a ROCR/HIP_VISIBLE_DEVICES list.  -1 = unknown."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = Path("/sys/class/kfd/kfd/topology/nodes")
+    if not base.is_dir():
+        return -1
+    n = 0
+    for node in base.iterdir():
+        try:
+            props = dict(line.split(None, 1) for line in (node / "properties").read_text().splitlines() if " " in line)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return -1
+    return n
+
+
+def launch_ranks(n_ranks: int, argv, share_gpu: bool, script=None) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <same arguments>` as a child (rendezvous on 127.0.0.1, a free port), pass its stdout — rank 0's
+    one JSON line — through, return its exit code."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if not share_gpu and 0 <= have < n_ranks:
+        print(f"bench.py: --gpus {n_ranks} but this node shows {have} GPU(s); --share-gpu runs every rank on cuda:0 (self-test)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script or Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 class DeviceImageQueue:
     """The per-GPU image queue of BASELINE configs[3]: a rank's share of the job, cut into batches whose files are
     assembled and uploaded once (inputs resident in HBM), then decoded batch after batch.  A batch of a few hundred
@@ -303,6 +344,14 @@ def main():
                     help="process group for the barrier / MAX of timings (gloo: nothing of this job needs RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks.  It has not imported torch and has not
+        # touched the GPU; the ranks are CHILD processes (no exec of a process that initialised HIP), and rank 0's JSON line is
+        # this process's stdout
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.share_gpu))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's rank count is the one that runs",
+              file=sys.stderr)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

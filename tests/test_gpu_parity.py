@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the reference's goldens and with the CPU oracle.
 Needs a real MI355X: run with `-m gpu`."""
 import hashlib
+import os
 from pathlib import Path
 
 import numpy as np
@@ -1261,6 +1262,24 @@ def test_config4_sharded_queue_two_ranks_on_one_gpu():
     assert line["config"]["images_all_gpus"] == 50 and line["config"]["images_per_gpu"] == 25
     assert line["parity"].startswith("bit-exact")
     assert abs(line["value"] - 50 * 1920 * 1080 / 1e6 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]      # whole job / time per pass
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """Plain `python bench.py --gpus 2` (no launcher around it, the way the driver calls N = 1): the flag alone must produce two
+    ranks — both on cuda:0 here (--share-gpu) — and a line that says n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "64",
+           "--distinct", "8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                          # rank 0's line and nothing else
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["images_per_gpu"] == 64 and line["parity"].startswith("bit-exact")
 
 
 def _idct_blocks_through_stage2(dec, blocks_xy, layout, cols=2048):

@@ -58,3 +58,38 @@ def test_two_gloo_ranks_shard_and_aggregate():
     assert (lo0, hi1) == (0, len(names)) and hi0 == lo1            # disjoint, complete
     assert tot0 == tot1 == px0 + px1                               # job-wide aggregate on every rank
     assert slow0 == slow1 == 2.0                                   # MAX over ranks
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher around it starts the N ranks itself (torch.distributed.run as a child of a
+    process that never touched the GPU) and hands rank 0's stdout through — here with a stand-in script for the rank body."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    script = tmp_path / "rank_body.py"
+    script.write_text("import json, os, sys\n"
+                      "import torch.distributed as dist\n"
+                      "dist.init_process_group('gloo')\n"
+                      "dist.barrier()\n"
+                      "if os.environ['RANK'] == '0':\n"
+                      "    print(json.dumps({'world': int(os.environ['WORLD_SIZE']), 'argv': sys.argv[1:],\n"
+                      "                      'addr': os.environ['MASTER_ADDR']}), flush=True)\n"
+                      "dist.destroy_process_group()\n")
+    code = ("import sys, bench; sys.exit(bench.launch_ranks(2, ['--gpus', '2', '--steps', '3'], True, script=%r))" % str(script))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(bench.ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"world": 2, "argv": ["--gpus", "2", "--steps", "3"], "addr": "127.0.0.1"}
+
+
+def test_bench_refuses_more_ranks_than_gpus(monkeypatch):
+    import subprocess
+    import sys
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpus() == 1
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    out = subprocess.run([sys.executable, str(bench.ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=120, cwd=str(bench.ROOT))
+    assert out.returncode == 2 and "--share-gpu" in out.stderr and out.stdout.strip() == ""
