@@ -188,6 +188,7 @@ struct mj_plan {
     int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
     int64_t total_tiles = 0;
     int32_t tiles_per_image = 0;
+    int32_t chunk_strips = 16;          // strips per ticket of the fast stage 2's work counter (the word behind d_tile_prefix)
     int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
@@ -727,6 +728,16 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         p->total_tiles = tp[b->n_images];
         p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
+        // the fast kernel hands its strips out in chunks (reconstruct_fast.hip): one MCU column of the image where that is
+        // 8..32 strips, else a few columns / a part of one; its ticket counter is the (zero) word behind the prefix
+        {
+            const int rows0 = p->transposed ? imgs[0].mcu_count_h : imgs[0].mcu_count_v;
+            const int spc = (rows0 + tm - 1) / tm;
+            int k = 16;
+            if (p->uniform) k = spc > 32 ? (spc + (spc + 23) / 24 - 1) / ((spc + 23) / 24) : (spc >= 8 ? spc : spc * ((11 + spc) / spc));
+            p->chunk_strips = k;
+        }
+        tp.push_back(0); tp.push_back(0);
         if ((rc = upload(ctx, &p->d_tile_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
     }
     if (have_entropy) {
@@ -1313,6 +1324,10 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.debug = 0;
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
+    a.work_counter = reinterpret_cast<uint32_t *>(p->d_tile_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
+#ifdef MJ_DIAGNOSTIC
+    if (getenv("MJ_STAGE2_CHUNK")) a.chunk_strips = atoi(getenv("MJ_STAGE2_CHUNK"));
+#endif
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(ctx->d_dump + mj::kStage2DumpBytes - 64, 0, 64, s));     // mj_plan_idct_levels
     if (p->generic) {
         MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
@@ -1521,6 +1536,25 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
             if (tot > 0) fprintf(stderr, "[mijpeg diag] phase shares: rounds %.1f %%, level3+next fetch %.1f %%, pixels %.1f %%, staging+stores %.1f %%, slow paths %.1f %%, loop head %.1f %%\n",
                                  100 * ph[0] / tot, 100 * ph[1] / tot, 100 * ph[2] / tot, 100 * ph[3] / tot, 100 * ph[4] / tot, 100 * ph[5] / tot);
             (void)hipMemset(ctx->d_dump + 393216 * 8, 0, 128);
+            if (atoi(getenv("MJ_DEBUG_STAGE2")) == 11) {      // start / end of every wave of the last launch (1024 workgroups x 4)
+                std::vector<unsigned long long> t(1024 * 4 * 4);
+                (void)hipMemcpy(t.data(), ctx->d_dump + (2u << 20), t.size() * 8, hipMemcpyDeviceToHost);
+                unsigned long long t0 = ~0ull;
+                for (size_t i = 0; i < t.size(); i += 4) if (t[i] && t[i] < t0) t0 = t[i];
+                std::vector<double> st, en;
+                FILE *f = getenv("MJ_DEBUG_WAVES_CSV") ? fopen(getenv("MJ_DEBUG_WAVES_CSV"), "w") : nullptr;
+                if (f) fprintf(f, "block,wave,start_us,end_us,hw_id,xcc_id\n");
+                for (size_t i = 0; i < t.size(); i += 4) if (t[i]) {
+                    st.push_back((double)(t[i] - t0) * 0.01); en.push_back((double)(t[i + 1] - t0) * 0.01);
+                    if (f) fprintf(f, "%zu,%zu,%.2f,%.2f,%llu,%llu\n", i / 16, (i / 4) % 4, st.back(), en.back(), t[i + 2] & 0xFFFFFFFFull, t[i + 2] >> 32);
+                }
+                if (f) fclose(f);
+                std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+                auto q = [](const std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[(size_t)(f * (v.size() - 1))]; };
+                fprintf(stderr, "[mijpeg diag] %zu waves; start us: max %.1f; end us: min %.1f p10 %.1f median %.1f p90 %.1f p99 %.1f max %.1f\n", st.size(),
+                        q(st, 1), q(en, 0), q(en, 0.1), q(en, 0.5), q(en, 0.9), q(en, 0.99), q(en, 1));
+                (void)hipMemset(ctx->d_dump + (2u << 20), 0, t.size() * 8);
+            }
         }
 #endif
     }

@@ -224,6 +224,10 @@ struct ReconArgs {
     // homogeneous-batch shortcut: all images share one geometry
     int32_t uniform_geometry;
     int32_t mcus_per_image;
+    // fast form: the launch's strips are handed out in chunks of `chunk_strips` consecutive strips, one wavefront at a time,
+    // through this ticket counter (zero before the launch; the wave that draws the launch's last ticket puts it back to zero)
+    uint32_t *work_counter;
+    int32_t chunk_strips;
 };
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);
 // any sampling factors 1..4 per component (DevImage::generic): reconstruct.hip

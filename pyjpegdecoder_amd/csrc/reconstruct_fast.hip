@@ -419,14 +419,30 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
     uint64_t dbg_wait = 0, dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = dbg_t0;
 #define MJ_STAMP(i) do { if (a.debug == 10) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dbg_acc[i] += s_ - dbg_last; dbg_last = s_; } } while (0)
 #endif
-    // A workgroup owns a contiguous range of strips and its four waves take them in turn: consecutive strips are
-    // vertically adjacent (same image columns), so the 192-byte column runs that share a 128-byte line are written by
-    // one CU within a few microseconds and merge in its XCD's L2 instead of leaving it as partial lines from eight L2s.
-    const uint32_t n_tiles = (uint32_t)total_tiles, stride_tiles = 4u;
-    const uint32_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    uint32_t tg = blockIdx.x * per_wg + wave;
-    const uint32_t tg_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
-    if (tg >= tg_end) return;
+    // Strips are handed out dynamically, a chunk of consecutive strips (one MCU column of an image, or thereabouts) per
+    // ticket and wavefront.  Why not a fixed share per wave: the four workgroups that share a CU are not served alike — the
+    // issue arbiter prefers the OLDEST wave of a SIMD, so with equal shares the first workgroup of a CU finished at 60 % of
+    // the launch and the last one ran its final fifth alone on the CU, one wave per SIMD (wave end times 2.7 .. 4.6 ms,
+    // mean 3.7: profiles/r04a_stage2_wave_end_times.txt).  A chunk's strips are vertically adjacent and go through one wave
+    // one after the other, so the column runs that share a 64-byte sector are written by one CU microseconds apart and
+    // merge in its XCD's L2.  The next chunk's ticket is drawn a chunk ahead (the atomic's latency is never waited for).
+    const uint32_t n_tiles = (uint32_t)total_tiles, chunk_len = (uint32_t)a.chunk_strips;
+    const uint32_t n_chunks = (n_tiles + chunk_len - 1) / chunk_len, last_ticket = n_chunks + gridDim.x * 4u - 1u;
+    auto draw = [&]() -> uint32_t {      // lane 0's ticket (other lanes 0); wave-uniform only after take()
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(a.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    };
+    auto take = [&](uint32_t t) -> uint32_t {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        // every wave draws exactly one ticket past the last chunk; the launch's very last ticket finds every other drawn
+        if (c == last_ticket && lane == 0) __hip_atomic_store(a.work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return c;
+    };
+    uint32_t chunk = take(draw());
+    if (chunk >= n_chunks) return;
+    uint32_t ticket_v = draw();
+    uint32_t tg = chunk * chunk_len, tg_end = min(n_tiles, tg + chunk_len);
     Strip cur = strip_of(tg);
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 #pragma unroll
         for (int t = 0; t < NT0; ++t) *reinterpret_cast<volatile u32x4_a4 *>(dump0) = u32x4_a4{0u, 0u, 0u, (uint32_t)t};
     }
-    for (; tg < tg_end; tg += stride_tiles) {
+    for (;;) {
         const DevImage *im_g = cur.im;
         const ConstImage im = cimg(im_g);
         const int W = T ? im->height : im->width, H = T ? im->width : im->height;
@@ -626,12 +642,22 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
         // they are consumed one iteration later, so HBM latency hides behind the pixel phase
-        const bool has_next = tg + stride_tiles < tg_end;
+        bool has_next = true;
         Strip nxt = cur;
-        if (has_next) {
-            nxt = strip_after(cur, tg + stride_tiles, (int)stride_tiles);
-            fetch(nxt, cw);
+        if (tg + 1 < tg_end) {
+            ++tg;
+            nxt = strip_after(cur, tg, 1);
+        } else {                                     // this wave's next chunk (drawn while the last one was under way)
+            chunk = take(ticket_v);
+            has_next = chunk < n_chunks;
+            if (has_next) {
+                ticket_v = draw();
+                tg = chunk * chunk_len;
+                tg_end = min(n_tiles, tg + chunk_len);
+                nxt = strip_of(tg);
+            }
         }
+        if (has_next) fetch(nxt, cw);
 
 #ifdef MJ_DIAGNOSTIC
         MJ_STAMP(1);          // level 3, next strip's geometry and fetch
@@ -908,6 +934,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
         MJ_STAMP(4);              // slow-path pixels, green patches
 #endif
         // the strip is private to this wave and LDS operations of one wave complete in order: no barrier
+        if (!has_next) break;
         cur = nxt;
     }
 #ifdef MJ_DIAGNOSTIC
@@ -920,6 +947,14 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
         atomicAdd(o, (unsigned long long)dbg_wait);
         atomicAdd(o + 1, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
         atomicAdd(o + 2, 1ull);
+    }
+    if (a.debug == 11 && lane == 0) {    // when does every wave start and finish?  (100 MHz wall clock: balance of the persistent grid)
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dump + (2u << 20)) + (blockIdx.x * 4 + wave) * 4;
+        o[0] = dbg_r0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // HW_REG_XCC_ID
+        o[3] = 0;
     }
     if (a.debug == 4 && blockIdx.x == 7 && tid == 0) {   // diagnostic only: shader clock vs 100 MHz wall clock
         uint64_t *o = reinterpret_cast<uint64_t *>(a.rgb);
@@ -944,7 +979,7 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
             resident = per_cu * cus;
         }
-        const int64_t want = (total_tiles + 3) / 4;
+        const int64_t want = ((total_tiles + a.chunk_strips - 1) / a.chunk_strips + 3) / 4;     // one chunk per wave at least
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, tile_prefix, total_tiles, tiles_per_image);
     };
