@@ -1320,6 +1320,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     }
 #ifdef MJ_DIAGNOSTIC      // phase ablations of the diagnostic build (make DIAG=1); the product never looks at the environment here
     a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
+    a.debug_mask = getenv("MJ_DEBUG_MASK") ? atoi(getenv("MJ_DEBUG_MASK")) : 0;
 #else
     a.debug = 0;
 #endif

@@ -221,6 +221,8 @@ struct ReconArgs {
     int32_t exact_only;
     int32_t debug;               // diagnostic builds only (make DIAG=1, MJ_DEBUG_STAGE2 env): 1 = no IDCT rounds, 2 = no
                                  // pixel phase, 3 = no stores, 4 = in-kernel clock probe
+    int32_t debug_mask;          // diagnostic builds only (MJ_DEBUG_MASK): ablations that combine — 1 no IDCT rounds (strip zeroed once),
+                                 // 2 no pixel arithmetic, 4 no staging / stores, 8 stores to the dump line, 16 no level 2, 32 no coefficient loads
     // homogeneous-batch shortcut: all images share one geometry
     int32_t uniform_geometry;
     int32_t mcus_per_image;

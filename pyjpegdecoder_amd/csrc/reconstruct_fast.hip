@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
     };
 
 #ifdef MJ_DIAGNOSTIC   // clock probe / phase ablations: separate diagnostic build only (make DIAG=1), never in the product
+    const int dm = a.debug_mask;
+    if (dm & 1) for (int i = lane; i < G::STRIP_BYTES / 2; i += 64) s_strip[i] = 0;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
     uint64_t dbg_wait = 0, dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = dbg_t0;
 #define MJ_STAMP(i) do { if (a.debug == 10) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dbg_acc[i] += s_ - dbg_last; dbg_last = s_; } } while (0)
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
 #ifdef MJ_DIAGNOSTIC
-            if (a.debug == 1) break;
+            if (a.debug == 1 || (dm & 1)) break;
 #endif
             const int bt = min(r * 8 + grp, G::NBT - 1);
             const bool real = G::NBT % 8 == 0 || r * 8 + grp < G::NBT;       // (4:1:1: the last round is half empty)
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
             // ---- level 2 (about one round in eight on noisy images): the groups whose block failed do it again in fp64
             if (__ballot(flagged) != 0) {
 #ifdef MJ_DIAGNOSTIC
-                if (a.debug == 5) continue;                // timing only (wrong pixels): what level 2 costs
+                if (a.debug == 5 || (dm & 16)) continue;                // timing only (wrong pixels): what level 2 costs
 #endif
                 int gf = flagged ? 1 : 0;                  // any lane of my group?
                 gf |= __builtin_amdgcn_update_dpp(0, gf, 0xB1, 0xF, 0xF, true);
@@ -657,7 +659,11 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                 nxt = strip_of(tg);
             }
         }
+#ifdef MJ_DIAGNOSTIC
+        if (has_next && !(dm & 32)) fetch(nxt, cw);
+#else
         if (has_next) fetch(nxt, cw);
+#endif
 
 #ifdef MJ_DIAGNOSTIC
         MJ_STAMP(1);          // level 3, next strip's geometry and fetch
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
         // ================= phase B: pixels ==================
         {
 #ifdef MJ_DIAGNOSTIC
-            const bool have = pk < n_valid && a.debug != 2;
+            const bool have = pk < n_valid && a.debug != 2 && !(dm & 2);
 #else
             const bool have = pk < n_valid;
 #endif
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                 MJ_STAMP(2);      // pixel arithmetic
 #endif
 #ifdef MJ_DIAGNOSTIC
-                const bool dbg_nostore = a.debug == 3;
+                const bool dbg_nostore = a.debug == 3 || (dm & 4);
                 if (dbg_nostore) { uint32_t acc = 0;
 #pragma unroll
                     for (int i = 0; i < (NBYTES + 3) / 4; ++i) acc ^= ob[i];
@@ -897,13 +903,13 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                     }
                     unsigned char *stbase = staged ? sbase : a.dump + (size_t)(blockIdx.x & 4095) * 1024;     // wave-uniform
 #ifdef MJ_DIAGNOSTIC
-                    if (a.debug == 7) stbase = a.dump + (size_t)(blockIdx.x & 4095) * 1024;    // timing only: every piece to the dump line
+                    if (a.debug == 7 || (dm & 8)) stbase = a.dump + (size_t)(blockIdx.x & 4095) * 1024;    // timing only: every piece to the dump line
 #endif
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         uint32_t off = staged ? doff[t] : (uint32_t)lane_o * 16u;
 #ifdef MJ_DIAGNOSTIC
-                        if (a.debug == 7) off = (uint32_t)lane_o * 16u;
+                        if (a.debug == 7 || (dm & 8)) off = (uint32_t)lane_o * 16u;
 #endif
                         *reinterpret_cast<u32x4_a4 *>(stbase + off) = u32x4_a4{pv[t].x, pv[t].y, pv[t].z, pv[t].w};
                     }
@@ -981,6 +987,17 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
         }
         const int64_t want = ((total_tiles + a.chunk_strips - 1) / a.chunk_strips + 3) / 4;     // one chunk per wave at least
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
+#ifdef MJ_DIAGNOSTIC      // occupancy experiment: MJ_LDS_PAD bytes of unused LDS per workgroup (grid = 3 per CU when it no longer fits 4 times)
+        if (getenv("MJ_LDS_PAD")) {
+            const int pad = atoi(getenv("MJ_LDS_PAD"));
+            int per_cu = 0, cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + pad);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES + pad) != hipSuccess || per_cu < 1) per_cu = 1;
+            hipLaunchKernelGGL(kernel, dim3(per_cu * cus), dim3(256), G::LDS_BYTES + pad, stream, a, tile_prefix, total_tiles, tiles_per_image);
+            return;
+        }
+#endif
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, tile_prefix, total_tiles, tiles_per_image);
     };
     if (a.planes || a.idct_out) launch(k_reconstruct_fast<HS, VS, NC, true, T>);
