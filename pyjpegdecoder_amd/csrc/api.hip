@@ -185,10 +185,10 @@ struct mj_plan {
     std::vector<int64_t> ordinal_kind_off;  // [n_ordinals][4]: within a level, where the segments of each kind of scan start
     uint16_t *d_qt = nullptr;
     int64_t *d_mcu_prefix = nullptr;
-    int64_t *d_tile_prefix = nullptr;   // fast stage 2: tiles of fast_tile_mcus() MCUs per image
-    int64_t total_tiles = 0;
-    int32_t tiles_per_image = 0;
-    int32_t chunk_strips = 16;          // strips per ticket of the fast stage 2's work counter (the word behind d_tile_prefix)
+    int64_t *d_job_prefix = nullptr;    // fast stage 2: first job of every image (+ total), then the kernel's ticket counter
+    int64_t total_jobs = 0;
+    int32_t jobs_per_image = 0;
+    int32_t chunk_strips = 16;          // strips per job (a piece of one MCU column) of the fast stage 2
     int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
@@ -411,7 +411,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_tile_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -718,27 +718,30 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 qn[(size_t)t * 64 + (p->transposed ? ((n & 7) << 3 | n >> 3) : n)] = b->qt[(size_t)t * 64 + z];
             }
         if ((rc = upload(ctx, &p->d_qt, qn.data(), qn.size())) != MJ_OK) return rc;
+        // the fast stage 2 hands its work out in JOBS (reconstruct_fast.hip): up to `chunk_strips` vertically consecutive strips
+        // (a strip = fast_tile_mcus() MCUs) of one MCU column — a whole column where that is at most 24 strips (1080p: 17),
+        // else equal pieces of one.  Jobs are numbered image by image; the kernel's ticket counter is the (zero) word behind
+        // the prefix.
         const int tm = p->generic ? 1 : mj::fast_tile_mcus(p->hmax, p->vmax, p->ncomp, p->transposed);
+        int max_spc = 1;
+        for (int i = 0; i < b->n_images; ++i) {
+            const int rows = p->transposed ? imgs[i].mcu_count_h : imgs[i].mcu_count_v;
+            max_spc = std::max(max_spc, (rows + tm - 1) / tm);
+        }
+        const int pieces_max = (max_spc + 23) / 24;
+        p->chunk_strips = (max_spc + pieces_max - 1) / pieces_max;
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
             // strips run down the MCU columns of the image the kernel sees (the transposed one for row-major plans)
             const int cols = p->transposed ? imgs[i].mcu_count_v : imgs[i].mcu_count_h;
             const int rows = p->transposed ? imgs[i].mcu_count_h : imgs[i].mcu_count_v;
-            tp[i + 1] = tp[i] + (int64_t)cols * ((rows + tm - 1) / tm);
+            const int spc = (rows + tm - 1) / tm;
+            tp[i + 1] = tp[i] + (int64_t)cols * ((spc + p->chunk_strips - 1) / p->chunk_strips);
         }
-        p->total_tiles = tp[b->n_images];
-        p->tiles_per_image = (int32_t)(tp[1] - tp[0]);
-        // the fast kernel hands its strips out in chunks (reconstruct_fast.hip): one MCU column of the image where that is
-        // 8..32 strips, else a few columns / a part of one; its ticket counter is the (zero) word behind the prefix
-        {
-            const int rows0 = p->transposed ? imgs[0].mcu_count_h : imgs[0].mcu_count_v;
-            const int spc = (rows0 + tm - 1) / tm;
-            int k = 16;
-            if (p->uniform) k = spc > 32 ? (spc + (spc + 23) / 24 - 1) / ((spc + 23) / 24) : (spc >= 8 ? spc : spc * ((11 + spc) / spc));
-            p->chunk_strips = k;
-        }
+        p->total_jobs = tp[b->n_images];
+        p->jobs_per_image = (int32_t)(tp[1] - tp[0]);
         tp.push_back(0); tp.push_back(0);
-        if ((rc = upload(ctx, &p->d_tile_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
+        if ((rc = upload(ctx, &p->d_job_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
     }
     if (have_entropy) {
         std::vector<mj::DevHuff> hh(b->n_huff);
@@ -1325,10 +1328,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.debug = 0;
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
-    a.work_counter = reinterpret_cast<uint32_t *>(p->d_tile_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
-#ifdef MJ_DIAGNOSTIC
-    if (getenv("MJ_STAGE2_CHUNK")) a.chunk_strips = atoi(getenv("MJ_STAGE2_CHUNK"));
-#endif
+    a.work_counter = reinterpret_cast<uint32_t *>(p->d_job_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(ctx->d_dump + mj::kStage2DumpBytes - 64, 0, 64, s));     // mj_plan_idct_levels
     if (p->generic) {
         MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
@@ -1336,8 +1336,8 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
         MJ_HIP(ctx, mj::launch_reconstruct(s, a, p->hmax, p->vmax, p->ncomp));
     } else {
         // row-major plans: the same kernel on the transposed problem, whose x-major output IS the row-major image
-        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->transposed, p->d_tile_prefix,
-                                               p->total_tiles, p->tiles_per_image));
+        MJ_HIP(ctx, mj::launch_reconstruct_fast(s, a, p->hmax, p->vmax, p->ncomp, p->transposed, p->d_job_prefix,
+                                               p->total_jobs, p->jobs_per_image));
     }
     if (planar) MJ_HIP(ctx, mj::launch_planes_from_interleaved(s, p->d_images, p->n_images, p->max_pixels, p->d_rgb_tmp, rgb_device));
     return MJ_OK;

@@ -226,8 +226,8 @@ struct ReconArgs {
     // homogeneous-batch shortcut: all images share one geometry
     int32_t uniform_geometry;
     int32_t mcus_per_image;
-    // fast form: the launch's strips are handed out in chunks of `chunk_strips` consecutive strips, one wavefront at a time,
-    // through this ticket counter (zero before the launch; the wave that draws the launch's last ticket puts it back to zero)
+    // fast form: the launch's strips are handed out in jobs of at most `chunk_strips` strips of one MCU column, one wavefront at
+    // a time, through this ticket counter (zero before the launch; the wave that draws the launch's last ticket puts it back to zero)
     uint32_t *work_counter;
     int32_t chunk_strips;
 };
@@ -237,8 +237,10 @@ hipError_t launch_reconstruct_generic(hipStream_t stream, const ReconArgs &a);
 // fast form: strips of fast_tile_mcus() MCUs in column-major MCU order.  transposed = the kernel runs on the transposed
 // image (blocks and tables stored [u][v]), so its x-major output is the row-major image (MJ_LAYOUT_ROWMAJOR)
 int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
+// jobs: pieces of at most a.chunk_strips strips of one MCU column, numbered image by image (job_prefix[i] = first job of image i)
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
-                                   const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image);
+                                   const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);
+constexpr int kMaxDevices = 64;      // launch-geometry caches are per device (one process may hold contexts on several)
 // MJ_LAYOUT_PLANAR_*: every image's interleaved pixels (x-major or row-major, as stage 2 wrote them) -> its three planes
 hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
                                           const uint8_t *interleaved, uint8_t *planar);

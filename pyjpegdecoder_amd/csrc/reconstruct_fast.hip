@@ -311,8 +311,8 @@ __device__ __noinline__ void block_exact(const int16_t *cblk, const uint16_t *qb
 // T: the kernel works on the transposed image (x' = y, y' = x) — its x-major output is the row-major image of the
 // original; HS/VS are then the transposed sampling factors, coefficient blocks and tables are stored [u][v].
 template <int HS, int VS, int NC, bool SEAMS, bool T>
-__global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ tile_prefix,
-                                                          int64_t total_tiles, int tiles_per_image) {
+__global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstruct_fast(ReconArgs a, const int64_t *__restrict__ job_prefix,
+                                                          int64_t total_jobs, int jobs_per_image) {
     using G = FGeo<HS, VS, NC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,74 +342,60 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 
     // A strip = TMW vertically adjacent MCUs of one MCU column (strips never wrap to the next column, so a
     // lane's MCU row is strip*TMW + k and every index below is either wave-uniform or a 24-bit multiply).
-    struct Strip {                       // all wave-uniform
+    // A JOB = up to a.chunk_strips vertically consecutive strips of one MCU column of one image: the unit the launch hands
+    // out (one ticket, one wavefront).  Jobs are numbered image by image, column by column, piece by piece.
+    struct Job {                         // all wave-uniform
         const DevImage *im;
-        const int16_t *cbase;            // coefficients of (MCU row 0, this MCU column)
-        int row_elems;                   // int16 elements per MCU row
-        int mcu_x, y_first, n_valid;
-        uint32_t tile;                   // strip number within the image
+        const int16_t *cfirst;           // coefficients of the job's first MCU row, this MCU column
+        int row_elems;                   // int16 elements from one MCU row to the next
+        int mcu_x, y_first, n_strips, mcv;
     };
-    auto strip_of = [&](uint32_t tg) -> Strip {
-        uint32_t img, tile;
+    auto job_of = [&](uint32_t jb) -> Job {
+        uint32_t img, r;
         if (a.uniform_geometry) {
-            img = tg / (uint32_t)tiles_per_image;
-            tile = tg - img * (uint32_t)tiles_per_image;
+            img = jb / (uint32_t)jobs_per_image;
+            r = jb - img * (uint32_t)jobs_per_image;
         } else {
             int lo = 0, hi = a.n_images;
             while (hi - lo > 1) {
                 int mid = (lo + hi) >> 1;
-                if (tile_prefix[mid] <= (int64_t)tg) lo = mid; else hi = mid;
+                if (job_prefix[mid] <= (int64_t)jb) lo = mid; else hi = mid;
             }
             img = (uint32_t)lo;
-            tile = tg - (uint32_t)tile_prefix[lo];
+            r = jb - (uint32_t)job_prefix[lo];
         }
         img = (uint32_t)__builtin_amdgcn_readfirstlane((int)img);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        Strip st;
-        st.im = a.images + img;
+        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+        Job jo;
+        jo.im = a.images + img;
         // MCU grid of the (possibly transposed) image: mch columns, mcv rows
-        const int mch = T ? cimg(st.im)->mcu_count_v : cimg(st.im)->mcu_count_h, mcv = T ? cimg(st.im)->mcu_count_h : cimg(st.im)->mcu_count_v;
+        const int mch = T ? cimg(jo.im)->mcu_count_v : cimg(jo.im)->mcu_count_h, mcv = T ? cimg(jo.im)->mcu_count_h : cimg(jo.im)->mcu_count_v;
         const uint32_t spc = (uint32_t)(mcv + G::TMW - 1) / G::TMW;     // strips per MCU column
-        st.tile = tile;
-        st.mcu_x = __builtin_amdgcn_readfirstlane((int)(tile / spc));
-        st.y_first = (int)(tile - (uint32_t)st.mcu_x * spc) * G::TMW;
-        st.n_valid = min(G::TMW, mcv - st.y_first);
+        const uint32_t S = (uint32_t)a.chunk_strips, pieces = (spc + S - 1) / S;
+        jo.mcv = mcv;
+        jo.mcu_x = __builtin_amdgcn_readfirstlane((int)(r / pieces));
+        const uint32_t s0 = (r - (uint32_t)jo.mcu_x * pieces) * S;      // first strip of the piece within its column
+        jo.n_strips = (int)min(S, spc - s0);
+        jo.y_first = (int)s0 * G::TMW;
         // coefficient blocks are in the ORIGINAL image's MCU raster: stepping down the strip moves one MCU row of the
         // original (or, transposed, one MCU to the right)
         if constexpr (T) {
-            st.cbase = a.coef + (cimg(st.im)->block_off + (int64_t)st.mcu_x * mcv * G::NB) * 64;
-            st.row_elems = G::NB * 64;
+            jo.row_elems = G::NB * 64;
+            jo.cfirst = a.coef + (cimg(jo.im)->block_off + (int64_t)jo.mcu_x * mcv * G::NB) * 64 + (int64_t)jo.y_first * jo.row_elems;
         } else {
-            st.cbase = a.coef + (cimg(st.im)->block_off + (int64_t)st.mcu_x * G::NB) * 64;
-            st.row_elems = mch * G::NB * 64;
+            jo.row_elems = mch * G::NB * 64;
+            jo.cfirst = a.coef + (cimg(jo.im)->block_off + (int64_t)jo.mcu_x * G::NB) * 64 + (int64_t)jo.y_first * jo.row_elems;
         }
-        return st;
+        return jo;
     };
-    // The strip `step` strips further on in the same workgroup's range: inside an image a few scalar additions (strip_of's
-    // two divisions by run-time values are some fifty instructions, a tenth of them on the vector unit)
-    auto strip_after = [&](const Strip &c, uint32_t tg_next, int step) -> Strip {
-        const int mch = T ? cimg(c.im)->mcu_count_v : cimg(c.im)->mcu_count_h, mcv = T ? cimg(c.im)->mcu_count_h : cimg(c.im)->mcu_count_v;
-        const int spc = (mcv + G::TMW - 1) / G::TMW;
-        const uint32_t tile = c.tile + (uint32_t)step;
-        if (tile >= (uint32_t)(spc * mch)) return strip_of(tg_next);       // the next image: once per image and wave
-        Strip st = c;
-        st.tile = tile;
-        int row = c.y_first / G::TMW + step, col = c.mcu_x;
-        while (row >= spc) { row -= spc; ++col; }
-        st.mcu_x = col;
-        st.y_first = row * G::TMW;
-        st.n_valid = min(G::TMW, mcv - st.y_first);
-        st.cbase = c.cbase + (int64_t)(col - c.mcu_x) * (T ? mcv * G::NB * 64 : G::NB * 64);
-        return st;
-    };
-    // all rounds' coefficient rows of a strip: ROUNDS x 16 B per lane
-    auto fetch = [&](const Strip &st, uint4 (&cw)[G::ROUNDS]) {
+    // all rounds' coefficient rows of a job's first strip: ROUNDS x 16 B per lane
+    auto fetch_first = [&](const Job &jo, uint4 (&cw)[G::ROUNDS]) {
+        const int nv = min(G::TMW, jo.mcv - jo.y_first);
 #pragma unroll
         for (int r = 0; r < G::ROUNDS; ++r) {
             const int bt = min(r * 8 + grp, G::NBT - 1);        // (groups past the strip's last block repeat it: never stored)
             const int k = bt / G::NB, b = bt - k * G::NB;
-            const int my = st.y_first + (k < st.n_valid ? k : 0);
-            cw[r] = *reinterpret_cast<const uint4 *>(st.cbase + __mul24(my, st.row_elems) + b * 64 + j * 8);
+            cw[r] = *reinterpret_cast<const uint4 *>(jo.cfirst + __mul24(k < nv ? k : 0, jo.row_elems) + b * 64 + j * 8);
             asm volatile("" ::: "memory");     // keep the loads in round order: the waits in front of the rounds count on it
         }
     };
@@ -421,15 +407,14 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
     uint64_t dbg_wait = 0, dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = dbg_t0;
 #define MJ_STAMP(i) do { if (a.debug == 10) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dbg_acc[i] += s_ - dbg_last; dbg_last = s_; } } while (0)
 #endif
-    // Strips are handed out dynamically, a chunk of consecutive strips (one MCU column of an image, or thereabouts) per
-    // ticket and wavefront.  Why not a fixed share per wave: the four workgroups that share a CU are not served alike — the
-    // issue arbiter prefers the OLDEST wave of a SIMD, so with equal shares the first workgroup of a CU finished at 60 % of
-    // the launch and the last one ran its final fifth alone on the CU, one wave per SIMD (wave end times 2.7 .. 4.6 ms,
-    // mean 3.7: profiles/r04a_stage2_wave_end_times.txt).  A chunk's strips are vertically adjacent and go through one wave
-    // one after the other, so the column runs that share a 64-byte sector are written by one CU microseconds apart and
-    // merge in its XCD's L2.  The next chunk's ticket is drawn a chunk ahead (the atomic's latency is never waited for).
-    const uint32_t n_tiles = (uint32_t)total_tiles, chunk_len = (uint32_t)a.chunk_strips;
-    const uint32_t n_chunks = (n_tiles + chunk_len - 1) / chunk_len, last_ticket = n_chunks + gridDim.x * 4u - 1u;
+    // Jobs are handed out dynamically, one per ticket and wavefront.  Why not a fixed share per wave: the four workgroups that
+    // share a CU are not served alike — the issue arbiter prefers the OLDEST wave of a SIMD, so with equal shares the first
+    // workgroup of a CU finished at 60 % of the launch and the last one ran its final fifth alone on the CU, one wave per
+    // SIMD (wave end times 2.7 .. 4.6 ms, mean 3.7: profiles/r04a_stage2_wave_end_times.txt).  A job's strips are vertically
+    // adjacent and go through one wave one after the other, so the column runs that share a 64-byte sector are written by one
+    // CU microseconds apart and merge in its XCD's L2.  The next job's ticket is drawn a job ahead (the atomic's latency is
+    // never waited for); one counter word takes ~90 tickets per microsecond, a 1080p job (17 strips) asks for 30.
+    const uint32_t n_jobs = (uint32_t)total_jobs, last_ticket = n_jobs + gridDim.x * 4u - 1u;
     auto draw = [&]() -> uint32_t {      // lane 0's ticket (other lanes 0); wave-uniform only after take()
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(a.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -437,18 +422,15 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
     };
     auto take = [&](uint32_t t) -> uint32_t {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        // every wave draws exactly one ticket past the last chunk; the launch's very last ticket finds every other drawn
+        // every wave draws exactly one ticket past the last job; the launch's very last ticket finds every other drawn
         if (c == last_ticket && lane == 0) __hip_atomic_store(a.work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return c;
     };
-    uint32_t chunk = take(draw());
-    if (chunk >= n_chunks) return;
-    uint32_t ticket_v = draw();
-    uint32_t tg = chunk * chunk_len, tg_end = min(n_tiles, tg + chunk_len);
-    Strip cur = strip_of(tg);
+    uint32_t job = take(draw());
+    if (job >= n_jobs) return;
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
-    fetch(cur, cw);
+    fetch_first(job_of(job), cw);
     if constexpr (!SEAMS) {
         // as many stores behind the first fetch as every later fetch has behind it (see the store phase): otherwise the
         // loop entry is the path "no store after the loads" and the wait in front of phase A becomes vmcnt(0) for every strip
@@ -457,17 +439,22 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 #pragma unroll
         for (int t = 0; t < NT0; ++t) *reinterpret_cast<volatile u32x4_a4 *>(dump0) = u32x4_a4{0u, 0u, 0u, (uint32_t)t};
     }
+    // Two loops.  Outer: the job — everything that takes divisions, descriptor loads or 64-bit products is done here, once
+    // per job (17 strips for 1080p).  Inner: the job's strips, top to bottom — from one to the next the coefficient pointer,
+    // the first MCU row and the output offset move by constants and the lanes' load offsets stay what they are.  (The kernel
+    // is bound by instruction issue; the compiler's per-strip code for "which strip is next and where does it live" was a
+    // quarter of the scalar and a tenth of the vector instructions.)
     for (;;) {
-        const DevImage *im_g = cur.im;
+        const uint32_t ticket_v = draw();           // the job after this one
+        const Job jo = job_of(job);                 // (its first strip's coefficients are already on their way)
+        const DevImage *im_g = jo.im;
         const ConstImage im = cimg(im_g);
         const int W = T ? im->height : im->width, H = T ? im->width : im->height;
         const int mch_o = im->mcu_count_h;              // MCUs per row of the ORIGINAL image (coefficient raster)
-        const int mcu_x = cur.mcu_x, y_first = cur.y_first, n_valid = cur.n_valid;
+        const int mcv_k = jo.mcv;                        // MCU rows of the image the kernel sees
+        const int mcu_x = jo.mcu_x;
+        const int row_elems = jo.row_elems;
         const int64_t block_off = im->block_off;
-        // first block of strip MCU k in the coefficient store
-        auto mcu_block = [&](int k) -> int64_t {
-            return block_off + (T ? (int64_t)(mcu_x * mch_o + y_first + k) : (int64_t)((y_first + k) * mch_o + mcu_x)) * G::NB;
-        };
         const uint16_t *qbase = a.qt;
         const int q0i = im->qt_index[0] * 64, q1i = im->qt_index[NC == 3 ? 1 : 0] * 64, q2i = im->qt_index[NC == 3 ? 2 : 0] * 64;
         if (im_g != qt_owner) {           // wave-uniform, rare: stage this image's tables (3 x 128 B) into the wave's LDS
@@ -478,6 +465,27 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                 reinterpret_cast<uint2 *>(s_qt)[c * 16 + part] = reinterpret_cast<const uint2 *>(qbase + qi)[part];
             }
         }
+        const uint32_t n_strips = (uint32_t)jo.n_strips;
+        // this lane's coefficient rows relative to a strip's first MCU row: byte offsets (k * row + block b, row j), one per round
+        uint32_t voff[G::ROUNDS];
+#pragma unroll
+        for (int r = 0; r < G::ROUNDS; ++r) {
+            const int bt = min(r * 8 + grp, G::NBT - 1);
+            const int k = bt / G::NB, b = bt - k * G::NB;
+            voff[r] = (uint32_t)(__mul24(k, row_elems) + b * 64 + j * 8) * 2u;
+        }
+        const int16_t *cptr = jo.cfirst;            // wave-uniform: the current strip's first MCU row
+        int y_first = jo.y_first;
+        const int64_t rgb_off = im->rgb_off;
+        const int hnc_i = H * NC;
+        // first byte of this MCU column's pixel columns in the image
+        unsigned char *const col_dst = a.rgb + rgb_off + (int64_t)(mcu_x * G::MW) * hnc_i;
+      for (uint32_t si = 0;; ++si) {
+        const int n_valid = min(G::TMW, mcv_k - y_first);
+        // first block of strip MCU k in the coefficient store
+        auto mcu_block = [&](int k) -> int64_t {
+            return block_off + (T ? (int64_t)(mcu_x * mch_o + y_first + k) : (int64_t)((y_first + k) * mch_o + mcu_x)) * G::NB;
+        };
 
 #ifdef MJ_DIAGNOSTIC
         MJ_STAMP(5);          // loop head (and, first time round, everything before the loop)
@@ -644,27 +652,31 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
         // they are consumed one iteration later, so HBM latency hides behind the pixel phase
-        bool has_next = true;
-        Strip nxt = cur;
-        if (tg + 1 < tg_end) {
-            ++tg;
-            nxt = strip_after(cur, tg, 1);
-        } else {                                     // this wave's next chunk (drawn while the last one was under way)
-            chunk = take(ticket_v);
-            has_next = chunk < n_chunks;
-            if (has_next) {
-                ticket_v = draw();
-                tg = chunk * chunk_len;
-                tg_end = min(n_tiles, tg + chunk_len);
-                nxt = strip_of(tg);
-            }
-        }
 #ifdef MJ_DIAGNOSTIC
-        if (has_next && !(dm & 32)) fetch(nxt, cw);
-#else
-        if (has_next) fetch(nxt, cw);
+        if (dm & 32) { if (si + 1 >= n_strips) job = take(ticket_v); } else
 #endif
-
+        if (si + 1 < n_strips) {                     // the strip below: same column, TMW MCU rows further down
+            const unsigned char *cn = reinterpret_cast<const unsigned char *>(cptr + (int64_t)G::TMW * row_elems);
+            const int nv = min(G::TMW, mcv_k - (y_first + G::TMW));
+            if (nv == G::TMW) {
+#pragma unroll
+                for (int r = 0; r < G::ROUNDS; ++r) {
+                    cw[r] = *reinterpret_cast<const uint4 *>(cn + voff[r]);
+                    asm volatile("" ::: "memory");
+                }
+            } else {                                 // the column's last strip has fewer MCUs: the missing ones repeat the first
+#pragma unroll
+                for (int r = 0; r < G::ROUNDS; ++r) {
+                    const int bt = min(r * 8 + grp, G::NBT - 1);
+                    const int k = bt / G::NB, b = bt - k * G::NB;
+                    cw[r] = *reinterpret_cast<const uint4 *>(cn + (k < nv ? voff[r] : (uint32_t)(b * 64 + j * 8) * 2u));
+                    asm volatile("" ::: "memory");
+                }
+            }
+        } else {                                     // the job ends: the first strip of this wave's next job
+            job = take(ticket_v);
+            if (job < n_jobs) fetch_first(job_of(job), cw);
+        }
 #ifdef MJ_DIAGNOSTIC
         MJ_STAMP(1);          // level 3, next strip's geometry and fetch
 #endif
@@ -678,7 +690,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
             const int gx = mcu_x * G::MW + px, gy0 = (y_first + pk) * G::MH;
             const int16_t *mt = s_strip + pk * G::MCU_STRIDE;
             const int nrows = min(G::MH, H - gy0);
-            unsigned char *dst = a.rgb + im->rgb_off + ((int64_t)gx * H + gy0) * NC;
+            unsigned char *dst = col_dst + (int64_t)px * hnc_i + gy0 * NC;
             constexpr int NBYTES = G::MH * NC;
 
             if constexpr (SEAMS) {
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                 // predecessor with the same values — so the store stays one 16-byte instruction per piece)
                 constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
                 const int runv = min(RUN, (H - y_first * G::MH) * NC);
-                const bool staged = runv >= 16 && ((H * NC) & 3) == 0 && (im->rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
+                const bool staged = runv >= 16 && (hnc_i & 3) == 0 && (rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
                 {
                     static_assert(RUN % 16 == 0 && NBYTES % 8 == 0, "column runs are whole 16-byte pieces");
                     unsigned char *s_out = smem + wave * G::WAVE_BYTES + G::STRIP_BYTES;
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                     // existing piece (the same bytes to the same address twice is harmless); a strip that takes the per-lane
                     // stores below sends its NT instructions to this workgroup's dump line instead.
                     const int ncol = min(G::MW, W - mcu_x * G::MW);
-                    unsigned char *sbase = a.rgb + im->rgb_off + ((int64_t)(mcu_x * G::MW) * H + (int64_t)y_first * G::MH) * NC;
+                    unsigned char *sbase = col_dst + y_first * (G::MH * NC);
                     // (the piece geometry is recomputed from the lane number every strip: as loop invariants the compiler
                     // keeps them in registers it does not have, and a spill reload is a vector-memory load that waits —
                     // vmcnt is in order — for the coefficient prefetch and for the previous piece's store)
@@ -881,7 +893,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
                     constexpr int NT = (NPIECE + 63) / 64;
                     uint4 pv[NT];
                     uint32_t doff[NT];                    // byte offset of piece t from sbase
-                    const uint32_t hnc = (uint32_t)(H * NC);
+                    const uint32_t hnc = (uint32_t)hnc_i;
                     if (runv == RUN && ncol == G::MW) {   // whole runs (wave-uniform; LDS reads may sit behind branches, stores may not)
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {    // all reads first: one LDS round trip, not one per store
@@ -940,8 +952,11 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
         MJ_STAMP(4);              // slow-path pixels, green patches
 #endif
         // the strip is private to this wave and LDS operations of one wave complete in order: no barrier
-        if (!has_next) break;
-        cur = nxt;
+        if (si + 1 >= n_strips) break;
+        y_first += G::TMW;
+        cptr += (int64_t)G::TMW * row_elems;
+      }
+        if (job >= n_jobs) break;
     }
 #ifdef MJ_DIAGNOSTIC
     if (a.debug == 10 && lane == 0) {
@@ -971,34 +986,36 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 4) void k_reconstru
 }
 
 template <int HS, int VS, int NC, bool T>
-static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const int64_t *tile_prefix, int64_t total_tiles,
-                                int tiles_per_image) {
+static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const int64_t *job_prefix, int64_t total_jobs,
+                                int jobs_per_image) {
     using G = FGeo<HS, VS, NC>;
-    if (total_tiles == 0) return hipSuccess;
-    // persistent grid = exactly what the chip can hold at once (a larger grid would run in two uneven rounds)
+    if (total_jobs == 0) return hipSuccess;
+    // persistent grid = at most what the chip can hold at once; its waves draw the jobs from a.work_counter
     auto launch = [&](auto kernel) {
-        static int resident = 0;     // per instantiation
+        static int resident_of[kMaxDevices] = {0};     // per instantiation and device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int &resident = resident_of[dev >= 0 && dev < kMaxDevices ? dev : 0];
         if (resident == 0) {
-            int dev = 0, cus = 256, per_cu = 0;
-            (void)hipGetDevice(&dev);
+            int cus = 256, per_cu = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
             resident = per_cu * cus;
         }
-        const int64_t want = ((total_tiles + a.chunk_strips - 1) / a.chunk_strips + 3) / 4;     // one chunk per wave at least
+        const int64_t want = (total_jobs + 3) / 4;      // one job per wave at least
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
-#ifdef MJ_DIAGNOSTIC      // occupancy experiment: MJ_LDS_PAD bytes of unused LDS per workgroup (grid = 3 per CU when it no longer fits 4 times)
+#ifdef MJ_DIAGNOSTIC      // occupancy experiment: MJ_LDS_PAD bytes of unused LDS per workgroup
         if (getenv("MJ_LDS_PAD")) {
             const int pad = atoi(getenv("MJ_LDS_PAD"));
             int per_cu = 0, cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + pad);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES + pad) != hipSuccess || per_cu < 1) per_cu = 1;
-            hipLaunchKernelGGL(kernel, dim3(per_cu * cus), dim3(256), G::LDS_BYTES + pad, stream, a, tile_prefix, total_tiles, tiles_per_image);
+            hipLaunchKernelGGL(kernel, dim3(per_cu * cus), dim3(256), G::LDS_BYTES + pad, stream, a, job_prefix, total_jobs, jobs_per_image);
             return;
         }
 #endif
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, tile_prefix, total_tiles, tiles_per_image);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), G::LDS_BYTES, stream, a, job_prefix, total_jobs, jobs_per_image);
     };
     if (a.planes || a.idct_out) launch(k_reconstruct_fast<HS, VS, NC, true, T>);
     else launch(k_reconstruct_fast<HS, VS, NC, false, T>);
@@ -1011,10 +1028,10 @@ int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed) {
 }
 
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
-                                   const int64_t *tile_prefix, int64_t total_tiles, int tiles_per_image) {
+                                   const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image) {
 #define MJ_FAST(H, V, C) \
-    (transposed ? launch_fast_t<V, H, C, true>(stream, a, tile_prefix, total_tiles, tiles_per_image) \
-                : launch_fast_t<H, V, C, false>(stream, a, tile_prefix, total_tiles, tiles_per_image))
+    (transposed ? launch_fast_t<V, H, C, true>(stream, a, job_prefix, total_jobs, jobs_per_image) \
+                : launch_fast_t<H, V, C, false>(stream, a, job_prefix, total_jobs, jobs_per_image))
     if (ncomp == 1) return MJ_FAST(1, 1, 1);
     if (hmax == 1 && vmax == 1) return MJ_FAST(1, 1, 3);
     if (hmax == 2 && vmax == 1) return MJ_FAST(2, 1, 3);
