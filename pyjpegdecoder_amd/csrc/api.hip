@@ -730,6 +730,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         const int pieces_max = (max_spc + 23) / 24;
         p->chunk_strips = (max_spc + pieces_max - 1) / pieces_max;
+#ifdef MJ_DIAGNOSTIC
+        if (getenv("MJ_STAGE2_CHUNK")) p->chunk_strips = std::max(1, atoi(getenv("MJ_STAGE2_CHUNK")));      // experiment: strips per job
+#endif
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
             // strips run down the MCU columns of the image the kernel sees (the transposed one for row-major plans)

@@ -42,6 +42,18 @@ namespace mj {
 
 namespace {
 
+// experiment switch (make XFLAGS=-DMJ_X_NTLOAD): the coefficient rows are read once — as streaming loads they would leave L2 to the pixel stores
+#ifdef MJ_X_NTLOAD
+typedef uint32_t mj_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 coef_load_nt(const uint4 *p) {
+    const mj_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const mj_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#define MJ_COEF_LOAD(p) coef_load_nt(p)
+#else
+#define MJ_COEF_LOAD(p) (*(p))
+#endif
+
 // K[x][u] = 0.5*c(u)*cos((2x+1)*u*pi/16), x = 0..3: even columns u = 0,2,4,6 and odd columns u = 1,3,5,7
 constexpr double kA = 0.35355339059327373;    // 0.5/sqrt(2)
 constexpr double kC2 = 0.46193976625564337, kC6 = 0.19134171618254492;
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
         for (int r = 0; r < G::ROUNDS; ++r) {
             const int bt = min(r * 8 + grp, G::NBT - 1);        // (groups past the strip's last block repeat it: never stored)
             const int k = bt / G::NB, b = bt - k * G::NB;
-            cw[r] = *reinterpret_cast<const uint4 *>(jo.cfirst + __mul24(k < nv ? k : 0, jo.row_elems) + b * 64 + j * 8);
+            cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(jo.cfirst + __mul24(k < nv ? k : 0, jo.row_elems) + b * 64 + j * 8));
             asm volatile("" ::: "memory");     // keep the loads in round order: the waits in front of the rounds count on it
         }
     };
@@ -403,6 +415,8 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
 #ifdef MJ_DIAGNOSTIC   // clock probe / phase ablations: separate diagnostic build only (make DIAG=1), never in the product
     const int dm = a.debug_mask;
     if (dm & 1) for (int i = lane; i < G::STRIP_BYTES / 2; i += 64) s_strip[i] = 0;
+    if (a.debug == 12 && wave >= 2) { for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127); }     // waves 2, 3 start ~4 us (half a strip) late
+    if (a.debug == 13 && (wave & 1)) { for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127); }    // odd waves instead
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
     uint64_t dbg_wait = 0, dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = dbg_t0;
 #define MJ_STAMP(i) do { if (a.debug == 10) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dbg_acc[i] += s_ - dbg_last; dbg_last = s_; } } while (0)
@@ -661,7 +675,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
             if (nv == G::TMW) {
 #pragma unroll
                 for (int r = 0; r < G::ROUNDS; ++r) {
-                    cw[r] = *reinterpret_cast<const uint4 *>(cn + voff[r]);
+                    cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(cn + voff[r]));
                     asm volatile("" ::: "memory");
                 }
             } else {                                 // the column's last strip has fewer MCUs: the missing ones repeat the first
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
                 for (int r = 0; r < G::ROUNDS; ++r) {
                     const int bt = min(r * 8 + grp, G::NBT - 1);
                     const int k = bt / G::NB, b = bt - k * G::NB;
-                    cw[r] = *reinterpret_cast<const uint4 *>(cn + (k < nv ? voff[r] : (uint32_t)(b * 64 + j * 8) * 2u));
+                    cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(cn + (k < nv ? voff[r] : (uint32_t)(b * 64 + j * 8) * 2u)));
                     asm volatile("" ::: "memory");
                 }
             }
