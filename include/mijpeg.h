@@ -85,10 +85,12 @@ extern "C" {
                                      _parse.py's find_entropy_end / find_restart_segments do on the host).  Every
                                      image then has n_segments = 1 and seg_begin/seg_end = first entropy-coded byte /
                                      any bound at or behind the end of the scan (e.g. the end of the file); the blob
-                                     must be 16-byte aligned with 16 readable bytes behind blob_len.  (No stage-1 form
-                                     reads the blob itself in such a plan: the marker scan and stage 0 read it inside
-                                     [seg_begin, seg_end) + 16 bytes, everything else reads stage 0's stream — which
-                                     is why the 512-byte rule of MJ_MEM_DEVICE blobs below does not apply here.)    */
+                                     must be 16-byte aligned with 16 readable bytes behind blob_len.  (The marker scan
+                                     and stage 0 read it inside [seg_begin, seg_end) + 16 bytes and the lane forms of
+                                     stage 1 read stage 0's stream, so the 512-byte rule of MJ_MEM_DEVICE blobs below
+                                     does not apply; a plan that takes the wave form of stage 1 — small batches,
+                                     unusual sampling layouts — reads the blob itself, further ahead, and works on a
+                                     padded copy of it made at plan creation when the blob lacks those 512 bytes.)  */
 
 #define MJ_FLAG_NO_SYNC     64u  /* never cut restart segments into synchronised pieces: one serial walk per segment (the
                                      fallback for images that came back MJ_ST_UNCONVERGED)                          */

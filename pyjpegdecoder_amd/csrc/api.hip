@@ -118,6 +118,8 @@ struct mj_plan {
     std::vector<mj::DevImage> h_images;
     // device
     uint8_t *d_blob_owned = nullptr;
+    const uint8_t *blob_src = nullptr;  // a caller's device blob that every execute copies into d_blob_owned first (wave form behind
+    int64_t blob_src_len = 0;           // MJ_FLAG_GPU_SEGMENT: the kernel reads further ahead than that flag makes the caller pad)
     const uint8_t *d_blob = nullptr;
     mj::DevSegment *d_segs = nullptr;
     int64_t n_segs = 0;
@@ -743,7 +745,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         p->total_jobs = tp[b->n_images];
         p->jobs_per_image = (int32_t)(tp[1] - tp[0]);
-        tp.push_back(0); tp.push_back(0);
+        tp.insert(tp.end(), 5, 0);         // the ticket counter, a spare word, the three level counters of mj_plan_idct_levels
         if ((rc = upload(ctx, &p->d_job_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
     }
     if (have_entropy) {
@@ -1129,12 +1131,24 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if (!jobs.empty() && ((uintptr_t)b->blob & 15) != 0)
                 return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT: device blob must be 16-byte aligned");
             p->d_blob = b->blob;
+            // MJ_FLAG_GPU_SEGMENT promises 16 readable bytes behind blob_len, which is all the marker scan and stage 0 need —
+            // but a plan that ends up in the wave form (small batches, generic sampling layouts, tables in both roles) reads the
+            // blob itself, up to 508 bytes behind a segment's aligned start: such a plan works on its own padded copy
+            // (copied at every execute, on the execute's stream: the caller's bytes need not be there yet when the plan is made)
+            if ((b->flags & MJ_FLAG_GPU_SEGMENT) && !p->use_lanes && last_end + 512 > b->blob_len) {
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_blob_owned, (size_t)b->blob_len + 1024 + 16));
+                MJ_HIP(ctx, hipMemsetAsync(p->d_blob_owned + b->blob_len, 0, 1024, ctx->setup_stream));
+                p->blob_src = b->blob; p->blob_src_len = b->blob_len;
+                p->d_blob = p->d_blob_owned;
+            }
         }
     }
     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_coef, (size_t)blk * 64 * sizeof(int16_t) + 16));
     // (the resolved-table lane form stores every block of every MCU of every segment it is given, zeros included: no need to
-    // clear 6 GB per plan first — 1.5 ms of a 1024-image plan's creation in a serving loop)
-    if (!(p->d_lut13 && p->use_lanes))
+    // clear 6 GB per plan first — 1.5 ms of a 1024-image plan's creation.  Only where the host listed the segments, though:
+    // virtual segments of an image that did not settle, or the segments of a file whose marker count is off, do not cover
+    // their image, and what a recycled buffer held before must not show through in a failed image's pixels)
+    if (!(p->d_lut13 && p->use_lanes && !p->use_sync && jobs.empty()))
         MJ_HIP(ctx, hipMemsetAsync(p->d_coef, 0, (size_t)blk * 64 * sizeof(int16_t), ctx->setup_stream));
     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_status, (size_t)b->n_images * sizeof(int32_t)));
     MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)b->n_images * sizeof(int32_t), ctx->setup_stream));
@@ -1253,6 +1267,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
         }
         return MJ_OK;
     }
+    if (p->blob_src) MJ_HIP(ctx, hipMemcpyAsync(p->d_blob_owned, p->blob_src, (size_t)p->blob_src_len, hipMemcpyDeviceToDevice, s));
     if (p->n_jobs)      // restart markers and the end of each scan, found on the GPU
         MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     if (p->use_lanes) {
@@ -1332,7 +1347,8 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
     a.work_counter = reinterpret_cast<uint32_t *>(p->d_job_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
-    if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(ctx->d_dump + mj::kStage2DumpBytes - 64, 0, 64, s));     // mj_plan_idct_levels
+    a.level_counts = reinterpret_cast<unsigned long long *>(p->d_job_prefix + p->n_images + 3);
+    if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(a.level_counts, 0, 3 * sizeof(unsigned long long), s));     // mj_plan_idct_levels
     if (p->generic) {
         MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
     } else if (a.exact_only) {
@@ -1487,7 +1503,7 @@ int mj_plan_idct_levels(mj_plan *p, uint64_t counts[3]) {
     if (!p || !counts) return MJ_ERR_INVALID;
     mj_context *ctx = p->ctx;
     if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
-    MJ_HIP(ctx, hipMemcpy(counts, ctx->d_dump + mj::kStage2DumpBytes - 64, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    MJ_HIP(ctx, hipMemcpy(counts, p->d_job_prefix + p->n_images + 3, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MJ_OK;
 }
 

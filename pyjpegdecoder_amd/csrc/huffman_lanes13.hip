@@ -261,7 +261,9 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
                 if (want) nxtw = ring_u32(voff);
                 // (the loop below reads at most 4 bytes per iteration and brings in 16 per two: a lane cannot run its window dry,
                 // but nothing is lost by looking)
-                if (__builtin_amdgcn_ballot_w64(lane < lpw2 && (int)(pf - voff) < 24) != 0) top_up(48);
+                // (32, not 24: the loop's first turn has no refill in flight and can take six dwords when an unresolved entry of
+                // 29+ bits — value sizes above 12, which the reference accepts — is followed by two-symbol rounds)
+                if (__builtin_amdgcn_ballot_w64(lane < lpw2 && (int)(pf - voff) < 32) != 0) top_up(48);
             }
             uint32_t pB;
             {
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(const uint32_t *__rest
 #ifdef MJ_X_STAMP
                       , [di] "+v"(dbg_iter), [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_w[0]), [d8] "+v"(dbg_w[1]), [d9] "+v"(dbg_w[2])
 #endif
-                    : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "s"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
+                    : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "v"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
                       [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [c96] "v"(c96), [rl] "s"(ring_lanes), [rot] "v"(rot)
                     : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72");
 #undef MJ_REFILL13

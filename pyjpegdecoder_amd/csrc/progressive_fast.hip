@@ -605,6 +605,15 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
         bp0 = ps->pos; k.eobrun = ps->eobrun; k.pred0 = ps->pred[0]; k.pred1 = ps->pred[1]; k.pred2 = ps->pred[2];
     }
 
+#ifdef MJ_X_PROGPRIO
+    // the issue arbiter serves the oldest wave first, then by priority: the longest chains are the launch's critical path
+    {
+        const int bits = seg_bits[seg_id];
+        if (bits > (1 << 20)) __builtin_amdgcn_s_setprio(3);
+        else if (bits > (1 << 18)) __builtin_amdgcn_s_setprio(2);
+        else if (bits > (1 << 16)) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     uint16_t *lut = s_lut[wave];
     if (is_dc) {
         for (int t = 0; t < sc->n_comp; ++t) load_dc_lut(lut + t * kPDcLut, lut11p, sc->dc_tab[t], lane);

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
                 fb |= fb >> 4; fb |= fb >> 2; fb |= fb >> 1; fb &= 0x0101010101010101ull;       // one bit per block with a flagged row
                 const uint64_t rb8 = __ballot(real && j == 0);
                 if (lane == 0) {
-                    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(a.dump + kStage2DumpBytes - 64);
+                    unsigned long long *cnt = a.level_counts;
                     atomicAdd(cnt, (unsigned long long)__builtin_popcountll(rb8));
                     if (fb) atomicAdd(cnt + 1, (unsigned long long)__builtin_popcountll(fb));
                 }
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
                 const uint64_t sb = __ballot(mine && errd > (0.5 - 9.5367431640625e-07));
                 if constexpr (SEAMS) {
                     const uint64_t s3 = __ballot(mine && j == 0 && ((sb >> (lane & 56)) & 0xFF) != 0);
-                    if (lane == 0 && s3) atomicAdd(reinterpret_cast<unsigned long long *>(a.dump + kStage2DumpBytes - 64) + 2, (unsigned long long)__builtin_popcountll(s3));
+                    if (lane == 0 && s3) atomicAdd(a.level_counts + 2, (unsigned long long)__builtin_popcountll(s3));
                 }
                 uint4 ow2;
                 ow2.x = (uint32_t)(o[0] & 0xFFFF) | ((uint32_t)o[1] << 16);

@@ -555,6 +555,46 @@ def test_gpu_segmentation_hands_back_what_it_cannot_segment(dec_gs):
     assert np.array_equal(dec_gs.decode([trailing])[0], vec["rgb"])
 
 
+def test_gpu_segmentation_device_blob_with_only_the_documented_slack(dec):
+    """MJ_FLAG_GPU_SEGMENT asks a caller for 16 readable bytes behind blob_len, no more.  A plan of such a blob that takes the
+    wave form of stage 1 (a generic sampling layout here; the kernel reads up to 508 bytes behind a segment's start) must
+    work on its own padded copy: the caller's allocation ends 16 bytes behind a tiny last file, what follows it in memory
+    is poison, and the decode has to come out right — twice, with the caller's bytes changed in between (the copy is made
+    at every execute, on the execute's stream)."""
+    import torch
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B, parse_jpeg
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import craft_jpeg
+    files = [craft_jpeg.craft_baseline(40, 24, [(1, 1), (2, 1), (1, 2)], seed=5, restart_interval=2),
+             craft_jpeg.craft_baseline(8, 8, [(1, 1), (2, 1), (1, 2)], seed=6, restart_interval=0)]        # one MCU: a few bytes of scan
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0, [parse_jpeg(f, headers_only=True) for f in files])
+    assert prep.flags & B.MJ_FLAG_GPU_SEGMENT
+    used = int(prep.file_offsets[-1])                       # the files, back to back (4-byte aligned each)
+    prep.blob = prep.blob[:used]                            # blob_len = what the files take: the caller pads 16 bytes, not 1024
+    dev = torch.device("cuda", 0)
+    arena = torch.full((used + 16 + 4096,), 0xFF, dtype=torch.uint8, device=dev)      # poison behind the 16 bytes
+    arena[:used] = torch.from_numpy(prep.blob).to(dev)
+    arena[used:used + 16] = 0
+    assert arena.data_ptr() % 16 == 0
+    plan = B.Plan(dec.ctx, prep.to_c(arena.data_ptr()), {"prep": prep, "n_images": 2})
+    try:
+        assert plan.stage1_form() & 15 == B.MJ_FORM_WAVE
+        for rep in range(2):
+            plan.execute()
+            plan.sync()
+            out = plan.read(rgb=True)
+            assert not out["status"].any()
+            off = 0
+            for f, (w, h, nc) in zip(files, prep.shapes):
+                ref = oracle.decode(f)["rgb"]
+                assert np.array_equal(out["rgb"][off:off + w * h * nc].reshape(ref.shape), ref), rep
+                off += w * h * nc
+            arena[:used] = torch.from_numpy(prep.blob).to(dev)          # (same bytes again: what matters is that execute re-reads them)
+    finally:
+        plan.close()
+
+
 def test_device_resident_output_and_dlpack(dec, dec_rm):
     """§8 f-4: pixels stay in HBM as torch tensors (views of one packed buffer); any DLPack consumer can take them."""
     import torch
