@@ -228,6 +228,17 @@ int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, u
  * stream, measured with HIP events recorded on that stream. */
 int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms);
 
+/* Test and tuning switches, process-wide.  The defaults are what the library measured as best; the parity tests use the
+ * switches to force every form of a stage through the same inputs, the probe scripts to sweep geometries.  The library does
+ * NOT read them from the environment (a stray variable must not change how a production decode runs).  Read when a plan is
+ * created (forms, orders, chunk sizes) or when it executes (lane geometry).  value NULL or "" = back to the default.
+ *   MJ_HUFFMAN        wave | lanes | lanes11 | sync   stage-1 form              MJ_SEG_ORDER     blob | binned | striped
+ *   MJ_SYNC_ROUNDS    0..64  repair rounds           MJ_SYNC_CHUNK   256..65536 bytes   MJ_SYNC_WARM   run-up bytes
+ *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
+ *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64   MJ_LANES_RING  64 | 128      MJ_STAGE2_CHUNK  strips per stage-2 job
+ * Returns MJ_ERR_INVALID for a name that is none of these.  mj_plan_stage1_form() reports what a plan ended up with. */
+int mj_set_option(const char *name, const char *value);
+
 /* Diagnostic of the fast stage 2 (reference :1561-1573): of the blocks the plan's latest stage-2 execute WITH seam outputs
  * (MJ_FLAG_KEEP_IDCT / MJ_FLAG_KEEP_PLANES) put through the IDCT, counts[0] = all of them, counts[1] = how many the fp32
  * first level could not decide (they went to the fp64 level), counts[2] = how many of those went on to the exact-order

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -311,6 +312,39 @@ int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 
 }  // namespace
 
 namespace mj {
+namespace {
+struct OptionTable {
+    std::mutex mu;
+    // (values live as long as the process: a returned pointer stays valid until the same option is set again)
+    struct Entry { const char *name; std::string value; bool set; };
+    Entry e[12] = {{"MJ_HUFFMAN", "", false},      {"MJ_SEG_ORDER", "", false},   {"MJ_SYNC_ROUNDS", "", false}, {"MJ_SYNC_CHUNK", "", false},
+                   {"MJ_SYNC_WARM", "", false},    {"MJ_PROG_BANDS", "", false},  {"MJ_PROG_ROWS", "", false},   {"MJ_PROG_FAST", "", false},
+                   {"MJ_LANES_WAVES", "", false},  {"MJ_LANES_PER_WAVE", "", false}, {"MJ_LANES_RING", "", false}, {"MJ_STAGE2_CHUNK", "", false}};
+};
+OptionTable g_options;
+}  // namespace
+const char *opt(const char *name) {
+    {
+        std::lock_guard<std::mutex> lk(g_options.mu);
+        for (auto &x : g_options.e)
+            if (!strcmp(x.name, name)) { if (x.set) return x.value.c_str(); break; }
+    }
+#ifdef MJ_DIAGNOSTIC
+    return getenv(name);
+#else
+    return nullptr;
+#endif
+}
+int set_opt(const char *name, const char *value) {
+    std::lock_guard<std::mutex> lk(g_options.mu);
+    for (auto &x : g_options.e)
+        if (!strcmp(x.name, name)) {
+            x.set = value != nullptr && value[0] != 0;
+            x.value = x.set ? value : "";
+            return MJ_OK;
+        }
+    return MJ_ERR_INVALID;
+}
 __constant__ uint8_t c_nat[64] = {
     0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
@@ -418,6 +452,11 @@ void mj_plan_destroy(mj_plan *p) {
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
     delete p;
+}
+
+int mj_set_option(const char *name, const char *value) {
+    if (!name) return MJ_ERR_INVALID;
+    return mj::set_opt(name, value);
 }
 
 int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
@@ -684,7 +723,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             int max_rows = 1;
             for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
             p->prog_banded = true;
-            if (const char *e = getenv("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
+            if (const char *e = mj::opt("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
             p->prog_rows_per_band = p->prog_banded ? 2 : max_rows;
             if (p->prog_banded) {
                 // every launch of the pipeline covers all segments, and more workgroups than the chip holds at once: the long
@@ -699,7 +738,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 p->prog_rest_off = 0;
                 while (p->prog_rest_off < (int64_t)psegs.size() && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
             }
-            if (const char *e = getenv("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
+            if (const char *e = mj::opt("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
             p->prog_steps = n_bands + n_ord - 1;
         }
@@ -732,9 +771,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         const int pieces_max = (max_spc + 23) / 24;
         p->chunk_strips = (max_spc + pieces_max - 1) / pieces_max;
-#ifdef MJ_DIAGNOSTIC
-        if (getenv("MJ_STAGE2_CHUNK")) p->chunk_strips = std::max(1, atoi(getenv("MJ_STAGE2_CHUNK")));      // experiment: strips per job
-#endif
+        if (const char *e = mj::opt("MJ_STAGE2_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 4096) p->chunk_strips = v; }
         std::vector<int64_t> tp(b->n_images + 1, 0);
         for (int i = 0; i < b->n_images; ++i) {
             // strips run down the MCU columns of the image the kernel sees (the transposed one for row-major plans)
@@ -795,7 +832,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     if (role[t] == 2) ac_pk |= (uint64_t)n_ac++ << (8 * t);
                     else if (role[t] == 1) { dc_pk |= (uint64_t)n_dc << (8 * t); dct_pk |= (uint64_t)t << (8 * n_dc); ++n_dc; }
                 }
-                const char *f13 = getenv("MJ_HUFFMAN");
+                const char *f13 = mj::opt("MJ_HUFFMAN");
                 if (f13 && !strcmp(f13, "lanes11")) ok13 = false;
                 if (ok13 && mj::lanes13_fits(n_ac, n_dc)) {
                     const int AB = 13, AS = 1 << AB, SLOT = mj::kLanes13SlotBytes / 4;
@@ -881,7 +918,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             }
         }
         // one segment per lane pays off once there are enough segments to fill the chip that way
-        const char *force = getenv("MJ_HUFFMAN");
+        const char *force = mj::opt("MJ_HUFFMAN");
         // (a table serving as DC and as AC table at once, or a stream beyond 32-bit offsets, stays with the wave form)
         // stage 0 places segment i's stream at dword (begin_i >> 2) + i: that needs the segments (or, with the GPU
         // marker scan, the images' byte ranges) in ascending, non-overlapping blob order — what any packer produces
@@ -940,15 +977,15 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // image already wins: the alternative is one serial walk per segment); MJ_HUFFMAN=sync forces it, wave / lanes
         // exclude it.  With the GPU marker scan the segment lengths are not known here: possible when every image is one
         // segment (no DRI), whose byte range bounds its length.
-        if (const char *e = getenv("MJ_SYNC_ROUNDS")) { const int v = atoi(e); if (v >= 0 && v <= 64) p->sync_rounds = v; }
-        if (const char *e = getenv("MJ_SYNC_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536 && v % 4 == 0) p->sync_chunk_bytes = v; }
+        if (const char *e = mj::opt("MJ_SYNC_ROUNDS")) { const int v = atoi(e); if (v >= 0 && v <= 64) p->sync_rounds = v; }
+        if (const char *e = mj::opt("MJ_SYNC_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536 && v % 4 == 0) p->sync_chunk_bytes = v; }
         bool one_seg_each = true;
         for (const auto &jb : jobs) one_seg_each = one_seg_each && jb.n_seg == 1;
         if (!jobs.empty() && one_seg_each)
             for (size_t i = 0; i < jobs.size(); ++i) segs[(size_t)jobs[i].first_seg].len = (int32_t)(jobs[i].end - jobs[i].begin);   // upper bound; the scan writes the real one
         int64_t total_len = 0, est_chunks = 0;
         for (const auto &g : segs) total_len += g.len;
-        if (!getenv("MJ_SYNC_CHUNK")) {
+        if (!mj::opt("MJ_SYNC_CHUNK")) {
             // Chunk size by the amount of stream: small batches want many short chunks (a single 1080p image: 1.65 ms with
             // 512-byte chunks, 3.0 ms with 2 KiB ones — six wavefronts' worth), big ones fewer long ones (the run-up in
             // front of every chunk and the per-chunk records cost; 1024 images: 19.0 ms at 2 KiB, 20.2 ms at 512 bytes).
@@ -1039,7 +1076,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         }
         if (p->use_lanes && !p->use_sync && p->d_lut13 && jobs.empty() && segs.size() > 1) {
             // the lane form deals restart segments out by length (huffman_lanes13.hip); MJ_SEG_ORDER = blob | binned | striped (tests, measurements)
-            const char *e = getenv("MJ_SEG_ORDER");
+            const char *e = mj::opt("MJ_SEG_ORDER");
             // (measured, 1024 x 1080p: files of mixed content 7.5 ms in blob order, 7.9 binned, 6.65 striped; files of one kind
             // 4.01 / 4.13 — so segments of similar length stay in blob order)
             int64_t sum_len = 0;
@@ -1070,7 +1107,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             p->prog_fast = false;
             for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
                 p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
-            if (const char *e = getenv("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
+            if (const char *e = mj::opt("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
             if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
             if (p->prog_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts

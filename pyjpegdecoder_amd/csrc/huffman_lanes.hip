@@ -389,19 +389,12 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
 // Lanes per wavefront for `n_segs` units of work with `n_slots` tables in LDS (api.hip asks too: a batch with more
 // tables than LDS holds gets per-workgroup table lists, which depend on how the launch groups the segments).
 int lanes_per_wave(int64_t n_segs, int n_slots) {
-    static int lpw = 0;
-    if (lpw == 0) { const char *e = getenv("MJ_LANES_PER_WAVE"); lpw = e ? atoi(e) : -1; if (lpw != -1 && (lpw < 2 || lpw > 64)) lpw = -1; }
-    if (lpw > 0) return lpw;
+    if (const char *e = opt("MJ_LANES_PER_WAVE")) { const int lpw = atoi(e); if (lpw >= 2 && lpw <= 64) return lpw; }
     // measured on MI355X: the kernel is instruction-issue bound, every instruction costing the same
     // whatever the number of active lanes, and latency bound below ~2 waves per SIMD.  All workgroups are resident
     // at once and run equally long, so what matters besides ~3-4 waves per SIMD is that every CU gets the SAME
     // number of workgroups: lanes per wave = segments / (4 workgroups x 4 waves x CUs), rounded up.
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    }
+    const int cus = device_cus();
     // ... and when there are more segments than one such round holds, as many equal rounds as needed: lanes per wave
     // capped where four workgroups still fit a CU's LDS, then spread evenly over the rounds
     auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_slots * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16; };
@@ -434,11 +427,11 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
     const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {false};
+    if (!attr_set[current_device()]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
+        attr_set[current_device()] = true;
     }
     if (wg_tabs)
         hipLaunchKernelGGL(k_huffman_lanes<true>, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images,

@@ -659,16 +659,11 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
                                   int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk,
                                   int16_t *coef, int32_t *status, int transposed, const DevVSeg *vsegs, const int32_t *by_length, int order_mode) {
     if (n_segs == 0) return hipSuccess;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    }
-    // tuning hooks (tools/stage_probe.py): waves per workgroup, lanes per wave
+    const int cus = device_cus();
+    // tuning switches (mj_set_option; tools/stage_probe.py): waves per workgroup, lanes per wave
     int env_nw = -1, env_lpw = -1;
-    if (const char *e = getenv("MJ_LANES_WAVES")) { env_nw = atoi(e); if (env_nw < 1 || env_nw > 16) env_nw = -1; }
-    if (const char *e = getenv("MJ_LANES_PER_WAVE")) { env_lpw = atoi(e); if (env_lpw < 1 || env_lpw > 64) env_lpw = -1; }
+    if (const char *e = opt("MJ_LANES_WAVES")) { env_nw = atoi(e); if (env_nw < 1 || env_nw > 16) env_nw = -1; }
+    if (const char *e = opt("MJ_LANES_PER_WAVE")) { env_lpw = atoi(e); if (env_lpw < 1 || env_lpw > 64) env_lpw = -1; }
     // One workgroup per CU (the tables take most of its LDS), all workgroups resident at once and equally loaded: the
     // segments a CU gets are spread over `nw` waves (the kernel is bound by instruction issue and LDS latency: about three
     // waves per SIMD keep a SIMD busy, more lanes per wave cost lock-step waiting).
@@ -687,12 +682,12 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
         blocks = (n_segs + (int64_t)nw * lpw - 1) / ((int64_t)nw * lpw);
         if (rounds == 1 || ring == 64) break;
     }
-    if (const char *e = getenv("MJ_LANES_RING")) { const int v = atoi(e); if ((v == 64 || v == 128) && lds13(n_ac, n_dc, nw, lpw, v) <= 160 * 1024) ring = v; }
+    if (const char *e = opt("MJ_LANES_RING")) { const int v = atoi(e); if ((v == 64 || v == 128) && lds13(n_ac, n_dc, nw, lpw, v) <= 160 * 1024) ring = v; }
     const size_t lds = lds13(n_ac, n_dc, nw, lpw, ring);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {false};
+    if (!attr_set[current_device()]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes13), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[current_device()] = true;
     }
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, dstream, seg_bits, segs, n_segs, images, huff,
                        lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk, coef, status, lpw, transposed, vsegs, by_length, order_mode, ring);

@@ -298,13 +298,13 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
     if (wg_tabs) n_huff = wg_slots;                             // table slots in LDS
     const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
-    static bool attr_set = false;
-    if (!attr_set) {                                            // 16 table slots: just over the 64 KiB default
+    static bool attr_set[kMaxDevices] = {false};
+    if (!attr_set[current_device()]) {                          // 16 table slots: just over the 64 KiB default
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
+        attr_set[current_device()] = true;
     }
-    const int warm = getenv("MJ_SYNC_WARM") ? atoi(getenv("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
+    const int warm = opt("MJ_SYNC_WARM") ? atoi(opt("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
                            chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs);

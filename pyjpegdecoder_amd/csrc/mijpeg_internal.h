@@ -200,6 +200,13 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
 // how that launch groups its units of work: lanes per wavefront (a workgroup = 4 waves = 4 x this many consecutive units)
 int lanes_per_wave(int64_t n_segs, int n_slots);
 
+// Test and tuning switches (mj_set_option, include/mijpeg.h): process-wide, set through the API only — the product library does
+// not look at the environment for them (a stray variable must not change how a production decode runs); the diagnostic build
+// (make DIAG=1) falls back to an environment variable of the same name so that the probe scripts can flip them per run.
+// Returns the value or nullptr.
+const char *opt(const char *name);
+int set_opt(const char *name, const char *value);
+
 constexpr size_t kStage2DumpBytes = 4096 * 1024;    // 1 KiB per workgroup of the largest persistent grid
 struct ReconArgs {
     const DevImage *images;
@@ -241,7 +248,20 @@ int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
 // jobs: pieces of at most a.chunk_strips strips of one MCU column, numbered image by image (job_prefix[i] = first job of image i)
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);
-constexpr int kMaxDevices = 64;      // launch-geometry caches are per device (one process may hold contexts on several)
+// Launch-geometry caches are per device: one process may hold contexts on several GPUs (mijpeg.h: one context per GPU per
+// thread), and a function attribute set on one device says nothing about the next.  (Racing first uses write the same values.)
+constexpr int kMaxDevices = 64;
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < kMaxDevices ? d : 0; }
+inline int device_cus() {
+    static int cus[kMaxDevices] = {0};
+    const int d = current_device();
+    if (cus[d] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c < 1) c = 256;
+        cus[d] = c;
+    }
+    return cus[d];
+}
 // MJ_LAYOUT_PLANAR_*: every image's interleaved pixels (x-major or row-major, as stage 2 wrote them) -> its three planes
 hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
                                           const uint8_t *interleaved, uint8_t *planar);

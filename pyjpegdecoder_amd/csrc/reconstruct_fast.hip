@@ -1007,12 +1007,10 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
     // persistent grid = at most what the chip can hold at once; its waves draw the jobs from a.work_counter
     auto launch = [&](auto kernel) {
         static int resident_of[kMaxDevices] = {0};     // per instantiation and device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        int &resident = resident_of[dev >= 0 && dev < kMaxDevices ? dev : 0];
+        int &resident = resident_of[current_device()];
         if (resident == 0) {
-            int cus = 256, per_cu = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            int per_cu = 0;
+            const int cus = device_cus();
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
             resident = per_cu * cus;
         }

@@ -34,3 +34,17 @@ def load_golden(name):
     raw = (GOLDEN / "files" / f"{name}.jpg").read_bytes()
     vec = np.load(GOLDEN / "files" / f"{name}.npz")
     return raw, vec
+
+
+@pytest.fixture
+def tune():
+    """Library switches (mj_set_option: stage-1 form, segment order, chunk sizes ...) for one test; back to the defaults afterwards."""
+    from pyjpegdecoder_amd import _binding as B
+    touched = []
+
+    def _set(name, value):
+        B.set_option(name, value)
+        touched.append(name)
+    yield _set
+    for name in touched:
+        B.set_option(name, None)

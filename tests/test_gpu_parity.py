@@ -353,10 +353,10 @@ def test_batch_of_1080p_roundtrip_properties(dec):
 
 
 @pytest.mark.parametrize("mode", ["wave", "lanes"])
-def test_both_stage1_forms_every_fixture(dec, mode, monkeypatch):
+def test_both_stage1_forms_every_fixture(dec, mode, monkeypatch, tune):
     """Stage 1 exists in two forms (one restart segment per wavefront / per lane); force each in turn and
     require the reference's coefficients and pixels from both."""
-    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    tune("MJ_HUFFMAN", mode)
     names = golden_names()
     raws = [load_golden(n)[0] for n in names]
     imgs, seams = dec.decode(raws, return_seams=True)
@@ -367,9 +367,9 @@ def test_both_stage1_forms_every_fixture(dec, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["wave", "lanes"])
-def test_both_stage1_forms_1080p_and_errors(dec, mode, monkeypatch):
+def test_both_stage1_forms_1080p_and_errors(dec, mode, monkeypatch, tune):
     from pyjpegdecoder_amd import CorruptedJpeg, parse_jpeg
-    monkeypatch.setenv("MJ_HUFFMAN", mode)
+    tune("MJ_HUFFMAN", mode)
     name = "c3_1920x1080_420_dri120"
     raw, _ = load_golden(name)
     meta = golden_index()[name]
@@ -417,8 +417,8 @@ def test_progressive_rowmajor(dec_rm, name):
 
 
 @pytest.mark.parametrize("mode", ["wave", "lanes"])
-def test_rowmajor_both_stage1_forms(dec_rm, mode, monkeypatch):
-    monkeypatch.setenv("MJ_HUFFMAN", mode)
+def test_rowmajor_both_stage1_forms(dec_rm, mode, monkeypatch, tune):
+    tune("MJ_HUFFMAN", mode)
     names = golden_names()
     imgs, seams = dec_rm.decode([load_golden(n)[0] for n in names], return_seams=True)
     for n, img, seam in zip(names, imgs, seams):
@@ -507,8 +507,8 @@ def test_gpu_segmentation_fixture_every_seam(dec_gs, name):
 
 
 @pytest.mark.parametrize("mode", ["wave", "lanes"])
-def test_gpu_segmentation_batches_and_1080p(dec_gs, mode, monkeypatch):
-    monkeypatch.setenv("MJ_HUFFMAN", mode)
+def test_gpu_segmentation_batches_and_1080p(dec_gs, mode, monkeypatch, tune):
+    tune("MJ_HUFFMAN", mode)
     names = golden_names()
     for n, img in zip(names, dec_gs.decode([load_golden(n)[0] for n in names])):
         assert np.array_equal(img, load_golden(n)[1]["rgb"]), n
@@ -593,6 +593,63 @@ def test_gpu_segmentation_device_blob_with_only_the_documented_slack(dec):
             arena[:used] = torch.from_numpy(prep.blob).to(dev)          # (same bytes again: what matters is that execute re-reads them)
     finally:
         plan.close()
+
+
+def test_two_contexts_on_one_device_from_two_threads():
+    """mijpeg.h: one context per GPU per thread.  Two threads, a context each on device 0, decode different batches at the same
+    time through every stage-1 form's launcher (whose launch-geometry caches are per device, not per process)."""
+    import threading
+    from oracle import oracle
+    from pyjpegdecoder_amd import BatchDecoder
+    from tools import synth
+    jobs = [[synth.synth_jpeg(300 + 10 * t + i, 160 + 16 * i, 120 + 8 * t, 80, ("420", "444")[t], (0, 4)[i % 2], 14.0) for i in range(6)] for t in range(2)]
+    outs, errs = [None, None], []
+
+    def work(t):
+        try:
+            d = BatchDecoder(device=0)
+            try:
+                for _ in range(3):
+                    outs[t] = d.decode(jobs[t])
+            finally:
+                d.close()
+        except Exception as exc:      # noqa: BLE001 — reported below, in the main thread
+            errs.append(exc)
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errs, errs
+    for t in range(2):
+        for f, img in zip(jobs[t], outs[t]):
+            assert np.array_equal(img, oracle.decode(f)["rgb"])
+
+
+def test_the_environment_does_not_choose_the_stage1_form(dec, monkeypatch):
+    """The library's switches are set through mj_set_option only: a stray MJ_HUFFMAN in the environment of a production
+    process changes nothing (round 3's library read it with getenv at every plan creation)."""
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    raw, _ = load_golden("c3_1920x1080_420_dri120")
+    prep = prepare_batch([raw] * 16, B.MJ_LAYOUT_XMAJOR, 0)
+    forms = []
+    for env in (None, "wave"):
+        if env:
+            monkeypatch.setenv("MJ_HUFFMAN", env)
+        plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 16})
+        forms.append(plan.stage1_form() & 15)
+        plan.close()
+    assert forms[0] == forms[1] != B.MJ_FORM_WAVE
+    B.set_option("MJ_HUFFMAN", "wave")
+    try:
+        plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 16})
+        assert plan.stage1_form() & 15 == B.MJ_FORM_WAVE
+        plan.close()
+    finally:
+        B.set_option("MJ_HUFFMAN", None)
+    with pytest.raises(ValueError):
+        B.set_option("MJ_NO_SUCH_SWITCH", "1")
 
 
 def test_device_resident_output_and_dlpack(dec, dec_rm):
@@ -802,7 +859,7 @@ def test_files_with_their_own_huffman_tables_keep_the_fast_forms(seg):
         d.close()
 
 
-def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
+def test_damaged_streams_never_hang_or_crash(dec, dec_gs, tune):
     """Robustness: random byte damage inside the entropy-coded data either decodes to some image or raises the
     reference's CorruptedJpeg — in both stage-1 forms and with either segmentation — and never takes the GPU down."""
     import os
@@ -822,7 +879,7 @@ def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
         damaged.append(raw[:lo + (hi - lo) // 2] + raw[hi:])          # half the entropy data missing
         damaged.append(raw[:hi] + b"\xff\xd9")
         for mode in ("wave", "lanes"):
-            os.environ["MJ_HUFFMAN"] = mode
+            tune("MJ_HUFFMAN", mode)
             try:
                 for d in (dec, dec_gs):
                     for f in damaged:
@@ -833,10 +890,10 @@ def test_damaged_streams_never_hang_or_crash(dec, dec_gs):
                             pass
                     assert np.array_equal(d.decode([raw])[0], vec["rgb"])       # the decoder is still healthy
             finally:
-                os.environ.pop("MJ_HUFFMAN", None)
+                tune("MJ_HUFFMAN", None)
 
 
-def test_damaged_progressive_streams_both_walks_agree(dec, monkeypatch):
+def test_damaged_progressive_streams_both_walks_agree(dec, monkeypatch, tune):
     """Random byte damage inside the scans of progressive files: the stream walks (progressive_fast.hip) and the general
     walk (progressive.hip) implement the same reader — zeros behind a segment's end, the same overrun / desync / bad-code
     rules — so they must fail on the same files and, where the damage still decodes, leave the same pixels."""
@@ -858,9 +915,9 @@ def test_damaged_progressive_streams_both_walks_agree(dec, monkeypatch):
         outcomes = {}
         for walk in ("stream", "general"):
             if walk == "general":
-                monkeypatch.setenv("MJ_PROG_FAST", "0")
+                tune("MJ_PROG_FAST", "0")
             else:
-                monkeypatch.delenv("MJ_PROG_FAST", raising=False)
+                tune("MJ_PROG_FAST", None)
             res = []
             for f in damaged:
                 try:
@@ -924,7 +981,7 @@ def test_caller_stream_and_device_blob(dec):
             plan.close()
 
 
-def test_one_large_image_and_ragged_batch(dec, dec_rm):
+def test_one_large_image_and_ragged_batch(dec, dec_rm, tune):
     """A 24-megapixel 4:2:0 image (6016x4000, no DRI: one 4 MB segment through the wave form; with DRI through the
     lane form) and a batch whose images differ in size (per-image tile prefix, binary search in stage 2)."""
     from tools import synth
@@ -936,11 +993,11 @@ def test_one_large_image_and_ragged_batch(dec, dec_rm):
     big_dri = synth.synth_jpeg(5, 6016, 4000, 85, "420", 47, 12.0)          # 47 MCUs per segment: 2000 segments
     ragged = [big_dri] + [synth.synth_jpeg(100 + i, 333 + 160 * i, 1200 - 97 * i, 85, "420", 11, 12.0) for i in range(9)]
     import os
-    os.environ["MJ_HUFFMAN"] = "lanes"
+    tune("MJ_HUFFMAN", "lanes")
     try:
         outs = dec.decode(ragged)
     finally:
-        os.environ.pop("MJ_HUFFMAN", None)
+        tune("MJ_HUFFMAN", None)
     assert np.array_equal(outs[0], ref)
     for f, img in zip(ragged[1:], outs[1:]):
         assert np.array_equal(img, oracle.decode(f)["rgb"])
@@ -980,7 +1037,7 @@ def test_full_config3_batch_properties(dec):
         assert np.array_equal(rgb[i].reshape(W, H, 3), oracle.decode(raws[d])["rgb"]), d
 
 
-def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
+def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs, tune):
     """80 seeded files over size x sampling x quality x restart interval x noise, decoded in mixed batches by the
     x-major, the row-major and the GPU-segmenting decoder; every pixel against the oracle."""
     from tools import synth
@@ -1001,19 +1058,19 @@ def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs):
     # and once more with every stage-1 form forced (the sync form then cuts even these small segments where it can)
     import os
     for mode in ("wave", "lanes", "sync"):
-        os.environ["MJ_HUFFMAN"] = mode
+        tune("MJ_HUFFMAN", mode)
         try:
             for i, (img, ref) in enumerate(zip(dec.decode(files), refs)):
                 assert np.array_equal(img, ref), (mode, i)
         finally:
-            os.environ.pop("MJ_HUFFMAN", None)
+            tune("MJ_HUFFMAN", None)
 
 
 # ---- long segments: synchronisation passes + virtual segments (huffman_sync.hip) ---------------------------------------
-def test_sync_form_every_fixture(dec, monkeypatch):
+def test_sync_form_every_fixture(dec, monkeypatch, tune):
     """MJ_HUFFMAN=sync forces the third stage-1 form on everything: segments shorter than a chunk are one virtual
     segment each, longer ones are cut up; coefficients and pixels as the reference's."""
-    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    tune("MJ_HUFFMAN", "sync")
     names = golden_names()
     imgs, seams = dec.decode([load_golden(n)[0] for n in names], return_seams=True)
     for n, img, seam in zip(names, imgs, seams):
@@ -1027,10 +1084,10 @@ def test_sync_form_every_fixture(dec, monkeypatch):
     ("420", 1920, 1080, 0, 85, 12.0), ("420", 1024, 768, 1500, 90, 30.0), ("440", 333, 999, 0, 85, 5.0), ("420", 800, 600, 0, 100, 60.0),
     ("420", 1200, 900, 0, 40, 0.0),
 ])
-def test_sync_form_files_without_restart_markers(dec, dec_rm, ss, w, h, ri, q, sigma, monkeypatch):
+def test_sync_form_files_without_restart_markers(dec, dec_rm, ss, w, h, ri, q, sigma, monkeypatch, tune):
     from oracle import oracle
     from tools import synth
-    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    tune("MJ_HUFFMAN", "sync")
     raw = synth.synth_jpeg(w * 7 + h, w, h, q, ss, ri, sigma)
     ref = oracle.decode(raw)
     (img,), (seam,) = dec.decode([raw], return_seams=True)
@@ -1039,7 +1096,7 @@ def test_sync_form_files_without_restart_markers(dec, dec_rm, ss, w, h, ri, q, s
     assert np.array_equal(np.swapaxes(dec_rm.decode([raw])[0], 0, 1), ref["rgb"])
 
 
-def test_sync_form_batch_and_damage(dec, monkeypatch):
+def test_sync_form_batch_and_damage(dec, monkeypatch, tune):
     """A batch of DRI-less files picks the form by itself (no env); damaged streams still end in CorruptedJpeg or an image."""
     from oracle import oracle
     from tools import synth
@@ -1055,7 +1112,7 @@ def test_sync_form_batch_and_damage(dec, monkeypatch):
             assert np.array_equal(np.swapaxes(img, 0, 1), oracle.decode(f)["rgb"])
     finally:
         d2.close()
-    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    tune("MJ_HUFFMAN", "sync")
     rng = np.random.default_rng(99)
     raw = files[0]
     sc = parse_jpeg(raw).scans[0]
@@ -1070,14 +1127,14 @@ def test_sync_form_batch_and_damage(dec, monkeypatch):
     assert np.array_equal(dec.decode([raw])[0], oracle.decode(raw)["rgb"])
 
 
-def test_sync_form_piece_boundaries_inside_stuffing(dec, monkeypatch):
+def test_sync_form_piece_boundaries_inside_stuffing(dec, monkeypatch, tune):
     """Stage 0 of long segments works in 16 KiB pieces; a piece whose first byte is the 00 of an FF 00 pair must drop it
     on the word of the piece before.  A big, noisy, quality-100 file has hundreds of pieces and an 0xFF every ~100
     bytes: make sure some boundaries do split a pair, then require the reference's coefficients."""
     from oracle import oracle
     from tools import synth
     from pyjpegdecoder_amd import parse_jpeg
-    monkeypatch.setenv("MJ_HUFFMAN", "sync")
+    tune("MJ_HUFFMAN", "sync")
     hits = 0
     for seed in (1, 2, 3):
         raw = synth.synth_jpeg(900 + seed, 1600, 1200, 100, "420", 0, 70.0)
@@ -1119,7 +1176,7 @@ def test_progressive_randomised_sweep(dec, dec_rm):
 
 
 @pytest.mark.parametrize("form", ["levels", "one_row_bands", "general_walk", "general_walk_levels"])
-def test_progressive_launch_forms(dec, dec_rm, form, monkeypatch):
+def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
     launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, two MCU rows per
     band — is what every other progressive test runs; here the other combinations decode every progressive fixture in one
@@ -1131,7 +1188,7 @@ def test_progressive_launch_forms(dec, dec_rm, form, monkeypatch):
     env = {"levels": {"MJ_PROG_BANDS": "0"}, "one_row_bands": {"MJ_PROG_ROWS": "1"}, "general_walk": {"MJ_PROG_FAST": "0"},
            "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"}}[form]
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune(k, v)
     names = prog_names()
     imgs, seams = dec.decode([load_golden(n)[0] for n in names], return_seams=True)
     for n, img, seam in zip(names, imgs, seams):
@@ -1184,7 +1241,7 @@ def test_one_shot_entry_point_through_ctypes(dec):
             boff += nb
 
 
-def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkeypatch):
+def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkeypatch, tune):
     """The synchronisation rounds are a fixed number, queued without a host round trip.  Make them fail on purpose — no
     run-up in front of the chunks, tiny chunks: nearly every guessed entry state is wrong and a chain of wrong guesses
     only gets one link shorter per round — and require (a) the device to notice (MJ_ST_UNCONVERGED, not a wrong image,
@@ -1193,10 +1250,10 @@ def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkey
     from tools import synth
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
-    monkeypatch.setenv("MJ_HUFFMAN", "sync")
-    monkeypatch.setenv("MJ_SYNC_WARM", "0")
-    monkeypatch.setenv("MJ_SYNC_CHUNK", "256")
-    monkeypatch.setenv("MJ_SYNC_ROUNDS", "0")          # (real streams re-synchronise within a chunk: four rounds always settle them)
+    tune("MJ_HUFFMAN", "sync")
+    tune("MJ_SYNC_WARM", "0")
+    tune("MJ_SYNC_CHUNK", "256")
+    tune("MJ_SYNC_ROUNDS", "0")          # (real streams re-synchronise within a chunk: four rounds always settle them)
     raw = synth.synth_jpeg(4242, 640, 480, 85, "420", 0, 12.0)
     prep = prepare_batch([raw], B.MJ_LAYOUT_XMAJOR, 0)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})
@@ -1457,7 +1514,7 @@ def test_colour_lattice_around_the_green_patch_threshold(dec):
 
 
 @pytest.mark.parametrize("order", ["striped", "binned", "blob"])
-def test_mixed_content_batch_at_size(dec, order, monkeypatch):
+def test_mixed_content_batch_at_size(dec, order, monkeypatch, tune):
     """1024 x 1080p DRI files of MIXED content (bench.py's `mixed_content`: quality 50..95, noise 0..80 above / below a random
     split row, so restart segments differ several-fold in bits), through the lane form with its segments dealt out by length
     in each of the three orders (MJ_SEG_ORDER): four files — the smallest, the largest, two others — against the oracle;
@@ -1471,7 +1528,7 @@ def test_mixed_content_batch_at_size(dec, order, monkeypatch):
     blob, offs = synth.synth_mixed_batch(nd, 424200, W, H, "420", 120)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(nd)]
     files = [raws[i % nd] for i in range(n)]
-    monkeypatch.setenv("MJ_SEG_ORDER", order)
+    tune("MJ_SEG_ORDER", order)
     dev = torch.device("cuda", 0)
     prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
     d_blob = torch.from_numpy(prep.blob).to(dev)
@@ -1551,7 +1608,7 @@ def _craft_grey_stream(width, blocks):
 
 
 @pytest.mark.parametrize("form", ["lanes", "lanes11", "wave", "sync"])
-def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch):
+def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch, tune):
     """The reference ends a block when a run carries the index to 64 or beyond and leaves that symbol's value bits unread
     (jpeg_decoder.py:849, :855-856); a symbol that lands exactly on index 63 ends it too, after its value.  Hand-written
     streams drive both through every stage-1 form — for the resolved-table lane form that is its after-the-loop store of
@@ -1573,7 +1630,7 @@ def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch):
     raw = _craft_grey_stream(8 * len(blocks), blocks)
     ref = oracle.decode(raw)
     assert ref["coef"][4, 63] == 1 and ref["coef"][3, 63] == 511 and ref["coef"][6, 63] == -1 and ref["coef"][8, 1] == 5
-    monkeypatch.setenv("MJ_HUFFMAN", form)
+    tune("MJ_HUFFMAN", form)
     (img,), (seam,) = dec.decode([raw], return_seams=True)
     assert np.array_equal(seam["coef"], ref["coef"])
     assert np.array_equal(img, ref["rgb"])
@@ -1653,12 +1710,12 @@ def _crafted_progressive_names():
 
 @pytest.mark.parametrize("fast", ["1", "0"])
 @pytest.mark.parametrize("name", _crafted_progressive_names())
-def test_crafted_progressive_scripts_against_the_reference(dec, name, fast, monkeypatch):
+def test_crafted_progressive_scripts_against_the_reference(dec, name, fast, monkeypatch, tune):
     """Interleaved DC scans over a subset of the components (also refined through the same subsets), several bands and
     refinement levels, end-of-band runs over hundreds of blocks, restart intervals, 4:1:0 / 2x4 / 3x1 luma and luma below the
     chroma resolution — decoded by the reference (tools/make_layout_goldens.py).  Both families of walks (MJ_PROG_FAST)."""
     g = np.load(GOLDEN / "crafted_progressive.npz")
-    monkeypatch.setenv("MJ_PROG_FAST", fast)
+    tune("MJ_PROG_FAST", fast)
     (img,), (seam,) = dec.decode([g[name + ".jpg"].tobytes()], return_seams=True)
     assert np.array_equal(seam["coef"], g[name + ".coef"])
     assert np.array_equal(seam["planes"], g[name + ".planes"])

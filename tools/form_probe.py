@@ -10,8 +10,8 @@ raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(min(n, 16))
 files = [raws[i % len(raws)] for i in range(n)]
 dec = BatchDecoder(0)
 for mode in ("wave", "lanes", "sync", None):
-    if mode: os.environ["MJ_HUFFMAN"] = mode
-    else: os.environ.pop("MJ_HUFFMAN", None)
+    if mode: B.set_option("MJ_HUFFMAN", mode)
+    else: B.set_option("MJ_HUFFMAN", None)
     prep = prepare_batch(files)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": n})
     plan.execute(); plan.sync()

@@ -12,7 +12,7 @@ files = [raws[i % 16] for i in range(n)]
 dec = BatchDecoder(0)
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ("wave", "lanes", "sync")
 for mode in modes:
-    os.environ["MJ_HUFFMAN"] = mode
+    B.set_option("MJ_HUFFMAN", mode)
     prep = prepare_batch(files)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": n})
     plan.execute(); plan.sync()

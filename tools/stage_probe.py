@@ -2,7 +2,8 @@
 environment settings, one line each.  Usage:
     python tools/stage_probe.py [--lib pyjpegdecoder_amd/libmijpeg_diag.so] [--batch 1024] [--distinct 64] \
         [--ri 120] [--layout xmajor] [--subsampling 420] NAME=VALUE[,NAME=VALUE]... (one experiment per argument; "" = defaults)
-Settings that the library reads at plan creation (MJ_HUFFMAN, MJ_LANES_PER_WAVE, ...) get a fresh plan."""
+Library switches (MJ_HUFFMAN, MJ_LANES_PER_WAVE, ...: mj_set_option) are set through the API, everything else (MJ_DEBUG_* of the
+diagnostic build) as environment; every experiment gets a fresh plan."""
 import argparse
 import os
 import sys
@@ -49,8 +50,13 @@ def main():
     for exp in args.exps:
         sets = [kv.split("=", 1) for kv in exp.split(",") if kv]
         old = {k: os.environ.get(k) for k, _ in sets}
-        for k, v in sets:
-            os.environ[k] = v
+        api_opts = []
+        for k, v in sets:          # the library's own switches go through mj_set_option; MJ_DEBUG_* etc. are the diagnostic build's environment
+            try:
+                B.set_option(k, v)
+                api_opts.append(k)
+            except ValueError:
+                os.environ[k] = v
         plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
         if d_rgb is None:
             d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
@@ -60,6 +66,8 @@ def main():
         s1, s2 = plan.time_stages(args.iters, d_rgb.data_ptr())
         print(f"{exp or 'default':50s} stage0+1 {s1:7.3f} ms   stage2 {s2:7.3f} ms", flush=True)
         plan.close()
+        for k in api_opts:
+            B.set_option(k, None)
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)

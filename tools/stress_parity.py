@@ -58,11 +58,11 @@ for seg in ("host", "gpu"):
         total += check(f"decode_device segment={seg} layout={layout}", dec.decode_device(files), layout == "rowmajor")
         dec.close()
 for form in ("wave", "lanes", "lanes11", "sync"):
-    os.environ["MJ_HUFFMAN"] = form
+    B.set_option("MJ_HUFFMAN", form)
     dec = BatchDecoder(0, segment="host")
     total += check(f"decode        stage-1 form forced: {form}", dec.decode(files))
     dec.close()
-os.environ.pop("MJ_HUFFMAN")
+B.set_option("MJ_HUFFMAN", None)
 dec = BatchDecoder(0, segment="gpu")
 chunks = [files[i:i + 97] for i in range(0, len(files), 97)]
 outs = [t for batch in dec.decode_device_iter(chunks) for t in batch]

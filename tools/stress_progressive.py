@@ -9,7 +9,7 @@ import numpy as np
 from PIL import Image
 from tools import synth
 from oracle import oracle
-from pyjpegdecoder_amd import BatchDecoder
+from pyjpegdecoder_amd import BatchDecoder, _binding as _B
 
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -39,7 +39,7 @@ bad = 0
 forms = {"bands": {}, "one-row bands": {"MJ_PROG_ROWS": "1"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"}}
 for name, env in forms.items():
     for k, v in env.items():
-        os.environ[k] = v
+        _B.set_option(k, v)
     for layout in ("xmajor", "rowmajor"):
         dec = BatchDecoder(device=0, layout=layout)
         t0 = time.time()
@@ -54,6 +54,6 @@ for name, env in forms.items():
         print(f"{name:14s} {layout:9s}: {len(files)} files, {n_bad} mismatches, {time.time() - t0:.1f} s", flush=True)
         bad += n_bad
     for k in env:
-        os.environ.pop(k, None)
+        _B.set_option(k, None)
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
