@@ -48,3 +48,17 @@ def tune():
     yield _set
     for name in touched:
         B.set_option(name, None)
+
+
+def oracle_rgb_all(raws, workers=None):
+    """The oracle's pixels of every file in `raws`, on a pool of threads (the C oracle runs outside the GIL): what lets the
+    at-size tests hold EVERY distinct image of a 1024-image batch to the oracle instead of a sample."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    if not raws:
+        return []
+    first = oracle.decode(raws[0])["rgb"]                     # (builds the oracle's tables once, before the threads start)
+    workers = workers or max(1, min(16, (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(workers) as pool:
+        return [first] + list(pool.map(lambda r: oracle.decode(r)["rgb"], raws[1:]))

@@ -7,7 +7,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, golden_index, golden_names, load_golden
+from conftest import GOLDEN, ROOT, golden_index, golden_names, load_golden, oracle_rgb_all
 
 pytestmark = pytest.mark.gpu
 
@@ -1006,7 +1006,7 @@ def test_one_large_image_and_ragged_batch(dec, dec_rm, tune):
 def test_full_config3_batch_properties(dec):
     """BASELINE configs[2] at full size: 1024 x 1920x1080 4:2:0 with DRI = one MCU row, 64 distinct images tiled.
     Size-independent properties: every copy of an image decodes to the same bytes wherever it sits in the batch
-    (checksums of all 1024 outputs), no image reports a status, and a sample of the distinct images equals the oracle."""
+    (checksums of all 1024 outputs), no image reports a status, and every one of the distinct images equals the oracle."""
     from tools import synth
     from oracle import oracle
     from pyjpegdecoder_amd import _binding as B
@@ -1032,9 +1032,9 @@ def test_full_config3_batch_properties(dec):
         by_image.setdefault((7 * i + i // distinct) % distinct, set()).add(int(sums[i]))
     assert all(len(v) == 1 for v in by_image.values()), "copies of one image differ"
     assert len({next(iter(v)) for v in by_image.values()}) == distinct
-    for d in (0, 17, 63):
+    for d, want in enumerate(oracle_rgb_all(raws)):           # every distinct image against the oracle, its copies against each other (above)
         i = next(k for k in range(n) if (7 * k + k // distinct) % distinct == d)
-        assert np.array_equal(rgb[i].reshape(W, H, 3), oracle.decode(raws[d])["rgb"]), d
+        assert np.array_equal(rgb[i].reshape(W, H, 3), want), d
 
 
 def test_randomised_sweep_against_oracle(dec, dec_rm, dec_gs, tune):
@@ -1305,7 +1305,7 @@ def test_planar_layouts(layout):
 
 def test_config5_progressive_1080p_batch_at_size(dec):
     """BASELINE configs[4] at its stated size: 1024 x 1080p 4:2:0 progressive (libjpeg's default 10-scan script as Pillow
-    writes it; 8 distinct files tiled).  Two images against the oracle, every replica against its first instance."""
+    writes it; 8 distinct files tiled).  Every distinct image against the oracle, every replica against its first instance."""
     import io
     torch = pytest.importorskip("torch")
     Image = pytest.importorskip("PIL.Image")
@@ -1332,8 +1332,8 @@ def test_config5_progressive_1080p_batch_at_size(dec):
         assert not plan.read(rgb=False)["status"].any()
         per = W * H * 3
         imgs = d_rgb.view(n, per)
-        for i in (0, 5):
-            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), oracle.decode(raws[i])["rgb"]), i
+        for i, want in enumerate(oracle_rgb_all(raws)):
+            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), want), i
         first = imgs[:nd]
         for k in range(1, n // nd):
             assert torch.equal(imgs[k * nd:(k + 1) * nd], first), k
@@ -1517,8 +1517,8 @@ def test_colour_lattice_around_the_green_patch_threshold(dec):
 def test_mixed_content_batch_at_size(dec, order, monkeypatch, tune):
     """1024 x 1080p DRI files of MIXED content (bench.py's `mixed_content`: quality 50..95, noise 0..80 above / below a random
     split row, so restart segments differ several-fold in bits), through the lane form with its segments dealt out by length
-    in each of the three orders (MJ_SEG_ORDER): four files — the smallest, the largest, two others — against the oracle;
-    every replica against its first instance."""
+    in each of the three orders (MJ_SEG_ORDER): all 64 distinct files against the oracle, every replica against its first
+    instance."""
     torch = pytest.importorskip("torch")
     from oracle import oracle
     from tools import synth
@@ -1541,9 +1541,8 @@ def test_mixed_content_batch_at_size(dec, order, monkeypatch, tune):
         assert not plan.read(rgb=False)["status"].any()
         per = W * H * 3
         imgs = d_rgb.view(n, per)
-        sizes = [len(r) for r in raws]
-        for i in sorted({int(np.argmin(sizes)), int(np.argmax(sizes)), 1, nd - 1}):
-            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), oracle.decode(raws[i])["rgb"]), i
+        for i, want in enumerate(oracle_rgb_all(raws)):
+            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), want), i
         first = imgs[:nd]
         for k in range(1, n // nd):
             assert torch.equal(imgs[k * nd:(k + 1) * nd], first), k
