@@ -6,6 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tools import synth
 from pyjpegdecoder_amd import BatchDecoder
+if os.environ.get("MJ_PROBE_LIB"):      # A/B against another build of the library
+    from pathlib import Path
+    from pyjpegdecoder_amd import _binding as _B
+    _B.LIB_PATH = Path(os.environ["MJ_PROBE_LIB"]).resolve()
 W, H = 1920, 1080
 blob, offs = synth.synth_batch(64, 0, W, H, 85, "420", 120)
 raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(64)]
