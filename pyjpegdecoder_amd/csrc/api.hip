@@ -1571,6 +1571,7 @@ int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage
             mj::dbg_lanes_report();
             mj::dbg_prog_report();
             if (getenv("MJ_DEBUG_STAGE1_WAVES")) mj::dbg_lanes13_waves_report();
+            if (getenv("MJ_DEBUG_PROG_STEP")) mj::dbg_prog_waves_report();
 #endif
         }
     }

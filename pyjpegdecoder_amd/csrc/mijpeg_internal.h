@@ -158,6 +158,7 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *blob, const DevSegm
 #ifdef MJ_DIAGNOSTIC
 void dbg_lanes_report();     // huffman_lanes.hip: prints and clears the in-loop stamps of MJ_DEBUG_STAGE1=3
 void dbg_prog_report();      // progressive_fast.hip: ... of the refining walk
+void dbg_prog_waves_report();       // progressive_fast.hip: when the waves of band launch MJ_DEBUG_PROG_STEP finished
 void dbg_lanes13_waves_report();   // huffman_lanes13.hip: when every wave of the last launch finished
 #endif
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS

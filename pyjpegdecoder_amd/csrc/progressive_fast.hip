@@ -47,6 +47,10 @@
 // a DevProgState.
 #include "mijpeg_internal.h"
 #include "prog_stream.h"
+#ifdef MJ_DIAGNOSTIC
+#include <algorithm>
+#include <vector>
+#endif
 
 namespace mj {
 
@@ -65,6 +69,33 @@ void dbg_prog_report() {
     fprintf(stderr, "[diag] refining walk of the Ah=1 luma scans, %llu waves: ", h[7]);
     for (int i = 0; i < 7; ++i) fprintf(stderr, "%s %.1f%%  ", nm[i], 100.0 * (double)h[i] / (double)tot);
     fprintf(stderr, "(%.1f Mcycles per wave)\n", (double)tot / (double)(h[7] ? h[7] : 1) / 1e6);
+}
+// when does every wave of one band launch (MJ_DEBUG_PROG_STEP) finish, and what was it walking?
+__device__ unsigned long long g_dbg_prog_waves[16384 * 3];
+void dbg_prog_waves_report() {
+    std::vector<unsigned long long> t(16384 * 3), z(16384 * 3, 0);
+    (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_dbg_prog_waves), t.size() * 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_prog_waves), z.data(), z.size() * 8);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < t.size(); i += 3) if (t[i] && t[i] < t0) t0 = t[i];
+    if (t0 == ~0ull) return;
+    // kinds: 0 DC first, 1 AC first, 2 AC refine luma, 3 AC refine chroma
+    std::vector<double> en[4], st[4], all;
+    for (size_t i = 0; i < t.size(); i += 3) if (t[i]) {
+        const int kind = (int)(t[i + 2] & 3);
+        en[kind].push_back((double)(t[i + 1] - t0) * 0.01); st[kind].push_back((double)(t[i] - t0) * 0.01); all.push_back(en[kind].back());
+    }
+    std::sort(all.begin(), all.end());
+    fprintf(stderr, "[diag prog] %zu waves that walked a band in this launch; end us: p10 %.0f median %.0f p90 %.0f p99 %.0f max %.0f\n", all.size(),
+            all[(size_t)(0.1 * (all.size() - 1))], all[all.size() / 2], all[(size_t)(0.9 * (all.size() - 1))], all[(size_t)(0.99 * (all.size() - 1))], all.back());
+    static const char *nm[4] = {"DC first", "AC first", "AC refine luma", "AC refine chroma"};
+    for (int k = 0; k < 4; ++k) if (!en[k].empty()) {
+        std::sort(en[k].begin(), en[k].end()); std::sort(st[k].begin(), st[k].end());
+        double dur = 0; for (size_t i = 0; i < en[k].size(); ++i) dur += en[k][i];
+        double sst = 0; for (size_t i = 0; i < st[k].size(); ++i) sst += st[k][i];
+        fprintf(stderr, "[diag prog]   %-16s %6zu waves: start median %.0f max %.0f; end median %.0f p90 %.0f max %.0f; mean walk %.0f us\n", nm[k], en[k].size(),
+                st[k][st[k].size() / 2], st[k].back(), en[k][en[k].size() / 2], en[k][(size_t)(0.9 * (en[k].size() - 1))], en[k].back(), (dur - sst) / en[k].size());
+    }
 }
 #define PSTAMP(i) do { if (dbg_on) { uint64_t s_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s_) :: "memory"); dacc[i] += s_ - dlast; dlast = s_; } } while (0)
 #else
@@ -571,11 +602,14 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int seg_id = blockIdx.x * 4 + wave;
     if (seg_id >= n_segs) return;                              // wave-uniform; no workgroup barriers below
+#ifdef MJ_DIAGNOSTIC
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     Walk k;
     k.sg = segs + seg_id;
     k.sc = scans + k.sg->scan;
     const DevProgScan *sc = k.sc;
-    k.ss = sc->ss; k.se = sc->se; k.al = sc->al; k.tr = tr; k.lane = lane; k.spec = spec_refine != 0;
+    k.ss = sc->ss; k.se = sc->se; k.al = sc->al; k.tr = tr & 1; k.lane = lane; k.spec = spec_refine != 0;
     const bool sequential = k.ss == 0 && k.se == 63;
     const bool is_dc = k.ss == 0;
     if (sequential || (is_dc && sc->ah != 0)) return;          // progressive.hip's
@@ -627,6 +661,13 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     else if (sc->ah == 0) walk_ac_first(k, st, lut);
     else walk_ac_refine(k, st, lut);
 
+#ifdef MJ_DIAGNOSTIC
+    if (lane == 0 && seg_id < 16384 && spec_refine >= 0 && (tr >> 8) == step + 1) {     // (tr's upper bits: the launch to record, plus one)
+        unsigned long long *o = g_dbg_prog_waves + (size_t)seg_id * 3;
+        o[0] = dbg_r0; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = is_dc ? 0 : (sc->ah == 0 ? 1 : (sc->comp[0] == 0 ? 2 : 3));
+    }
+#endif
     int err = k.err;
     if (BANDED && !finish && lane == 0) {
         ps->pos = st.bp; ps->eobrun = k.eobrun; ps->pred[0] = k.pred0; ps->pred[1] = k.pred1; ps->pred[2] = k.pred2;
@@ -643,6 +684,9 @@ hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, 
                                    DevProgState *states, int step, int rows_per_band) {
     if (n_segs == 0) return hipSuccess;
     const dim3 grid((unsigned)((n_segs + 3) / 4));
+#ifdef MJ_DIAGNOSTIC
+    if (const char *e = getenv("MJ_DEBUG_PROG_STEP")) transposed |= (atoi(e) + 1) << 8;
+#endif
     if (rows_per_band > 0)
         hipLaunchKernelGGL(k_progressive_fast<true>, grid, dim3(256), 0, stream, dstream, seg_bits, segs, n_segs, scans, images, huff,
                            lut11p, coef, status, spec_refine, transposed, states, step, rows_per_band);
