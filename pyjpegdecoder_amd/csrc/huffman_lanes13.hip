@@ -42,8 +42,7 @@ namespace mj {
 
 namespace {
 
-constexpr int kABits = 13;                   // AC LUT index bits
-constexpr int kASize = 1 << kABits;
+// (AC LUT index bits: 13 — kASlotBytes below is the table with its second-level tables)
 constexpr int kASlotBytes = kLanes13SlotBytes;   // main table + second-level tables of one AC table
 constexpr int kDBits = kLaneLutBits;         // DC LUTs: the 11-bit (len << 8 | symbol) tables of the other lane form
 constexpr int kDSize = 1 << kDBits;

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 from tools import synth
 from oracle import oracle
-from pyjpegdecoder_amd import BatchDecoder
+from pyjpegdecoder_amd import BatchDecoder, _binding as B
 
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
