@@ -192,6 +192,7 @@ struct mj_plan {
     int64_t total_jobs = 0;
     int32_t jobs_per_image = 0;
     int32_t chunk_strips = 16;          // strips per job (a piece of one MCU column) of the fast stage 2
+    int32_t jobs_per_ticket = 1;        // consecutive jobs a wave draws at once
     int16_t *d_tmp_coef = nullptr;      // staging for zig-zag <-> natural conversion
     int16_t *d_coef = nullptr;
     uint8_t *d_rgb = nullptr;       // plan-owned, allocated on first use
@@ -781,6 +782,11 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             tp[i + 1] = tp[i] + (int64_t)cols * ((spc + p->chunk_strips - 1) / p->chunk_strips);
         }
         p->total_jobs = tp[b->n_images];
+        {   // a ticket should be worth ~400 blocks of IDCT work (a 1080p 4:2:0 column: 17 strips x 24 blocks): consecutive jobs per ticket
+            const int blocks_per_strip = p->generic ? 1 : tm * (p->ncomp == 1 ? 1 : p->hmax * p->vmax + 2);
+            const int per_job = std::max(1, blocks_per_strip * std::min(p->chunk_strips, max_spc));
+            p->jobs_per_ticket = std::max(1, (400 + per_job / 2) / per_job);
+        }
         p->jobs_per_image = (int32_t)(tp[1] - tp[0]);
         tp.insert(tp.end(), 5, 0);         // the ticket counter, a spare word, the three level counters of mj_plan_idct_levels
         if ((rc = upload(ctx, &p->d_job_prefix, tp.data(), tp.size())) != MJ_OK) return rc;
@@ -1384,6 +1390,7 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
 #endif
     a.uniform_geometry = p->uniform ? 1 : 0; a.mcus_per_image = p->mcus_per_image;
     a.work_counter = reinterpret_cast<uint32_t *>(p->d_job_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
+    a.jobs_per_ticket = p->jobs_per_ticket;
     a.level_counts = reinterpret_cast<unsigned long long *>(p->d_job_prefix + p->n_images + 3);
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(a.level_counts, 0, 3 * sizeof(unsigned long long), s));     // mj_plan_idct_levels
     if (p->generic) {

@@ -239,6 +239,7 @@ struct ReconArgs {
     // a time, through this ticket counter (zero before the launch; the wave that draws the launch's last ticket puts it back to zero)
     uint32_t *work_counter;
     int32_t chunk_strips;
+    int32_t jobs_per_ticket;     // >= 1
     unsigned long long *level_counts;   // seam-output launches: blocks seen / sent to level 2 / sent to level 3 (mj_plan_idct_levels), per plan
 };
 hipError_t launch_reconstruct(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp);

@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
     // adjacent and go through one wave one after the other, so the column runs that share a 64-byte sector are written by one
     // CU microseconds apart and merge in its XCD's L2.  The next job's ticket is drawn a job ahead (the atomic's latency is
     // never waited for); one counter word takes ~90 tickets per microsecond, a 1080p job (17 strips) asks for 30.
-    const uint32_t n_jobs = (uint32_t)total_jobs, last_ticket = n_jobs + gridDim.x * 4u - 1u;
+    // (a ticket is `jobs_per_ticket` consecutive jobs: layouts with little work per job — greyscale: 8 blocks per strip — would
+    // otherwise ask the counter for more tickets than it serves, 88 per microsecond)
+    const uint32_t n_jobs = (uint32_t)total_jobs, jpt = (uint32_t)a.jobs_per_ticket, n_tickets = (n_jobs + jpt - 1) / jpt;
+    const uint32_t last_ticket = n_tickets + gridDim.x * 4u - 1u;
     auto draw = [&]() -> uint32_t {      // lane 0's ticket (other lanes 0); wave-uniform only after take()
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(a.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -440,8 +443,9 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
         if (c == last_ticket && lane == 0) __hip_atomic_store(a.work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return c;
     };
-    uint32_t job = take(draw());
-    if (job >= n_jobs) return;
+    uint32_t ticket = take(draw());
+    if (ticket >= n_tickets) return;
+    uint32_t job = ticket * jpt;
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
     fetch_first(job_of(job), cw);
@@ -458,8 +462,10 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
     // the first MCU row and the output offset move by constants and the lanes' load offsets stay what they are.  (The kernel
     // is bound by instruction issue; the compiler's per-strip code for "which strip is next and where does it live" was a
     // quarter of the scalar and a tenth of the vector instructions.)
-    for (;;) {
-        const uint32_t ticket_v = draw();           // the job after this one
+    for (;;) {                                      // tickets
+      const uint32_t ticket_v = draw();             // the ticket after this one
+      const uint32_t job_end = min(n_jobs, (ticket + 1) * jpt);
+      for (;;) {                                    // the ticket's jobs
         const Job jo = job_of(job);                 // (its first strip's coefficients are already on their way)
         const DevImage *im_g = jo.im;
         const ConstImage im = cimg(im_g);
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
         // the next strip's coefficient rows are requested now, into the registers phase A has just finished with;
         // they are consumed one iteration later, so HBM latency hides behind the pixel phase
 #ifdef MJ_DIAGNOSTIC
-        if (dm & 32) { if (si + 1 >= n_strips) job = take(ticket_v); } else
+        if (dm & 32) { if (si + 1 >= n_strips) { if (job + 1 < job_end) ++job; else { ticket = take(ticket_v); job = ticket < n_tickets ? ticket * jpt : n_jobs; } } } else
 #endif
         if (si + 1 < n_strips) {                     // the strip below: same column, TMW MCU rows further down
             const unsigned char *cn = reinterpret_cast<const unsigned char *>(cptr + (int64_t)G::TMW * row_elems);
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
                 }
             }
         } else {                                     // the job ends: the first strip of this wave's next job
-            job = take(ticket_v);
+            if (job + 1 < job_end) ++job;
+            else { ticket = take(ticket_v); job = ticket < n_tickets ? ticket * jpt : n_jobs; }
             if (job < n_jobs) fetch_first(job_of(job), cw);
         }
 #ifdef MJ_DIAGNOSTIC
@@ -970,7 +977,9 @@ __global__ __launch_bounds__(256, (HS == 4 || VS == 4) ? 2 : 3) void k_reconstru
         y_first += G::TMW;
         cptr += (int64_t)G::TMW * row_elems;
       }
-        if (job >= n_jobs) break;
+        if (job >= job_end) break;                  // (the next job belongs to the next ticket — or there is none)
+      }
+      if (job >= n_jobs) break;
     }
 #ifdef MJ_DIAGNOSTIC
     if (a.debug == 10 && lane == 0) {
@@ -1014,7 +1023,7 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
             resident = per_cu * cus;
         }
-        const int64_t want = (total_jobs + 3) / 4;      // one job per wave at least
+        const int64_t want = ((total_jobs + a.jobs_per_ticket - 1) / a.jobs_per_ticket + 3) / 4;      // one ticket per wave at least
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
 #ifdef MJ_DIAGNOSTIC      // occupancy experiment: MJ_LDS_PAD bytes of unused LDS per workgroup
         if (getenv("MJ_LDS_PAD")) {
