@@ -121,16 +121,19 @@ __device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int fr
 //               ZRL_IS_COEF: a ZRL is class 0 with value 0 (the refining walk: "skip r zeros, take the next zero" for
 //               both, and a ZRL then places 0 into a coefficient that is 0)
 //   bits 5..2   zero run r (15 for ZRL)
-//   bits 10..6  bits consumed by the code and what belongs to it (value bits / the EOB run's extra bits)
+//   bits 9..8   the class again (bits 7..6 are zero): the 8 bits from bit 2 on read  r + 64 * class, so a symbol loop that
+//               adds them to a position of at most 63 finds every entry that is no plain coefficient behind its limit — one
+//               test for "special entry" and "run past the end" (round 4: two instructions less per symbol)
+//   bits 15..11 bits consumed by the code and what belongs to it (value bits / the EOB run's extra bits)
 //   bits 31..16 class 0: the coefficient, extended (:1636-1646), shifted by Al and cut to int16 (:1225, :1248);
 //               class 2: the length of the end-of-band run, (1 << r) + extra bits (:1160-1166)
 template <bool ZRL_IS_COEF>
 __device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al) {
     const int r = hv >> 4, s = hv & 15;
-    if (len == 0) return 3u;
+    if (len == 0) return 3u | (3u << 8);
     if (s == 0 && r != 15) {
         const uint32_t extra = r ? (w << len) >> (32 - r) : 0u;
-        return 2u | ((uint32_t)r << 2) | ((uint32_t)(len + r) << 6) | (((1u << r) + extra) << 16);
+        return 2u | (2u << 8) | ((uint32_t)r << 2) | ((uint32_t)(len + r) << 11) | (((1u << r) + extra) << 16);
     }
     uint32_t val16 = 0;
     if (s > 0) {
@@ -138,7 +141,8 @@ __device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al
         const int val = (raw >> (s - 1)) ? (int)raw : (int)raw - ((1 << s) - 1);
         val16 = (uint32_t)(uint16_t)(int16_t)(val << al);
     }
-    return ((!ZRL_IS_COEF && s == 0) ? 1u : 0u) | ((uint32_t)r << 2) | ((uint32_t)(len + s) << 6) | (val16 << 16);
+    const uint32_t cls = (!ZRL_IS_COEF && s == 0) ? 1u : 0u;
+    return cls | (cls << 8) | ((uint32_t)r << 2) | ((uint32_t)(len + s) << 11) | (val16 << 16);
 }
 
 // ... and about a DC symbol (:1012-1029): bits 1..0 = 0, or 3 = not in the table / a size above 16; bits 11..6 the bits

@@ -240,13 +240,11 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "s_cbranch_scc1 Lfwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     "Lfsym%=:\n\t"
-                    "s_and_b32 %[t0], %[e], 3\n\t"
-                    "s_cbranch_scc1 Lfspec%=\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x40002\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 64 * class: what is no plain coefficient lands past 63 too
                     "s_add_u32 %[kk], %[kk], %[t0]\n\t"
                     "s_cmp_gt_u32 %[kk], 63\n\t"
                     "s_cbranch_scc1 Lfover%=\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
                     "s_add_u32 %[bp], %[bp], %[t0]\n\t"
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
@@ -271,7 +269,7 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "s_cbranch_scc0 Lfother%=\n\t"
                     "s_lshr_b32 %[eob], %[e], 16\n\t"
                     "s_sub_u32 %[eob], %[eob], 1\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
                     "s_add_u32 %[bp], %[bp], %[t0]\n\t"
                     "s_mov_b32 %[code], 4\n\t"
                     "s_branch Lfend%=\n"
@@ -279,6 +277,12 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lfend%=\n"
                     "Lfover%=:\n\t"
+                    "s_and_b32 %[code], %[e], 3\n\t"             // a special entry (the position is put back), or a run past the block
+                    "s_cbranch_scc0 Lfrun%=\n\t"
+                    "s_sub_u32 %[kk], %[kk], %[t0]\n\t"
+                    "s_mov_b32 %[t0], %[code]\n\t"
+                    "s_branch Lfspec%=\n"
+                    "Lfrun%=:\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lfend%=:"
                     : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [bp] "+s"(st.bp), [kk] "+s"(kk),
@@ -297,12 +301,12 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                 }
                 if (e & 2u) {                              // end of band: the run counts this block (:1160-1166)
                     eobrun = (int)(e >> 16) - 1;
-                    st.bp += (int)((e >> 6) & 31u);
+                    st.bp += (int)((e >> 11) & 31u);
                     break;
                 }
                 if (e & 1u) {                              // ZRL: sixteen zeros (:1170)
                     kk += 16;
-                    st.bp += (int)((e >> 6) & 31u);
+                    st.bp += (int)((e >> 11) & 31u);
                     if (kk > se) break;
                     continue;
                 }
@@ -311,7 +315,7 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                 if (kk > 63) { err = MJ_ST_OVERRUN; break; }
                 write_lane(cf, (int)e >> 16, kk);          // (:1248-1250)
                 touched |= (uint64_t)1 << kk;
-                st.bp += (int)((e >> 6) & 31u);
+                st.bp += (int)((e >> 11) & 31u);
                 if (++kk > se) break;
             }
             if (touched != 0) {
@@ -435,22 +439,20 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_cbranch_scc1 Lwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     "Lsym%=:\n\t"
-                    "s_and_b32 %[t0], %[e], 3\n\t"
-                    "s_cbranch_scc1 Lspec%=\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x40002\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 64 * class: what is no plain coefficient overshoots every zero count
                     "s_add_u32 %[jt], %[jz], %[t0]\n\t"
                     "s_cmp_ge_u32 %[jt], %[nzeros]\n\t"
                     "s_cbranch_scc1 Lover%=\n\t"
                     "v_readlane_b32 %[cn], %[ztab], %[jt]\n\t"
                     "v_readlane_b32 %[pz], %[zpos], %[jt]\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
                     "s_add_u32 %[u], %[u], %[t0]\n\t"
                     "s_add_u32 %[bp], %[u], %[cn]\n\t"
                     // the next symbol's entry is requested before this symbol's bookkeeping (a window offset past 63 reads some
                     // lane's entry, which is then not used)
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
-                    "v_mov_b32 %[vt], %[u]\n\t"
+                    "v_mov_b32 %[vt], %[u]\n\t"                  // (v_cndmask cannot take u from its SGPR: vcc is the one constant-bus operand)
                     "v_cmp_le_u32 vcc, %[k], %[vlane]\n\t"
                     "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
                     "s_ashr_i32 %[e], %[e], 16\n\t"
@@ -473,7 +475,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_bitcmp1_b32 %[e], 0\n\t"
                     "s_cbranch_scc1 Llong%=\n\t"
                     "s_lshr_b32 %[eob], %[e], 16\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x50006\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
                     "s_add_u32 %[bp], %[bp], %[t0]\n\t"
                     "s_add_u32 %[u], %[u], %[t0]\n\t"
                     "s_mov_b32 %[code], 4\n\t"
@@ -482,6 +484,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lend%=\n"
                     "Lover%=:\n\t"
+                    "s_and_b32 %[t0], %[e], 3\n\t"               // a special entry, or a zero run past the last zero
+                    "s_cbranch_scc1 Lspec%=\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lend%=:"
                     : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [cn] "=&s"(cn),
@@ -509,8 +513,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 }
                 if (e & 2u) {                              // end of band: this block's rest and eobrun - 1 further blocks (:1160-1166)
                     eobrun = (int)(e >> 16);
-                    st.bp += (int)((e >> 6) & 31u);
-                    u += (int)((e >> 6) & 31u);
+                    st.bp += (int)((e >> 11) & 31u);
+                    u += (int)((e >> 11) & 31u);
                     break;
                 }
                 // (a long code's coefficient: the same step as above, once)
@@ -518,7 +522,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
                 const int pz2 = (int)rdl(zpos, jt2);
                 write_lane(cf, (int)e >> 16, pz2);         // (:1225)
-                u += (int)((e >> 6) & 31u);                // the symbol's corrections follow its value bits (:1202, :1231)
+                u += (int)((e >> 11) & 31u);                // the symbol's corrections follow its value bits (:1202, :1231)
                 vbase = lane >= k ? u : vbase;
                 st.bp = u + (int)rdl(ztab, jt2);
                 k = pz2 + 1; jz = jt2 + 1;
