@@ -120,7 +120,8 @@ __device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int fr
 //   bits 1..0   class: 0 = coefficient (size > 0), 1 = ZRL, 2 = end of band (EOBn), 3 = not in the table.
 //               ZRL_IS_COEF: a ZRL is class 0 with value 0 (the refining walk: "skip r zeros, take the next zero" for
 //               both, and a ZRL then places 0 into a coefficient that is 0)
-//   bits 5..2   zero run r (15 for ZRL)
+//   bits 5..2   zero run r (15 for ZRL) — ZRL_IS_COEF (the refining walk's entries): bits 6..2 = r + 1, what the walk's count of
+//               zeros passed moves on by
 //   bits 9..8   the class again (bits 7..6 are zero): the 8 bits from bit 2 on read  r + 64 * class, so a symbol loop that
 //               adds them to a position of at most 63 finds every entry that is no plain coefficient behind its limit — one
 //               test for "special entry" and "run past the end" (round 4: two instructions less per symbol)
@@ -142,7 +143,7 @@ __device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al
         val16 = (uint32_t)(uint16_t)(int16_t)(val << al);
     }
     const uint32_t cls = (!ZRL_IS_COEF && s == 0) ? 1u : 0u;
-    return cls | (cls << 8) | ((uint32_t)r << 2) | ((uint32_t)(len + s) << 11) | (val16 << 16);
+    return cls | (cls << 8) | ((uint32_t)(ZRL_IS_COEF ? r + 1 : r) << 2) | ((uint32_t)(len + s) << 11) | (val16 << 16);
 }
 
 // ... and about a DC symbol (:1012-1029): bits 1..0 = 0, or 3 = not in the table / a size above 16; bits 11..6 the bits

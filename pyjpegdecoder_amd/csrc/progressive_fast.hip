@@ -426,8 +426,12 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 // 3: the zero run passes the last zero;  4: end of band, run length in eobrun.
                 // Wait states: no v_readlane takes its lane select from a VALU-written SGPR; SALU reads of those are interlocked.
                 uint32_t e, e2;
-                int code, t0, jt, pz, cn, off;
+                int code, t0, cn, off;
                 int vt;
+                // (inside the loop the position is kept as k1 = k - 1, the last position taken, and the zeros passed as zl = jz - 1,
+                // the ordinal of the last zero taken: the entry's run field holds r + 1, v_readlane writes the new position
+                // straight into k1 — two additions per symbol less)
+                int k1 = k - 1, zl = jz - 1;
                 PSTAMP(dbg_first ? 0 : 3);
 #ifdef MJ_DIAGNOSTIC
                 dbg_first = false;
@@ -439,12 +443,13 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_cbranch_scc1 Lwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     "Lsym%=:\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 64 * class: what is no plain coefficient overshoots every zero count
-                    "s_add_u32 %[jt], %[jz], %[t0]\n\t"
-                    "s_cmp_ge_u32 %[jt], %[nzeros]\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 1 + 64 * class: what is no plain coefficient overshoots every zero count
+                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"
+                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"
                     "s_cbranch_scc1 Lover%=\n\t"
-                    "v_readlane_b32 %[cn], %[ztab], %[jt]\n\t"
-                    "v_readlane_b32 %[pz], %[zpos], %[jt]\n\t"
+                    "v_cmp_lt_u32 vcc, %[k1], %[vlane]\n\t"        // the lanes from the old k on (they take this symbol's u below)
+                    "v_readlane_b32 %[cn], %[ztab], %[zl]\n\t"
+                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
                     "s_add_u32 %[u], %[u], %[t0]\n\t"
                     "s_add_u32 %[bp], %[u], %[cn]\n\t"
@@ -453,15 +458,12 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
                     "v_mov_b32 %[vt], %[u]\n\t"                  // (v_cndmask cannot take u from its SGPR: vcc is the one constant-bus operand)
-                    "v_cmp_le_u32 vcc, %[k], %[vlane]\n\t"
                     "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
                     "s_ashr_i32 %[e], %[e], 16\n\t"
-                    "s_mov_b32 m0, %[pz]\n\t"
+                    "s_mov_b32 m0, %[k1]\n\t"
                     "v_writelane_b32 %[cf], %[e], m0\n\t"
-                    "s_add_u32 %[k], %[pz], 1\n\t"
-                    "s_add_u32 %[jz], %[jt], 1\n\t"
                     "s_mov_b32 %[e], %[e2]\n\t"
-                    "s_cmp_gt_u32 %[k], %[se]\n\t"
+                    "s_cmp_ge_u32 %[k1], %[se]\n\t"
                     "s_cbranch_scc1 Ldone%=\n\t"
                     "s_cmp_le_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lsym%=\n"
@@ -484,16 +486,18 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lend%=\n"
                     "Lover%=:\n\t"
+                    "s_sub_u32 %[zl], %[zl], %[t0]\n\t"          // (not taken: the count goes back)
                     "s_and_b32 %[t0], %[e], 3\n\t"               // a special entry, or a zero run past the last zero
                     "s_cbranch_scc1 Lspec%=\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lend%=:"
-                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [jt] "=&s"(jt), [pz] "=&s"(pz), [cn] "=&s"(cn),
-                      [off] "=&s"(off), [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k] "+s"(k), [jz] "+s"(jz), [cf] "+v"(cf),
+                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [cn] "=&s"(cn),
+                      [off] "=&s"(off), [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k1] "+s"(k1), [zl] "+s"(zl), [cf] "+v"(cf),
                       [vbase] "+v"(vbase), [eob] "+s"(eobrun)
                     : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
                       [nzeros] "s"(nzeros)
                     : "vcc", "scc", "m0");
+                k = k1 + 1; jz = zl + 1;
                 PSTAMP(1);
                 if (code == 0 || code == 4) break;         // the band is done / end of band (:1160-1166)
                 if (code == 1) {                           // next window of looked-up symbols
@@ -518,7 +522,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     break;
                 }
                 // (a long code's coefficient: the same step as above, once)
-                const int jt2 = jz + (int)((e >> 2) & 15u);
+                const int jt2 = jz + (int)((e >> 2) & 31u) - 1;          // (the refining walk's entries hold r + 1)
                 if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
                 const int pz2 = (int)rdl(zpos, jt2);
                 write_lane(cf, (int)e >> 16, pz2);         // (:1225)
