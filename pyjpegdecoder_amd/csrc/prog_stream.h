@@ -130,20 +130,17 @@ __device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int fr
 //               class 2: the length of the end-of-band run, (1 << r) + extra bits (:1160-1166)
 template <bool ZRL_IS_COEF>
 __device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al) {
+    // (no branches: a window's 64 lanes hold every kind of entry, so a branch would be walked on both sides anyway)
     const int r = hv >> 4, s = hv & 15;
-    if (len == 0) return 3u | (3u << 8);
-    if (s == 0 && r != 15) {
-        const uint32_t extra = r ? (w << len) >> (32 - r) : 0u;
-        return 2u | (2u << 8) | ((uint32_t)r << 2) | ((uint32_t)(len + r) << 11) | (((1u << r) + extra) << 16);
-    }
-    uint32_t val16 = 0;
-    if (s > 0) {
-        const uint32_t raw = (w << len) >> (32 - s);
-        const int val = (raw >> (s - 1)) ? (int)raw : (int)raw - ((1 << s) - 1);
-        val16 = (uint32_t)(uint16_t)(int16_t)(val << al);
-    }
-    const uint32_t cls = (!ZRL_IS_COEF && s == 0) ? 1u : 0u;
-    return cls | (cls << 8) | ((uint32_t)(ZRL_IS_COEF ? r + 1 : r) << 2) | ((uint32_t)(len + s) << 11) | (val16 << 16);
+    const bool eob = s == 0 && r != 15;
+    const int n = eob ? r : s;                                              // bits behind the code: the run's extra bits / the value
+    const uint32_t raw = ((w << len) >> 1) >> (31 - n);                     // (0 for n = 0)
+    const uint32_t neg = ((raw << 1) >> s) ? 0u : (1u << s) - 1u;           // top bit clear: the value is raw - (2^s - 1) (:1636-1646)
+    const uint32_t val16 = (uint32_t)(uint16_t)(int16_t)((int)(raw - neg) << al);
+    const uint32_t cls = eob ? 2u : (!ZRL_IS_COEF && s == 0) ? 1u : 0u;
+    const uint32_t hi = eob ? (1u << r) + raw : val16;
+    const uint32_t e = cls | (cls << 8) | ((uint32_t)(ZRL_IS_COEF && !eob ? r + 1 : r) << 2) | ((uint32_t)(len + n) << 11) | (hi << 16);
+    return len == 0 ? (3u | (3u << 8)) : e;
 }
 
 // ... and about a DC symbol (:1012-1029): bits 1..0 = 0, or 3 = not in the table / a size above 16; bits 11..6 the bits

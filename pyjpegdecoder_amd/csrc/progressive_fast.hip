@@ -57,9 +57,9 @@ namespace mj {
 using namespace progstream;
 
 #ifdef MJ_DIAGNOSTIC   // separate diagnostic build only (make DIAG=1): where the final luma refinement's cycles go
-__device__ unsigned long long g_dbg_prog[8];
+__device__ unsigned long long g_dbg_prog[11];     // 7 phase sums, waves, walked blocks, blocks inside EOB runs, coefficients placed
 void dbg_prog_report() {
-    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long h[11], z[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_prog), sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_prog), z, sizeof(z));
     unsigned long long tot = 0;
@@ -69,6 +69,8 @@ void dbg_prog_report() {
     fprintf(stderr, "[diag] refining walk of the Ah=1 luma scans, %llu waves: ", h[7]);
     for (int i = 0; i < 7; ++i) fprintf(stderr, "%s %.1f%%  ", nm[i], 100.0 * (double)h[i] / (double)tot);
     fprintf(stderr, "(%.1f Mcycles per wave)\n", (double)tot / (double)(h[7] ? h[7] : 1) / 1e6);
+    fprintf(stderr, "[diag]   %llu walked blocks (%.2f coefficients placed per block, %.0f cycles per block all phases but EOB-run blocks), %llu blocks inside EOB runs (%.0f cycles each)\n",
+            h[8], (double)h[10] / (double)(h[8] ? h[8] : 1), (double)(tot - h[5]) / (double)(h[8] ? h[8] : 1), h[9], (double)h[5] / (double)(h[9] ? h[9] : 1));
 }
 // when does every wave of one band launch (MJ_DEBUG_PROG_STEP) finish, and what was it walking?
 __device__ unsigned long long g_dbg_prog_waves[16384 * 3];
@@ -362,6 +364,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
 #ifdef MJ_DIAGNOSTIC
     const bool dbg_on = sc->ah == 1 && c == 0;
     uint64_t dacc[7] = {0, 0, 0, 0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
+    unsigned long long dblocks = 0, deob = 0, dplaced = 0;
 #endif
 
     // What a block's walk needs from its history, worked out one block ahead (the two cross-lane permutes are LDS round trips)
@@ -419,19 +422,26 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
             bool dbg_first = true;
 #endif
             for (;;) {                                     // (Ss <= Se: a scan has at least one coefficient per block)
+                uint32_t e;
+                int code, off;
+                for (;;) {                                 // (the common way round on its own: symbols, next window, symbols ...)
                 // The run of plain coefficient symbols inside the current window, hand-scheduled and software-pipelined: 28
                 // instructions per symbol, two v_readlane deep, the next symbol's entry in flight during this symbol's
                 // bookkeeping (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
                 // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not in the LUT;
                 // 3: the zero run passes the last zero;  4: end of band, run length in eobrun.
                 // Wait states: no v_readlane takes its lane select from a VALU-written SGPR; SALU reads of those are interlocked.
-                uint32_t e, e2;
-                int code, t0, cn, off;
+                uint32_t e2;
+                int t0, cn;
                 int vt;
                 // (inside the loop the position is kept as k1 = k - 1, the last position taken, and the zeros passed as zl = jz - 1,
                 // the ordinal of the last zero taken: the entry's run field holds r + 1, v_readlane writes the new position
                 // straight into k1 — two additions per symbol less)
+#ifdef MJ_DIAGNOSTIC   // (with the stamps in between, the compiler otherwise keeps these two in vector registers)
+                int k1 = __builtin_amdgcn_readfirstlane(k - 1), zl = __builtin_amdgcn_readfirstlane(jz - 1);
+#else
                 int k1 = k - 1, zl = jz - 1;
+#endif
                 PSTAMP(dbg_first ? 0 : 3);
 #ifdef MJ_DIAGNOSTIC
                 dbg_first = false;
@@ -497,16 +507,18 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
                       [nzeros] "s"(nzeros)
                     : "vcc", "scc", "m0");
-                k = k1 + 1; jz = zl + 1;
+                // (the compiler takes what an asm statement writes for lane-varying, whatever the constraint says, and does the
+                // arithmetic on it with vector instructions and mask branches: readfirstlane tells it otherwise and folds away)
+                k = rfl(k1) + 1; jz = rfl(zl) + 1;
+                e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); u = rfl(u); st.bp = rfl(st.bp); eobrun = rfl(eobrun);
                 PSTAMP(1);
-                if (code == 0 || code == 4) break;         // the band is done / end of band (:1160-1166)
-                if (code == 1) {                           // next window of looked-up symbols
-                    win.move_to(st, lut, al, lane, off);
+                if (code != 1) break;
+                win.move_to(st, lut, al, lane, off);       // next window of looked-up symbols
 #ifdef MJ_DIAGNOSTIC
-                    PSTAMP(2);
+                PSTAMP(2);
 #endif
-                    continue;
                 }
+                if (code == 0 || code == 4) break;         // the band is done / end of band (:1160-1166)
                 if (code == 3) { err = MJ_ST_OVERRUN; break; }              // fewer zeros left than the run passes (:1190)
                 if (e & 1u) {                              // a code longer than the LUT's index (rare) or no code at all
                     const uint32_t w = rdl(win.vw0, off);
@@ -557,6 +569,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         // coefficients of the block at the same time
         if (dirty && in_band) *p = (int16_t)cf;
 #ifdef MJ_DIAGNOSTIC
+        if (dbg_on) {
+            if (dbg_eob) ++deob; else { ++dblocks; dplaced += __builtin_popcountll(__ballot(cf != 0 && lane >= ss) & ~nzb); }
+        }
         PSTAMP(dbg_eob ? 5 : 4);
 #endif
     };
@@ -591,6 +606,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     if (dbg_on && lane == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&g_dbg_prog[i], (unsigned long long)dacc[i]);
         atomicAdd(&g_dbg_prog[7], 1ull);
+        atomicAdd(&g_dbg_prog[8], dblocks); atomicAdd(&g_dbg_prog[9], deob); atomicAdd(&g_dbg_prog[10], dplaced);
     }
 #endif
 }
