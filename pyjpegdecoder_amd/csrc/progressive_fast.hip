@@ -390,7 +390,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         // lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
         const int slot = (cf == 0 && lane >= ss) ? zrank : q.nzeros + lane - zrank;
         q.zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
-        q.ztab = (uint32_t)__builtin_amdgcn_ds_bpermute((int)q.zpos << 2, q.rank0);
+        q.ztab = q.zpos - (uint32_t)(ss + lane);           // of the zpos - Ss positions in front of zero number `lane`, `lane` are zeros
         return q;
     };
     auto one_block = [&](int cf, int16_t *p, const Prep &pr) __attribute__((always_inline)) {
