@@ -183,6 +183,9 @@ struct mj_plan {
     uint16_t *d_lut11p = nullptr;            // [n_huff][1 << kProgLutBits], (len << 8 | symbol)
     bool prog_fast = false;
     int64_t prog_rest_off = 0;               // banded: d_psegs[prog_rest_off..] are the segments of the scans progressive.hip walks
+    mj::DevProgSub *d_psubs = nullptr;       // [n_split][2][kProgSub]: by segment, two sets (even and odd bands)
+    int prog_parts = 4;                      // ... parts per band
+    int64_t n_split = 0;                     // banded: d_psegs[0..n_split) are the segments of the scans walked as scout + parts
     // (one launch per dependency level only — MJ_PROG_BANDS=0; the band pipeline orders d_psegs by length instead)
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs
     std::vector<int64_t> ordinal_kind_off;  // [n_ordinals][4]: within a level, where the segments of each kind of scan start
@@ -318,9 +321,10 @@ struct OptionTable {
     std::mutex mu;
     // (values live as long as the process: a returned pointer stays valid until the same option is set again)
     struct Entry { const char *name; std::string value; bool set; };
-    Entry e[12] = {{"MJ_HUFFMAN", "", false},      {"MJ_SEG_ORDER", "", false},   {"MJ_SYNC_ROUNDS", "", false}, {"MJ_SYNC_CHUNK", "", false},
+    Entry e[14] = {{"MJ_HUFFMAN", "", false},      {"MJ_SEG_ORDER", "", false},   {"MJ_SYNC_ROUNDS", "", false}, {"MJ_SYNC_CHUNK", "", false},
                    {"MJ_SYNC_WARM", "", false},    {"MJ_PROG_BANDS", "", false},  {"MJ_PROG_ROWS", "", false},   {"MJ_PROG_FAST", "", false},
-                   {"MJ_LANES_WAVES", "", false},  {"MJ_LANES_PER_WAVE", "", false}, {"MJ_LANES_RING", "", false}, {"MJ_STAGE2_CHUNK", "", false}};
+                   {"MJ_LANES_WAVES", "", false},  {"MJ_LANES_PER_WAVE", "", false}, {"MJ_LANES_RING", "", false}, {"MJ_STAGE2_CHUNK", "", false},
+                   {"MJ_PROG_SPLIT", "", false},  {"MJ_PROG_PARTS", "", false}};
 };
 OptionTable g_options;
 }  // namespace
@@ -448,7 +452,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -612,6 +616,58 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     std::vector<mj::DevProgScan> pscans;
     std::vector<mj::DevProgSeg> psegs;
     if (prog) {
+        // (what decides the walks' form comes first: the dependency levels below depend on it)
+        p->prog_fast = false;
+        for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
+            p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
+        if (const char *e = mj::opt("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
+        if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
+        int max_rows = 1;
+        for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
+        p->prog_banded = true;
+        if (const char *e = mj::opt("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
+        p->prog_rows_per_band = p->prog_banded ? 2 : max_rows;
+        if (const char *e = mj::opt("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
+        // Split scans (progressive_fast.hip): a refining AC scan is one serial chain — a batch lasts as long as its longest scan's
+        // walk — and more than half of a block's walk is placing what the symbols say, which needs no order once the bit position
+        // of the block is known.  A scout follows the positions alone; a few walks per band (MJ_PROG_PARTS, 4), one launch
+        // behind, place.  Worth it where a band's walk is long: from 1 KiB of entropy-coded bytes per band on (MJ_PROG_SPLIT: 0 never,
+        // 2 every refining AC scan).
+        int split_mode = 1;
+        if (const char *e = mj::opt("MJ_PROG_SPLIT")) split_mode = atoi(e);
+        if (const char *e = mj::opt("MJ_PROG_PARTS")) p->prog_parts = std::min(std::max(atoi(e), 1), mj::kProgSub);
+        if (!p->prog_fast || !p->prog_banded) split_mode = 0;
+        std::vector<char> split_of(b->n_scans, 0);
+        if (split_mode) {
+            // ... and while the chip has wave slots for it: past that the added work — a split scan is walked one and a half
+            // times — costs more than the shorter chain gains.
+            const int64_t n_bands = std::max(1, (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band);
+            std::vector<std::pair<int64_t, int>> cand;
+            for (int k = 0; k < b->n_scans; ++k) {
+                const mj_scan_desc &sd = b->scans[k];
+                if (sd.ss == 0 || sd.ah == 0 || sd.n_comp != 1) continue;
+                if (sd.first_segment < 0 || sd.n_segments < 1 || sd.first_segment + sd.n_segments > b->n_segments) continue;   // (refused below)
+                int64_t bytes = 0;
+                for (int g = 0; g < sd.n_segments; ++g) bytes += b->seg_end[sd.first_segment + g] - b->seg_begin[sd.first_segment + g];
+                if (split_mode >= 2 || bytes / n_bands >= 1024) cand.push_back({-bytes, k});
+            }
+            std::sort(cand.begin(), cand.end());
+            // Every such scan if their scouts and parts all find a wave slot at once, else each image's largest if those do,
+            // else none.  (1024 x 1080p, libjpeg's script: both luma refinements 92.9 ms, the last one only 80.9, none 85.9;
+            // 768 files: both 75.6, none 84.3; 2048: the last one 153, none 122.  Part of the images, whatever fits: worse than either.)
+            const int64_t slots = (int64_t)mj::device_cus() * 32;
+            std::vector<char> top(b->n_scans, 0), seen_image(b->n_images, 0);
+            int64_t need_all = 0, need_top = 0;
+            for (auto &c : cand) {
+                const mj_scan_desc &sd = b->scans[c.second];
+                const int64_t need = (int64_t)sd.n_segments * (1 + p->prog_parts);
+                need_all += need;
+                if (sd.image >= 0 && sd.image < b->n_images && !seen_image[sd.image]) { seen_image[sd.image] = 1; top[c.second] = 1; need_top += need; }
+            }
+            const int tier = split_mode >= 2 || need_all <= slots ? 2 : (need_top <= slots ? 1 : 0);
+            for (auto &c : cand) split_of[c.second] = tier == 2 || (tier == 1 && top[c.second]);
+        }
+        auto want_split = [&](int k) { return split_of[k] != 0; };
         std::vector<int> ordinal_of(b->n_scans, 0);
         std::vector<int> seen(b->n_images, 0);
         int n_ord = 0;
@@ -629,12 +685,13 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     bool comp_overlap = false;
                     for (int a1 = 0; a1 < sd.n_comp && a1 < 3; ++a1)
                         for (int a2 = 0; a2 < pj.n_comp && a2 < 3; ++a2) comp_overlap |= sd.comp[a1] == pj.comp[a2];
-                    if (comp_overlap && sd.ss <= pj.se && pj.ss <= sd.se) lvl = std::max(lvl, ordinal_of[j] + 1);
+                    // (a split scan's parts run one launch behind its scout: what follows it waits for them)
+                    if (comp_overlap && sd.ss <= pj.se && pj.ss <= sd.se) lvl = std::max(lvl, ordinal_of[j] + 1 + (want_split(j) ? 1 : 0));
                 }
                 ordinal_of[k] = lvl;
             }
             (void)seen;
-            n_ord = std::max(n_ord, ordinal_of[k] + 1);
+            n_ord = std::max(n_ord, ordinal_of[k] + 1 + (want_split(k) ? 1 : 0));
             const mj_image_desc &d = b->images[sd.image];
             const mj::DevImage &im = imgs[sd.image];
             mj::DevProgScan ps{};
@@ -674,6 +731,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 return fail(ctx, MJ_ERR_INVALID, "scan %d: MCU counts %dx%d, expected %dx%d", k, sd.mcu_count_h, sd.mcu_count_v, want_h, want_v);
             ps.ss = sd.ss; ps.se = sd.se; ps.ah = sd.ah; ps.al = sd.al;
             ps.level = ordinal_of[k];
+            ps.split = want_split(k) ? 1 : 0;
             ps.mcu_count_h = sd.mcu_count_h; ps.mcu_count_v = sd.mcu_count_v;
             pscans.push_back(ps);
         }
@@ -721,11 +779,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // MJ_PROG_BANDS=0 keeps one launch per level.  (MJ_PROG_BANDS, MJ_PROG_ROWS, MJ_PROG_FAST, MJ_SYNC_ROUNDS,
             // MJ_SYNC_CHUNK, MJ_HUFFMAN, MJ_SEG_ORDER and the MJ_LANES_* variables are hooks of the test-suite and of
             // tools/stage_probe.py: read once, at plan creation or launch; mj_plan_stage1_form() reports the form in effect.)
-            int max_rows = 1;
-            for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
-            p->prog_banded = true;
-            if (const char *e = mj::opt("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
-            p->prog_rows_per_band = p->prog_banded ? 2 : max_rows;
             if (p->prog_banded) {
                 // every launch of the pipeline covers all segments, and more workgroups than the chip holds at once: the long
                 // walks go first (a launch lasts as long as its slowest wave; started last, the final luma refinement — half
@@ -733,13 +786,18 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 // (behind them the segments of the scans progressive.hip walks — DC refinement, sequential scans — so that its
                 // launches cover only those)
                 auto rest = [&](const mj::DevProgSeg &g) { return kind_of(b->scans[g.scan]) == 3; };
+                // (in front of them all the split scans' segments: the kernel finds their parts by position)
+                auto split = [&](const mj::DevProgSeg &g) { return pscans[g.scan].split != 0; };
                 std::stable_sort(psegs.begin(), psegs.end(), [&](const mj::DevProgSeg &x, const mj::DevProgSeg &y) {
-                    return rest(x) != rest(y) ? rest(y) : x.len > y.len;
+                    if (rest(x) != rest(y)) return rest(y);
+                    if (split(x) != split(y)) return split(x);
+                    return x.len > y.len;
                 });
+                p->n_split = 0;
+                while (p->n_split < (int64_t)psegs.size() && split(psegs[p->n_split])) ++p->n_split;
                 p->prog_rest_off = 0;
                 while (p->prog_rest_off < (int64_t)psegs.size() && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
             }
-            if (const char *e = mj::opt("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
             p->prog_steps = n_bands + n_ord - 1;
         }
@@ -1110,11 +1168,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_fast.hip)
             // (a plan none of whose scans they take — non-interleaved baseline files, DC refinement only — needs neither the
             // stage-0 stream nor its pass per execute)
-            p->prog_fast = false;
-            for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
-                p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
-            if (const char *e = mj::opt("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
-            if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
             if (p->prog_fast) {
                 // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
                 // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if
@@ -1159,6 +1212,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 if ((rc = upload(ctx, &p->d_lut11p, lp.data(), lp.size())) != MJ_OK) return rc;
             }
             if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
+            if (p->n_split)     // by segment (the first n_split of them), two sets: even and odd bands
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_psubs, (size_t)p->n_split * 2 * mj::kProgSub * sizeof(mj::DevProgSub)));
         }
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
@@ -1278,6 +1333,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
         // The scans are pipelined over bands of MCU rows: in launch number `step` a scan of dependency level L does band
         // step - L, so a refining scan follows one band behind what it refines instead of waiting for the whole scan.
         MJ_HIP(ctx, hipMemsetAsync(p->d_pstates, 0xFF, (size_t)p->n_psegs * sizeof(mj::DevProgState), s));
+        if (p->n_split) MJ_HIP(ctx, hipMemsetAsync(p->d_psubs, 0xFF, (size_t)p->n_split * 2 * mj::kProgSub * sizeof(mj::DevProgSub), s));
         const bool fast = p->prog_fast;
         const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
         if (fast)       // stage 0 for every segment: what progressive_fast.hip's walks read
@@ -1287,7 +1343,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
                 if (fast)
                     MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)p->prog_rest_off, p->d_pscans, p->d_images,
                                                             p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates, step,
-                                                            p->prog_rows_per_band));
+                                                            p->prog_rows_per_band, (int)p->n_split, p->d_psubs, p->prog_parts));
                 const int64_t r0 = fast ? p->prog_rest_off : 0;
                 MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(p->n_psegs - r0), p->d_pscans, p->d_images, p->d_huff,
                                                         p->d_coef, p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates + r0, step,

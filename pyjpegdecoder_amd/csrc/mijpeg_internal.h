@@ -110,6 +110,8 @@ struct DevProgScan {
     int32_t ss, se, ah, al;
     int32_t mcu_count_h, mcu_count_v;
     int32_t level;                  // dependency level: scans of level L need the same rows of level L - 1 scans done
+    int32_t split;                  // 1: a refining AC scan walked twice (progressive_fast.hip): a scout that only follows the bit
+                                    // position, and — one launch behind, at level + 1 — a few walks per band that place
 };
 
 // What a scan's restart segment carries from one band of MCU rows to the next (progressive.hip).
@@ -122,6 +124,13 @@ struct DevProgState {
     int32_t mcu_next;               // first MCU the next band starts with
     int32_t reserved;
 };
+
+// Where a split scan's scout stood at the first MCU of a part of a band (progressive_fast.hip): what the part's walk starts from.
+struct DevProgSub {
+    int32_t pos, eobrun, err;
+    int32_t mcu;                    // the MCU this entry belongs to (bands alternate between two sets of entries: a stale one does not match)
+};
+constexpr int kProgSub = 8;         // parts per band: at most (entries per band and segment)
 
 // One restart segment of one progressive scan.
 struct DevProgSeg {
@@ -142,7 +151,7 @@ constexpr int kProgLutBits = 11;
 hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
                                    int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
-                                   DevProgState *states, int step, int rows_per_band);
+                                   DevProgState *states, int step, int rows_per_band, int n_split = 0, DevProgSub *subs = nullptr, int parts = 1);
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,

@@ -73,25 +73,25 @@ void dbg_prog_report() {
             h[8], (double)h[10] / (double)(h[8] ? h[8] : 1), (double)(tot - h[5]) / (double)(h[8] ? h[8] : 1), h[9], (double)h[5] / (double)(h[9] ? h[9] : 1));
 }
 // when does every wave of one band launch (MJ_DEBUG_PROG_STEP) finish, and what was it walking?
-__device__ unsigned long long g_dbg_prog_waves[16384 * 3];
+__device__ unsigned long long g_dbg_prog_waves[32768 * 3];
 void dbg_prog_waves_report() {
-    std::vector<unsigned long long> t(16384 * 3), z(16384 * 3, 0);
+    std::vector<unsigned long long> t(32768 * 3), z(32768 * 3, 0);
     (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_dbg_prog_waves), t.size() * 8);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_prog_waves), z.data(), z.size() * 8);
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < t.size(); i += 3) if (t[i] && t[i] < t0) t0 = t[i];
     if (t0 == ~0ull) return;
-    // kinds: 0 DC first, 1 AC first, 2 AC refine luma, 3 AC refine chroma
-    std::vector<double> en[4], st[4], all;
+    // kinds: 0 DC first, 1 AC first, 2 AC refine luma (whole walk or scout), 3 AC refine chroma, 4 a part of a split scan's band
+    std::vector<double> en[5], st[5], all;
     for (size_t i = 0; i < t.size(); i += 3) if (t[i]) {
-        const int kind = (int)(t[i + 2] & 3);
+        const int kind = (int)(t[i + 2] & 7);
         en[kind].push_back((double)(t[i + 1] - t0) * 0.01); st[kind].push_back((double)(t[i] - t0) * 0.01); all.push_back(en[kind].back());
     }
     std::sort(all.begin(), all.end());
     fprintf(stderr, "[diag prog] %zu waves that walked a band in this launch; end us: p10 %.0f median %.0f p90 %.0f p99 %.0f max %.0f\n", all.size(),
             all[(size_t)(0.1 * (all.size() - 1))], all[all.size() / 2], all[(size_t)(0.9 * (all.size() - 1))], all[(size_t)(0.99 * (all.size() - 1))], all.back());
-    static const char *nm[4] = {"DC first", "AC first", "AC refine luma", "AC refine chroma"};
-    for (int k = 0; k < 4; ++k) if (!en[k].empty()) {
+    static const char *nm[5] = {"DC first", "AC first", "AC refine luma", "AC refine chroma", "parts that place"};
+    for (int k = 0; k < 5; ++k) if (!en[k].empty()) {
         std::sort(en[k].begin(), en[k].end()); std::sort(st[k].begin(), st[k].end());
         double dur = 0; for (size_t i = 0; i < en[k].size(); ++i) dur += en[k][i];
         double sst = 0; for (size_t i = 0; i < st[k].size(); ++i) sst += st[k][i];
@@ -119,6 +119,9 @@ struct Walk {
     // carried from band to band
     int eobrun, pred0, pred1, pred2;
     int err;
+    // a split scan's scout: where it stands at the first MCU of each part of the band (m_lo + i * sub_q) goes to sub_out[i]
+    DevProgSub *sub_out;
+    int sub_q;
 };
 
 // ------------------------------------------------------------------------------------------------ DC, first scan (:974-1029)
@@ -334,6 +337,11 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
 }
 
 // -------------------------------------------------------------------------------------- AC, refining scan (:1122-1298, :1100-1115)
+// SCOUT: the same walk without placing anything — symbols and correction counts only, the stream position and the end-of-band
+// run at the first MCU of every part of the band written to k.sub_out.  A refining scan is one serial chain of ~6 000 cycles per
+// block, and a batch lasts as long as the longest scan's chain; the scout's chain is about half of that, and the walks that place
+// (this function without SCOUT, started from the scout's entries, kProgSub per band) run side by side one launch later.
+template <bool SCOUT>
 __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16_t *lut) {
     const DevProgScan *sc = k.sc;
     const int lane = k.lane, al = k.al, ss = k.ss, se = k.se;
@@ -362,7 +370,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     const int m_lo = k.m_lo, m_hi = k.m_hi;
     int err = 0, eobrun = k.eobrun;
 #ifdef MJ_DIAGNOSTIC
-    const bool dbg_on = sc->ah == 1 && c == 0;
+    const bool dbg_on = !SCOUT && sc->ah == 1 && c == 0;
     uint64_t dacc[7] = {0, 0, 0, 0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
     unsigned long long dblocks = 0, deob = 0, dplaced = 0;
 #endif
@@ -390,10 +398,111 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         // lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
         const int slot = (cf == 0 && lane >= ss) ? zrank : q.nzeros + lane - zrank;
         q.zpos = (uint32_t)__builtin_amdgcn_ds_permute(slot << 2, lane);
-        q.ztab = q.zpos - (uint32_t)(ss + lane);           // of the zpos - Ss positions in front of zero number `lane`, `lane` are zeros
+        if (!SCOUT) q.ztab = q.zpos - (uint32_t)(ss + lane);           // of the zpos - Ss positions in front of zero number `lane`, `lane` are zeros
         return q;
     };
+    // the scout's block: the symbol chain and the counts of correction bits, nothing else
+    auto scout_block = [&](const Prep &pr) __attribute__((always_inline)) {
+        st.top_up();
+        if (eobrun > 0) { st.bp += pr.nband; --eobrun; return; }
+        const int nzeros = pr.nzeros;
+        const uint32_t zpos = pr.zpos;
+        int k = ss, jz = 0;
+        int u = st.bp;
+        for (;;) {
+            uint32_t e;
+            int code, off;
+            for (;;) {
+                // 14 instructions per symbol.  In front of zero number zl at position k1 lie k1 - Ss - zl history-non-zero
+                // coefficients — the correction bits read so far — so the next symbol starts at u + k1 - Ss - zl; ur = u - gbase - Ss
+                // makes that a window offset in two additions.  Codes as in the placing loop below.
+                int t0, k1 = k - 1, zl = jz - 1;
+                const int gss = win.gbase + ss;
+                int ur = u - gss;
+                asm volatile(
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
+                    "s_cmp_gt_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lcwin%=\n\t"
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    "Lcsym%=:\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"
+                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"
+                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"
+                    "s_cbranch_scc1 Lcover%=\n\t"
+                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
+                    "s_add_u32 %[ur], %[ur], %[t0]\n\t"
+                    "s_sub_u32 %[t0], %[k1], %[zl]\n\t"
+                    "s_add_u32 %[off], %[ur], %[t0]\n\t"
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n\t"        // (an offset past 63 reads some lane's entry, which is then not used)
+                    "s_cmp_ge_u32 %[k1], %[se]\n\t"
+                    "s_cbranch_scc1 Lcdone%=\n\t"
+                    "s_cmp_le_u32 %[off], 63\n\t"
+                    "s_cbranch_scc1 Lcsym%=\n"
+                    "Lcwin%=:\n\t"
+                    "s_mov_b32 %[code], 1\n\t"
+                    "s_branch Lcend%=\n"
+                    "Lcdone%=:\n\t"
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch Lcend%=\n"
+                    "Lcspec%=:\n\t"
+                    "s_bitcmp1_b32 %[e], 0\n\t"
+                    "s_cbranch_scc1 Lclong%=\n\t"
+                    "s_lshr_b32 %[eob], %[e], 16\n\t"
+                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
+                    "s_add_u32 %[off], %[off], %[t0]\n\t"
+                    "s_add_u32 %[ur], %[ur], %[t0]\n\t"
+                    "s_mov_b32 %[code], 4\n\t"
+                    "s_branch Lcend%=\n"
+                    "Lclong%=:\n\t"
+                    "s_mov_b32 %[code], 2\n\t"
+                    "s_branch Lcend%=\n"
+                    "Lcover%=:\n\t"
+                    "s_sub_u32 %[zl], %[zl], %[t0]\n\t"
+                    "s_and_b32 %[t0], %[e], 3\n\t"
+                    "s_cbranch_scc1 Lcspec%=\n\t"
+                    "s_mov_b32 %[code], 3\n"
+                    "Lcend%=:"
+                    : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [ur] "+s"(ur), [k1] "+s"(k1), [zl] "+s"(zl),
+                      [eob] "+s"(eobrun)
+                    : [bp] "s"(st.bp), [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [se] "s"(se), [nzeros] "s"(nzeros)
+                    : "scc");
+                k = rfl(k1) + 1; jz = rfl(zl) + 1;
+                e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); eobrun = rfl(eobrun);
+                u = rfl(ur) + gss; st.bp = win.gbase + off;
+                if (code != 1) break;
+                win.move_to(st, lut, al, lane, off);
+            }
+            if (code == 0 || code == 4) break;
+            if (code == 3) { err = MJ_ST_OVERRUN; break; }
+            if (e & 1u) {
+                const uint32_t w = rdl(win.vw0, off);
+                int len, hv;
+                long_code(w, tab, kProgLutBits + 1, len, hv);
+                e = ac_entry<true>(w, len, hv, al);
+                if (len == 0) { err = MJ_ST_BAD_CODE; break; }
+            }
+            if (e & 2u) {
+                eobrun = (int)(e >> 16);
+                st.bp += (int)((e >> 11) & 31u);
+                u += (int)((e >> 11) & 31u);
+                break;
+            }
+            const int jt2 = jz + (int)((e >> 2) & 31u) - 1;
+            if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
+            const int pz2 = (int)rdl(zpos, jt2);
+            u += (int)((e >> 11) & 31u);
+            st.bp = u + pz2 - ss - jt2;
+            k = pz2 + 1; jz = jt2 + 1;
+            if (k > se) break;
+        }
+        if (!err && eobrun > 0) {
+            if (k <= se) st.bp = u + pr.nband;
+            --eobrun;
+        }
+    };
     auto one_block = [&](int cf, int16_t *p, const Prep &pr) __attribute__((always_inline)) {
+        if constexpr (SCOUT) { scout_block(pr); return; }
         PSTAMP(6);
         st.top_up();
         const uint64_t nzb = pr.nzb;
@@ -577,6 +686,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     };
 
 
+    DevProgSub *sub_entry = k.sub_out;
+    int sub_next = SCOUT ? m_lo : -1;
     // four blocks' coefficients in flight: a block is ~1 us of HBM latency away and takes less than that to walk
     constexpr int D = 4;
     int cfq[D];
@@ -594,6 +705,10 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 const int cf = cfq[u];
                 int16_t *p = pq[u];
                 if (m + u + D < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
+                if (SCOUT && m + u == sub_next) {          // the first MCU of a part of the band: what its walk starts from
+                    if (lane == 0) *sub_entry = DevProgSub{st.bp, eobrun, 0, m + u};
+                    ++sub_entry; sub_next += k.sub_q;
+                }
                 // (working the next block's tables out one block ahead, to hide the permutes' latency, was slower: the tables
                 // of two blocks alive at once cost scalar registers the symbol loop's surroundings need)
                 one_block(cf, p, prepare(cf, eobrun > 0));
@@ -619,13 +734,22 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
                                                           const DevProgScan *__restrict__ scans, const DevImage *__restrict__ images,
                                                           const DevHuff *__restrict__ huff, const uint16_t *__restrict__ lut11p,
                                                           int16_t *__restrict__ coef, int32_t *__restrict__ status, int spec_refine, int tr,
-                                                          DevProgState *__restrict__ states, int step, int rows_per_band) {
+                                                          DevProgState *__restrict__ states, int step, int rows_per_band,
+                                                          int n_split, DevProgSub *__restrict__ subs, int parts) {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][kPLut];        // AC: one table of 11 bits; DC: up to three of 9 bits
     __shared__ __attribute__((aligned(16))) uint32_t s_ring[4][kRingDw];
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int seg_id = blockIdx.x * 4 + wave;
-    if (seg_id >= n_segs) return;                              // wave-uniform; no workgroup barriers below
+    // One wave per segment, the longest walks first (a launch lasts as long as its slowest wave, and holds more waves than the
+    // chip has slots): the split scans' segments — the first n_split — as scouts, then their kProgSub parts of the band each, the
+    // walks that place, then the other segments.  (wave-uniform; no workgroup barriers below)
+    int seg_id = blockIdx.x * 4 + wave, part = -1;
+    if (seg_id >= n_split) {
+        const int r = seg_id - n_split;
+        if (r < n_split * parts) { seg_id = r / parts; part = r - seg_id * parts; }
+        else seg_id = r - n_split * (parts - 1);
+    }
+    if (seg_id >= n_segs) return;
 #ifdef MJ_DIAGNOSTIC
     const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -643,9 +767,12 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
 
     // ---- which part of the scan this launch does
     int b_lo = k.sg->mcu0, b_hi = k.sg->mcu0 + k.sg->n_mcu;
+    const bool scout = BANDED && sc->split != 0 && part < 0;
+    DevProgSub *sub = nullptr;
     if (BANDED) {
-        const int band = step - sc->level;
+        const int band = step - sc->level - (part >= 0 ? 1 : 0);   // the parts follow the scout one launch behind
         if (band < 0) return;
+        if (sc->split) sub = subs + ((size_t)seg_id * 2 + (band & 1)) * kProgSub;
         const int v_scan = sc->n_comp == 1 ? k.im->comp_v[sc->comp[0]] : 1;   // block rows per frame MCU row
         const int64_t mpb = (int64_t)sc->mcu_count_h * rows_per_band * v_scan;
         const int64_t lo = (int64_t)band * mpb, hi = lo + mpb;
@@ -654,10 +781,18 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
         if (b_lo >= b_hi) return;
     }
     k.m_lo = b_lo; k.m_hi = b_hi;
-    const bool resume = BANDED && b_lo != k.sg->mcu0, finish = !BANDED || b_hi == k.sg->mcu0 + k.sg->n_mcu;
+    k.sub_out = sub; k.sub_q = (b_hi - b_lo + parts - 1) / parts;
+    const bool resume = BANDED && part < 0 && b_lo != k.sg->mcu0, finish = !BANDED || (part < 0 && b_hi == k.sg->mcu0 + k.sg->n_mcu);
     DevProgState *ps = states + seg_id;
     int bp0 = 0;
     k.eobrun = 0; k.pred0 = k.pred1 = k.pred2 = 0; k.err = 0;
+    if (part >= 0) {                                           // a part of the band: from where the scout stood at its first MCU
+        const int lo = b_lo + part * k.sub_q;
+        const DevProgSub e = sub[part];
+        if (lo >= b_hi || e.mcu != lo || e.err != 0) return;   // (no such part; the scout did not get there: the scan's status is set)
+        k.m_lo = lo; k.m_hi = min(b_hi, lo + k.sub_q);
+        bp0 = e.pos; k.eobrun = e.eobrun;
+    }
     if (resume) {
         if (ps->err != 0 || ps->mcu_next != b_lo) return;      // the scan failed earlier (its status is set)
         bp0 = ps->pos; k.eobrun = ps->eobrun; k.pred0 = ps->pred[0]; k.pred1 = ps->pred[1]; k.pred2 = ps->pred[2];
@@ -683,21 +818,23 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
 
     if (is_dc) walk_dc_first(k, st, lut);
     else if (sc->ah == 0) walk_ac_first(k, st, lut);
-    else walk_ac_refine(k, st, lut);
+    else if (scout) walk_ac_refine<true>(k, st, lut);
+    else walk_ac_refine<false>(k, st, lut);
 
 #ifdef MJ_DIAGNOSTIC
-    if (lane == 0 && seg_id < 16384 && spec_refine >= 0 && (tr >> 8) == step + 1) {     // (tr's upper bits: the launch to record, plus one)
-        unsigned long long *o = g_dbg_prog_waves + (size_t)seg_id * 3;
+    const int dbg_slot = blockIdx.x * 4 + wave;
+    if (lane == 0 && dbg_slot < 32768 && spec_refine >= 0 && (tr >> 8) == step + 1) {     // (tr's upper bits: the launch to record, plus one)
+        unsigned long long *o = g_dbg_prog_waves + (size_t)dbg_slot * 3;
         o[0] = dbg_r0; o[1] = __builtin_amdgcn_s_memrealtime();
-        o[2] = is_dc ? 0 : (sc->ah == 0 ? 1 : (sc->comp[0] == 0 ? 2 : 3));
+        o[2] = part >= 0 ? 4 : is_dc ? 0 : (sc->ah == 0 ? 1 : (sc->comp[0] == 0 ? 2 : 3));
     }
 #endif
     int err = k.err;
-    if (BANDED && !finish && lane == 0) {
+    if (BANDED && part < 0 && !finish && lane == 0) {
         ps->pos = st.bp; ps->eobrun = k.eobrun; ps->pred[0] = k.pred0; ps->pred[1] = k.pred1; ps->pred[2] = k.pred2;
         ps->err = err; ps->mcu_next = b_hi;
     }
-    if (!err && finish) err = st.end_status(k.sg->last != 0);
+    if (!err && finish) err = st.end_status(k.sg->last != 0);      // (a split scan's scout reads every bit the parts read)
     if (err && lane == 0) atomicMax(status + sc->image, err);
 }
 
@@ -705,18 +842,20 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
 hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs,
                                    int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
-                                   DevProgState *states, int step, int rows_per_band) {
+                                   DevProgState *states, int step, int rows_per_band, int n_split, DevProgSub *subs, int parts) {
     if (n_segs == 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_segs + 3) / 4));
+    if (rows_per_band <= 0) n_split = 0;
+    parts = std::min(std::max(parts, 1), kProgSub);
+    const dim3 grid((unsigned)((n_segs + n_split * parts + 3) / 4));
 #ifdef MJ_DIAGNOSTIC
     if (const char *e = getenv("MJ_DEBUG_PROG_STEP")) transposed |= (atoi(e) + 1) << 8;
 #endif
     if (rows_per_band > 0)
         hipLaunchKernelGGL(k_progressive_fast<true>, grid, dim3(256), 0, stream, dstream, seg_bits, segs, n_segs, scans, images, huff,
-                           lut11p, coef, status, spec_refine, transposed, states, step, rows_per_band);
+                           lut11p, coef, status, spec_refine, transposed, states, step, rows_per_band, n_split, subs, parts);
     else
         hipLaunchKernelGGL(k_progressive_fast<false>, grid, dim3(256), 0, stream, dstream, seg_bits, segs, n_segs, scans, images, huff,
-                           lut11p, coef, status, spec_refine, transposed, states, 0, 0);
+                           lut11p, coef, status, spec_refine, transposed, states, 0, 0, 0, nullptr, 1);
     return hipGetLastError();
 }
 

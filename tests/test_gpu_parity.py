@@ -1175,7 +1175,7 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
 
 
-@pytest.mark.parametrize("form", ["levels", "one_row_bands", "general_walk", "general_walk_levels"])
+@pytest.mark.parametrize("form", ["levels", "one_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_one_row", "split_none"])
 def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
     launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, two MCU rows per
@@ -1186,7 +1186,10 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
     from oracle import oracle
     from tools import synth
     env = {"levels": {"MJ_PROG_BANDS": "0"}, "one_row_bands": {"MJ_PROG_ROWS": "1"}, "general_walk": {"MJ_PROG_FAST": "0"},
-           "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"}}[form]
+           "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"},
+           # (round 4) every refining AC scan walked as scout + parts (by default only those with 1 KiB or more per band), or none
+           "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_one_row": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "1"},
+           "split_none": {"MJ_PROG_SPLIT": "0"}}[form]
     for k, v in env.items():
         tune(k, v)
     names = prog_names()

@@ -11,6 +11,8 @@ W, H, nd = 1920, 1080, 8
 if os.environ.get("MJ_PROBE_LIB"):      # e.g. pyjpegdecoder_amd/libmijpeg_diag.so: its stage timing prints the refining walk's phase shares
     from pathlib import Path
     B.LIB_PATH = Path(os.environ["MJ_PROBE_LIB"]).resolve()
+for kv in filter(None, os.environ.get("MJ_OPTS", "").split(",")):      # e.g. MJ_OPTS=MJ_PROG_SPLIT=0,MJ_PROG_ROWS=1
+    B.set_option(*kv.split("=", 1))
 raws = []
 for i in range(nd):
     b = io.BytesIO(); Image.fromarray(synth.synth_rgb(500000 + i, W, H)).save(b, "JPEG", quality=85, subsampling=2, progressive=True); raws.append(b.getvalue())

@@ -17,6 +17,9 @@ from tools.craft_jpeg import random_baseline, random_progressive   # noqa: E402
 
 
 def main():
+    from pyjpegdecoder_amd import _binding as B
+    for kv in filter(None, os.environ.get("MJ_OPTS", "").split(",")):      # e.g. MJ_OPTS=MJ_PROG_SPLIT=2: every refining AC scan as scout + parts
+        B.set_option(*kv.split("=", 1))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)

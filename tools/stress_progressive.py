@@ -36,7 +36,9 @@ for i in range(n_files):
     want.append(oracle.decode(b.getvalue())["rgb"])
 print("made %d files + oracle answers in %.1f s" % (len(files), time.time() - t0), flush=True)
 bad = 0
-forms = {"bands": {}, "one-row bands": {"MJ_PROG_ROWS": "1"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"}}
+forms = {"bands": {}, "one-row bands": {"MJ_PROG_ROWS": "1"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"},
+         "split scans": {"MJ_PROG_SPLIT": "2"}, "split, 1-row, 3 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "1", "MJ_PROG_PARTS": "3"},
+         "split, 7 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_PARTS": "7"}}
 for name, env in forms.items():
     for k, v in env.items():
         _B.set_option(k, v)
@@ -51,7 +53,7 @@ for name, env in forms.items():
                 if not np.array_equal(got, want[lo + i]):
                     n_bad += 1
         dec.close()
-        print(f"{name:14s} {layout:9s}: {len(files)} files, {n_bad} mismatches, {time.time() - t0:.1f} s", flush=True)
+        print(f"{name:22s} {layout:9s}: {len(files)} files, {n_bad} mismatches, {time.time() - t0:.1f} s", flush=True)
         bad += n_bad
     for k in env:
         _B.set_option(k, None)
