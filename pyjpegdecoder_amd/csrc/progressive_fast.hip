@@ -233,12 +233,15 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
             uint64_t touched = 0;
             int kk = ss;
             for (;;) {
+                uint32_t e;
+                int code, off;
+                for (;;) {                                 // (the common way round on its own, as in the refining walk)
                 // The run of coefficient symbols inside the current window, hand-scheduled like the refining walk's: 20
                 // instructions per symbol, the next symbol's entry in flight during this one's placement.  Leaves with code
                 // 0: kk > Se;  1: the next symbol starts behind the window;  2: ZRL, or entry not in the LUT;
                 // 3: position past 63;  4: end of band, eobrun set (the run counts this block, :1160-1166).
-                uint32_t e, e2;
-                int code, t0, off;
+                uint32_t e2;
+                int t0;
                 asm volatile(
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "s_cmp_gt_u32 %[off], 63\n\t"
@@ -294,8 +297,11 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                       [touched] "+s"(touched), [cf] "+v"(cf), [eob] "+s"(eobrun)
                     : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [se] "s"(se)
                     : "vcc", "scc", "m0");
+                e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); st.bp = rfl(st.bp); kk = rfl(kk); eobrun = rfl(eobrun);
+                if (code != 1) break;
+                win.move_to(st, lut, al, lane, off);
+                }
                 if (code == 0 || code == 4) break;
-                if (code == 1) { win.move_to(st, lut, al, lane, off); continue; }
                 if (code == 3) { err = MJ_ST_OVERRUN; break; }
                 if ((e & 3u) == 3u) {                      // a code longer than the LUT's index (rare) or no code at all
                     const uint32_t w = rdl(win.vw0, off);
