@@ -694,32 +694,23 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
 
     DevProgSub *sub_entry = k.sub_out;
     int sub_next = SCOUT ? m_lo : -1;
-    // four blocks' coefficients in flight: a block is ~1 us of HBM latency away and takes less than that to walk
-    constexpr int D = 4;
-    int cfq[D];
-    int16_t *pq[D];
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-        pq[u] = cbase + nat;
-        cfq[u] = 0;
-        if (m_lo + u < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
-    }
-    for (int m = m_lo; m < m_hi && !err; m += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            if (m + u < m_hi && !err) {
-                const int cf = cfq[u];
-                int16_t *p = pq[u];
-                if (m + u + D < m_hi) { pq[u] = next_elem(); cfq[u] = *pq[u]; }
-                if (SCOUT && m + u == sub_next) {          // the first MCU of a part of the band: what its walk starts from
-                    if (lane == 0) *sub_entry = DevProgSub{st.bp, eobrun, 0, m + u};
-                    ++sub_entry; sub_next += k.sub_q;
-                }
-                // (working the next block's tables out one block ahead, to hide the permutes' latency, was slower: the tables
-                // of two blocks alive at once cost scalar registers the symbol loop's surroundings need)
-                one_block(cf, p, prepare(cf, eobrun > 0));
-            }
+    // The next block's coefficients are asked for before this block is walked (a block is ~1 us of HBM latency away and takes
+    // 1.4 us or more to walk).  One copy of the block's code, not four with four blocks in flight: the walks are instruction-fetch
+    // bound as much as anything — 16 files 60.2 -> 51.9 ms, 1024: 81.1 -> 79.2, 2048: 122.6 -> 120.3 with the smaller loop.
+    int16_t *pn = cbase + nat;
+    int cfn = 0;
+    if (m_lo < m_hi) { pn = next_elem(); cfn = *pn; }
+    for (int m = m_lo; m < m_hi && !err; ++m) {
+        const int cf = cfn;
+        int16_t *p = pn;
+        if (m + 1 < m_hi) { pn = next_elem(); cfn = *pn; }
+        if (SCOUT && m == sub_next) {                      // the first MCU of a part of the band: what its walk starts from
+            if (lane == 0) *sub_entry = DevProgSub{st.bp, eobrun, 0, m};
+            ++sub_entry; sub_next += k.sub_q;
         }
+        // (working the next block's tables out one block ahead, to hide the permute's latency, was slower: the tables
+        // of two blocks alive at once cost scalar registers the symbol loop's surroundings need)
+        one_block(cf, p, prepare(cf, eobrun > 0));
     }
     k.eobrun = eobrun;
     k.err = err;
