@@ -106,6 +106,27 @@ void dbg_prog_waves_report() {
 
 namespace {
 
+// Where a symbol loop starts matters: the walks are lone wavefronts bound by instruction fetch, and the scout's 72-byte loop runs
+// 7 % faster from byte 16 of a 32-byte window than from byte 0, 8 or 24 (16 x 1080p: 52.1 ms against 56.1 / 55.8 / 55.5;
+// period 32 bytes).  Before the loops were aligned their speed moved by that much with whatever code happened to precede them.
+// (MJ_SKEW_*: s_nop's behind the alignment; the placing loop and the first scans' loop are indifferent.)
+#ifndef MJ_LOOP_ALIGN_LOG2
+#define MJ_LOOP_ALIGN_LOG2 6
+#endif
+#define MJ_STR2(x) #x
+#define MJ_STR(x) MJ_STR2(x)
+#define MJ_LOOP_ALIGN MJ_STR(MJ_LOOP_ALIGN_LOG2)
+#ifndef MJ_SKEW_R
+#define MJ_SKEW_R 4
+#endif
+#ifndef MJ_SKEW_C
+#define MJ_SKEW_C 4
+#endif
+#ifndef MJ_SKEW_F
+#define MJ_SKEW_F 4
+#endif
+#define MJ_LOOP_PAD(n) ".rept " MJ_STR(n) "\n s_nop 0\n .endr\n"
+
 // Everything a walk needs; wave-uniform
 struct Walk {
     const DevProgSeg *sg;
@@ -247,6 +268,7 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "s_cmp_gt_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lfwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_F)
                     "Lfsym%=:\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 64 * class: what is no plain coefficient lands past 63 too
                     "s_add_u32 %[kk], %[kk], %[t0]\n\t"
@@ -430,6 +452,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_cmp_gt_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lcwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_C)
                     "Lcsym%=:\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x80002\n\t"
                     "s_add_u32 %[zl], %[zl], %[t0]\n\t"
@@ -567,6 +590,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_cmp_gt_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lwin%=\n\t"
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
+                    ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_R)
                     "Lsym%=:\n\t"
                     "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 1 + 64 * class: what is no plain coefficient overshoots every zero count
                     "s_add_u32 %[zl], %[zl], %[t0]\n\t"
