@@ -115,29 +115,6 @@ __device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int fr
     }
 }
 
-// The same search with the code book in registers, all lengths at once: lane l holds length l's first code, count and first
-// symbol, the 256 symbols sit four to a lane.  (The scalar search above reads the book from memory, two dependent loads per
-// length: up to ~2 000 cycles for one code, and with libjpeg's optimised tables a refining scan meets a code of more than
-// kProgLutBits bits every few blocks.)  w, from: wave-uniform.
-struct LongCodes {
-    int fc, cnt, fs;
-    uint32_t vals;
-    __device__ __forceinline__ void init(const DevHuff *tab, int lane) {
-        const int l = lane <= 16 ? lane : 0;
-        fc = tab->first_code[l]; cnt = lane <= 16 ? tab->count[l] : 0; fs = tab->first_sym[l];
-        vals = reinterpret_cast<const uint32_t *>(tab->vals)[lane];
-    }
-    __device__ __forceinline__ void find(uint32_t w, int from, int lane, int &len, int &hv) const {
-        const int dlt = (int)(w >> ((32 - lane) & 31)) - fc;
-        const uint64_t hit = __ballot(lane >= from && dlt >= 0 && dlt < cnt);      // (cnt = 0 for lanes 0 and 17..63)
-        len = 0; hv = 0;
-        if (hit == 0) return;
-        len = __builtin_ctzll(hit);                                                 // the shortest length that matches
-        const int idx = (int)rdl((uint32_t)(fs + dlt), len) & 255;
-        hv = (int)((rdl(vals, idx >> 2) >> (8 * (idx & 3))) & 255u);
-    }
-};
-
 // What a walk needs to know about the AC symbol that starts at the top bit of `w`, given its Huffman code's length and
 // value (len = 0: no code of <= kProgLutBits bits matches):
 //   bits 1..0   class: 0 = coefficient (size > 0), 1 = ZRL, 2 = end of band (EOBn), 3 = not in the table.
