@@ -116,11 +116,14 @@ namespace {
 #define MJ_STR2(x) #x
 #define MJ_STR(x) MJ_STR2(x)
 #define MJ_LOOP_ALIGN MJ_STR(MJ_LOOP_ALIGN_LOG2)
+#ifndef MJ_SCOUT_UNROLL
+#define MJ_SCOUT_UNROLL 1
+#endif
 #ifndef MJ_SKEW_R
 #define MJ_SKEW_R 4
 #endif
 #ifndef MJ_SKEW_C
-#define MJ_SKEW_C 4
+#define MJ_SKEW_C 0
 #endif
 #ifndef MJ_SKEW_F
 #define MJ_SKEW_F 4
@@ -454,20 +457,24 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_C)
                     "Lcsym%=:\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"
-                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"
-                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"
-                    "s_cbranch_scc1 Lcover%=\n\t"
-                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
-                    "s_add_u32 %[ur], %[ur], %[t0]\n\t"
-                    "s_sub_u32 %[t0], %[k1], %[zl]\n\t"
-                    "s_add_u32 %[off], %[ur], %[t0]\n\t"
-                    "v_readlane_b32 %[e], %[ve0], %[off]\n\t"        // (an offset past 63 reads some lane's entry, which is then not used)
-                    "s_cmp_ge_u32 %[k1], %[se]\n\t"
-                    "s_cbranch_scc1 Lcdone%=\n\t"
+#define MJ_SCOUT_SYMBOL \
+                    "s_bfe_u32 %[t0], %[e], %[krun]\n\t"             \
+                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"              \
+                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"              \
+                    "s_cbranch_scc1 Lcover%=\n\t"                    \
+                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"       \
+                    "s_bfe_u32 %[t0], %[e], %[kbits]\n\t"            \
+                    "s_add_u32 %[ur], %[ur], %[t0]\n\t"              \
+                    "s_sub_u32 %[t0], %[k1], %[zl]\n\t"              \
+                    "s_add_u32 %[off], %[ur], %[t0]\n\t"             \
+                    "v_readlane_b32 %[e], %[ve0], %[off]\n\t"        /* (an offset past 63 reads some lane's entry, which is then not used) */ \
+                    "s_cmp_ge_u32 %[k1], %[se]\n\t"                  \
+                    "s_cbranch_scc1 Lcdone%=\n\t"                    \
                     "s_cmp_le_u32 %[off], 63\n\t"
-                    "s_cbranch_scc1 Lcsym%=\n"
+#if MJ_SCOUT_UNROLL >= 2
+                    MJ_SCOUT_SYMBOL "s_cbranch_scc0 Lcwin%=\n\t"      // (two symbols per turn: one taken branch per two symbols)
+#endif
+                    MJ_SCOUT_SYMBOL "s_cbranch_scc1 Lcsym%=\n"
                     "Lcwin%=:\n\t"
                     "s_mov_b32 %[code], 1\n\t"
                     "s_branch Lcend%=\n"
@@ -478,7 +485,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_bitcmp1_b32 %[e], 0\n\t"
                     "s_cbranch_scc1 Lclong%=\n\t"
                     "s_lshr_b32 %[eob], %[e], 16\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
+                    "s_bfe_u32 %[t0], %[e], %[kbits]\n\t"
                     "s_add_u32 %[off], %[off], %[t0]\n\t"
                     "s_add_u32 %[ur], %[ur], %[t0]\n\t"
                     "s_mov_b32 %[code], 4\n\t"
@@ -494,7 +501,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "Lcend%=:"
                     : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [ur] "+s"(ur), [k1] "+s"(k1), [zl] "+s"(zl),
                       [eob] "+s"(eobrun)
-                    : [bp] "s"(st.bp), [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [se] "s"(se), [nzeros] "s"(nzeros)
+                    : [bp] "s"(st.bp), [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [se] "s"(se), [nzeros] "s"(nzeros),
+                      [krun] "s"(0x80002), [kbits] "s"(0x5000b)      // (the two field selectors from registers: literals would make the loop 72 bytes, with them it is 64)
                     : "scc");
                 k = rfl(k1) + 1; jz = rfl(zl) + 1;
                 e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); eobrun = rfl(eobrun);
