@@ -235,6 +235,8 @@ int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *st
  *   MJ_HUFFMAN        wave | lanes | lanes11 | sync   stage-1 form              MJ_SEG_ORDER     blob | binned | striped
  *   MJ_SYNC_ROUNDS    0..64  repair rounds           MJ_SYNC_CHUNK   256..65536 bytes   MJ_SYNC_WARM   run-up bytes
  *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
+ *   MJ_PROG_SPLIT     0 | 1 | 2  refining AC scans as scout + parts: never | while the chip has wave slots for it | always
+ *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)
  *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64   MJ_LANES_RING  64 | 128      MJ_STAGE2_CHUNK  strips per stage-2 job
  * Returns MJ_ERR_INVALID for a name that is none of these.  mj_plan_stage1_form() reports what a plan ended up with. */
 int mj_set_option(const char *name, const char *value);
