@@ -642,7 +642,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // ... and while the chip has wave slots for it: past that the added work — a split scan is walked one and a half
             // times — costs more than the shorter chain gains.
             const int64_t n_bands = std::max(1, (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band);
-            std::vector<std::pair<int64_t, int>> cand;
+            std::vector<std::pair<int64_t, int>> cand;        // (bytes, scan)
             for (int k = 0; k < b->n_scans; ++k) {
                 const mj_scan_desc &sd = b->scans[k];
                 if (sd.ss == 0 || sd.ah == 0 || sd.n_comp != 1) continue;
@@ -651,21 +651,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 for (int g = 0; g < sd.n_segments; ++g) bytes += b->seg_end[sd.first_segment + g] - b->seg_begin[sd.first_segment + g];
                 if (split_mode >= 2 || bytes / n_bands >= 1024) cand.push_back({-bytes, k});
             }
-            std::sort(cand.begin(), cand.end());
-            // Every such scan if their scouts and parts all find a wave slot at once, else each image's largest if those do,
-            // else none.  (1024 x 1080p, libjpeg's script: both luma refinements 92.9 ms, the last one only 80.9, none 85.9;
-            // 768 files: both 75.6, none 84.3; 2048: the last one 153, none 122.  Part of the images, whatever fits: worse than either.)
+            // All of them if their scouts and parts find a wave slot at once, else none.  (libjpeg's script, 1080p: 512 files
+            // 56.2 ms split / 73.2 not, 768: 69.3 / 76.7, 1024: 92.1 / 78.6, 1536: 135 / 94.  Only each image's largest scan where
+            // those fit: 1024 files 79.5, 1536 116.  As many images as fit: worse than either, 99.7 at 1024.)
             const int64_t slots = (int64_t)mj::device_cus() * 32;
-            std::vector<char> top(b->n_scans, 0), seen_image(b->n_images, 0);
-            int64_t need_all = 0, need_top = 0;
-            for (auto &c : cand) {
-                const mj_scan_desc &sd = b->scans[c.second];
-                const int64_t need = (int64_t)sd.n_segments * (1 + p->prog_parts);
-                need_all += need;
-                if (sd.image >= 0 && sd.image < b->n_images && !seen_image[sd.image]) { seen_image[sd.image] = 1; top[c.second] = 1; need_top += need; }
-            }
-            const int tier = split_mode >= 2 || need_all <= slots ? 2 : (need_top <= slots ? 1 : 0);
-            for (auto &c : cand) split_of[c.second] = tier == 2 || (tier == 1 && top[c.second]);
+            int64_t need_all = 0;
+            for (auto &c : cand) need_all += (int64_t)b->scans[c.second].n_segments * (1 + p->prog_parts);
+            if (split_mode >= 2 || need_all <= slots)
+                for (auto &c : cand) split_of[c.second] = 1;
         }
         auto want_split = [&](int k) { return split_of[k] != 0; };
         std::vector<int> ordinal_of(b->n_scans, 0);
