@@ -161,6 +161,28 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             ok = ok and np.array_equal(host[i * per:(i + 1) * per].reshape(W, H, 3), oracle.decode(files[i])["rgb"])
     finally:
         plan.close()
+    # the same files in smaller batches: below ~900 files the plan walks the luma refinements as scout + parts
+    smaller = []
+    for m in (16, 256):
+        if m >= n_images:
+            continue
+        prep_m = prepare_batch(files[:m], B.MJ_LAYOUT_XMAJOR, 0)
+        d_blob_m = torch.from_numpy(prep_m.blob).to(dev)
+        plan_m = B.Plan(ctx, prep_m.to_c(d_blob_m.data_ptr()), {"prep": prep_m, "n_images": m})
+        try:
+            plan_m.execute(stream, d_rgb.data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                plan_m.execute(stream, d_rgb.data_ptr())
+            torch.cuda.synchronize()
+            dt_m = (time.perf_counter() - t0) / 3
+            ok_m = not plan_m.read(rgb=False)["status"].any()
+            ok_m = ok_m and bool(np.array_equal(d_rgb[:W * H * 3].cpu().numpy().reshape(W, H, 3), oracle.decode(files[0])["rgb"]))
+            smaller.append({"images": m, "ms_per_step": round(dt_m * 1e3, 2), "value": round(m * W * H / 1e6 / dt_m, 1),
+                            "parity": "bit-exact vs oracle (image 0)" if ok_m else "MISMATCH"})
+        finally:
+            plan_m.close()
     # algorithmic bytes of the scan walks: the entropy-coded bytes once, plus for every scan the coefficients it covers —
     # 2 B x (Se - Ss + 1) per block of its components, written by a first scan, read and written by a refining one
     from pyjpegdecoder_amd import parse_jpeg
@@ -178,12 +200,13 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             "algorithmic_bytes_per_step": int(s1_bytes), "stage1_ms": round(s1, 3),
             "note": "entropy bytes + per scan 2 B x (Se-Ss+1) per covered block (x2 for refining scans: read-modify-write); "
                     "serial-walk (instruction issue) bound, quoted against HBM as SURVEY 8d asks; launches per step and their "
-                    "average durations: profiles/r03c_progressive_kernel_stats.csv"}
+                    "average durations: profiles/r04d_progressive_kernel_stats.csv"}
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
             "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3), "roofline": roof,
             "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
                         "scan-by-scan entropy decode + the ordinary stage 2 (BASELINE configs[4])",
             "entropy_bytes_per_image": int(sum(map(len, raws)) // n_distinct),
+            "smaller_batches": smaller,
             "parity": "bit-exact vs oracle (images 0 and 1)" if ok else "MISMATCH"}
 
 

@@ -1306,9 +1306,12 @@ def test_planar_layouts(layout):
         d.close()
 
 
-def test_config5_progressive_1080p_batch_at_size(dec):
+@pytest.mark.parametrize("n", [1024, 256])
+def test_config5_progressive_1080p_batch_at_size(dec, n):
     """BASELINE configs[4] at its stated size: 1024 x 1080p 4:2:0 progressive (libjpeg's default 10-scan script as Pillow
-    writes it; 8 distinct files tiled).  Every distinct image against the oracle, every replica against its first instance."""
+    writes it; 8 distinct files tiled).  Every distinct image against the oracle, every replica against its first instance.
+    256 files: the size at which the plan walks the luma refinements as scout + parts (round 4; at 1024 the chip has no wave
+    slots to spare for that and every scan is walked once)."""
     import io
     torch = pytest.importorskip("torch")
     Image = pytest.importorskip("PIL.Image")
@@ -1316,7 +1319,7 @@ def test_config5_progressive_1080p_batch_at_size(dec):
     from tools import synth
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
-    W, H, nd, n = 1920, 1080, 8, 1024
+    W, H, nd = 1920, 1080, 8
     raws = []
     for i in range(nd):
         b = io.BytesIO()

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r04c'
-TAG=${1:-r04c}
+# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r04d'
+TAG=${1:-r04d}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1
@@ -11,7 +11,7 @@ mkdir -p "$O/prog_$TAG"
 bash "$R/tools/layout_sweep.sh" > /dev/null 2>&1
 ( cd "$R" && timeout 300 python3 tools/stage_probe.py --mixed --distinct 256 "" MJ_SEG_ORDER=blob MJ_SEG_ORDER=binned MJ_SEG_ORDER=striped MJ_HUFFMAN=lanes11 > "$O/mixed_orders_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 300 python3 tools/generic_layout_probe.py > "$O/generic_layouts_$TAG.txt" 2>&1 )
-( cd "$R" && timeout 300 python3 tools/prog_batch_probe.py 16 256 1024 > "$O/prog_sweep_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 300 python3 tools/prog_batch_probe.py 16 256 512 768 1024 2048 > "$O/prog_sweep_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 300 python3 tools/e2e_probe.py > "$O/e2e_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 600 python3 bench.py --gpus 2 --share-gpu --steps 20 --warmup 3 --no-cpu-baseline --no-progressive > "$O/bench_gpus2_sharegpu_$TAG.json" 2> "$O/bench_gpus2_sharegpu_$TAG.err" )
 ( cd "$R" && { [ -x tools/step_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm tools/step_probe.hip -o tools/step_probe.bin; } && timeout 300 ./tools/step_probe.bin > "$O/step_probe_$TAG.txt" 2>&1 )
