@@ -626,7 +626,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
         p->prog_banded = true;
         if (const char *e = mj::opt("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
-        p->prog_rows_per_band = p->prog_banded ? 2 : max_rows;
+        p->prog_rows_per_band = p->prog_banded ? 1 : max_rows;      // (one frame MCU row per band: 1-2 % faster than two up to 1024 files, equal above)
         if (const char *e = mj::opt("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
         // Split scans (progressive_fast.hip): a refining AC scan is one serial chain — a batch lasts as long as its longest scan's
         // walk — and more than half of a block's walk is placing what the symbols say, which needs no order once the bit position
@@ -764,7 +764,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
           }
         }
         p->ordinal_seg_off[n_ord] = (int64_t)psegs.size();
-        {   // Band pipelining (see progressive_fast.hip): two frame MCU rows per band, launches = bands + levels - 1.  It
+        {   // Band pipelining (see progressive_fast.hip): one frame MCU row per band (round 4; two before), launches = bands + levels - 1.  It
             // shortens the critical path from the sum of the levels' longest scans to about the longest scan — a refining scan
             // follows one band behind what it refines — and keeps all of an image's scans on the chip at once: faster than one
             // launch per dependency level at every batch size measured (profiles/r02d_progressive_sweep.txt: 16 x 1080p

@@ -1175,20 +1175,20 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
 
 
-@pytest.mark.parametrize("form", ["levels", "one_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_one_row", "split_none"])
+@pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none"])
 def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
-    launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, two MCU rows per
+    launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, one MCU row per
     band — is what every other progressive test runs; here the other combinations decode every progressive fixture in one
     mixed batch, coefficient store included, plus larger random files with long EOB runs and restart intervals."""
     Image = pytest.importorskip("PIL.Image")
     import io
     from oracle import oracle
     from tools import synth
-    env = {"levels": {"MJ_PROG_BANDS": "0"}, "one_row_bands": {"MJ_PROG_ROWS": "1"}, "general_walk": {"MJ_PROG_FAST": "0"},
+    env = {"levels": {"MJ_PROG_BANDS": "0"}, "two_row_bands": {"MJ_PROG_ROWS": "2"}, "general_walk": {"MJ_PROG_FAST": "0"},
            "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"},
            # (round 4) every refining AC scan walked as scout + parts (by default only those with 1 KiB or more per band), or none
-           "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_one_row": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "1"},
+           "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_three_rows": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3"},
            "split_none": {"MJ_PROG_SPLIT": "0"}}[form]
     for k, v in env.items():
         tune(k, v)

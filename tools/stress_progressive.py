@@ -36,8 +36,8 @@ for i in range(n_files):
     want.append(oracle.decode(b.getvalue())["rgb"])
 print("made %d files + oracle answers in %.1f s" % (len(files), time.time() - t0), flush=True)
 bad = 0
-forms = {"bands": {}, "one-row bands": {"MJ_PROG_ROWS": "1"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"},
-         "split scans": {"MJ_PROG_SPLIT": "2"}, "split, 1-row, 3 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "1", "MJ_PROG_PARTS": "3"},
+forms = {"bands": {}, "two-row bands": {"MJ_PROG_ROWS": "2"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"},
+         "split scans": {"MJ_PROG_SPLIT": "2"}, "split, 3 rows, 3 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3", "MJ_PROG_PARTS": "3"},
          "split, 7 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_PARTS": "7"}}
 for name, env in forms.items():
     for k, v in env.items():
