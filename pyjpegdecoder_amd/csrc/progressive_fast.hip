@@ -401,7 +401,11 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     const int m_lo = k.m_lo, m_hi = k.m_hi;
     int err = 0, eobrun = k.eobrun;
 #ifdef MJ_DIAGNOSTIC
+#ifdef MJ_DIAG_SCOUT      // (the stamps on the scout instead of the placing walk)
+    const bool dbg_on = SCOUT && sc->ah == 1 && c == 0;
+#else
     const bool dbg_on = !SCOUT && sc->ah == 1 && c == 0;
+#endif
     uint64_t dacc[7] = {0, 0, 0, 0, 0, 0, 0}, dlast = __builtin_amdgcn_s_memtime();
     unsigned long long dblocks = 0, deob = 0, dplaced = 0;
 #endif
@@ -434,8 +438,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     };
     // the scout's block: the symbol chain and the counts of correction bits, nothing else
     auto scout_block = [&](const Prep &pr) __attribute__((always_inline)) {
+        PSTAMP(6);
         st.top_up();
-        if (eobrun > 0) { st.bp += pr.nband; --eobrun; return; }
+        if (eobrun > 0) { st.bp += pr.nband; --eobrun; PSTAMP(5); return; }
         const int nzeros = pr.nzeros;
         const uint32_t zpos = pr.zpos;
         int k = ss, jz = 0;
@@ -447,9 +452,14 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 // 14 instructions per symbol.  In front of zero number zl at position k1 lie k1 - Ss - zl history-non-zero
                 // coefficients — the correction bits read so far — so the next symbol starts at u + k1 - Ss - zl; ur = u - gbase - Ss
                 // makes that a window offset in two additions.  Codes as in the placing loop below.
+#ifdef MJ_DIAGNOSTIC
+                int t0, k1 = rfl(k - 1), zl = rfl(jz - 1);
+#else
                 int t0, k1 = k - 1, zl = jz - 1;
+#endif
                 const int gss = win.gbase + ss;
                 int ur = u - gss;
+                PSTAMP(0);
                 asm volatile(
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "s_cmp_gt_u32 %[off], 63\n\t"
@@ -507,8 +517,10 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 k = rfl(k1) + 1; jz = rfl(zl) + 1;
                 e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); eobrun = rfl(eobrun);
                 u = rfl(ur) + gss; st.bp = win.gbase + off;
+                PSTAMP(1);
                 if (code != 1) break;
                 win.move_to(st, lut, al, lane, off);
+                PSTAMP(2);
             }
             if (code == 0 || code == 4) break;
             if (code == 3) { err = MJ_ST_OVERRUN; break; }
@@ -537,6 +549,10 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
             if (k <= se) st.bp = u + pr.nband;
             --eobrun;
         }
+#ifdef MJ_DIAGNOSTIC
+        if (dbg_on) ++dblocks;
+#endif
+        PSTAMP(4);
     };
     auto one_block = [&](int cf, int16_t *p, const Prep &pr) __attribute__((always_inline)) {
         if constexpr (SCOUT) { scout_block(pr); return; }
