@@ -618,8 +618,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     if (prog) {
         // (what decides the walks' form comes first: the dependency levels below depend on it)
         p->prog_fast = false;
-        for (int k = 0; k < b->n_scans; ++k)       // first scans of a band, and refining AC scans
-            p->prog_fast = p->prog_fast || (!(b->scans[k].ss == 0 && b->scans[k].se == 63) && (b->scans[k].ah == 0 || b->scans[k].ss > 0));
+        for (int k = 0; k < b->n_scans; ++k)       // every scan of a progressive frame (sequential scans — non-interleaved baseline files — stay with progressive.hip)
+            p->prog_fast = p->prog_fast || !(b->scans[k].ss == 0 && b->scans[k].se == 63);
         if (const char *e = mj::opt("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
         if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
         int max_rows = 1;
@@ -733,8 +733,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         auto kind_of = [&](const mj_scan_desc &sd) {
             const bool sequential = sd.ss == 0 && sd.se == 63;
             if (sequential) return 3;
-            if (sd.ah == 0) return sd.ss == 0 ? 0 : 1;
-            return sd.ss > 0 ? 2 : 3;
+            if (sd.ss == 0) return 0;           // DC scans, first and refining (round 4: the refinement is walked by progressive_fast.hip too)
+            return sd.ah == 0 ? 1 : 2;
         };
         p->ordinal_seg_off.assign(n_ord + 1, 0);
         p->ordinal_kind_off.assign((size_t)n_ord * 4, 0);

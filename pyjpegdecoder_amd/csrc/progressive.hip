@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_progressive_scan(const uint8_t *__restr
     if (KIND != 2 && (KIND == 1) != (refining && !is_dc && !sequential)) return;
     // spec_refine bit 1: the first scans and the refining AC scans are walked elsewhere (progressive_fast.hip); what is left
     // here is DC refinement and the sequential scans
-    if ((spec_refine & 2) && !sequential && !(is_dc && refining)) return;
+    if ((spec_refine & 2) && !sequential) return;
     const bool ac_refining = KIND == 1 ? true : (KIND == 0 ? false : refining);      // in the AC branch below
 
     // ---- which part of the scan this launch does.  The scans of an image are pipelined over bands of `rows_per_band`

@@ -222,6 +222,34 @@ __device__ __forceinline__ void walk_dc_first(Walk &k, Stream &st, const uint16_
     k.err = err;
 }
 
+// ------------------------------------------------------------------------------------------------ DC, refining scan (:1036-1038)
+// One bit per block, blocks in scan order: block t of the segment reads bit t of its stream — no chain at all.  64 blocks per step,
+// the bit straight from the stage-0 stream in global memory.  (Until round 4 the general walk did this from the raw bytes, in a
+// launch of its own behind every launch of this kernel: 70 launches x 40 us per 1024 files, all of it on the critical path.)
+__device__ __forceinline__ int walk_dc_refine(Walk &k, const uint32_t *sw, int n_dw) {
+    const DevProgScan *sc = k.sc;
+    const DevImage *im = k.im;
+    const int lane = k.lane, al = k.al, nsc = sc->n_comp;
+    const int bpm = im->blocks_per_mcu;
+    const int cA = sc->comp[0], cB = nsc > 1 ? sc->comp[1] : 0, cC = nsc > 2 ? sc->comp[2] : 0;
+    const int nA = nsc > 1 ? im->comp_h[cA] * im->comp_v[cA] : 1, nB = nsc > 1 ? im->comp_h[cB] * im->comp_v[cB] : 0;
+    const int nC = nsc > 2 ? im->comp_h[cC] * im->comp_v[cC] : 0;
+    const int bps = nA + nB + nC;
+    const int mcu0 = k.sg->mcu0;
+    const int t_lo = (k.m_lo - mcu0) * bps, t_hi = (k.m_hi - mcu0) * bps;      // blocks of the segment, in scan order = bits of its stream
+    for (int t = t_lo + lane; t < t_hi; t += 64) {
+        const int d = t >> 5;
+        const uint32_t w = (uint32_t)d < (uint32_t)n_dw ? sw[d] : 0u;            // behind the segment's end the stream reads as zeros
+        const int bit = (int)((w >> (31 - (t & 31))) & 1u);
+        const int mm = t / bps, jj = t - mm * bps;
+        const int cc = jj < nA ? cA : (jj < nA + nB ? cB : cC);
+        const int rr = jj < nA ? jj : (jj < nA + nB ? jj - nA : jj - nA - nB);
+        int16_t *p = k.cbase + ((int64_t)(mcu0 + mm) * bpm + im->comp_first[cc] + rr) * 64;
+        p[0] = (int16_t)(p[0] | (int16_t)(bit << al));                           // (:1038)
+    }
+    return t_hi;                                                                 // the bit position behind the band
+}
+
 // ------------------------------------------------------------------------- AC, first scan of the band (:1122-1179, :1236-1250)
 __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_t *lut) {
     const DevProgScan *sc = k.sc;
@@ -805,7 +833,7 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     k.ss = sc->ss; k.se = sc->se; k.al = sc->al; k.tr = tr & 1; k.lane = lane; k.spec = spec_refine != 0;
     const bool sequential = k.ss == 0 && k.se == 63;
     const bool is_dc = k.ss == 0;
-    if (sequential || (is_dc && sc->ah != 0)) return;          // progressive.hip's
+    if (sequential) return;                                    // progressive.hip's
     k.im = images + sc->image;
     k.huff = huff;
     k.cbase = coef + k.im->block_off * 64;
@@ -828,6 +856,16 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     k.m_lo = b_lo; k.m_hi = b_hi;
     k.sub_out = sub; k.sub_q = (b_hi - b_lo + parts - 1) / parts;
     const bool resume = BANDED && part < 0 && b_lo != k.sg->mcu0, finish = !BANDED || (part < 0 && b_hi == k.sg->mcu0 + k.sg->n_mcu);
+    if (is_dc && sc->ah != 0) {                                // DC refinement: nothing is carried from band to band
+        k.lane = lane;
+        const int total_bits = seg_bits[k.sg->stream_slot];
+        const int bp = walk_dc_refine(k, stream + (k.sg->begin >> 2) + k.sg->stream_slot, (total_bits + 31) >> 5);
+        if (finish && lane == 0) {                             // (Stream::end_status)
+            const int err = bp > total_bits ? MJ_ST_OVERRUN : (k.sg->last == 0 && total_bits - bp >= 8 ? MJ_ST_DESYNC : 0);
+            if (err) atomicMax(status + sc->image, err);
+        }
+        return;
+    }
     DevProgState *ps = states + seg_id;
     int bp0 = 0;
     k.eobrun = 0; k.pred0 = k.pred1 = k.pred2 = 0; k.err = 0;
