@@ -5,8 +5,10 @@
 // scan alone is half of a libjpeg-default file) and they cannot be cut into independent pieces: how many correction
 // bits follow a symbol depends on which coefficients of the block earlier scans left non-zero.  What is left to
 // optimise is the serial chain per symbol; one wavefront walks one restart segment of one scan, and a lone
-// wavefront issues one instruction every ~5 cycles whatever the instruction is, so the chain is counted in
-// instructions.  progressive.hip's general walk spends ~170 of them per symbol (bit-buffer refills with the 0xFF
+// wavefront issues one instruction every ~5 cycles whatever the instruction is — and fetches 32 bytes of them
+// in ~15 — so the chain is counted in instructions and in bytes of code (round 4: one copy of the block's code
+// instead of four unrolled ones, loops aligned to their fetch windows).
+// progressive.hip's general walk spends ~170 instructions per symbol (bit-buffer refills with the 0xFF
 // rule, an LDS round trip per Huffman symbol, a loop per skipped zero, a loop per 16 correction bits).  Here:
 //
 //   * stage 0 (destuff.hip) has already applied the byte rules: the segment is a big-endian dword stream, a bit
@@ -19,14 +21,17 @@
 //     while this one is being consumed;
 //   * per block, the zero-history positions are turned into a table once (ds_permute: ordinal -> position), so
 //     "skip r zeros, then the next zero" (:1184-1215) is one v_readlane at ordinal jz + r, and the number of
-//     history-non-zero coefficients passed on the way — the correction bits to skip — is a second v_readlane into the
-//     prefix count of the non-zero mask.  The masks of the block's history do not change while the block is walked
+//     history-non-zero coefficients passed on the way — the correction bits to skip — is a second v_readlane into a
+//     table that follows from the first by arithmetic (position - Ss - ordinal).  The masks of the block's history do not change while the block is walked
 //     (a coefficient placed by this scan lies behind everything later symbols look at);
 //   * correction bits are not read when their symbol is decoded: every lane remembers where its bit will be
 //     (one v_cmp/v_cndmask per symbol) and the whole block's corrections are fetched from the ring and applied at
 //     once when the block ends; the new coefficients go into the lanes with v_writelane.
 //
-// ~35 instructions per coefficient symbol; blocks inside an end-of-band run cost ~40 in all.
+// 22 instructions per coefficient symbol (round 2: 28); blocks inside an end-of-band run cost ~40 in all.
+//   * Split scans (round 4): where the chip has wave slots to spare, a refining scan is walked twice — a scout that follows
+//     the symbol chain and the correction counts alone (14 instructions, 64 bytes per symbol) and leaves its position at the
+//     first MCU of every part of a band, and one launch behind it the parts, walked side by side by the placing walk.
 //
 // ---- the first scans of a band (Ah = 0): DC scans (:974-1029) and AC scans (:1122-1179, :1236-1250) only write.
 //   * AC: the block's new coefficients are collected in the lanes (lane = zig-zag index, v_writelane) together with a mask
@@ -36,8 +41,9 @@
 //     window of bit offsets is looked up in all of them and the walk takes the entry of the component whose turn it is.
 //   ~20 instructions per symbol.
 //
-// progressive.hip's general walk keeps the scans that are neither (DC refinement: one bit per block; sequential scans
-// of non-interleaved baseline files).
+//   * DC refinement (Ah > 0, Ss = 0) is one bit per block in scan order: block t reads bit t of the stream, no chain.
+//
+// progressive.hip's general walk keeps the sequential scans of non-interleaved baseline files.
 //
 // ---- launches.  Scans of one image depend on each other (a refining scan needs what it refines), so they are grouped into
 // dependency levels.  Either one launch per level over that level's segments, or — BANDED — the scans of an image are
@@ -615,7 +621,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 uint32_t e;
                 int code, off;
                 for (;;) {                                 // (the common way round on its own: symbols, next window, symbols ...)
-                // The run of plain coefficient symbols inside the current window, hand-scheduled and software-pipelined: 28
+                // The run of plain coefficient symbols inside the current window, hand-scheduled and software-pipelined: 22
                 // instructions per symbol, two v_readlane deep, the next symbol's entry in flight during this symbol's
                 // bookkeeping (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
                 // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not in the LUT;
@@ -881,15 +887,6 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
         bp0 = ps->pos; k.eobrun = ps->eobrun; k.pred0 = ps->pred[0]; k.pred1 = ps->pred[1]; k.pred2 = ps->pred[2];
     }
 
-#ifdef MJ_X_PROGPRIO
-    // the issue arbiter serves the oldest wave first, then by priority: the longest chains are the launch's critical path
-    {
-        const int bits = seg_bits[seg_id];
-        if (bits > (1 << 20)) __builtin_amdgcn_s_setprio(3);
-        else if (bits > (1 << 18)) __builtin_amdgcn_s_setprio(2);
-        else if (bits > (1 << 16)) __builtin_amdgcn_s_setprio(1);
-    }
-#endif
     uint16_t *lut = s_lut[wave];
     if (is_dc) {
         for (int t = 0; t < sc->n_comp; ++t) load_dc_lut(lut + t * kPDcLut, lut11p, sc->dc_tab[t], lane);
