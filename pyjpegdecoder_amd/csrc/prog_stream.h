@@ -96,6 +96,41 @@ __device__ __forceinline__ void load_lut(uint16_t *lds, const uint16_t *lut11p, 
     for (int i = 0; i < kPLut * 2 / 16 / 64; ++i) reinterpret_cast<uint4 *>(lds)[i * 64 + lane] = src[i * 64 + lane];
 }
 
+// The refining scans' table (round 4): what ac_entry<true> would make of the symbol whose code fills the top of an 11-bit index,
+// worked out once per wave instead of once per bit offset and window — a refining scan's symbols are (run, 0 or 1 value bit), so
+// code and sign bit mostly fit the index.  16 bits: ac_entry's low half with the class copy's place (bits 9..8) taken by a value
+// code — 0: zero (ZRL), 1: +(1 << Al), 2: -(1 << Al), 3: an end-of-band run of one — expanded by refine_entry() below.
+// 0x0303 = "look again" (class 3): no code of <= 11 bits, code + value bit longer than the index, more than one value bit (the
+// reference takes them as they come), an end-of-band run with extra bits; the walk's slow path then searches the code book from
+// length 1.
+__device__ __forceinline__ void load_lut_refine(uint16_t *lds, const uint16_t *lut11p, int table, int lane) {
+    const uint16_t *src = lut11p + (size_t)table * kPLut;
+#pragma unroll 2
+    for (int i = lane; i < kPLut; i += 64) {
+        const uint32_t e0 = src[i];
+        const int len = (int)(e0 >> 8), r = (int)(e0 >> 4) & 15, sz = (int)e0 & 15;
+        const int nbits = len + sz;
+        const uint32_t bit = ((uint32_t)i >> ((kProgLutBits - 1 - len) & 15)) & 1u;         // the bit behind the code (len <= 10)
+        uint32_t c = 0x0303u;
+        if (len != 0) {
+            if (sz == 0 && r != 15) { if (r == 0) c = 2u | (3u << 8) | ((uint32_t)len << 11); }
+            else if (sz <= 1 && nbits <= kProgLutBits)
+                c = ((uint32_t)(r + 1) << 2) | ((sz == 0 ? 0u : (bit ? 1u : 2u)) << 8) | ((uint32_t)nbits << 11);
+        }
+        lds[i] = (uint16_t)c;
+    }
+}
+// vals = 0 | +(1 << Al) << 16 | -(1 << Al) << 32 | 1 << 48, each cut to 16 bits
+__device__ __forceinline__ uint64_t refine_values(int al) {
+    const uint64_t p = (uint64_t)((1u << al) & 0xFFFFu), n = (uint64_t)((0u - (1u << al)) & 0xFFFFu);
+    return (p << 16) | (n << 32) | ((uint64_t)1 << 48);
+}
+__device__ __forceinline__ uint32_t refine_entry(uint32_t c, uint64_t vals) {
+    const uint32_t vc = (c >> 8) & 3u;
+    const uint32_t hi = (uint32_t)(vals >> (16 * vc)) & 0xFFFFu;
+    return (c & 0xF87Fu) | ((c & 3u) << 8) | (hi << 16);
+}
+
 // the 9-bit LUT of a DC table from its 11-bit one: codes of 10 and 11 bits become misses (the long-code search finds them)
 __device__ __forceinline__ void load_dc_lut(uint16_t *lds, const uint16_t *lut11p, int table, int lane) {
     const uint16_t *src = lut11p + (size_t)table * kPLut;
@@ -164,18 +199,23 @@ template <bool ZRL_IS_COEF>
 struct AcWindows {
     uint32_t ve0, vw0, w1, e1, a2, b2;
     int gbase;
+    // (the refining walks' LUT holds finished entries, see load_lut_refine)
+    static __device__ __forceinline__ uint32_t entry_of(uint32_t w, uint32_t e0, int al) {
+        if constexpr (ZRL_IS_COEF) return refine_entry(e0, refine_values(al));
+        else return ac_entry<ZRL_IS_COEF>(w, (int)(e0 >> 8), (int)(e0 & 255u), al);
+    }
     __device__ __forceinline__ void start(const Stream &st, const uint16_t *lut, int al, int lane, int g) {
         gbase = g;
         vw0 = st.bits_at(g + lane);
         const uint32_t e0 = lut[vw0 >> (32 - kProgLutBits)];
-        ve0 = ac_entry<ZRL_IS_COEF>(vw0, (int)(e0 >> 8), (int)(e0 & 255u), al);
+        ve0 = entry_of(vw0, e0, al);
         w1 = st.bits_at(g + 64 + lane);
         e1 = lut[w1 >> (32 - kProgLutBits)];
         st.raw_at(g + 128 + lane, a2, b2);
     }
     __device__ __forceinline__ void advance(const Stream &st, const uint16_t *lut, int al, int lane) {
         gbase += 64;
-        ve0 = ac_entry<ZRL_IS_COEF>(w1, (int)(e1 >> 8), (int)(e1 & 255u), al);
+        ve0 = entry_of(w1, e1, al);
         vw0 = w1;
         w1 = Stream::combine(a2, b2, gbase + 64 + lane);
         e1 = lut[w1 >> (32 - kProgLutBits)];

@@ -561,7 +561,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
             if (e & 1u) {
                 const uint32_t w = rdl(win.vw0, off);
                 int len, hv;
-                long_code(w, tab, kProgLutBits + 1, len, hv);
+                long_code(w, tab, 1, len, hv);              // (the LUT holds finished entries only: any length)
                 e = ac_entry<true>(w, len, hv, al);
                 if (len == 0) { err = MJ_ST_BAD_CODE; break; }
             }
@@ -720,7 +720,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 if (e & 1u) {                              // a code longer than the LUT's index (rare) or no code at all
                     const uint32_t w = rdl(win.vw0, off);
                     int len, hv;
-                    long_code(w, tab, kProgLutBits + 1, len, hv);
+                    long_code(w, tab, 1, len, hv);              // (the LUT holds finished entries only: any length)
                     e = ac_entry<true>(w, len, hv, al);
                     if (len == 0) { err = MJ_ST_BAD_CODE; break; }
                 }
@@ -891,7 +891,8 @@ __global__ __launch_bounds__(256) void k_progressive_fast(const uint32_t *__rest
     if (is_dc) {
         for (int t = 0; t < sc->n_comp; ++t) load_dc_lut(lut + t * kPDcLut, lut11p, sc->dc_tab[t], lane);
     } else {
-        load_lut(lut, lut11p, sc->ac_tab[0], lane);
+        if (sc->ah != 0) load_lut_refine(lut, lut11p, sc->ac_tab[0], lane);
+        else load_lut(lut, lut11p, sc->ac_tab[0], lane);
     }
     Stream st;
     st.init(s_ring[wave], stream, seg_bits, k.sg, lane, bp0);
