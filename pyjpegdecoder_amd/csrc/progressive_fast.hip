@@ -450,6 +450,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         int rank0;            // ... how many of them below this lane
         int nband;            // ... how many of them in the band [Ss, Se]
         int nzeros;           // zero-history positions from Ss on
+        int nzband;           // ... of them inside the band [Ss, Se]: what the symbol loops may take (see there)
         uint32_t zpos;        // lane j: position of the j-th of them
         uint32_t ztab;        // lane j: history-non-zero coefficients in front of it = correction bits read up to there
     };
@@ -459,10 +460,11 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         q.nzb = nz0 & band_from;
         q.rank0 = mbcnt(q.nzb);
         q.nband = __builtin_popcountll(q.nzb & band);
-        q.nzeros = 0; q.zpos = 0; q.ztab = 0;
+        q.nzeros = 0; q.nzband = 0; q.zpos = 0; q.ztab = 0;
         if (in_eob_run) return q;                          // a bit for every non-zero coefficient of the band: no zero runs to follow
         const uint64_t zb = ~nz0 & band_from;
         q.nzeros = __builtin_popcountll(zb);
+        q.nzband = __builtin_popcountll(zb & band);
         const int zrank = mbcnt(zb);
         // lane l sends its number to lane zrank (zeros) / behind all zeros (the others)
         const int slot = (cf == 0 && lane >= ss) ? zrank : q.nzeros + lane - zrank;
@@ -512,8 +514,6 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_sub_u32 %[t0], %[k1], %[zl]\n\t"              \
                     "s_add_u32 %[off], %[ur], %[t0]\n\t"             \
                     "v_readlane_b32 %[e], %[ve0], %[off]\n\t"        /* (an offset past 63 reads some lane's entry, which is then not used) */ \
-                    "s_cmp_ge_u32 %[k1], %[se]\n\t"                  \
-                    "s_cbranch_scc1 Lcdone%=\n\t"                    \
                     "s_cmp_le_u32 %[off], 63\n\t"
 #if MJ_SCOUT_UNROLL >= 2
                     MJ_SCOUT_SYMBOL "s_cbranch_scc0 Lcwin%=\n\t"      // (two symbols per turn: one taken branch per two symbols)
@@ -539,13 +539,15 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_branch Lcend%=\n"
                     "Lcover%=:\n\t"
                     "s_sub_u32 %[zl], %[zl], %[t0]\n\t"
+                    "s_cmp_ge_u32 %[k1], %[se]\n\t"               // the band's last position is taken: `e` is the next block's symbol
+                    "s_cbranch_scc1 Lcdone%=\n\t"
                     "s_and_b32 %[t0], %[e], 3\n\t"
                     "s_cbranch_scc1 Lcspec%=\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lcend%=:"
                     : [e] "=&s"(e), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [ur] "+s"(ur), [k1] "+s"(k1), [zl] "+s"(zl),
                       [eob] "+s"(eobrun)
-                    : [bp] "s"(st.bp), [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [se] "s"(se), [nzeros] "s"(nzeros),
+                    : [bp] "s"(st.bp), [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [se] "s"(se), [nzeros] "s"(pr.nzband),
                       [krun] "s"(0x80002), [kbits] "s"(0x5000b)      // (the two field selectors from registers: literals would make the loop 72 bytes, with them it is 64)
                     : "scc");
                 k = rfl(k1) + 1; jz = rfl(zl) + 1;
@@ -557,7 +559,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 PSTAMP(2);
             }
             if (code == 0 || code == 4) break;
-            if (code == 3) { err = MJ_ST_OVERRUN; break; }
+            // (code 3: the loop takes zeros of the band only — it needs no test for the band's end per symbol that way: the symbol
+            // behind the band's last zero stops it, code 0 if the band is full — and a run that ends behind the band or behind all
+            // zeros is placed or refused by the single step below)
             if (e & 1u) {
                 const uint32_t w = rdl(win.vw0, off);
                 int len, hv;
@@ -624,8 +628,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 // The run of plain coefficient symbols inside the current window, hand-scheduled and software-pipelined: 22
                 // instructions per symbol, two v_readlane deep, the next symbol's entry in flight during this symbol's
                 // bookkeeping (the compiler's version of the same loop: ~40, a third of them branch bookkeeping).
-                // Leaves with code 0: k > Se;  1: the next symbol starts behind the window;  2: entry `e` is not in the LUT;
-                // 3: the zero run passes the last zero;  4: end of band, run length in eobrun.
+                // Leaves with code 0: the band is full;  1: the next symbol starts behind the window;  2: entry `e` is not in the LUT;
+                // 3: the zero run passes the band's last zero;  4: end of band, run length in eobrun.
                 // Wait states: no v_readlane takes its lane select from a VALU-written SGPR; SALU reads of those are interlocked.
                 uint32_t e2;
                 int t0, cn;
@@ -670,8 +674,6 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_mov_b32 m0, %[k1]\n\t"
                     "v_writelane_b32 %[cf], %[e], m0\n\t"
                     "s_mov_b32 %[e], %[e2]\n\t"
-                    "s_cmp_ge_u32 %[k1], %[se]\n\t"
-                    "s_cbranch_scc1 Ldone%=\n\t"
                     "s_cmp_le_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lsym%=\n"
                     "Lwin%=:\n\t"
@@ -694,7 +696,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "s_branch Lend%=\n"
                     "Lover%=:\n\t"
                     "s_sub_u32 %[zl], %[zl], %[t0]\n\t"          // (not taken: the count goes back)
-                    "s_and_b32 %[t0], %[e], 3\n\t"               // a special entry, or a zero run past the last zero
+                    "s_cmp_ge_u32 %[k1], %[se]\n\t"               // the band's last position is taken: `e` is the next block's symbol
+                    "s_cbranch_scc1 Ldone%=\n\t"
+                    "s_and_b32 %[t0], %[e], 3\n\t"               // a special entry, or a zero run past the band's last zero
                     "s_cbranch_scc1 Lspec%=\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lend%=:"
@@ -702,7 +706,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                       [off] "=&s"(off), [vt] "=&v"(vt), [bp] "+s"(st.bp), [u] "+s"(u), [k1] "+s"(k1), [zl] "+s"(zl), [cf] "+v"(cf),
                       [vbase] "+v"(vbase), [eob] "+s"(eobrun)
                     : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [zpos] "v"(zpos), [ztab] "v"(ztab), [vlane] "v"(lane), [se] "s"(se),
-                      [nzeros] "s"(nzeros)
+                      [nzeros] "s"(pr.nzband)
                     : "vcc", "scc", "m0");
                 // (the compiler takes what an asm statement writes for lane-varying, whatever the constraint says, and does the
                 // arithmetic on it with vector instructions and mask branches: readfirstlane tells it otherwise and folds away)
@@ -716,7 +720,9 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
 #endif
                 }
                 if (code == 0 || code == 4) break;         // the band is done / end of band (:1160-1166)
-                if (code == 3) { err = MJ_ST_OVERRUN; break; }              // fewer zeros left than the run passes (:1190)
+                // (code 3: the loop takes zeros of the band only — it needs no test for the band's end per symbol that way: the
+                // symbol behind the band's last zero stops it, code 0 if the band is full — and a run that ends behind the band or
+                // behind all zeros is placed or refused by the single step below, :1190)
                 if (e & 1u) {                              // a code longer than the LUT's index (rare) or no code at all
                     const uint32_t w = rdl(win.vw0, off);
                     int len, hv;
