@@ -599,6 +599,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
         const uint64_t nzb = pr.nzb;
         const int rank0 = pr.rank0;
         const bool hist = cf != 0 && lane >= ss;           // this lane's coefficient is history-non-zero (the walk only writes zero ones)
+        const int cf0 = cf;
         int vbase = 0;                                     // this lane's correction bit is bit vbase + rank0 of the stream
         int kend;                                          // corrections go to the history-non-zero lanes below kend
         bool dirty = false;
@@ -670,9 +671,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
                     "v_mov_b32 %[vt], %[u]\n\t"                  // (v_cndmask cannot take u from its SGPR: vcc is the one constant-bus operand)
                     "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
-                    "s_ashr_i32 %[e], %[e], 16\n\t"
                     "s_mov_b32 m0, %[k1]\n\t"
-                    "v_writelane_b32 %[cf], %[e], m0\n\t"
+                    "v_writelane_b32 %[cf], %[e], m0\n\t"         // (the whole entry: its value is taken out of the lanes once per block)
                     "s_mov_b32 %[e], %[e2]\n\t"
                     "s_cmp_le_u32 %[off], 63\n\t"
                     "s_cbranch_scc1 Lsym%=\n"
@@ -740,7 +740,7 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 const int jt2 = jz + (int)((e >> 2) & 31u) - 1;          // (the refining walk's entries hold r + 1)
                 if (jt2 >= nzeros) { err = MJ_ST_OVERRUN; break; }
                 const int pz2 = (int)rdl(zpos, jt2);
-                write_lane(cf, (int)e >> 16, pz2);         // (:1225)
+                write_lane(cf, (int)e, pz2);               // (:1225; the whole entry, as the loop above leaves it)
                 u += (int)((e >> 11) & 31u);                // the symbol's corrections follow its value bits (:1202, :1231)
                 vbase = lane >= k ? u : vbase;
                 st.bp = u + (int)rdl(ztab, jt2);
@@ -748,6 +748,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                 if (k > se) break;
             }
             PSTAMP(3);
+            // the lanes this scan wrote hold whole entries (value in the upper half): only zero-history lanes can be among them
+            cf = cf0 == 0 ? cf >> 16 : cf;
             dirty = true;
             kend = k;
             if (!err && eobrun > 0) {                      // rest of the band, then the run continues in the next blocks
