@@ -655,26 +655,30 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_R)
                     "Lsym%=:\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 1 + 64 * class: what is no plain coefficient overshoots every zero count
-                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"
-                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"
-                    "s_cbranch_scc1 Lover%=\n\t"
-                    "v_cmp_lt_u32 vcc, %[k1], %[vlane]\n\t"        // the lanes from the old k on (they take this symbol's u below)
-                    "v_readlane_b32 %[cn], %[ztab], %[zl]\n\t"
-                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
-                    "s_add_u32 %[u], %[u], %[t0]\n\t"
-                    "s_add_u32 %[bp], %[u], %[cn]\n\t"
-                    // the next symbol's entry is requested before this symbol's bookkeeping (a window offset past 63 reads some
-                    // lane's entry, which is then not used)
-                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
-                    "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
-                    "v_mov_b32 %[vt], %[u]\n\t"                  // (v_cndmask cannot take u from its SGPR: vcc is the one constant-bus operand)
-                    "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t"
-                    "s_mov_b32 m0, %[k1]\n\t"
-                    "v_writelane_b32 %[cf], %[e], m0\n\t"         // (the whole entry: its value is taken out of the lanes once per block)
-                    "s_mov_b32 %[e], %[e2]\n\t"
+                    // (two symbols per turn, the entry registers swapping roles: no move of the next entry into the current one's place)
+#define MJ_PLACE_SYMBOL(E, E2, OVER) \
+                    "s_bfe_u32 %[t0], %[" E "], 0x80002\n\t"      /* run + 1 + 64 * class: what is no plain coefficient overshoots every zero count */ \
+                    "s_add_u32 %[zl], %[zl], %[t0]\n\t"           \
+                    "s_cmp_ge_u32 %[zl], %[nzeros]\n\t"           \
+                    "s_cbranch_scc1 " OVER "%=\n\t"               \
+                    "v_cmp_lt_u32 vcc, %[k1], %[vlane]\n\t"       /* the lanes from the old k on (they take this symbol's u below) */ \
+                    "v_readlane_b32 %[cn], %[ztab], %[zl]\n\t"    \
+                    "v_readlane_b32 %[k1], %[zpos], %[zl]\n\t"    \
+                    "s_bfe_u32 %[t0], %[" E "], 0x5000b\n\t"      \
+                    "s_add_u32 %[u], %[u], %[t0]\n\t"             \
+                    "s_add_u32 %[bp], %[u], %[cn]\n\t"            \
+                    /* the next symbol's entry is requested before this symbol's bookkeeping (a window offset past 63 reads some */ \
+                    /* lane's entry, which is then not used) */     \
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"       \
+                    "v_readlane_b32 %[" E2 "], %[ve0], %[off]\n\t" \
+                    "v_mov_b32 %[vt], %[u]\n\t"                   /* (v_cndmask cannot take u from its SGPR: vcc is the one constant-bus operand) */ \
+                    "v_cndmask_b32 %[vbase], %[vbase], %[vt], vcc\n\t" \
+                    "s_mov_b32 m0, %[k1]\n\t"                     \
+                    "v_writelane_b32 %[cf], %[" E "], m0\n\t"     /* (the whole entry: its value is taken out of the lanes once per block) */ \
                     "s_cmp_le_u32 %[off], 63\n\t"
+                    MJ_PLACE_SYMBOL("e", "e2", "Lover")
+                    "s_cbranch_scc0 Lwin%=\n\t"
+                    MJ_PLACE_SYMBOL("e2", "e", "Lover2")
                     "s_cbranch_scc1 Lsym%=\n"
                     "Lwin%=:\n\t"
                     "s_mov_b32 %[code], 1\n\t"
@@ -694,6 +698,8 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
                     "Llong%=:\n\t"
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lend%=\n"
+                    "Lover2%=:\n\t"
+                    "s_mov_b32 %[e], %[e2]\n"
                     "Lover%=:\n\t"
                     "s_sub_u32 %[zl], %[zl], %[t0]\n\t"          // (not taken: the count goes back)
                     "s_cmp_ge_u32 %[k1], %[se]\n\t"               // the band's last position is taken: `e` is the next block's symbol
