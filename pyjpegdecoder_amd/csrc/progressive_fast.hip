@@ -421,11 +421,20 @@ __device__ __forceinline__ void walk_ac_refine(Walk &k, Stream &st, const uint16
     const int nat = k.tr ? ((nz_nat & 7) << 3 | nz_nat >> 3) : nz_nat;        // tr: blocks are kept [u][v] for the row-major stage 2
     // this lane's coefficient of the scan's blocks, one after the other in scan order (h, v are 1, 2 or 4: shifts)
     const int lh = h == 4 ? 2 : h - 1, lv = v == 4 ? 2 : v - 1;
+    // (the block's offset — wave-uniform — moves on by a constant from block to block: 1 block inside an MCU, to the component's first
+    // block of the row in the next MCU otherwise; worked out in full only where a block row starts)
     int nby = k.m_lo / smh, nbx = k.m_lo - nby * smh;
+    auto offset_of = [&](int bx, int by) -> int64_t {
+        const int mx = bx >> lh, my = by >> lv;
+        return ((int64_t)(my * fmx + mx) * bpm + first + ((by - (my << lv)) << lh) + (bx - (mx << lh))) * 64;
+    };
+    int64_t boff = offset_of(nbx, nby);
+    const int hmask = (1 << lh) - 1, mcu_step = (bpm - hmask) * 64;
+    int16_t *const lane_base = cbase + nat;
     auto next_elem = [&]() -> int16_t * {
-        const int mx = nbx >> lh, my = nby >> lv;
-        int16_t *p = cbase + ((int64_t)(my * fmx + mx) * bpm + first + ((nby - (my << lv)) << lh) + (nbx - (mx << lh))) * 64 + nat;
-        if (++nbx == smh) { nbx = 0; ++nby; }
+        int16_t *p = lane_base + boff;
+        if (++nbx == smh) { nbx = 0; ++nby; boff = offset_of(0, nby); }
+        else boff += (nbx & hmask) ? 64 : mcu_step;
         return p;
     };
     AcWindows<true> win;                      // symbols of 64 consecutive bit offsets (see ac_entry)
