@@ -1117,7 +1117,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stateB, ck.size() * 8 + 16));
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
-                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_changed, 16));
+                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_changed, (size_t)(p->sync_rounds + 8) * sizeof(int32_t)));   // [0]: round 0's, [r]: repair round r's count of changed exit states
                 // stage 0 of long segments runs piece by piece (16 KiB of source bytes per wavefront)
                 std::vector<mj::DevPiece> pcs;
                 for (size_t i = 0; i < segs.size(); ++i) {
@@ -1380,10 +1380,11 @@ static int stage1_impl(mj_plan *p, void *stream) {
             // nothing).  Whether they sufficed is decided on the device: k_build_vsegs marks the images whose chunk states
             // had not settled (MJ_ST_UNCONVERGED) and the caller decodes those again with MJ_FLAG_NO_SYNC.  No host
             // round trip: the execute is asynchronous and can be captured into a graph like every other form.
-            MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, 4 * sizeof(int32_t), s));
+            MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, (size_t)(p->sync_rounds + 8) * sizeof(int32_t), s));
             for (int round = 1; round <= p->sync_rounds; ++round) {
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + 3, p->d_wg_tabs_count, p->wg_slots_count));
+                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + round, p->d_wg_tabs_count, p->wg_slots_count,
+                                                  round >= 2 ? p->d_changed + round - 1 : nullptr));
                 std::swap(in, out);
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,

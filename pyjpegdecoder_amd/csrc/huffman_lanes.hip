@@ -65,14 +65,22 @@ struct LaneBits {
 
 // Codes longer than the 11-bit LUT (rare): canonical search (jpeg_decoder.py:366-377 semantics).
 // Returns (len << 8) | symbol, or -1.
-__device__ __forceinline__ int long_code(const DevHuff *t, uint32_t p16) {
-    int r = -1;
-#pragma unroll 1
-    for (int l = kLBits + 1; l <= 16; ++l) {
-        const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
-        if (r < 0 && d >= 0 && d < t->count[l]) r = (l << 8) | t->vals[t->first_sym[l] + d];
+// The code book of the lengths 12..16 sits in LDS, kLongInts ints per table slot: first_code, count, first_sym per length, then
+// the 256 symbol values (round 4: it used to be read from global memory, three dependent loads per length, by every lane of
+// the wave that met such a code — rare per lane, but with 64 lanes some lane meets one in a good part of the turns).
+constexpr int kLongInts = 16 + 64;
+__device__ __forceinline__ int long_code(const int32_t *book, uint32_t p16) {
+    int l = 0, at = 0;
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {                                  // (the shortest length that matches wins: walked downwards)
+        const int len = kLBits + 1 + i;
+        const int d = (int)(p16 >> (16 - len)) - book[i];
+        const bool ok = d >= 0 && d < book[5 + i];
+        l = ok ? len : l;
+        at = ok ? book[10 + i] + d : at;
     }
-    return r;
+    if (l == 0) return -1;
+    return (l << 8) | reinterpret_cast<const uint8_t *>(book + 16)[at & 255];
 }
 
 // Branch-free: when the buffer is at most half full the next dword goes in.  The load of the dword after it is
@@ -137,8 +145,22 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
     // the all-zero "longer than 11 bits" entries; real lengths are 1..11 and use bits 11..14)
     uint16_t *s_null = reinterpret_cast<uint16_t *>(smem + (size_t)n_huff * kLSize * 2 + (size_t)4 * wstride * 4 + (size_t)4 * lpw2 * 8);
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));
+    int32_t *s_long = reinterpret_cast<int32_t *>(s_null + 8);                      // [n_huff][kLongInts], see long_code
 
     const int32_t *my_tabs = WGT ? wg_tabs + (size_t)blockIdx.x * kMaxWgTables : nullptr;
+    for (int i = tid; i < n_huff * kLongInts; i += 256) {
+        const int j = i / kLongInts, q = i - j * kLongInts;
+        const int t = WGT ? my_tabs[j] : j;
+        int32_t v = 0;
+        if (t >= 0) {
+            const DevHuff *h = huff + t;
+            if (q < 5) v = h->first_code[kLBits + 1 + q];
+            else if (q < 10) v = h->count[kLBits + 1 + q - 5];
+            else if (q < 15) v = h->first_sym[kLBits + 1 + q - 10];
+            else if (q >= 16) v = reinterpret_cast<const int32_t *>(h->vals)[q - 16];
+        }
+        s_long[i] = v;
+    }
     if (WGT) {
         for (int j = 0; j < n_huff; ++j) {                  // n_huff = slots in LDS here
             const int t = my_tabs[j];
@@ -240,8 +262,6 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
             const int comp = (int)((comp_pk_u >> (8 * b)) & 0xFF);          // wave-uniform
             const int dct = comp == 0 ? dcT[0] : (comp == 1 ? dcT[1] : dcT[2]);
             const int act_ = comp == 0 ? acT[0] : (comp == 1 ? acT[1] : acT[2]);
-            const int dcg = WGT ? (comp == 0 ? dcG[0] : (comp == 1 ? dcG[1] : dcG[2])) : dct;
-            const int acg = WGT ? (comp == 0 ? acG[0] : (comp == 1 ? acG[1] : acG[2])) : act_;
             const bool act = in_mcu && err == 0;
 
             // ---- DC (:810-820): one symbol per lane, straight-line
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 int len = e >> 8, s = e & 0xFF;
                 if (__builtin_amdgcn_ballot_w64(act && len == 0) != 0) {                              // code longer than 11 bits: rare
                     if (act && len == 0) {
-                        const int r = long_code(huff + dcg, p16);
+                        const int r = long_code(s_long + dct * kLongInts, p16);
                         len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF;
                     }
                 }
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
                 const int e = *(on ? ep : s_null);
                 int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
                 if (e < 2048) {                                               // code longer than 11 bits: rare (the branch
-                    const int r = long_code(huff + acg, hi >> 16);            // is skipped when no lane has one)
+                    const int r = long_code(s_long + act_ * kLongInts, hi >> 16);   // is skipped when no lane has one)
                     err = r < 0 ? MJ_ST_BAD_CODE : err;
                     const int hv = r & 0xFF;
                     ln = r < 0 ? 0 : r >> 8;
@@ -397,7 +417,7 @@ int lanes_per_wave(int64_t n_segs, int n_slots) {
     const int cus = device_cus();
     // ... and when there are more segments than one such round holds, as many equal rounds as needed: lanes per wave
     // capped where four workgroups still fit a CU's LDS, then spread evenly over the rounds
-    auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_slots * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16; };
+    auto lds_of = [&](int l) { const int l2 = (l + 1) & ~1; return (size_t)n_slots * kLSize * 2 + (size_t)4 * ((l2 * kBlkStride + 3) & ~3) * 4 + (size_t)4 * l2 * 8 + 16 + (size_t)n_slots * 320; };
     int fit = 64;
     while (fit > 8 && 4 * lds_of(fit) > 160 * 1024) --fit;
     const int64_t per = (int64_t)16 * cus;                   // waves of one round: 4 workgroups x 4 waves x CUs
@@ -426,7 +446,7 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
 #endif
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
-    const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16;
+    const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16 + (size_t)n_slots * kLongInts * 4;
     static bool attr_set[kMaxDevices] = {false};
     if (!attr_set[current_device()]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -43,14 +43,23 @@ __device__ __forceinline__ void refill(LaneBits &s, const unsigned char *streamb
     if (want) s.nxtw = *reinterpret_cast<const uint32_t *>(streamb + s.voff);     // 64 lanes, 64 cache lines: only who needs it
 }
 
-__device__ __forceinline__ int long_code(const DevHuff *t, uint32_t p16) {
-    int r = -1;
-#pragma unroll 1
-    for (int l = kLBits + 1; l <= 16; ++l) {
-        const int d = (int)(p16 >> (16 - l)) - t->first_code[l];
-        if (r < 0 && d >= 0 && d < t->count[l]) r = (l << 8) | t->vals[t->first_sym[l] + d];
+// Codes of 12..16 bits (0.4 % of the symbols — but with 128 symbols per wave and turn, 40 % of the turns meet one): the
+// canonical search over the five lengths with the code book in LDS.  Per table slot kLongInts ints: first_code, count,
+// first_sym for the lengths 12..16, then the 256 symbol values.  (Round 4: the book used to be read from global memory,
+// three dependent loads per length, by every lane of the wave that had such a code.)
+constexpr int kLongInts = 16 + 64;
+__device__ __forceinline__ int long_code(const int32_t *book, uint32_t p16) {
+    int l = 0, at = 0;
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {                                  // (the shortest length that matches wins: walked downwards)
+        const int len = kLBits + 1 + i;
+        const int d = (int)(p16 >> (16 - len)) - book[i];
+        const bool ok = d >= 0 && d < book[5 + i];
+        l = ok ? len : l;
+        at = ok ? book[10 + i] + d : at;
     }
-    return r;
+    if (l == 0) return -1;
+    return (l << 8) | reinterpret_cast<const uint8_t *>(book + 16)[at & 255];
 }
 }  // namespace
 
@@ -69,11 +78,30 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
                                                     int n_huff, const DevChunk *__restrict__ chunks, int64_t n_chunks, int cbits, int warm,
                                                     const uint64_t *__restrict__ entry, uint64_t *__restrict__ exit_out,
                                                     DevChunkOut *__restrict__ outs, int32_t *__restrict__ changed,
-                                                    const int32_t *__restrict__ wg_tabs /* or null: [gridDim.x][kMaxWgTables] */) {
+                                                    const int32_t *__restrict__ wg_tabs /* or null: [gridDim.x][kMaxWgTables] */,
+                                                    const int32_t *__restrict__ prev_changed /* or null: the round before this one's count */) {
+    // A repair round that changed no chunk's exit state leaves both state buffers equal and every record valid: the rounds queued
+    // behind it have nothing to do (they are queued blind, a fixed number: no host round trip) and leave at once.
+    if (!WARM && prev_changed && *prev_changed == 0) return;
+    if constexpr (!WARM) {
+        // ... and a workgroup none of whose chunks has a new entry state (nearly all of them, from the first repair round on)
+        // passes its exit states on before it has loaded a table
+        const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        bool keep = true;
+        if (c0 < n_chunks) {
+            const uint64_t e0 = chunks[c0].j == 0 ? pack_state(0, 0, 0) : entry[c0 - 1];
+            keep = outs[c0].entry == e0 && outs[c0].blocks >= 0;
+        }
+        if (__syncthreads_and(keep)) {
+            if (c0 < n_chunks) exit_out[c0] = entry[c0];
+            return;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(smem);
     uint16_t *s_null = s_lut + (size_t)n_huff * kLSize;                 // n_huff = table slots in LDS
     int32_t *s_glob = reinterpret_cast<int32_t *>(s_null + 8);           // slot -> index of the table in the batch
+    int32_t *s_long = s_glob + kMaxWgTables;                            // per slot: the code book of the lengths 12..16 (long_code)
     const int tid = threadIdx.x;
     // a batch with more tables than LDS holds: this workgroup's chunks use the (at most n_huff = 8 or 16) tables listed in
     // wg_tabs, and "slot" below is a position in that list
@@ -91,6 +119,19 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
     }
     if (tid < kMaxWgTables) s_glob[tid] = my_tabs ? my_tabs[tid] : tid;
     if (tid == 0) *s_null = (uint16_t)(0x8000u | (64u << 4));          // length 0, run 64, size 0: a lane that is done
+    for (int i = tid; i < n_huff * kLongInts; i += 256) {
+        const int j = i / kLongInts, q = i - j * kLongInts;
+        const int t = my_tabs ? my_tabs[j] : j;
+        int32_t v = 0;
+        if (t >= 0) {
+            const DevHuff *h = huff + t;
+            if (q < 5) v = h->first_code[kLBits + 1 + q];
+            else if (q < 10) v = h->count[kLBits + 1 + q - 5];
+            else if (q < 15) v = h->first_sym[kLBits + 1 + q - 10];
+            else if (q >= 16) v = reinterpret_cast<const int32_t *>(h->vals)[q - 16];
+        }
+        s_long[i] = v;
+    }
     __syncthreads();
 
     const int64_t c = (int64_t)blockIdx.x * 256 + tid;
@@ -161,7 +202,7 @@ __global__ __launch_bounds__(256) void k_sync_count(const uint32_t *__restrict__
         const int e = *reinterpret_cast<const uint16_t *>(on ? ep : reinterpret_cast<const unsigned char *>(s_null));
         int ln = (e >> 11) & 15, run = (e >> 4) & 127, size = e & 15;
         if (e < 2048) {                                               // longer than 11 bits: rare
-            const int r = long_code(huff + s_glob[slot], hi >> 16);
+            const int r = long_code(s_long + slot * kLongInts, hi >> 16);
             const int hv = r & 0xFF;
             ln = r < 0 ? 1 : r >> 8;                                  // no code at all: skip a bit (the data is garbage anyway)
             run = r < 0 ? 0 : (isdc ? 0 : (hv == 0 ? 64 : hv >> 4));
@@ -293,10 +334,10 @@ __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chu
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs, int wg_slots) {
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs, int wg_slots, const int32_t *prev_changed) {
     if (n_chunks == 0) return hipSuccess;
     if (wg_tabs) n_huff = wg_slots;                             // table slots in LDS
-    const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4;
+    const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4 + (size_t)n_huff * kLongInts * 4;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
     static bool attr_set[kMaxDevices] = {false};
     if (!attr_set[current_device()]) {                          // 16 table slots: just over the 64 KiB default
@@ -307,10 +348,10 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
     const int warm = opt("MJ_SYNC_WARM") ? atoi(opt("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs);
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs, prev_changed);
     else
         hipLaunchKernelGGL(k_sync_count<true>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
-                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs);
+                           chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs, nullptr);
     return hipGetLastError();
 }
 
