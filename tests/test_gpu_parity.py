@@ -1244,6 +1244,38 @@ def test_one_shot_entry_point_through_ctypes(dec):
             boff += nb
 
 
+def test_files_without_restart_markers_at_size_every_image_settles(dec):
+    """256 x 1080p written without restart markers (bench.py's `without_restart_markers` family; 16 distinct files): the plan takes
+    the synchronisation form, EVERY image's status is ok — round 4 found a quarter of such a batch MJ_ST_UNCONVERGED after the four
+    repair rounds queued until then (flat image regions re-synchronise badly: chains of five and six wrongly guessed entry states) —
+    and every distinct image equals the oracle's, every replica its first instance."""
+    torch = pytest.importorskip("torch")
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, nd, n = 1920, 1080, 16, 256
+    blob, offs = synth.synth_batch(nd, 0, W, H, 85, "420", 0)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(nd)]
+    dev = torch.device("cuda", 0)
+    prep = prepare_batch([raws[i % nd] for i in range(n)], B.MJ_LAYOUT_XMAJOR, 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+    try:
+        assert plan.stage1_form() & 15 == B.MJ_FORM_SYNC
+        d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        plan.execute(0, d_rgb.data_ptr())
+        plan.sync()
+        status = plan.read(rgb=False)["status"]
+        assert not status.any(), np.unique(status, return_counts=True)
+        imgs = d_rgb.view(n, W * H * 3)
+        for i, want in enumerate(oracle_rgb_all(raws)):
+            assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), want), i
+        for k in range(1, n // nd):
+            assert torch.equal(imgs[k * nd:(k + 1) * nd], imgs[:nd]), k
+    finally:
+        plan.close()
+
+
 def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkeypatch, tune):
     """The synchronisation rounds are a fixed number, queued without a host round trip.  Make them fail on purpose — no
     run-up in front of the chunks, tiny chunks: nearly every guessed entry state is wrong and a chain of wrong guesses
@@ -1256,7 +1288,7 @@ def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkey
     tune("MJ_HUFFMAN", "sync")
     tune("MJ_SYNC_WARM", "0")
     tune("MJ_SYNC_CHUNK", "256")
-    tune("MJ_SYNC_ROUNDS", "0")          # (real streams re-synchronise within a chunk: four rounds always settle them)
+    tune("MJ_SYNC_ROUNDS", "0")          # (sixteen are queued by default; see test_files_without_restart_markers_at_size_every_image_settles)
     raw = synth.synth_jpeg(4242, 640, 480, 85, "420", 0, 12.0)
     prep = prepare_batch([raw], B.MJ_LAYOUT_XMAJOR, 0)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})
