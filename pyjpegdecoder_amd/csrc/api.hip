@@ -141,10 +141,10 @@ struct mj_plan {
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
     bool use_sync = false;
-    int sync_rounds = 16;          // repair rounds of the synchronisation form queued per execute (MJ_SYNC_ROUNDS at plan creation: tests).
+    int sync_rounds = 32;          // repair rounds of the synchronisation form queued per execute (MJ_SYNC_ROUNDS at plan creation: tests).
                                    // A round behind one that changed nothing returns at once, so the number only bounds the longest
                                    // chain of wrongly guessed entry states that still settles (flat image regions re-synchronise badly:
-                                   // round 4 found a quarter of a synthetic batch's images unconverged after four rounds, none after six)
+                                   // round 4 found a quarter of a synthetic batch's images unconverged after four rounds, none after six; an idle round costs ~2 us)
     int sync_chunk_bytes = 2048;
     uint16_t *d_lut11u = nullptr;       // every table as len << 11 | run << 4 | size
     mj::DevChunk *d_chunks = nullptr;

@@ -1288,7 +1288,7 @@ def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkey
     tune("MJ_HUFFMAN", "sync")
     tune("MJ_SYNC_WARM", "0")
     tune("MJ_SYNC_CHUNK", "256")
-    tune("MJ_SYNC_ROUNDS", "0")          # (sixteen are queued by default; see test_files_without_restart_markers_at_size_every_image_settles)
+    tune("MJ_SYNC_ROUNDS", "0")          # (32 are queued by default; see test_files_without_restart_markers_at_size_every_image_settles)
     raw = synth.synth_jpeg(4242, 640, 480, 85, "420", 0, 12.0)
     prep = prepare_batch([raw], B.MJ_LAYOUT_XMAJOR, 0)
     plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})

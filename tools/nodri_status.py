@@ -9,7 +9,7 @@ raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(ND)]
 files = [raws[i % ND] for i in range(N)]
 dev = torch.device("cuda", 0)
 ctx = B.Context(0)
-for rounds in (None, "8", "2", "1"):
+for rounds in (None, "32", "64", "8"):
     B.set_option("MJ_SYNC_ROUNDS", rounds)
     prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
     d_blob = torch.from_numpy(prep.blob).to(dev)
