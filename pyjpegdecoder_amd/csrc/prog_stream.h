@@ -155,8 +155,7 @@ __device__ __forceinline__ void long_code(uint32_t w, const DevHuff *tab, int fr
 //   bits 1..0   class: 0 = coefficient (size > 0), 1 = ZRL, 2 = end of band (EOBn), 3 = not in the table.
 //               ZRL_IS_COEF: a ZRL is class 0 with value 0 (the refining walk: "skip r zeros, take the next zero" for
 //               both, and a ZRL then places 0 into a coefficient that is 0)
-//   bits 5..2   zero run r (15 for ZRL) — ZRL_IS_COEF (the refining walk's entries): bits 6..2 = r + 1, what the walk's count of
-//               zeros passed moves on by
+//   bits 6..2   coefficients (class 0): zero run r + 1, what the walks' positions move on by; ZRL and end-of-band entries: r
 //   bits 9..8   the class again (bits 7..6 are zero): the 8 bits from bit 2 on read  r + 64 * class, so a symbol loop that
 //               adds them to a position of at most 63 finds every entry that is no plain coefficient behind its limit — one
 //               test for "special entry" and "run past the end" (round 4: two instructions less per symbol)
@@ -174,7 +173,7 @@ __device__ __forceinline__ uint32_t ac_entry(uint32_t w, int len, int hv, int al
     const uint32_t val16 = (uint32_t)(uint16_t)(int16_t)((int)(raw - neg) << al);
     const uint32_t cls = eob ? 2u : (!ZRL_IS_COEF && s == 0) ? 1u : 0u;
     const uint32_t hi = eob ? (1u << r) + raw : val16;
-    const uint32_t e = cls | (cls << 8) | ((uint32_t)(ZRL_IS_COEF && !eob ? r + 1 : r) << 2) | ((uint32_t)(len + n) << 11) | (hi << 16);
+    const uint32_t e = cls | (cls << 8) | ((uint32_t)((ZRL_IS_COEF ? !eob : cls == 0u) ? r + 1 : r) << 2) | ((uint32_t)(len + n) << 11) | (hi << 16);
     return len == 0 ? (3u | (3u << 8)) : e;
 }
 

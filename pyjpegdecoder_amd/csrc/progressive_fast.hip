@@ -39,7 +39,7 @@
 //   * DC: the predictor chain (:1018-1020) is the serial part; the values of 64 consecutive blocks of the scan are
 //     collected in the lanes and stored together.  An interleaved scan uses one Huffman table per component, so each
 //     window of bit offsets is looked up in all of them and the walk takes the entry of the component whose turn it is.
-//   ~20 instructions per symbol.
+//   12 instructions per symbol (round 4; 20 before).
 //
 //   * DC refinement (Ah > 0, Ss = 0) is one bit per block in scan order: block t reads bit t of the stream, no chain.
 //
@@ -287,19 +287,21 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
         }
         {
             st.top_up();
-            int cf = 0;
-            uint64_t touched = 0;
+            int cf = 0;                                    // the lanes take whole entries (value in the upper half) until the block ends
             int kk = ss;
             for (;;) {
                 uint32_t e;
                 int code, off;
                 for (;;) {                                 // (the common way round on its own, as in the refining walk)
-                // The run of coefficient symbols inside the current window, hand-scheduled like the refining walk's: 20
-                // instructions per symbol, the next symbol's entry in flight during this one's placement.  Leaves with code
-                // 0: kk > Se;  1: the next symbol starts behind the window;  2: ZRL, or entry not in the LUT;
-                // 3: position past 63;  4: end of band, eobrun set (the run counts this block, :1160-1166).
+                // The run of coefficient symbols inside the current window, hand-scheduled like the refining walk's and with the same
+                // trims (round 4): the entry's run field holds r + 1 and the loop keeps the last position taken; the whole entry goes
+                // into the lane; positions are tested against Se once, in front — what is no plain coefficient lands past it too,
+                // and so does the symbol behind a full band; two symbols per turn with the entry registers swapping roles.
+                // 12 instructions per symbol (20 before).  Leaves with code 0: the band is full;  1: the next symbol starts behind
+                // the window;  2: ZRL, or entry not in the LUT;  3: a run that ends behind the band;  4: end of band, eobrun set
+                // (the run counts this block, :1160-1166).
                 uint32_t e2;
-                int t0;
+                int t0, kk1 = kk - 1;
                 asm volatile(
                     "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
                     "s_cmp_gt_u32 %[off], 63\n\t"
@@ -307,23 +309,21 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "v_readlane_b32 %[e], %[ve0], %[off]\n"
                     ".p2align " MJ_LOOP_ALIGN "\n" MJ_LOOP_PAD(MJ_SKEW_F)
                     "Lfsym%=:\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x80002\n\t"          // run + 64 * class: what is no plain coefficient lands past 63 too
-                    "s_add_u32 %[kk], %[kk], %[t0]\n\t"
-                    "s_cmp_gt_u32 %[kk], 63\n\t"
-                    "s_cbranch_scc1 Lfover%=\n\t"
-                    "s_bfe_u32 %[t0], %[e], 0x5000b\n\t"
-                    "s_add_u32 %[bp], %[bp], %[t0]\n\t"
-                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"
-                    "v_readlane_b32 %[e2], %[ve0], %[off]\n\t"
-                    "s_ashr_i32 %[e], %[e], 16\n\t"
-                    "s_mov_b32 m0, %[kk]\n\t"
-                    "v_writelane_b32 %[cf], %[e], m0\n\t"           // (:1248-1250)
-                    "s_bitset1_b64 %[touched], %[kk]\n\t"
-                    "s_add_u32 %[kk], %[kk], 1\n\t"
-                    "s_mov_b32 %[e], %[e2]\n\t"
-                    "s_cmp_gt_u32 %[kk], %[se]\n\t"
-                    "s_cbranch_scc1 Lfdone%=\n\t"
+#define MJ_FIRST_SYMBOL(E, E2, OVER) \
+                    "s_bfe_u32 %[t0], %[" E "], 0x80002\n\t"      /* run + 1 + 64 * class */ \
+                    "s_add_u32 %[kk1], %[kk1], %[t0]\n\t"         \
+                    "s_cmp_gt_u32 %[kk1], %[se]\n\t"              \
+                    "s_cbranch_scc1 " OVER "%=\n\t"               \
+                    "s_bfe_u32 %[t0], %[" E "], 0x5000b\n\t"      \
+                    "s_add_u32 %[bp], %[bp], %[t0]\n\t"           \
+                    "s_sub_u32 %[off], %[bp], %[gbase]\n\t"       \
+                    "v_readlane_b32 %[" E2 "], %[ve0], %[off]\n\t" \
+                    "s_mov_b32 m0, %[kk1]\n\t"                    \
+                    "v_writelane_b32 %[cf], %[" E "], m0\n\t"     /* (:1248-1250) */ \
                     "s_cmp_le_u32 %[off], 63\n\t"
+                    MJ_FIRST_SYMBOL("e", "e2", "Lfover")
+                    "s_cbranch_scc0 Lfwin%=\n\t"
+                    MJ_FIRST_SYMBOL("e2", "e", "Lfover2")
                     "s_cbranch_scc1 Lfsym%=\n"
                     "Lfwin%=:\n\t"
                     "s_mov_b32 %[code], 1\n\t"
@@ -331,8 +331,15 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "Lfdone%=:\n\t"
                     "s_mov_b32 %[code], 0\n\t"
                     "s_branch Lfend%=\n"
-                    "Lfspec%=:\n\t"
-                    "s_cmp_eq_u32 %[t0], 2\n\t"                    // EOBn found in the LUT
+                    "Lfover2%=:\n\t"
+                    "s_mov_b32 %[e], %[e2]\n"
+                    "Lfover%=:\n\t"
+                    "s_sub_u32 %[kk1], %[kk1], %[t0]\n\t"        // (not taken: the position goes back)
+                    "s_cmp_ge_u32 %[kk1], %[se]\n\t"             // the band's last position is taken: `e` is the next block's symbol
+                    "s_cbranch_scc1 Lfdone%=\n\t"
+                    "s_and_b32 %[code], %[e], 3\n\t"             // a special entry, or a run that ends behind the band
+                    "s_cbranch_scc0 Lfrun%=\n\t"
+                    "s_cmp_eq_u32 %[code], 2\n\t"                // EOBn found in the LUT
                     "s_cbranch_scc0 Lfother%=\n\t"
                     "s_lshr_b32 %[eob], %[e], 16\n\t"
                     "s_sub_u32 %[eob], %[eob], 1\n\t"
@@ -343,25 +350,20 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     "Lfother%=:\n\t"
                     "s_mov_b32 %[code], 2\n\t"
                     "s_branch Lfend%=\n"
-                    "Lfover%=:\n\t"
-                    "s_and_b32 %[code], %[e], 3\n\t"             // a special entry (the position is put back), or a run past the block
-                    "s_cbranch_scc0 Lfrun%=\n\t"
-                    "s_sub_u32 %[kk], %[kk], %[t0]\n\t"
-                    "s_mov_b32 %[t0], %[code]\n\t"
-                    "s_branch Lfspec%=\n"
                     "Lfrun%=:\n\t"
                     "s_mov_b32 %[code], 3\n"
                     "Lfend%=:"
-                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [bp] "+s"(st.bp), [kk] "+s"(kk),
-                      [touched] "+s"(touched), [cf] "+v"(cf), [eob] "+s"(eobrun)
+                    : [e] "=&s"(e), [e2] "=&s"(e2), [code] "=&s"(code), [t0] "=&s"(t0), [off] "=&s"(off), [bp] "+s"(st.bp), [kk1] "+s"(kk1),
+                      [cf] "+v"(cf), [eob] "+s"(eobrun)
                     : [gbase] "s"(win.gbase), [ve0] "v"(win.ve0), [se] "s"(se)
-                    : "vcc", "scc", "m0");
-                e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); st.bp = rfl(st.bp); kk = rfl(kk); eobrun = rfl(eobrun);
+                    : "scc", "m0");
+                e = (uint32_t)rfl((int)e); code = rfl(code); off = rfl(off); st.bp = rfl(st.bp); kk = rfl(kk1) + 1; eobrun = rfl(eobrun);
                 if (code != 1) break;
                 win.move_to(st, lut, al, lane, off);
                 }
                 if (code == 0 || code == 4) break;
-                if (code == 3) { err = MJ_ST_OVERRUN; break; }
+                // (code 3 — a plain coefficient whose run ends behind the band — goes through the single step below: placed up to
+                // position 63 as the reference does, refused behind it)
                 if ((e & 3u) == 3u) {                      // a code longer than the LUT's index (rare) or no code at all
                     const uint32_t w = rdl(win.vw0, off);
                     int len, hv;
@@ -380,14 +382,15 @@ __device__ __forceinline__ void walk_ac_first(Walk &k, Stream &st, const uint16_
                     if (kk > se) break;
                     continue;
                 }
-                // (a long code's coefficient)
-                kk += (int)((e >> 2) & 15u);
+                // (a long code's coefficient, or one behind the band)
+                kk += (int)((e >> 2) & 31u) - 1;           // (the field holds r + 1)
                 if (kk > 63) { err = MJ_ST_OVERRUN; break; }
-                write_lane(cf, (int)e >> 16, kk);          // (:1248-1250)
-                touched |= (uint64_t)1 << kk;
+                write_lane(cf, (int)e, kk);                // (:1248-1250; the whole entry, as the loop leaves it)
                 st.bp += (int)((e >> 11) & 31u);
                 if (++kk > se) break;
             }
+            const uint64_t touched = __ballot(cf != 0);    // (an entry is never zero: it holds the bits it consumed)
+            cf >>= 16;
             if (touched != 0) {
                 const int mx = bx >> lh;
                 int16_t *p = k.cbase + (int64_t)(rbase + mx * bpm + (bx - (mx << lh))) * 64;
