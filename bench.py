@@ -301,47 +301,6 @@ def launch_ranks(n_ranks: int, argv, share_gpu: bool, script=None) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-class DeviceImageQueue:
-    """The per-GPU image queue of BASELINE configs[3]: a rank's share of the job, cut into batches whose files are
-    assembled and uploaded once (inputs resident in HBM), then decoded batch after batch.  A batch of a few hundred
-    images does not fill the chip (stage 1's time is one restart segment's serial walk however few segments there
-    are), so `depth` plans are in flight at once, each on its own stream and with its own output buffer: plan k is
-    created and queued, then plan k - depth is collected (a consumer would take its pixels from HBM there)."""
-
-    def __init__(self, ctx, dev, torch, files, batch_size, layout, depth=3):
-        from pyjpegdecoder_amd import _binding as B
-        from pyjpegdecoder_amd.batch import prepare_batch
-        self.B, self.ctx, self.torch = B, ctx, torch
-        self.batches = []
-        for i in range(0, len(files), batch_size):
-            prep = prepare_batch(files[i:i + batch_size], layout, 0)
-            self.batches.append((prep, torch.from_numpy(prep.blob).to(dev), len(files[i:i + batch_size])))
-        cap = max((sum(w * h * nc for (w, h, nc) in p.shapes) for p, _, _ in self.batches), default=0)
-        self.depth = max(1, min(depth, len(self.batches)))
-        self.out = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)]
-        self.n_images = len(files)
-        self.bad = 0
-
-    def _collect(self, plan):
-        plan.sync()
-        self.bad += int(plan.read(rgb=False)["status"].any())
-        plan.close()
-
-    def run(self):
-        """One pass over the whole share; returns when every batch's pixels are in HBM."""
-        B = self.B
-        flying = []
-        for k, (prep, d_blob, n) in enumerate(self.batches):
-            if len(flying) == self.depth:                # slot k % depth is still in use by plan k - depth
-                self._collect(flying.pop(0))
-            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
-            plan.execute(self.streams[k % self.depth].cuda_stream, self.out[k % self.depth].data_ptr())
-            flying.append(plan)
-        for plan in flying:
-            self._collect(plan)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -361,6 +320,7 @@ def main():
     ap.add_argument("--restart-interval", type=int, default=120,
                     help="MCUs per restart segment of the synthetic files (120 = one MCU row = BASELINE configs[2]; 0 = no DRI: "
                          "one segment per image, decoded through the synchronisation passes)")
+    ap.add_argument("--parity-images", type=int, default=0, help="distinct images held to the oracle after the timed region (0 = all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the side measurements")
     ap.add_argument("--no-progressive", action="store_true")
     ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
@@ -409,6 +369,7 @@ def main():
 
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd.batch import prepare_batch
+    from pyjpegdecoder_amd.queue import DeviceImageQueue
     from pyjpegdecoder_amd.sharding import max_over_ranks, shard, sum_over_ranks
     from tools import synth
 
@@ -432,7 +393,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     if queue_mode:
-        queue = DeviceImageQueue(ctx, dev, torch, files, args.queue_batch, layout, args.queue_depth)
+        queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank)
         torch.cuda.synchronize()
         host_prep_s, h2d_s = time.perf_counter() - t0, None
         step = queue.run
@@ -473,33 +434,55 @@ def main():
     dt = max_over_ranks(dt, dev if (world > 1 and args.backend == "nccl") else None)
     images_all_ranks = int(sum_over_ranks(float(n_mine), dev if (world > 1 and args.backend == "nccl") else None))
 
-    # ---- parity spot check of what was just timed (first and last image of the rank's share vs the oracle) -------
+    # ---- parity of what was just timed, outside the timed region.  One plan: EVERY distinct image of the rank's batch against
+    # the oracle (a pool of host threads), every replica against its first instance on the device, every image's status.
+    # Queue mode: first and last image of the share against the oracle, every plan's statuses. -------------------------------
     parity = "unchecked"
     per = W * H * 3
+
+    def as_reference_order(got, ref):
+        got = got.reshape(ref.shape if args.layout == "xmajor" else (H, W, 3))
+        return got if args.layout == "xmajor" else np.swapaxes(got, 0, 1)
     if queue_mode:
         status_bad = queue.bad
         k_last = len(queue.batches) - 1
-        n_last = queue.batches[k_last][2]
-        got_last = queue.out[k_last % queue.depth][(n_last - 1) * per:n_last * per].cpu().numpy()
-        queue.batches = queue.batches[:1]                     # image 0: decode the first batch once more
-        queue.run()
-        got_first = queue.out[0][:per].cpu().numpy()
-        checks = [(0, got_first), (n_mine - 1, got_last)]
+        n_last = queue.batches[k_last][3]
+        got_last = queue.out_tensor(queue.slot_of(k_last))[(n_last - 1) * per:n_last * per].cpu().numpy()
+        queue.run(first=0, count=1)                           # image 0: decode the first batch once more
+        got_first = queue.out_tensor(0)[:per].cpu().numpy()
+        if rank == 0:
+            from oracle import oracle
+            ok = status_bad == 0
+            for i, got in ((0, got_first), (n_mine - 1, got_last)):
+                ref = oracle.decode(files[i])["rgb"]
+                ok = ok and np.array_equal(as_reference_order(got, ref), ref)
+            parity = "bit-exact vs oracle (first and last image of rank 0's share), every plan's statuses ok" if ok else "MISMATCH"
     else:
         out = plan.read(rgb=False)
         status_bad = int(np.count_nonzero(out["status"]))
-        rgb_host = d_rgb.cpu().numpy()
-        checks = [(i, rgb_host[i * per:(i + 1) * per]) for i in (0, args.batch - 1)]
-    if rank == 0:
-        from oracle import oracle
-        ok = status_bad == 0
-        for i, got in checks:
-            ref = oracle.decode(files[i])["rgb"]
-            got = got.reshape(ref.shape if args.layout == "xmajor" else (H, W, 3))
-            if args.layout != "xmajor":
-                got = np.swapaxes(got, 0, 1)
-            ok = ok and np.array_equal(got, ref)
-        parity = "bit-exact vs oracle (first and last image of rank 0's share)" if ok else "MISMATCH"
+        if rank == 0:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle
+            n_chk = distinct if args.parity_images <= 0 else min(distinct, args.parity_images)
+            ok = status_bad == 0
+            imgs = d_rgb[:args.batch * per].view(args.batch, per)
+            for k in range(1, (args.batch + distinct - 1) // distinct):          # replicas of the distinct files: on the device
+                m = min(distinct, args.batch - k * distinct)
+                ok = ok and bool(torch.equal(imgs[k * distinct:k * distinct + m], imgs[:m]))
+            t0 = time.perf_counter()
+            oracle.decode(raws[0])                               # (builds the oracle's tables before the threads start)
+            bad_imgs = []
+
+            def check(i):
+                ref = oracle.decode(raws[i])["rgb"]
+                if not np.array_equal(as_reference_order(imgs[i].cpu().numpy(), ref), ref):
+                    bad_imgs.append(i)
+            with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as ex:
+                list(ex.map(check, range(n_chk)))
+            ok = ok and not bad_imgs
+            parity = (f"bit-exact vs oracle: all {n_chk} distinct images of the batch ({time.perf_counter() - t0:.1f} s of oracle time on host threads), "
+                      f"every replica identical to its first instance (device-side compare), every image's status ok") if ok else \
+                     f"MISMATCH (images {sorted(bad_imgs)[:8]}, statuses not ok: {status_bad})"
 
     base_cfg = "BASELINE configs[3]" if queue_mode else "BASELINE configs[2]"
     std = args.restart_interval == 120 and (queue_mode or args.batch == 1024)
@@ -536,6 +519,9 @@ def main():
 
     # ---- roofline of the two stages: HIP events on the launch stream, algorithmic bytes per launch ----------------
     if rank == 0 and not queue_mode:
+        for _ in range(20):                     # the parity check above left the GPU idle for seconds: back to the clocks of the timed region
+            step()
+        torch.cuda.synchronize()
         s1_ms, s2_ms = plan.time_stages(10, d_rgb.data_ptr())
         copy_gbs = None
         try:                                    # second denominator SURVEY 8d asks for: a plain device-to-device copy here

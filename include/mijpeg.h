@@ -188,12 +188,15 @@ void mj_plan_destroy(mj_plan *plan);
 int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
 /* Which form of stage 1 the plan chose: one restart segment per wavefront, one per lane, long segments
  * cut into self-synchronised pieces, or scan by scan (progressive / non-interleaved); MJ_FORM_WG_TABLES is or-ed in when
- * the batch has more Huffman tables than LDS holds and every workgroup loads only the tables of its own images. */
+ * the batch has more Huffman tables than LDS holds and every workgroup loads only the tables of its own images,
+ * MJ_FORM_RESOLVED when the lane / synchronisation form decodes with the resolved 13-bit AC tables (huffman_lanes13.hip:
+ * every batch whose distinct tables fit LDS in that format — at most 3 AC and 4 DC tables). */
 #define MJ_FORM_WAVE      0
 #define MJ_FORM_LANES     1
 #define MJ_FORM_SYNC      2
 #define MJ_FORM_SCANS     3
 #define MJ_FORM_WG_TABLES 16
+#define MJ_FORM_RESOLVED  32
 int mj_plan_stage1_form(const mj_plan *plan);
 /* offsets (in elements of the respective output) of image i inside the packed outputs */
 int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off, int64_t *rgb_off);
@@ -202,6 +205,8 @@ int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off
  * void*, NULL = the context's own stream).  `rgb_device` is a device buffer of rgb_bytes bytes, or NULL to
  * use a plan-owned one.  Asynchronous for every kind of batch: nothing in it waits for the device. */
 int mj_plan_execute(mj_plan *plan, void *stream, uint8_t *rgb_device);
+/* (A plan owns ONE coefficient store, one set of stage-1 scratch and one stage-2 work counter: executes of the same plan must
+ * not overlap — queue them on one stream, or wait for mj_plan_sync before using another.  Different plans overlap freely.) */
 /* The two stages separately (profiling, config 2). */
 int mj_plan_execute_stage1(mj_plan *plan, void *stream);
 int mj_plan_execute_stage2(mj_plan *plan, void *stream, uint8_t *rgb_device);
@@ -237,9 +242,15 @@ int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *st
  *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
  *   MJ_PROG_SPLIT     0 | 1 | 2  refining AC scans as scout + parts: never | while the chip has wave slots for it | always
  *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)
- *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64   MJ_LANES_RING  64 | 128      MJ_STAGE2_CHUNK  strips per stage-2 job
- * Returns MJ_ERR_INVALID for a name that is none of these.  mj_plan_stage1_form() reports what a plan ended up with. */
+ *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64 (the 11-bit lane form reads 1 as 2)   MJ_LANES_RING  64 | 128
+ *   MJ_STAGE2_CHUNK   1..4096 strips per stage-2 job
+ * Returns MJ_ERR_INVALID for a name that is none of these AND for a value outside the range or word list given here (a probe
+ * sweep must not report the default under another label); the option then keeps what it had.  Values are copied when they are
+ * read: setting an option from one thread while another creates or executes a plan is safe (that plan sees the old or the new
+ * value, each option read once).  mj_plan_stage1_form() reports what a plan ended up with. */
 int mj_set_option(const char *name, const char *value);
+/* The value an option holds ("" = the default) into value_out[cap]; MJ_ERR_INVALID for a name that is no option. */
+int mj_get_option(const char *name, char *value_out, int32_t cap);
 
 /* Diagnostic of the fast stage 2 (reference :1561-1573): of the blocks the plan's latest stage-2 execute WITH seam outputs
  * (MJ_FLAG_KEEP_IDCT / MJ_FLAG_KEEP_PLANES) put through the IDCT, counts[0] = all of them, counts[1] = how many the fp32

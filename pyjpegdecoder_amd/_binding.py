@@ -27,9 +27,9 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option",
 )
-MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES = 0, 1, 2, 3, 16
+MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED = 0, 1, 2, 3, 16, 32
 MJ_HOST_DECLINED = 1
 
 
@@ -130,16 +130,31 @@ def load_library():
     L.mj_plan_stage1_form.argtypes = [vp]
     L.mj_plan_idct_levels.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mj_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.mj_get_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
     _lib = L
     return L
 
 
+class UnknownOption(ValueError):
+    """mj_set_option / mj_get_option: no such option in this library."""
+
+
+def get_option(name: str) -> str:
+    """mj_get_option: the value an option holds, "" = the default."""
+    buf = ctypes.create_string_buffer(64)
+    if load_library().mj_get_option(name.encode(), buf, 64) != MJ_OK:
+        raise UnknownOption(f"libmijpeg has no option {name!r}")
+    return buf.value.decode()
+
+
 def set_option(name: str, value=None):
     """mj_set_option: a test / tuning switch of the library, process-wide (the library does not read the environment for
-    these).  value None = back to the default."""
+    these).  value None = back to the default.  UnknownOption for a name the library does not have, ValueError for a value
+    outside the option's range (the option keeps what it had)."""
+    get_option(name)
     rc = load_library().mj_set_option(name.encode(), None if value is None else str(value).encode())
     if rc != MJ_OK:
-        raise ValueError(f"libmijpeg has no option {name!r}")
+        raise ValueError(f"libmijpeg: {value!r} is outside what option {name} takes (include/mijpeg.h)")
 
 
 def _ptr(a: Optional[np.ndarray]):

@@ -146,6 +146,7 @@ struct mj_plan {
                                    // chain of wrongly guessed entry states that still settles (flat image regions re-synchronise badly:
                                    // round 4 found a quarter of a synthetic batch's images unconverged after four rounds, none after six; an idle round costs ~2 us)
     int sync_chunk_bytes = 2048;
+    int sync_warm_bits = -1;       // run-up in front of every chunk of the counting rounds (MJ_SYNC_WARM at plan creation; -1 = half a chunk)
     uint16_t *d_lut11u = nullptr;       // every table as len << 11 | run << 4 | size
     mj::DevChunk *d_chunks = nullptr;
     int64_t n_chunks = 0;
@@ -320,22 +321,53 @@ int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 
 
 namespace mj {
 namespace {
+// name, and what a value must look like: one of `words` (separated by '|'), or an integer in [lo, hi] (a multiple of `step`)
+struct OptionRule { const char *name; const char *words; int lo, hi, step; };
+const OptionRule kOptionRules[] = {
+    {"MJ_HUFFMAN", "wave|lanes|lanes11|sync", 0, 0, 1}, {"MJ_SEG_ORDER", "blob|binned|striped", 0, 0, 1},
+    {"MJ_SYNC_ROUNDS", nullptr, 0, 64, 1},   {"MJ_SYNC_CHUNK", nullptr, 256, 65536, 4}, {"MJ_SYNC_WARM", nullptr, 0, 65536, 1},
+    {"MJ_PROG_BANDS", nullptr, 0, 1, 1},     {"MJ_PROG_ROWS", nullptr, 1, 4096, 1},     {"MJ_PROG_FAST", nullptr, 0, 1, 1},
+    {"MJ_LANES_WAVES", nullptr, 1, 16, 1},   {"MJ_LANES_PER_WAVE", nullptr, 1, 64, 1},  {"MJ_LANES_RING", "64|128", 0, 0, 1},
+    {"MJ_STAGE2_CHUNK", nullptr, 1, 4096, 1}, {"MJ_PROG_SPLIT", nullptr, 0, 2, 1},      {"MJ_PROG_PARTS", nullptr, 1, kProgSub, 1},
+    {"MJ_FUSED", nullptr, 0, 1, 1},          {"MJ_FUSED_CONSUMERS", nullptr, 0, 8, 1},
+};
+constexpr int kNumOptions = (int)(sizeof(kOptionRules) / sizeof(kOptionRules[0]));
 struct OptionTable {
     std::mutex mu;
-    // (values live as long as the process: a returned pointer stays valid until the same option is set again)
-    struct Entry { const char *name; std::string value; bool set; };
-    Entry e[14] = {{"MJ_HUFFMAN", "", false},      {"MJ_SEG_ORDER", "", false},   {"MJ_SYNC_ROUNDS", "", false}, {"MJ_SYNC_CHUNK", "", false},
-                   {"MJ_SYNC_WARM", "", false},    {"MJ_PROG_BANDS", "", false},  {"MJ_PROG_ROWS", "", false},   {"MJ_PROG_FAST", "", false},
-                   {"MJ_LANES_WAVES", "", false},  {"MJ_LANES_PER_WAVE", "", false}, {"MJ_LANES_RING", "", false}, {"MJ_STAGE2_CHUNK", "", false},
-                   {"MJ_PROG_SPLIT", "", false},  {"MJ_PROG_PARTS", "", false}};
+    struct Entry { std::string value; bool set = false; };
+    Entry e[kNumOptions];
 };
 OptionTable g_options;
+bool option_value_ok(const OptionRule &r, const char *v) {
+    if (r.words) {
+        const size_t n = strlen(v);
+        for (const char *w = r.words; *w;) {
+            const char *bar = strchr(w, '|');
+            const size_t len = bar ? (size_t)(bar - w) : strlen(w);
+            if (len == n && !strncmp(w, v, n)) return true;
+            w += len + (bar ? 1 : 0);
+        }
+        return false;
+    }
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    return end != v && *end == 0 && x >= r.lo && x <= r.hi && x % r.step == 0;
+}
 }  // namespace
+// The value is COPIED under the lock (another thread may set the option while this one parses it) into a small per-thread
+// ring: the pointer stays good for this thread's next seven opt() calls — every caller consumes it on the spot.
 const char *opt(const char *name) {
+    thread_local std::string ring[8];
+    thread_local unsigned turn = 0;
     {
         std::lock_guard<std::mutex> lk(g_options.mu);
-        for (auto &x : g_options.e)
-            if (!strcmp(x.name, name)) { if (x.set) return x.value.c_str(); break; }
+        for (int i = 0; i < kNumOptions; ++i)
+            if (!strcmp(kOptionRules[i].name, name)) {
+                if (!g_options.e[i].set) break;
+                std::string &slot = ring[turn++ & 7u];
+                slot = g_options.e[i].value;
+                return slot.c_str();
+            }
     }
 #ifdef MJ_DIAGNOSTIC
     return getenv(name);
@@ -343,12 +375,23 @@ const char *opt(const char *name) {
     return nullptr;
 #endif
 }
+int get_opt(const char *name, char *out, int cap) {
+    std::lock_guard<std::mutex> lk(g_options.mu);
+    for (int i = 0; i < kNumOptions; ++i)
+        if (!strcmp(kOptionRules[i].name, name)) {
+            if (cap > 0) { strncpy(out, g_options.e[i].set ? g_options.e[i].value.c_str() : "", (size_t)cap - 1); out[cap - 1] = 0; }
+            return MJ_OK;
+        }
+    return MJ_ERR_INVALID;
+}
 int set_opt(const char *name, const char *value) {
     std::lock_guard<std::mutex> lk(g_options.mu);
-    for (auto &x : g_options.e)
-        if (!strcmp(x.name, name)) {
-            x.set = value != nullptr && value[0] != 0;
-            x.value = x.set ? value : "";
+    for (int i = 0; i < kNumOptions; ++i)
+        if (!strcmp(kOptionRules[i].name, name)) {
+            const bool set = value != nullptr && value[0] != 0;
+            if (set && !option_value_ok(kOptionRules[i], value)) return MJ_ERR_INVALID;     // a sweep must not time the default under another label
+            g_options.e[i].set = set;
+            g_options.e[i].value = set ? value : "";
             return MJ_OK;
         }
     return MJ_ERR_INVALID;
@@ -465,6 +508,11 @@ void mj_plan_destroy(mj_plan *p) {
 int mj_set_option(const char *name, const char *value) {
     if (!name) return MJ_ERR_INVALID;
     return mj::set_opt(name, value);
+}
+
+int mj_get_option(const char *name, char *value_out, int32_t cap) {
+    if (!name || (cap > 0 && !value_out)) return MJ_ERR_INVALID;
+    return mj::get_opt(name, value_out, cap);
 }
 
 int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
@@ -1039,6 +1087,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         // segment (no DRI), whose byte range bounds its length.
         if (const char *e = mj::opt("MJ_SYNC_ROUNDS")) { const int v = atoi(e); if (v >= 0 && v <= 64) p->sync_rounds = v; }
         if (const char *e = mj::opt("MJ_SYNC_CHUNK")) { const int v = atoi(e); if (v >= 256 && v <= 65536 && v % 4 == 0) p->sync_chunk_bytes = v; }
+        if (const char *e = mj::opt("MJ_SYNC_WARM")) p->sync_warm_bits = atoi(e) * 8;
         bool one_seg_each = true;
         for (const auto &jb : jobs) one_seg_each = one_seg_each && jb.n_seg == 1;
         if (!jobs.empty() && one_seg_each)
@@ -1264,7 +1313,7 @@ int mj_plan_stage1_form(const mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
     if (p->progressive) return MJ_FORM_SCANS;
     const int base = p->use_sync ? MJ_FORM_SYNC : (p->use_lanes ? MJ_FORM_LANES : MJ_FORM_WAVE);
-    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0);
+    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0);
 }
 
 int mj_plan_get_info(const mj_plan *p, mj_plan_info *info) {
@@ -1376,7 +1425,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
             const int cbits = p->sync_chunk_bytes * 8;
             MJ_HIP(ctx, hipMemsetAsync(p->d_couts, 0xFF, (size_t)p->n_chunks * sizeof(mj::DevChunkOut), s));
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
-                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count));
+                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count, nullptr, p->sync_warm_bits));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
             // repair rounds: a fixed number, queued without looking (a chain of wrongly guessed entry states gets one link
             // shorter per round; after round 0's run-up nearly every guess is right and the second repair round changes
@@ -1387,7 +1436,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
             for (int round = 1; round <= p->sync_rounds; ++round) {
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
                                                   p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + round, p->d_wg_tabs_count, p->wg_slots_count,
-                                                  round >= 2 ? p->d_changed + round - 1 : nullptr));
+                                                  round >= 2 ? p->d_changed + round - 1 : nullptr, p->sync_warm_bits));
                 std::swap(in, out);
             }
             MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,
@@ -1446,6 +1495,10 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.jobs_per_ticket = p->jobs_per_ticket;
     a.level_counts = reinterpret_cast<unsigned long long *>(p->d_job_prefix + p->n_images + 3);
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(a.level_counts, 0, 3 * sizeof(unsigned long long), s));     // mj_plan_idct_levels
+    // the launch's ticket counter starts from zero whatever an earlier launch left behind (one that was aborted never drew its
+    // last ticket).  The kernel still resets it itself at its end: the word is per PLAN, so a plan's executes must not overlap
+    // (mijpeg.h) — two plans, or one plan's executes one after the other on any streams, are fine.
+    if (!p->generic && !a.exact_only) MJ_HIP(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), s));
     if (p->generic) {
         MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
     } else if (a.exact_only) {

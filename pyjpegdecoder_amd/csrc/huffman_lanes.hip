@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_huffman_lanes(const uint32_t *__restric
 // Lanes per wavefront for `n_segs` units of work with `n_slots` tables in LDS (api.hip asks too: a batch with more
 // tables than LDS holds gets per-workgroup table lists, which depend on how the launch groups the segments).
 int lanes_per_wave(int64_t n_segs, int n_slots) {
-    if (const char *e = opt("MJ_LANES_PER_WAVE")) { const int lpw = atoi(e); if (lpw >= 2 && lpw <= 64) return lpw; }
+    if (const char *e = opt("MJ_LANES_PER_WAVE")) { const int lpw = atoi(e); if (lpw >= 1 && lpw <= 64) return lpw < 2 ? 2 : lpw; }   // (this form's flush wants two lanes at least)
     // measured on MI355X: the kernel is instruction-issue bound, every instruction costing the same
     // whatever the number of active lanes, and latency bound below ~2 waves per SIMD.  All workgroups are resident
     // at once and run equally long, so what matters besides ~3-4 waves per SIMD is that every CU gets the SAME

@@ -334,7 +334,7 @@ __global__ void k_build_vsegs(const DevChunk *__restrict__ chunks, int64_t n_chu
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs, int wg_slots, const int32_t *prev_changed) {
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs, int wg_slots, const int32_t *prev_changed, int warm_bits) {
     if (n_chunks == 0) return hipSuccess;
     if (wg_tabs) n_huff = wg_slots;                             // table slots in LDS
     const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4 + (size_t)n_huff * kLongInts * 4;
@@ -345,7 +345,7 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set[current_device()] = true;
     }
-    const int warm = opt("MJ_SYNC_WARM") ? atoi(opt("MJ_SYNC_WARM")) * 8 : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best)
+    const int warm = warm_bits >= 0 ? warm_bits : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best; MJ_SYNC_WARM is read once, when the plan is created)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,
                            chunks, n_chunks, cbits, warm, entry, exit_out, outs, changed, wg_tabs, prev_changed);

@@ -186,7 +186,8 @@ hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const De
 hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                              const DevImage *images, const DevHuff *huff, const uint16_t *lut11u, int n_huff,
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
-                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr, int wg_slots = 0, const int32_t *prev_changed = nullptr);   // wg_tabs: per 256 chunks
+                             DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr, int wg_slots = 0, const int32_t *prev_changed = nullptr,
+                             int warm_bits = -1);   // wg_tabs: per 256 chunks; warm_bits: run-up in front of every chunk, -1 = half a chunk
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
                               const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs,
                               const uint64_t *final_exit, int32_t *status);
@@ -217,6 +218,7 @@ int lanes_per_wave(int64_t n_segs, int n_slots);
 // Returns the value or nullptr.
 const char *opt(const char *name);
 int set_opt(const char *name, const char *value);
+int get_opt(const char *name, char *out, int cap);
 
 constexpr size_t kStage2DumpBytes = 4096 * 1024;    // 1 KiB per workgroup of the largest persistent grid
 struct ReconArgs {

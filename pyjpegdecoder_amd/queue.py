@@ -1,0 +1,114 @@
+"""Per-GPU image queue (BASELINE configs[3]): one rank's share of a job, decoded plan after plan with a few
+plans in flight.
+
+The reference decodes one file per ``JpegDecoder(path)`` call (jpeg_decoder.py:56-110); a job of thousands of files on a
+node of GPUs is sharded by image (``sharding.shard``) and each rank feeds ITS GPU from this queue — no collective on the
+data path.  The share's files are assembled and uploaded once (inputs resident in HBM), cut into batches of
+``batch_size`` images; ``run()`` makes one pass: plan k is created and queued on stream ``k % depth`` into output slot
+``k % depth``, then — before slot ``k % depth`` is used again — plan ``k - depth`` is collected (synchronised, its
+per-image status read, destroyed: where a consumer takes the pixels from HBM).
+
+Why a queue and not one plan per batch back to back: stage 1 lasts as long as ONE restart segment's serial walk however
+few segments a plan holds, so a plan of a few hundred images leaves most of the chip idle, and plan creation
+(descriptor uploads, buffer clears) is host work that would otherwise sit between two plans' kernels.
+
+Everything that touches the device goes through a small backend object (default: torch for memory and streams,
+``_binding.Plan`` for the plans), so that the slot / collection logic is testable without a GPU (tests/test_queue.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+
+class TorchBackend:
+    """Device memory and streams from torch, plans from libmijpeg.so (through ``_binding``)."""
+
+    def __init__(self, ctx, device=None):
+        import torch
+        from . import _binding as B
+        self.torch, self.B, self.ctx = torch, B, ctx
+        self.dev = torch.device("cuda", ctx.device if device is None else device)
+
+    def upload(self, host_array):
+        t = self.torch.from_numpy(host_array).to(self.dev)
+        return t, t.data_ptr()
+
+    def empty(self, nbytes: int):
+        t = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.dev)
+        return t, t.data_ptr()
+
+    def stream(self):
+        s = self.torch.cuda.Stream(device=self.dev)
+        return s, s.cuda_stream
+
+    def make_plan(self, prep, blob_ptr: int, n_images: int):
+        return self.B.Plan(self.ctx, prep.to_c(blob_ptr), {"prep": prep, "n_images": n_images})
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+
+class DeviceImageQueue:
+    """``files``: this rank's share (a list of file bytes).  ``depth`` plans are in flight at once, each on its own stream
+    and with its own output buffer."""
+
+    def __init__(self, ctx, files: Sequence[bytes], batch_size: int, layout: int, depth: int = 2, device=None, backend=None,
+                 prepare: Optional[Callable] = None, on_collect: Optional[Callable] = None):
+        if batch_size < 1 or depth < 1:
+            raise ValueError("batch_size and depth must be at least 1")
+        if prepare is None:
+            from .batch import prepare_batch as prepare
+        self.backend = backend if backend is not None else TorchBackend(ctx, device)
+        self.layout = layout
+        self.batches = []                 # (prep, device blob handle, device blob pointer, images)
+        for i in range(0, len(files), batch_size):
+            part = files[i:i + batch_size]
+            prep = prepare(part, layout, 0)
+            handle, ptr = self.backend.upload(prep.blob)
+            self.batches.append((prep, handle, ptr, len(part)))
+        cap = max((sum(w * h * nc for (w, h, nc) in b[0].shapes) for b in self.batches), default=0)
+        self.depth = max(1, min(depth, len(self.batches)))
+        self.out = [self.backend.empty(cap) for _ in range(self.depth)]           # (handle, pointer) per slot
+        self.streams = [self.backend.stream() for _ in range(self.depth)]        # (handle, raw stream) per slot
+        self.n_images = len(files)
+        self.bad = 0                      # plans with an image whose status was not MJ_ST_OK, over every run() so far
+        self.collected: List[int] = []    # batch numbers in the order they were collected (the latest run())
+        # called as on_collect(batch number, slot, plan) when a plan's pixels are in HBM, before the plan is destroyed
+        self.on_collect = on_collect
+
+    def slot_of(self, k: int) -> int:
+        return k % self.depth
+
+    def out_tensor(self, slot: int):
+        """The output buffer of a slot (the backend's handle: a ``torch.uint8`` tensor with the default backend)."""
+        return self.out[slot][0]
+
+    def _collect(self, k: int, plan):
+        try:
+            plan.sync()
+            self.bad += int(plan.read(rgb=False)["status"].any())
+            self.collected.append(k)
+            if self.on_collect is not None:
+                self.on_collect(k, self.slot_of(k), plan)
+        finally:
+            plan.close()
+
+    def run(self, first: int = 0, count: Optional[int] = None):
+        """One pass over the share (or over ``count`` batches from batch ``first``); returns when every batch's pixels are
+        in HBM.  Batch k's pixels are in ``out_tensor(slot_of(k))`` until batch k + depth overwrites them."""
+        self.collected = []
+        last = len(self.batches) if count is None else min(len(self.batches), first + count)
+        flying = []                       # (batch number, plan), oldest first
+        try:
+            for k in range(first, last):
+                prep, _, ptr, n = self.batches[k]
+                if len(flying) == self.depth:            # slot k % depth is still in use by plan k - depth
+                    self._collect(*flying.pop(0))
+                plan = self.backend.make_plan(prep, ptr, n)
+                flying.append((k, plan))
+                plan.execute(self.streams[self.slot_of(k)][1], self.out[self.slot_of(k)][1])
+            while flying:
+                self._collect(*flying.pop(0))
+        finally:
+            for _, plan in flying:        # (an exception on the way: nothing of this pass stays alive)
+                plan.close()

@@ -98,3 +98,58 @@ def test_header_is_plain_c_and_layouts_match_the_binding(tmp_path):
         assert got[0] == cname
         want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(x) for x in got[1:]] == want, cname
+
+
+def test_option_values_are_validated_and_readable(lib):
+    """mj_set_option refuses a value outside the documented range or word list (MJ_ERR_INVALID) and keeps what the option
+    had — a probe sweep must not time the defaults under another label; mj_get_option reads it back; both refuse a name
+    that is no option.  (No GPU: the option table is host state.)"""
+    from pyjpegdecoder_amd import _binding as B
+    try:
+        B.set_option("MJ_LANES_PER_WAVE", 34)
+        assert B.get_option("MJ_LANES_PER_WAVE") == "34"
+        for bad in ("0", "65", "-3", "12x", "lots"):
+            with pytest.raises(ValueError):
+                B.set_option("MJ_LANES_PER_WAVE", bad)
+            assert B.get_option("MJ_LANES_PER_WAVE") == "34"
+        for name, good, bad in (("MJ_HUFFMAN", "lanes11", "lanes12"), ("MJ_SEG_ORDER", "striped", "sorted"), ("MJ_LANES_RING", "64", "96"),
+                                ("MJ_SYNC_CHUNK", "1024", "1022"), ("MJ_SYNC_ROUNDS", "0", "65"), ("MJ_PROG_PARTS", "8", "9"),
+                                ("MJ_PROG_SPLIT", "2", "3"), ("MJ_LANES_WAVES", "16", "17")):
+            B.set_option(name, good)
+            assert B.get_option(name) == good
+            with pytest.raises(ValueError):
+                B.set_option(name, bad)
+            assert B.get_option(name) == good
+            B.set_option(name, None)
+            assert B.get_option(name) == ""
+        with pytest.raises(B.UnknownOption):
+            B.set_option("MJ_NO_SUCH_SWITCH", "1")
+        with pytest.raises(B.UnknownOption):
+            B.get_option("PATH")
+        assert lib.mj_set_option(None, b"1") == B.MJ_ERR_INVALID
+    finally:
+        B.set_option("MJ_LANES_PER_WAVE", None)
+
+
+def test_options_set_from_another_thread_while_being_read(lib):
+    """The value handed to a reader is a copy made under the lock: a thread that keeps re-setting an option cannot pull the
+    string out from under a plan-creating thread (here: 20 000 reads against 20 000 writes of values of different lengths)."""
+    import threading
+    from pyjpegdecoder_amd import _binding as B
+    stop = threading.Event()
+
+    def writer():
+        vals = ["1", "16", "7", "12"]
+        i = 0
+        while not stop.is_set():
+            B.set_option("MJ_LANES_WAVES", vals[i & 3])
+            i += 1
+    t = threading.Thread(target=writer)
+    t.start()
+    try:
+        for _ in range(20000):
+            assert B.get_option("MJ_LANES_WAVES") in ("", "1", "16", "7", "12")
+    finally:
+        stop.set()
+        t.join()
+        B.set_option("MJ_LANES_WAVES", None)

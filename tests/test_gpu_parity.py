@@ -1603,13 +1603,36 @@ def test_config4_one_ranks_share_at_size():
     assert line["value"] > 0
 
 
-def _craft_grey_stream(width, blocks):
+def _with_ac_table(base, bits, vals):
+    """`base` (a greyscale baseline file) with its AC table 0 replaced by (bits, vals) — DHT payloads may hold several tables."""
+    out, pos = bytearray(base[:2]), 2
+    while True:
+        assert base[pos] == 0xFF
+        marker, ln = base[pos + 1], int.from_bytes(base[pos + 2:pos + 4], "big")
+        body = base[pos + 4:pos + 2 + ln]
+        if marker == 0xC4:
+            tabs, q = [], 0
+            while q < len(body):
+                n = sum(body[q + 1:q + 17])
+                tabs.append(body[q:q + 17 + n])
+                q += 17 + n
+            body = b"".join(bytes([0x10]) + bytes(bits) + bytes(vals) if t[0] == 0x10 else t for t in tabs)
+        out += bytes([0xFF, marker]) + (len(body) + 2).to_bytes(2, "big") + body
+        pos += 2 + ln
+        if marker == 0xDA:
+            return bytes(out) + base[pos:]
+
+
+def _craft_grey_stream(width, blocks, ac_table=None):
     """A greyscale baseline file of `width` x 8 whose entropy-coded data is written here symbol by symbol: `blocks` = per block
     the list of AC (run, size, value-bits or None) symbols after a zero DC difference; value-bits None = the symbol's value
-    bits are NOT written (what follows a run past index 63, jpeg_decoder.py:855-856)."""
+    bits are NOT written (what follows a run past index 63, jpeg_decoder.py:855-856).  `ac_table` = (bits, vals) replaces the
+    file's AC table (symbols the Annex-K table does not have: sizes above 10)."""
     from pyjpegdecoder_amd import parse_jpeg
     from tools import synth
     base = synth.synth_jpeg(3, width, 8, 85, "grey", 0)
+    if ac_table is not None:
+        base = _with_ac_table(base, *ac_table)
     p = parse_jpeg(base)
     sc = p.scans[0]
 
@@ -1671,6 +1694,100 @@ def test_runs_past_the_block_and_coefficient_63(dec, form, monkeypatch, tune):
     (img,), (seam,) = dec.decode([raw], return_seams=True)
     assert np.array_equal(seam["coef"], ref["coef"])
     assert np.array_equal(img, ref["rgb"])
+
+
+@pytest.mark.parametrize("form", ["lanes", "lanes11", "wave", "sync"])
+def test_value_sizes_up_to_15_and_bursts_of_unresolved_entries(dec, form, tune):
+    """The reference reads whatever size a symbol names (jpeg_decoder.py:862: sizes 11..15 are outside T.81's baseline tables but
+    inside its code).  A table with every (run, size) up to size 15 and code lengths 2..16, and hand-written blocks whose
+    symbols are ALL of the kind the resolved-table lane form cannot finish in its table — code + value bits beyond 13, codes
+    of 14..16 bits — eight to sixty-two in a row, up to 31 bits each: the per-lane stream window has to keep up with a lane
+    that takes a dword per symbol (huffman_lanes13.hip: the top-up margin), the arithmetic step has to EXTEND 15-bit values,
+    and the forms have to agree with the oracle on the coefficients.  (Pixels are compared where the samples fit int16:
+    jpeg_decoder.py:1573's cast is undefined beyond.)"""
+    from oracle import oracle
+    from tools import craft_jpeg
+    bits, vals = craft_jpeg.wide_ac_table(5)
+    length = {}
+    k = 0
+    for l in range(1, 17):
+        for _ in range(bits[l - 1]):
+            length[vals[k]] = l
+            k += 1
+    rng = np.random.default_rng(11)
+
+    def burst(n, sizes, run=0):
+        out = []
+        for _ in range(n):
+            s = int(rng.choice(sizes))
+            mag = int(rng.integers(1 << (s - 1), 1 << s))
+            v = mag if rng.random() < 0.5 else -mag
+            out.append((run, s, v if v >= 0 else v + (1 << s) - 1))
+        return out
+    big = [s for s in range(11, 16)]
+    # sizes whose code + value bits exceed 13 in this table (entries that are not resolved), by size
+    open_sizes = [s for s in range(7, 16) if length[s] + s > 13]
+    assert set(big) <= set(open_sizes)
+    blocks = [
+        burst(8, big) + [(0, 0, None)],                       # eight symbols of 11..15 value bits in a row, then end of block
+        burst(62, big) + [(0, 1, 1)],                         # a whole block of them: 62 x up to 31 bits, coefficient 63 from a resolved entry
+        burst(63, open_sizes),                                # ... ending on coefficient 63 with an unresolved entry
+        [(0, 2, 3), (0, 0, None)],                            # an ordinary block behind them
+        burst(20, [15]) + [(0, 0, None)],                     # twenty 15-bit values (EXTEND at its widest)
+        burst(12, big, run=1) + [(0, 0, None)],               # with runs in between
+        [(0, 1, 1)] * 5 + burst(9, big) + [(0, 1, 0)] * 5 + burst(9, big) + [(0, 0, None)],   # resolved and unresolved stretches alternate
+        [(0, 3, 5), (0, 0, None)],
+    ]
+    raw = _craft_grey_stream(8 * len(blocks), blocks, ac_table=(bits, vals))
+    ref = oracle.decode(raw)
+    assert int(np.abs(ref["coef"].astype(np.int64)).max()) >= 16384 and ref["coef"][7, 1] == 5 and ref["coef"][3, 1] == 3
+    tune("MJ_HUFFMAN", form)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"])
+    small = [3, 7]                                            # blocks whose samples fit int16
+    for b in small:
+        assert np.array_equal(img[8 * b:8 * b + 8], ref["rgb"][8 * b:8 * b + 8]), b
+
+
+def test_lane_form_waves_whose_lanes_use_different_ac_tables(dec, tune):
+    """A batch of >= 1024 restart segments from files that assign the batch's three AC tables to their components in four
+    different ways (the Annex-K pair as it is, swapped, and a third table on luma or on Cb): consecutive segments — the lanes of
+    one wavefront of the resolved-table lane form — then read different tables for the same block of the MCU, so the table base
+    must be a per-lane operand of the symbol loop (huffman_lanes13.hip: `lutb`), as must the canonical search's table.  Every
+    file against the oracle, coefficients and pixels; value sizes up to 15 on the third table."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from tools import craft_jpeg
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    wide = craft_jpeg.wide_ac_table(9)
+    maps = [((0, 0), (1, 1), (1, 1)), ((0, 1), (1, 0), (1, 0)), ((0, 2), (1, 0), (1, 1)), ((1, 1), (0, 2), (0, 0))]
+    W, H = 256, 128                                           # 16 x 8 MCUs, restart interval 8: 16 segments per file
+    raws = [craft_jpeg.craft_baseline(W, H, ((2, 2), (1, 1), (1, 1)), seed=100 + i, restart_interval=8, tables=maps[i % 4],
+                                      ac_tables=[wide], max_size=6 if i % 8 < 4 else 12, density=0.3)
+            for i in range(24)]
+    files = [raws[(i * 7) % 24] for i in range(72)]           # 1152 segments; neighbours in the batch have different maps
+    tune("MJ_HUFFMAN", "lanes")
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    dev = torch.device("cuda", 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
+    try:
+        form = plan.stage1_form()
+        assert form & 15 == B.MJ_FORM_LANES and form & B.MJ_FORM_RESOLVED, form
+        plan.execute(0, 0)
+        plan.sync()
+        out = plan.read(rgb=True, coef=True)
+        assert not out["status"].any(), out["status"]
+        refs = [oracle.decode(r) for r in raws]
+        per_rgb, per_blk = W * H * 3, (W // 16) * (H // 16) * 6
+        for i in range(len(files)):
+            ref = refs[(i * 7) % 24]
+            assert np.array_equal(out["coef"][i * per_blk:(i + 1) * per_blk], ref["coef"]), i
+            if (i * 7) % 24 % 8 < 4:                          # (modest coefficients: samples fit int16, pixels are defined)
+                assert np.array_equal(out["rgb"][i * per_rgb:(i + 1) * per_rgb].reshape(W, H, 3), ref["rgb"]), i
+    finally:
+        plan.close()
 
 
 # ---- sampling layouts outside the common ones (any factors 1..4 per component) ----------------------------------------

@@ -113,9 +113,26 @@ def _encode_block(w: _Bits, zz, dc_codes, ac_codes):
         w.put(*ac_codes[0x00])
 
 
+def wide_ac_table(seed: int = 0):
+    """(bits, vals) of an AC table that holds every (run, size) symbol with sizes 0..15 and run 0..15 that fits 256 symbols —
+    the reference takes whatever size a symbol names (jpeg_decoder.py:862) — with code lengths from 2 to 16 bits, so that
+    finished LUT entries, entries whose value bits are taken arithmetically, and second-level tables all occur."""
+    rng = np.random.default_rng(seed)
+    likely = [0x00, 0x01, 0x02, 0x11, 0x03, 0x21, 0xF0, 0x04, 0x12, 0x31, 0x05, 0x41]
+    rest = [(r << 4) | s for s in range(0, 16) for r in range(16) if ((r << 4) | s) not in likely and not (s == 0 and r not in (0, 15))]
+    rng.shuffle(rest)
+    order = likely + rest
+    counts = {2: 1, 3: 1, 4: 2, 5: 4, 6: 4, 7: 8, 8: 12, 9: 20, 10: 24, 11: 30, 12: 30, 13: 30, 14: 30, 15: 24, 16: len(order) - 220}
+    assert sum(counts.values()) == len(order) and counts[16] > 0
+    return bytes(counts.get(l, 0) for l in range(1, 17)), bytes(order)
+
+
 def craft_baseline(width: int, height: int, factors, seed: int = 0, restart_interval: int = 0, density: float = 0.35,
-                   max_size: int = 5, dc_size: int = 5) -> bytes:
-    """A baseline file of `width` x `height` with one interleaved scan; `factors` = ((h, v), ...) per component (1 or 3 of them)."""
+                   max_size: int = 5, dc_size: int = 5, tables=None, ac_tables=None) -> bytes:
+    """A baseline file of `width` x `height` with one interleaved scan; `factors` = ((h, v), ...) per component (1 or 3 of them).
+    `tables` = per component (dc table, ac table) as indices into the table lists (default: luma tables for the first
+    component, chroma tables for the others); `ac_tables` = extra (bits, vals) AC tables behind the two Annex-K ones (index
+    2..): files whose components share or swap tables, up to four tables per class."""
     factors = [tuple(f) for f in factors]
     ncomp = len(factors)
     assert ncomp in (1, 3)
@@ -130,16 +147,22 @@ def craft_baseline(width: int, height: int, factors, seed: int = 0, restart_inte
     for c, (h, v) in enumerate(factors):
         sof += bytes([c + 1, (h << 4) | v, 0 if c == 0 else 1])
     out += _seg(0xC0, sof)
-    out += _seg(0xC4, b"\x00" + _T["STD_DC_LUMA_BITS"] + _T["STD_DC_LUMA_VALS"])
-    out += _seg(0xC4, b"\x10" + _T["STD_AC_LUMA_BITS"] + _T["STD_AC_LUMA_VALS"])
-    if ncomp > 1:
-        out += _seg(0xC4, b"\x01" + _T["STD_DC_CHROMA_BITS"] + _T["STD_DC_CHROMA_VALS"])
-        out += _seg(0xC4, b"\x11" + _T["STD_AC_CHROMA_BITS"] + _T["STD_AC_CHROMA_VALS"])
+    if tables is None:
+        tables = [(0, 0) if c == 0 else (1, 1) for c in range(ncomp)]
+    tables = [tuple(t) for t in tables]
+    ac_specs = [(_T["STD_AC_LUMA_BITS"], _T["STD_AC_LUMA_VALS"]), (_T["STD_AC_CHROMA_BITS"], _T["STD_AC_CHROMA_VALS"])] + list(ac_tables or [])
+    dc_specs = [(_T["STD_DC_LUMA_BITS"], _T["STD_DC_LUMA_VALS"]), (_T["STD_DC_CHROMA_BITS"], _T["STD_DC_CHROMA_VALS"])]
+    ac_codes = [_codes(b, v) for b, v in ac_specs]
+    for t in range(4):
+        if t in {d for d, _ in tables}:
+            out += _seg(0xC4, bytes([t]) + dc_specs[t][0] + dc_specs[t][1])
+        if t in {a for _, a in tables}:
+            out += _seg(0xC4, bytes([0x10 | t]) + ac_specs[t][0] + ac_specs[t][1])
     if restart_interval:
         out += _seg(0xDD, restart_interval.to_bytes(2, "big"))
     sos = bytes([ncomp])
     for c in range(ncomp):
-        sos += bytes([c + 1, 0x00 if c == 0 else 0x11])
+        sos += bytes([c + 1, (tables[c][0] << 4) | tables[c][1]])
     sos += bytes([0, 63, 0])
     out += _seg(0xDA, sos)
     w = _Bits()
@@ -148,9 +171,10 @@ def craft_baseline(width: int, height: int, factors, seed: int = 0, restart_inte
     for m in range(n_mcu):
         for c, (h, v) in enumerate(factors):
             rep = h * v if ncomp > 1 else 1
-            t = 0 if c == 0 else 1
             for _ in range(rep):
-                _encode_block(w, random_block(rng, density, max_size, dc_size), _DC[t], _AC[t])
+                # (the Annex-K tables have no symbol for sizes above 10)
+                _encode_block(w, random_block(rng, density, max_size if tables[c][1] >= 2 else min(max_size, 10), dc_size),
+                              _DC[tables[c][0]], ac_codes[tables[c][1]])
         if restart_interval and (m + 1) % restart_interval == 0 and m + 1 != n_mcu:
             w.flush()
             w.out += bytes([0xFF, 0xD0 + (rst & 7)])

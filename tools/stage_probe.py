@@ -55,7 +55,7 @@ def main():
             try:
                 B.set_option(k, v)
                 api_opts.append(k)
-            except ValueError:
+            except B.UnknownOption:
                 os.environ[k] = v
         plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
         if d_rgb is None:
