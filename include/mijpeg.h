@@ -61,6 +61,9 @@ extern "C" {
                                  settled when the rounds were over (a pathological or crafted stream): nothing is wrong
                                  with the file — decode it again in a plan created with MJ_FLAG_NO_SYNC                */
 
+#define MJ_ST_INTERNAL    6   /* a wavefront of a fused launch gave up waiting for its workgroup's decoder wavefronts (a bound on
+                                 what is otherwise a spin loop: cannot happen; the image's pixels are not valid)        */
+
 /* memory spaces */
 #define MJ_MEM_NONE   0
 #define MJ_MEM_HOST   1
@@ -197,6 +200,10 @@ int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
 #define MJ_FORM_SCANS     3
 #define MJ_FORM_WG_TABLES 16
 #define MJ_FORM_RESOLVED  32
+#define MJ_FORM_FUSED     64   /* mj_plan_execute runs stages 1 and 2 as ONE launch (fused.hip): lane-walk wavefronts and
+                                  reconstruction wavefronts side by side in one workgroup per CU.  Uniform x-major batches of
+                                  4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 files with one restart interval per MCU row and the resolved
+                                  tables; mj_plan_execute_stage1 / _stage2 of such a plan are the two launches as ever */
 int mj_plan_stage1_form(const mj_plan *plan);
 /* offsets (in elements of the respective output) of image i inside the packed outputs */
 int mj_plan_image_offsets(const mj_plan *plan, int32_t image, int64_t *block_off, int64_t *rgb_off);
@@ -244,6 +251,8 @@ int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *st
  *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)
  *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64 (the 11-bit lane form reads 1 as 2)   MJ_LANES_RING  64 | 128
  *   MJ_STAGE2_CHUNK   1..4096 strips per stage-2 job
+ *   MJ_FUSED          0 | 1  (0 = mj_plan_execute always launches the stages separately)
+ *   MJ_FUSED_CONSUMERS 0..8  reconstruction wavefronts beside the lane walk of a fused launch (as many as LDS allows)
  * Returns MJ_ERR_INVALID for a name that is none of these AND for a value outside the range or word list given here (a probe
  * sweep must not report the default under another label); the option then keeps what it had.  Values are copied when they are
  * read: setting an option from one thread while another creates or executes a plan is safe (that plan sees the old or the new

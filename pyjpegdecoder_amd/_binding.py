@@ -14,7 +14,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libmijpeg.so"
 
 MJ_OK, MJ_ERR_INVALID, MJ_ERR_HIP, MJ_ERR_UNSUPPORTED = 0, -1, -2, -3
-MJ_ST_OK, MJ_ST_BAD_CODE, MJ_ST_OVERRUN, MJ_ST_DESYNC, MJ_ST_TAIL, MJ_ST_UNCONVERGED = 0, 1, 2, 3, 4, 5
+MJ_ST_OK, MJ_ST_BAD_CODE, MJ_ST_OVERRUN, MJ_ST_DESYNC, MJ_ST_TAIL, MJ_ST_UNCONVERGED, MJ_ST_INTERNAL = 0, 1, 2, 3, 4, 5, 6
 MJ_MEM_NONE, MJ_MEM_HOST, MJ_MEM_DEVICE = 0, 1, 2
 MJ_LAYOUT_XMAJOR, MJ_LAYOUT_ROWMAJOR, MJ_LAYOUT_PLANAR_XMAJOR, MJ_LAYOUT_PLANAR_ROWMAJOR = 0, 1, 2, 3
 MJ_FLAG_KEEP_COEF, MJ_FLAG_KEEP_PLANES, MJ_FLAG_KEEP_IDCT, MJ_FLAG_EXACT_ONLY, MJ_FLAG_SPEC_REFINE = 1, 2, 4, 8, 16
@@ -29,7 +29,7 @@ EXPORTS = (
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
     "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option",
 )
-MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED = 0, 1, 2, 3, 16, 32
+MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED = 0, 1, 2, 3, 16, 32, 64
 MJ_HOST_DECLINED = 1
 
 

@@ -340,6 +340,8 @@ def raise_for_status(status: np.ndarray):
     bad = np.flatnonzero(status)
     if bad.size:
         i = int(bad[0])
+        if int(status[i]) == B.MJ_ST_INTERNAL:          # not the file's fault (include/mijpeg.h)
+            raise B.BackendError(f"image {i}: a fused launch gave up waiting for its decoder wavefronts (internal error)")
         raise CorruptedJpeg(f"image {i}: {_STATUS_TEXT.get(int(status[i]), 'decode failed')}")
 
 

@@ -131,6 +131,8 @@ struct mj_plan {
     int32_t *d_by_length = nullptr;     // restart segments, longest first (how the lane form deals them out to its waves)
     int seg_order_mode = 0;
     uint32_t *d_lut13 = nullptr;        // [n_ac13][8192]
+    uint32_t *d_lut12 = nullptr;        // the same with a 12-bit main level, [n_ac13][lut12_slot_bytes / 4] (fused launches)
+    int lut12_slot_bytes = 0;
     int n_ac13 = 0, n_dc13 = 0;
     uint64_t ac_slot_pk = 0, dc_slot_pk = 0, dc_tab_pk = 0;
     // batches with more tables than LDS holds (files with their own optimised tables): per workgroup, the tables its
@@ -174,6 +176,10 @@ struct mj_plan {
     int n_jobs = 0;
     int n_huff = 0;
     bool use_lanes = false;
+    // stages 1 + 2 in one launch (fused.hip) for mj_plan_execute, where the batch is of the kind it takes
+    bool use_fused = false;
+    mj::FusedShape fused{};
+    int fused_spi = 0;                  // restart segments (= MCU rows) per image
     // progressive batches: scans grouped by dependency level, one launch per level
     bool progressive = false;
     mj::DevProgScan *d_pscans = nullptr;
@@ -315,6 +321,91 @@ int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 
         MJ_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // big (a host blob) or no arena: the plain way
     }
     return MJ_OK;
+}
+
+
+// Resolved AC tables (huffman_lanes13.hip's entry format) with AB index bits for every table of the batch used as an AC table:
+// per table a main level of 2^AB entries — the FINISHED symbol wherever code + value bits fit the index (jpeg_decoder.py:834-866 and
+// bin_twos_complement :1636-1646 evaluated here), else what the arithmetic step needs — and second-level tables of 2^(16 - AB)
+// entries for the prefixes of longer codes.  fixed_slot_bytes: the stride of a table in `out` (0 = as small as the batch's codes
+// allow: main level + the largest number of second-level tables any table needs; slot_bytes returns it).  false: does not fit.
+bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint64_t ac_pk, int n_ac, int AB, int fixed_slot_bytes,
+                           std::vector<uint32_t> &out, int &slot_bytes) {
+    const int AS = 1 << AB, SUB = 1 << (16 - AB);
+    const int res_limit = AB;
+    int max_sub = 1;
+    if (fixed_slot_bytes) {
+        max_sub = (fixed_slot_bytes / 4 - AS) / SUB;
+    } else {
+        for (int t = 0; t < b->n_huff; ++t) {
+            if (role[t] != 2) continue;
+            std::vector<char> seen(AS, 0);
+            int n = 1, code = 0, k = 0;
+            for (int l = 1; l <= 16; ++l) {
+                code <<= 1;
+                for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                    if (code >= (1 << l) || l <= AB) continue;
+                    const int prefix = code >> (l - AB);
+                    if (!seen[prefix]) { seen[prefix] = 1; ++n; }
+                }
+            }
+            max_sub = std::max(max_sub, n);
+        }
+    }
+    const int SLOT = fixed_slot_bytes ? fixed_slot_bytes / 4 : ((AS + max_sub * SUB) * 4 + 15) / 16 * 4;
+    if ((size_t)SLOT * 4 > 65535u) return false;                // (second-level tables are addressed by a 16-bit byte offset)
+    slot_bytes = SLOT * 4;
+    out.assign((size_t)n_ac * SLOT, 0xFFFFFFFFu);
+    for (int t = 0; t < b->n_huff; ++t) {
+        if (role[t] != 2) continue;
+        uint32_t *tab = out.data() + (size_t)((ac_pk >> (8 * t)) & 0xFF) * SLOT;
+        // second-level tables behind the main one: for the 16 - AB bits that follow an AB-bit prefix of longer codes;
+        // table 0 = "no such code" (where every other unset main entry points as well)
+        int n_sub = 1;
+        for (int i = 0; i < SUB; ++i) tab[AS + i] = 0x8000u;
+        int code = 0, k = 0;
+        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
+            for (uint32_t f = 0; f < count; ++f)
+                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
+        };
+        for (int l = 1; l <= 16; ++l) {
+            code <<= 1;
+            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                if (code >= (1 << l)) continue;
+                const int hv = b->huff[t].vals[k], run = hv >> 4, size = hv & 15;
+                const uint32_t adv = hv == 0 ? 127u : 2u * (uint32_t)(run + 1);
+                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | ((uint32_t)l << 16) | 0x8000u | ((hv == 0 ? 0u : (uint32_t)(run + 1)) << 8);   // value bits taken arithmetically
+                if (l > AB) {
+                    const uint32_t prefix = (uint32_t)code >> (l - AB);
+                    uint32_t &m = tab[prefix];
+                    if (m == 0xFFFFFFFFu) {                       // first long code under this prefix: a new table
+                        if (n_sub >= max_sub) return false;
+                        for (int j = 0; j < SUB; ++j) tab[AS + n_sub * SUB + j] = 0xFFFFFFFFu;
+                        m = ((uint32_t)(AS * 4 + n_sub * SUB * 4) << 16) | 0xC000u;
+                        ++n_sub;
+                    }
+                    if ((m & 0xC0FFu) != 0xC000u) continue;       // a shorter code owns the prefix (over-subscribed table)
+                    uint32_t *sub = tab + ((m >> 16) / 4);
+                    put(sub, ((uint32_t)code << (16 - l)) & (uint32_t)(SUB - 1), 1u << (16 - l), open_entry);
+                } else if (hv == 0 ? l <= res_limit : l + size <= res_limit) {
+                    const int n = hv == 0 ? 0 : size, rest = AB - l - n;
+                    for (uint32_t vb = 0; vb < (1u << n); ++vb) {
+                        // bin_twos_complement (:1636-1646): leading 1 = the value itself, leading 0 = value - (2^n - 1)
+                        const int val = n == 0 ? 0 : ((vb >> (n - 1)) ? (int)vb : (int)vb - ((1 << n) - 1));
+                        put(tab, (((uint32_t)code << n) | vb) << rest, 1u << rest,
+                            ((uint32_t)(uint16_t)(int16_t)val << 16) | (adv << 8) | (uint32_t)(l + n));
+                    }
+                } else {
+                    put(tab, (uint32_t)code << (AB - l), 1u << (AB - l), open_entry);
+                }
+            }
+        }
+        for (int i = 0; i < AS; ++i)
+            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0xC000u;          // no such code: the empty second-level table
+        for (int i = AS; i < SLOT; ++i)
+            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x8000u;
+    }
+    return true;
 }
 
 }  // namespace
@@ -498,7 +589,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -943,62 +1034,17 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 const char *f13 = mj::opt("MJ_HUFFMAN");
                 if (f13 && !strcmp(f13, "lanes11")) ok13 = false;
                 if (ok13 && mj::lanes13_fits(n_ac, n_dc)) {
-                    const int AB = 13, AS = 1 << AB, SLOT = mj::kLanes13SlotBytes / 4;
-                    std::vector<uint32_t> l13((size_t)n_ac * SLOT, 0xFFFFFFFFu);
-                    for (int t = 0; t < b->n_huff && ok13; ++t) {
-                        if (role[t] != 2) continue;
-                        uint32_t *tab = l13.data() + (size_t)((ac_pk >> (8 * t)) & 0xFF) * SLOT;
-                        // second-level tables behind the main one: 8 entries for the three bits that follow a 13-bit prefix of
-                        // codes of 14..16 bits; table 0 = "no such code" (where every other unset main entry points as well)
-                        int n_sub = 1;
-                        for (int i = 0; i < 8; ++i) tab[AS + i] = 0x8000u;
-                        int code = 0, k = 0;
-                        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
-                            for (uint32_t f = 0; f < count; ++f)
-                                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
-                        };
-                        for (int l = 1; l <= 16; ++l) {
-                            code <<= 1;
-                            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
-                                if (code >= (1 << l)) continue;
-                                const int hv = b->huff[t].vals[k], run = hv >> 4, size = hv & 15;
-                                const uint32_t adv = hv == 0 ? 127u : 2u * (uint32_t)(run + 1);
-                                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | ((uint32_t)l << 16) | 0x8000u | ((hv == 0 ? 0u : (uint32_t)(run + 1)) << 8);   // value bits taken arithmetically
-                                if (l > AB) {
-                                    const uint32_t prefix = (uint32_t)code >> (l - AB);
-                                    uint32_t &m = tab[prefix];
-                                    if (m == 0xFFFFFFFFu) {                       // first long code under this prefix: a new table
-                                        if (n_sub >= mj::kLanes13SubTables) { ok13 = false; break; }
-                                        for (int j = 0; j < 8; ++j) tab[AS + n_sub * 8 + j] = 0xFFFFFFFFu;
-                                        m = ((uint32_t)(AS * 4 + n_sub * 32) << 16) | 0xC000u;
-                                        ++n_sub;
-                                    }
-                                    if ((m & 0xC0FFu) != 0xC000u) continue;       // a shorter code owns the prefix (over-subscribed table)
-                                    uint32_t *sub = tab + ((m >> 16) / 4);
-                                    put(sub, ((uint32_t)code << (16 - l)) & 7u, 1u << (16 - l), open_entry);
-                                } else if (hv == 0 || l + size <= AB) {
-                                    const int n = hv == 0 ? 0 : size, rest = AB - l - n;
-                                    for (uint32_t vb = 0; vb < (1u << n); ++vb) {
-                                        // bin_twos_complement (:1636-1646): leading 1 = the value itself, leading 0 = value - (2^n - 1)
-                                        const int val = n == 0 ? 0 : ((vb >> (n - 1)) ? (int)vb : (int)vb - ((1 << n) - 1));
-                                        put(tab, (((uint32_t)code << n) | vb) << rest, 1u << rest,
-                                            ((uint32_t)(uint16_t)(int16_t)val << 16) | (adv << 8) | (uint32_t)(l + n));
-                                    }
-                                } else {
-                                    put(tab, (uint32_t)code << (AB - l), 1u << (AB - l), open_entry);
-                                }
-                            }
-                            if (!ok13) break;
-                        }
-                        for (int i = 0; i < AS; ++i)
-                            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0xC000u;          // no such code: the empty second-level table
-                        for (int i = AS; i < SLOT; ++i)
-                            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x8000u;
-                    }
-                    if (!ok13) goto no_lanes13;
+                    std::vector<uint32_t> l13;
+                    int slot_bytes = 0;
+                    if (!build_resolved_tables(b, role, ac_pk, n_ac, 13, mj::kLanes13SlotBytes, l13, slot_bytes)) goto no_lanes13;
                     if ((rc = upload(ctx, &p->d_lut13, l13.data(), l13.size())) != MJ_OK) return rc;
                     p->n_ac13 = n_ac; p->n_dc13 = n_dc;
                     p->ac_slot_pk = ac_pk; p->dc_slot_pk = dc_pk; p->dc_tab_pk = dct_pk;
+                    // the same tables with a 12-bit main level, as small as the batch's codes allow: what a fused launch keeps in
+                    // LDS beside its reconstruction wavefronts' strips (fused.hip)
+                    std::vector<uint32_t> l12;
+                    if (build_resolved_tables(b, role, ac_pk, n_ac, 12, 0, l12, p->lut12_slot_bytes))
+                        if ((rc = upload(ctx, &p->d_lut12, l12.data(), l12.size())) != MJ_OK) return rc;
                 }
             no_lanes13:;
             }
@@ -1200,6 +1246,27 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 if ((rc = upload(ctx, &p->d_by_length, ord.data(), ord.size())) != MJ_OK) return rc;
             }
         }
+        {   // One launch for both stages (fused.hip) where the batch allows it: the resolved-table lane form in blob order on
+            // a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files whose restart interval is ONE MCU ROW (a producer
+            // wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
+            // x-major pixels, no seam outputs, a stage-2 job = a whole MCU column, and LDS left for at least one consumer
+            // wavefront beside the producers.  MJ_FUSED=0 keeps the two launches; MJ_FUSED_CONSUMERS bounds the consumers.
+            int want_cons = 8;
+            bool allow = true;
+            if (const char *e = mj::opt("MJ_FUSED")) allow = atoi(e) != 0;
+            if (const char *e = mj::opt("MJ_FUSED_CONSUMERS")) want_cons = atoi(e);
+            const mj::DevImage &i0 = imgs[0];
+            const bool shape_ok = p->use_lanes && !p->use_sync && p->d_lut13 && p->seg_order_mode == 0 && p->uniform && !p->generic && !prog &&
+                                  p->ncomp == 3 && (p->hmax == 1 || p->hmax == 2) && (p->vmax == 1 || p->vmax == 2) && !p->transposed &&
+                                  p->layout == MJ_LAYOUT_XMAJOR && !(p->flags & (MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT)) &&
+                                  i0.restart_interval == i0.mcu_count_h && p->jobs_per_image == i0.mcu_count_h &&
+                                  (int64_t)segs.size() == (int64_t)b->n_images * i0.mcu_count_v;
+            if (allow && want_cons > 0 && shape_ok && p->d_lut12) {
+                p->fused = mj::fused_shape(p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, b->n_images, i0.mcu_count_v, want_cons);
+                p->fused_spi = i0.mcu_count_v;
+                p->use_fused = p->fused.ok;
+            }
+        }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;
         if (!jobs.empty()) {
             if (prog) return fail(ctx, MJ_ERR_INVALID, "MJ_FLAG_GPU_SEGMENT is for baseline batches");
@@ -1313,7 +1380,7 @@ int mj_plan_stage1_form(const mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
     if (p->progressive) return MJ_FORM_SCANS;
     const int base = p->use_sync ? MJ_FORM_SYNC : (p->use_lanes ? MJ_FORM_LANES : MJ_FORM_WAVE);
-    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0);
+    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0) | (p->use_fused ? MJ_FORM_FUSED : 0);
 }
 
 int mj_plan_get_info(const mj_plan *p, mj_plan_info *info) {
@@ -1463,27 +1530,19 @@ static int stage1_impl(mj_plan *p, void *stream) {
     return MJ_OK;
 }
 
-static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
-    if (int rc = plan_ready(p, stream ? (hipStream_t)stream : p->ctx->stream)) return rc;
+// what every stage-2 launch of the plan is told (the output buffer resolved, allocated on first use)
+static int recon_args(mj_plan *p, uint8_t *rgb_device, mj::ReconArgs &a) {
     mj_context *ctx = p->ctx;
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (!rgb_device) {
         if (!p->d_rgb) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb, (size_t)p->info.rgb_bytes + 16));
         rgb_device = p->d_rgb;
     }
     p->last_rgb = rgb_device;
-    mj::ReconArgs a{};
+    a = mj::ReconArgs{};
     a.images = p->d_images; a.n_images = p->n_images; a.mcu_prefix = p->d_mcu_prefix;
     a.total_mcus = p->info.total_mcus; a.coef = p->d_coef; a.qt = p->d_qt; a.idct_tt = ctx->d_idct_tt;
     a.up_taps = nullptr; a.rgb = rgb_device; a.dump = ctx->d_dump; a.planes = p->d_planes; a.idct_out = p->d_idct;
     a.layout = p->layout & 1; a.exact_only = (p->flags & MJ_FLAG_EXACT_ONLY) ? 1 : 0;
-    // planar layouts: the kernels write the interleaved image of the same orientation into a plan-owned buffer and a copy
-    // kernel separates the components (one extra pass over the pixels; the interleaved layouts are the fast ones)
-    const bool planar = p->layout >= MJ_LAYOUT_PLANAR_XMAJOR && p->ncomp == 3;
-    if (planar) {
-        if (!p->d_rgb_tmp) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb_tmp, (size_t)p->info.rgb_bytes + 16));
-        a.rgb = p->d_rgb_tmp;
-    }
 #ifdef MJ_DIAGNOSTIC      // phase ablations of the diagnostic build (make DIAG=1); the product never looks at the environment here
     a.debug = getenv("MJ_DEBUG_STAGE2") ? atoi(getenv("MJ_DEBUG_STAGE2")) : 0;
     a.debug_mask = getenv("MJ_DEBUG_MASK") ? atoi(getenv("MJ_DEBUG_MASK")) : 0;
@@ -1494,6 +1553,23 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     a.work_counter = reinterpret_cast<uint32_t *>(p->d_job_prefix + p->n_images + 1); a.chunk_strips = p->chunk_strips;
     a.jobs_per_ticket = p->jobs_per_ticket;
     a.level_counts = reinterpret_cast<unsigned long long *>(p->d_job_prefix + p->n_images + 3);
+    return MJ_OK;
+}
+
+static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (int rc = plan_ready(p, stream ? (hipStream_t)stream : p->ctx->stream)) return rc;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    mj::ReconArgs a{};
+    if (int rc = recon_args(p, rgb_device, a)) return rc;
+    rgb_device = p->last_rgb;
+    // planar layouts: the kernels write the interleaved image of the same orientation into a plan-owned buffer and a copy
+    // kernel separates the components (one extra pass over the pixels; the interleaved layouts are the fast ones)
+    const bool planar = p->layout >= MJ_LAYOUT_PLANAR_XMAJOR && p->ncomp == 3;
+    if (planar) {
+        if (!p->d_rgb_tmp) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb_tmp, (size_t)p->info.rgb_bytes + 16));
+        a.rgb = p->d_rgb_tmp;
+    }
     if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(a.level_counts, 0, 3 * sizeof(unsigned long long), s));     // mj_plan_idct_levels
     // the launch's ticket counter starts from zero whatever an earlier launch left behind (one that was aborted never drew its
     // last ticket).  The kernel still resets it itself at its end: the word is per PLAN, so a plan's executes must not overlap
@@ -1510,6 +1586,42 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     }
     if (planar) MJ_HIP(ctx, mj::launch_planes_from_interleaved(s, p->d_images, p->n_images, p->max_pixels, p->d_rgb_tmp, rgb_device));
     return MJ_OK;
+}
+
+// Both stages in one launch (fused.hip), for the plans that can (use_fused): the marker scan and stage 0 as in stage1_impl,
+// then producers and consumers side by side.
+static int fused_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    mj_context *ctx = p->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (int rc = plan_ready(p, s)) return rc;
+    mj::ReconArgs a{};
+    if (int rc = recon_args(p, rgb_device, a)) return rc;
+    MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
+    if (p->n_jobs) MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
+    MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
+#ifdef MJ_DIAGNOSTIC
+    const bool dbg_fused = getenv("MJ_DEBUG_FUSED") != nullptr;
+    if (dbg_fused) { (void)hipStreamSynchronize(s); mj::dbg_fused_clear(ctx->d_dump); }
+#endif
+    MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
+                                 p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->d_coef, p->d_status, a, p->hmax, p->vmax,
+                                 p->fused_spi, p->d_job_prefix, p->total_jobs, p->jobs_per_image));
+#ifdef MJ_DIAGNOSTIC
+    if (dbg_fused) {
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[diag fused] shape: %d images per workgroup, %d producers x %d lanes, %d consumers beside them\n", p->fused.ipw, p->fused.n_prod, p->fused.lpw, p->fused.n_cons);
+        mj::dbg_fused_report(ctx->d_dump, (p->n_images + p->fused.ipw - 1) / p->fused.ipw);
+    }
+#endif
+    return MJ_OK;
+}
+
+// one execute's launches: fused where the plan can, else stage 1 then stage 2
+static int execute_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
+    if (p->use_fused && p->d_blob) return fused_impl(p, stream, rgb_device);
+    int rc = stage1_impl(p, stream);
+    if (rc == MJ_OK) rc = stage2_impl(p, stream, rgb_device);
+    return rc;
 }
 
 int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
@@ -1535,8 +1647,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
         if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = stage1_impl(p, s);
-            if (rc == MJ_OK) rc = stage2_impl(p, s, rgb_device);
+            const int rc = execute_impl(p, s, rgb_device);
             const hipError_t ce = hipStreamEndCapture(s, &g);
             if (rc == MJ_OK && ce == hipSuccess && g && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 (void)hipGraphDestroy(g);
@@ -1551,9 +1662,7 @@ int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
             (void)hipGetLastError();
         }
     }
-    int rc = stage1_impl(p, stream);
-    if (rc != MJ_OK) return rc;
-    rc = stage2_impl(p, stream, rgb_device);
+    const int rc = execute_impl(p, stream, rgb_device);
     p->executed_once = rc == MJ_OK;
     p->last_was_graph = false;
     p->prev_stream = s;

@@ -1,0 +1,260 @@
+// Stages 1 and 2 in ONE launch for the batch the benchmark is about: baseline files with one restart interval per MCU row
+// (jpeg_decoder.py:805-891 decodes, dequantises, transforms and stores block by block in one loop; :894-900 the restart).
+//
+// Why.  The lane form of stage 1 (huffman_lanes13.hip) lasts as long as ONE restart segment's serial walk — a dependent chain
+// of LDS round trips that leaves ~86 % of its CU's instruction-issue slots empty — and stage 2 (reconstruct_fast.hip) is the
+// opposite: bound by issue slots and by the memory pipeline, with nothing to wait for.  As two launches they add up
+// (2.7 + 3.9 ms per 1024 x 1080p); side by side as two kernels they do not fit a CU (the lane kernel wants its whole LDS, stage 2
+// its whole register file: DESIGN.md §5b, tools/overlap_probe.py).  Here one workgroup per CU holds both kinds of wavefront:
+//
+//   PRODUCERS   `n_prod` wavefronts walk the workgroup's restart segments, one per lane — lanes13_walk.h, the code of the
+//               stage-1 kernel, unchanged — and store the coefficient blocks as always.  A workgroup takes WHOLE images
+//               (`ipw` of them), so every block a consumer needs comes from its own workgroup: no dependency crosses a
+//               workgroup, nothing crosses an XCD's L2, no wavefront ever waits for one outside its CU.
+//   CONSUMERS   `n_cons` wavefronts run stage 2's strip worker — reconstruct_fast_strips.h, unchanged — on JOBS of this
+//               workgroup's images (a job = one MCU column of one image, top to bottom), column by column behind the
+//               producers: with one restart segment per MCU row, a producer wave that is through MCU m has finished column
+//               m of all its rows.  A producer publishes its progress in LDS when its stores of an MCU are known to be in
+//               L2 (lanes13_walk.h: the hook behind the AC loop; vmcnt is zero there anyway); a consumer reads it before it
+//               asks for a job's blocks — same CU, same vector cache, workgroup scope: no cache maintenance.
+//   PHASE 2     a producer that is done waits for the others (the tables they read sit where its strip will be), then
+//               becomes a consumer; the jobs left are handed out from the same LDS ticket counter.
+//
+// Why the coefficients still go through memory.  Stage 2 needs whole MCUs (chroma comes last), a CU holds 272 segments in
+// lock-step, and 272 MCUs of coefficients are 209 KB — more than the CU's 160 KB of LDS, which the Huffman tables, block rows
+// and stream windows already fill to 136 KB.  That remaining LDS (24 KB; a consumer wave needs 8.3 KB) is also what bounds
+// the number of consumers beside the producers.  The blocks are written to the plan's coefficient store and read back
+// microseconds later by the same CU — through its L2 while the walk lasts.
+//
+// Applies to: uniform batches of the five common sampling layouts' 4:2:0 / 4:2:2 / 4:4:4 three-component files in x-major
+// output whose restart interval is one MCU row, decoded with the resolved 13-bit tables in blob order (api.hip: fused_ok).
+// Everything else — and mj_plan_execute_stage1 / _stage2, MJ_FLAG_KEEP_* — takes the two launches as before.
+#include <stdio.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "mijpeg_internal.h"
+#include "lanes13_walk.h"
+#include "reconstruct_fast_strips.h"
+
+#pragma clang fp contract(off)
+
+namespace mj {
+
+namespace {
+
+constexpr int kFusedLds = 160 * 1024;
+constexpr int kFusedCtrl = 128;            // control words at the very top of LDS: ticket, producers done, progress per producer wave
+constexpr int kFusedThreads = 1024;        // 16 wavefronts = 4 per SIMD, 128 registers each: 8 producers and up to 8 consumers beside them
+constexpr int kFusedAB = 12;               // main-level index bits of the AC tables in LDS (lanes13_walk.h)
+
+struct FusedArgs {
+    lanes13::Args L;                       // the stage-1 launch (lpw = lanes per producer wave)
+    ReconArgs R;                           // the stage-2 launch
+    const int64_t *job_prefix;
+    int64_t total_jobs;
+    int32_t jobs_per_image;                // = MCU columns: a job is a whole column
+    int32_t n_prod, n_cons;                // producer wavefronts; consumer wavefronts beside them
+    int32_t ipw;                           // images per workgroup
+    int32_t spi;                           // restart segments (= MCU rows) per image
+    int32_t n_images;
+};
+
+typedef uint32_t __attribute__((address_space(3))) *lds_word;
+
+// Jobs of this workgroup's images from a ticket counter in LDS, column by column (ticket t = column t / images, image
+// t % images), each gated by the progress of the producer waves that hold the image's rows.
+struct FusedSource {
+    static constexpr bool kSingleJobs = true;      // a ticket = one job, and consecutive tickets are not consecutive jobs
+    uint32_t ctrl;                         // LDS address of the control words
+    uint32_t n_tickets;
+    uint32_t images_here, image0;
+    uint32_t jobs_per_image, lpw, spi;
+    int32_t *status;
+    int lane;
+    __device__ __forceinline__ uint32_t draw() const {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((lds_word)(uintptr_t)ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
+    __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
+        const uint32_t m = ticket / images_here, j = ticket - m * images_here;
+        return (image0 + j) * jobs_per_image + m;
+    }
+    __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
+    // complete MCUs of every row of the job's image > the job's column?
+    __device__ __forceinline__ bool ready(uint32_t job) const {
+        const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image, j = img - image0;
+        const uint32_t w0 = (j * spi) / lpw, w1 = (j * spi + spi - 1u) / lpw;
+        uint32_t least = 0x7FFFFFFFu;
+        for (uint32_t w = w0; w <= w1; ++w) {
+            const uint32_t p = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
+            least = min(least, p);
+        }
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > m;
+    }
+    // (bounded: ~0.3 s of sleeps; a producer never waits for anything, so the bound only guards the GPU against a defect here)
+    __device__ __forceinline__ void wait_ready(uint32_t job) const {
+        for (uint32_t spins = 0; !ready(job); ++spins) {
+            __builtin_amdgcn_s_sleep(8);
+            if (spins > (1u << 16)) {
+                if (lane == 0) atomicMax(status + job / jobs_per_image, MJ_ST_INTERNAL);
+                break;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+template <int HS, int VS>
+__global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
+    using G = rfast::FGeo<HS, VS, 3>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_prod = F.n_prod, n_cons = F.n_cons;
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem + kFusedLds - kFusedCtrl);
+    float4 *wts = reinterpret_cast<float4 *>(smem + kFusedLds - kFusedCtrl - G::WTS_BYTES);
+    if (tid < kFusedCtrl / 4) ctrl[tid] = 0;
+    lanes13::stage<true>(F.L, smem, tid, kFusedThreads, n_prod);
+    rfast::fill_weights<HS, VS, 3, false>(wts, tid, kFusedThreads);
+    __syncthreads();
+
+    FusedSource src;
+    src.ctrl = lanes13::lds_addr(ctrl);
+    src.image0 = (uint32_t)blockIdx.x * (uint32_t)F.ipw;
+    src.images_here = min((uint32_t)F.ipw, (uint32_t)F.n_images - src.image0);
+    src.jobs_per_image = (uint32_t)F.jobs_per_image;
+    src.n_tickets = src.images_here * src.jobs_per_image;
+    src.lpw = (uint32_t)F.L.lpw;
+    src.spi = (uint32_t)F.spi;
+    src.lane = lane;
+    src.status = F.L.status;
+
+#ifdef MJ_DIAGNOSTIC     // per workgroup (100 MHz wall clock): start, first / last producer through, last wave out, tickets drawn by then
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(F.R.dump + (3u << 20)) + (size_t)(blockIdx.x & 1023) * 8;
+    if (tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    unsigned char *my_lds;
+    if (wave < n_prod) {
+        lanes13::walk<true, kFusedAB>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
+        __builtin_amdgcn_s_setprio(0);
+#ifdef MJ_DIAGNOSTIC
+        if (lane == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            atomicMin(dbg + 1, t);
+            atomicMax(dbg + 2, t);
+            atomicMax(dbg + 4, (unsigned long long)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)src.ctrl);
+        }
+#endif
+        if (lane == 0) __hip_atomic_fetch_add((lds_word)(uintptr_t)lanes13::lds_addr(ctrl + 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (wave >= n_prod && wave < n_prod + n_cons) {
+        // beside the producers from the start: a strip of its own under the weights, above everything the producers use
+        my_lds = smem + kFusedLds - kFusedCtrl - G::WTS_BYTES - (wave - n_prod + 1) * G::WAVE_BYTES;
+    } else {
+        // phase 2: once every producer is through (their tables and rows are where these strips go)
+        for (uint32_t spins = 0; (int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(src.ctrl + 4u) < n_prod; ++spins) {
+            __builtin_amdgcn_s_sleep(16);
+            if (spins > (1u << 18)) {         // (cannot happen: see FusedSource::wait_ready)
+                if (lane == 0) atomicMax(F.L.status + src.image0, MJ_ST_INTERNAL);
+                return;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int k = wave < n_prod ? wave : wave - n_cons;
+        my_lds = smem + k * G::WAVE_BYTES;
+    }
+    rfast::strips_worker<HS, VS, 3, false, false>(F.R, F.job_prefix, F.total_jobs, F.jobs_per_image, my_lds, wts, lane, (int)blockIdx.x, wave, src);
+#ifdef MJ_DIAGNOSTIC
+    if (lane == 0) atomicMax(dbg + 3, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+}
+
+#ifdef MJ_DIAGNOSTIC
+void dbg_fused_report(const uint8_t *dump, int n_wg) {
+    std::vector<unsigned long long> h((size_t)1024 * 8);
+    (void)hipMemcpy(h.data(), dump + (3u << 20), h.size() * 8, hipMemcpyDeviceToHost);
+    double first = 0, last = 0, end = 0, drawn = 0, end_max = 0;
+    const int n = std::min(n_wg, 1024);
+    unsigned long long t0 = ~0ull;
+    for (int i = 0; i < n; ++i) t0 = std::min(t0, h[(size_t)i * 8]);
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long *r = h.data() + (size_t)i * 8;
+        first += (double)(r[1] - r[0]) * 0.01; last += (double)(r[2] - r[0]) * 0.01; end += (double)(r[3] - r[0]) * 0.01; drawn += (double)r[4];
+        end_max = std::max(end_max, (double)(r[3] - t0) * 0.01);
+    }
+    fprintf(stderr, "[diag fused] %d workgroups; per workgroup (us from its start): first producer through %.0f, last %.0f, last wave out %.0f; tickets drawn when the "
+                    "last producer was through %.0f; launch (first start to last end) %.0f us\n", n, first / n, last / n, end / n, drawn / n, end_max);
+}
+void dbg_fused_clear(uint8_t *dump) {
+    std::vector<unsigned long long> z((size_t)1024 * 8, 0);
+    for (size_t i = 0; i < 1024; ++i) z[i * 8 + 1] = ~0ull;
+    (void)hipMemcpy(dump + (3u << 20), z.data(), z.size() * 8, hipMemcpyHostToDevice);
+}
+#endif
+
+
+// How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
+FusedShape fused_shape(int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, int n_images, int spi, int want_consumers) {
+    FusedShape s{};
+    const int cus = device_cus();
+    if (n_images < 1 || spi < 1) return s;
+    s.ipw = (n_images + cus - 1) / cus;                        // whole images per workgroup, every workgroup resident at once
+    const int lanes = s.ipw * spi;
+    if (lanes > 8 * 64) return s;
+    s.n_prod = std::min(8, std::max(1, (lanes + 33) / 34));
+    s.lpw = (lanes + s.n_prod - 1) / s.n_prod;
+    s.ring = 64;
+    s.ac_slot_bytes = ac_slot_bytes;
+    s.dbits = 8;                                                // (Annex K's DC codes of 9..11 bits — differences beyond +-255 in chroma, +-1023 in luma — take the canonical search)
+    size_t wave_bytes, wts_bytes;
+    if (hmax == 2 && vmax == 2) { wave_bytes = rfast::FGeo<2, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 2, 3>::WTS_BYTES; }
+    else if (hmax == 2 && vmax == 1) { wave_bytes = rfast::FGeo<2, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 1, 3>::WTS_BYTES; }
+    else if (hmax == 1 && vmax == 2) { wave_bytes = rfast::FGeo<1, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 2, 3>::WTS_BYTES; }
+    else if (hmax == 1 && vmax == 1) { wave_bytes = rfast::FGeo<1, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 1, 3>::WTS_BYTES; }
+    else return s;
+    const size_t prod = lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits);
+    const size_t top = (size_t)kFusedLds - kFusedCtrl - wts_bytes;
+    if (prod > top) return s;
+    const int waves = kFusedThreads / 64;
+    int fit = (int)((top - prod) / wave_bytes);
+    fit = std::min(fit, waves - s.n_prod);
+    s.n_cons = std::max(0, std::min(fit, want_consumers));
+    if ((size_t)(waves - s.n_cons) * wave_bytes + (size_t)s.n_cons * wave_bytes > top) return s;      // phase 2: every wave a strip
+    s.ok = s.n_cons >= 1;
+    return s;
+}
+
+hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
+                        int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
+                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
+                        const ReconArgs &a, int hmax, int vmax, int spi, const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image) {
+    if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
+    FusedArgs F{};
+    F.L = lanes13::Args{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
+                        coef, status, shape.lpw, 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits};
+    F.R = a;
+    F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
+    F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;
+    const unsigned blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
+    auto go = [&](auto kernel) {
+        static bool attr_set[kMaxDevices] = {false};
+        if (!attr_set[current_device()]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
+            attr_set[current_device()] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFusedThreads), kFusedLds, stream, F);
+    };
+    if (hmax == 2 && vmax == 2) go(k_fused<2, 2>);
+    else if (hmax == 2 && vmax == 1) go(k_fused<2, 1>);
+    else if (hmax == 1 && vmax == 2) go(k_fused<1, 2>);
+    else if (hmax == 1 && vmax == 1) go(k_fused<1, 1>);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace mj

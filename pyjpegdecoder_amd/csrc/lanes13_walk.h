@@ -76,35 +76,50 @@ struct Args {
     const int32_t *by_length;      // or null: segment numbers, longest first
     int order_mode;                // 1 = a wave takes neighbours of that list, 2 = one of every stride
     int kRing;                     // bytes of stream per lane in LDS: 128, or 64 to fit more lanes
+    // fused.hip only (the stage-1 kernel keeps the constants): bytes of one AC table in LDS — its main table of 2^AB entries
+    // plus the second-level tables the batch's codes need, lut13 holding the tables at this stride — and index bits of the DC
+    // tables in LDS (taken out of lut11's 11-bit ones: every 2^(11 - dbits)-th entry, where its code is short enough)
+    int ac_slot_bytes, dbits;
 };
 
 // LDS bytes of `nw` waves of `lpw` lanes: tables, block rows, block addresses, stream windows — in this order from `smem`
-__host__ __device__ inline size_t lds_bytes(int n_ac, int n_dc, int nw, int lpw, int kRing) {
+__host__ __device__ inline size_t lds_bytes(int n_ac, int n_dc, int nw, int lpw, int kRing, int ac_slot_bytes = kASlotBytes, int dbits = kDBits) {
     const int wstride = (lpw * kRow + 3) & ~3;
-    return (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw + 8) * 8 + 127) & ~(size_t)127) +
+    return (((size_t)n_ac * ac_slot_bytes + ((size_t)n_dc << dbits) * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw + 8) * 8 + 127) & ~(size_t)127) +
            (size_t)nw * lpw * kRing;
 }
 
 // the tables into LDS, the rows cleared: `nthreads` threads (tid = 0 .. nthreads - 1) of the workgroup, all of them
+template <bool FUSED>
 __device__ __forceinline__ void stage(const Args &A, unsigned char *smem, int tid, int nthreads, int nw) {
     const int n_ac = A.n_ac, n_dc = A.n_dc;
-    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][kASize]
-    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * kASlotBytes);          // [n_dc][kDSize]
+    const int aslot = FUSED ? A.ac_slot_bytes : kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
+    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][aslot / 4]
+    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * aslot);                // [n_dc][dsize]
     const int wstride = (A.lpw * kRow + 3) & ~3;
-    unsigned char *rows0 = smem + (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2;
-    for (int i = tid; i < n_ac * (kASlotBytes / 16); i += nthreads)
+    unsigned char *rows0 = smem + (size_t)n_ac * aslot + (size_t)n_dc * dsize * 2;
+    for (int i = tid; i < n_ac * (aslot / 16); i += nthreads)
         reinterpret_cast<uint4 *>(s_ac)[i] = reinterpret_cast<const uint4 *>(A.lut13)[i];
     for (int s = 0; s < n_dc; ++s) {
         const int t = (int)((A.dc_tab_pk >> (8 * s)) & 0xFF);
-        for (int i = tid; i < kDSize / 8; i += nthreads)
-            reinterpret_cast<uint4 *>(s_dc + s * kDSize)[i] = reinterpret_cast<const uint4 *>(A.lut11 + (size_t)t * kDSize)[i];
+        if (!FUSED || dbits == kDBits) {
+            for (int i = tid; i < kDSize / 8; i += nthreads)
+                reinterpret_cast<uint4 *>(s_dc + s * kDSize)[i] = reinterpret_cast<const uint4 *>(A.lut11 + (size_t)t * kDSize)[i];
+        } else {        // a shorter index: the entry of the index padded with zeros, if its code fits the shorter index (else 0 = "longer")
+            for (int i = tid; i < dsize; i += nthreads) {
+                const uint16_t e = A.lut11[(size_t)t * kDSize + ((size_t)i << (kDBits - dbits))];
+                s_dc[s * dsize + i] = (e >> 8) <= dbits ? e : (uint16_t)0;
+            }
+        }
     }
     for (int i = tid; i < nw * wstride; i += nthreads) reinterpret_cast<uint32_t *>(rows0)[i] = 0;
 }
 
 // One wavefront's walk: wave `wave` of the `nw` of workgroup `wg` (of `n_wg`).  FUSED: the wave reports, in the LDS word at
 // `progress_addr`, how many MCUs of its lanes' segments are complete in memory (see the hook behind the AC loop).
-template <bool FUSED>
+// AB: index bits of the AC tables' main level (13; fused.hip: 12 — half the LDS, 1.5 % of the symbols instead of 0.4 % then take
+// the arithmetic step); their second-level tables have 2^(16 - AB) entries
+template <bool FUSED, int AB = 13>
 __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const int lane, const int wave, const int nw, const int wg, const int n_wg,
                                      const uint32_t progress_addr) {
     const uint32_t *__restrict__ stream = A.stream;
@@ -124,17 +139,19 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
 #ifdef MJ_DIAGNOSTIC
     const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][kASize]
-    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * kASlotBytes);          // [n_dc][kDSize]
+    static_assert(FUSED || AB == 13, "the stage-1 kernel's tables are the 13-bit ones");
+    const int aslot = FUSED ? A.ac_slot_bytes : kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
+    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][aslot / 4]
+    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * aslot);                // [n_dc][dsize]
     // (the flush moves blocks eight at a time and may read up to seven rows and positions past a wave's last: the next wave's,
     // or the slack behind the last wave's — never stored)
     const int lpw2 = lpw;
     const int wstride = (lpw2 * kRow + 3) & ~3;                                                  // dwords per wave, 16-byte multiple
-    unsigned char *rows0 = smem + (size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2;
+    unsigned char *rows0 = smem + (size_t)n_ac * aslot + (size_t)n_dc * dsize * 2;
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(rows0) + wave * wstride;
     uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4 + 8 * kRow * 4) + wave * lpw2;
     // per-lane window on the lane's stream: kRing bytes, the stream's bytes at their offsets modulo kRing (see the bit reader)
-    unsigned char *rings0 = smem + (((size_t)n_ac * kASlotBytes + (size_t)n_dc * kDSize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127);
+    unsigned char *rings0 = smem + (((size_t)n_ac * aslot + (size_t)n_dc * dsize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127);
 
     // Which segment a lane takes.  Without a length list: the segments in blob order.  With one (restart segments whose
     // lengths the host knows), mode 2 deals the list out one segment per wave and round, so that the long ones sit in
@@ -262,8 +279,14 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
         if ((m & 7) == 0) {
             const int groups = (nw + 3) >> 2;
             const int turn = groups > 1 ? ((wave >> 2) + (m >> 3)) % groups : 0;
-            if (turn == 0) __builtin_amdgcn_s_setprio(0); else if (turn == 1) __builtin_amdgcn_s_setprio(1);
-            else if (turn == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+            // (fused.hip: the walk is the launch's critical path — its waves stay above the consumer waves, which run at 0)
+#ifdef MJ_X_FUSED_PRIO3
+            const int pr = FUSED ? 3 : turn;
+#else
+            const int pr = FUSED ? (turn & 1) + 2 : turn;
+#endif
+            if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
         }
 #endif
         const bool in_mcu = m < n_mcu;
@@ -293,11 +316,11 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
             uint32_t pB;
             {
                 const uint32_t p16 = (uint32_t)(bb >> 48);
-                const int e = s_dc[dcs * kDSize + (p16 >> (16 - kDBits))];
+                const int e = s_dc[dcs * dsize + (p16 >> (16 - dbits))];
                 int len = e >> 8, s = e & 0xFF;
                 if (__builtin_amdgcn_ballot_w64(act && len == 0) != 0) {                              // code longer than 11 bits: rare
                     if (act && len == 0) {
-                        const int r = canon_code(huff + dcg, p16, kDBits + 1);
+                        const int r = canon_code(huff + dcg, p16, dbits + 1);
                         len = r < 0 ? 0 : r >> 8; s = r < 0 ? 255 : r & 0xFF;
                     }
                 }
@@ -318,7 +341,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 pB = ok ? mybase : lastB;                                      // position of the last coefficient written; lastB = lane is done
             }
             // ---- AC (:833-866): until every lane is at its end of block.  See the header for the entry formats.
-            const uint32_t lutb = ac_base + (uint32_t)acs * kASlotBytes;
+            const uint32_t lutb = ac_base + (uint32_t)acs * (uint32_t)aslot;
             uint32_t e_last = 0xFFu;                 // the lane's latest entry; 0xFF = "nothing a correction below could use"
 #ifdef MJ_X_STAMP
             const uint64_t dbg_a0 = __builtin_amdgcn_s_memtime();
@@ -332,7 +355,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
 #endif
                 // LUT address from the 13 bits on top of the buffer, and the read
 #define MJ_LOOK13 \
-    "v_bfe_u32 %[t0], v3, 19, 13\n\t"                   \
+    "v_bfe_u32 %[t0], v3, %[ash], %[abits]\n\t"         \
     "v_lshl_add_u32 %[t0], %[t0], 2, %[lutb]\n\t"       \
     "ds_read_b32 %[e], %[t0]\n\t"
                 // the entry applied: position, buffer, count; exec keeps the lanes that are still inside their block AFTER this
@@ -467,7 +490,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                     "v_cmp_ne_u32 vcc, 0, %[t1]\n\t"
                     "s_cbranch_vccz L_arith%=\n\t"
                     "s_and_saveexec_b64 s[50:51], vcc\n\t"
-                    "v_bfe_u32 %[t0], v3, 16, 3\n\t"          // the three bits behind the 13 of the index
+                    "v_bfe_u32 %[t0], v3, 16, %[sbits]\n\t"   // the 16 - AB bits behind the AB of the index
                     "v_lshlrev_b32 %[t0], 2, %[t0]\n\t"
                     "v_add_u32_sdwa %[t0], %[t0], %[t5] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
                     "v_add_u32 %[t0], %[t0], %[lutb]\n\t"
@@ -524,6 +547,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                       , [di] "+v"(dbg_iter), [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_w[0]), [d8] "+v"(dbg_w[1]), [d9] "+v"(dbg_w[2])
 #endif
                     : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "v"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
+                      [ash] "n"(32 - AB), [abits] "n"(AB), [sbits] "n"(16 - AB),
                       [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [c96] "v"(c96), [rl] "s"(ring_lanes), [rot] "v"(rot)
                     : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72");
 #undef MJ_REFILL13
@@ -685,9 +709,9 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
         if (!err && (vsegs ? vs.last == 2 : !sg.last) && left >= 8) err = MJ_ST_DESYNC;
         if (err) atomicMax(status + sg.image, err);
     }
-    if constexpr (FUSED) {      // the last MCU's blocks: in memory before the wave says so
+    if constexpr (FUSED) {      // the last MCU's blocks: in memory before the wave says "everything"
         uint32_t t_prog;
-        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %1\n\tds_write_b32 %2, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog) : "s"((uint32_t)max_mcu), "v"(progress_addr) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tds_write_b32 %1, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog) : "v"(progress_addr) : "memory");
     }
 }
 

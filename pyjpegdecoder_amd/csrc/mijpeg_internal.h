@@ -169,6 +169,8 @@ void dbg_lanes_report();     // huffman_lanes.hip: prints and clears the in-loop
 void dbg_prog_report();      // progressive_fast.hip: ... of the refining walk
 void dbg_prog_waves_report();       // progressive_fast.hip: when the waves of band launch MJ_DEBUG_PROG_STEP finished
 void dbg_lanes13_waves_report();   // huffman_lanes13.hip: when every wave of the last launch finished
+void dbg_fused_clear(uint8_t *dump);                   // fused.hip (MJ_DEBUG_FUSED): per-workgroup time stamps of the next launch ...
+void dbg_fused_report(const uint8_t *dump, int n_wg);  // ... and their averages
 #endif
 // lane-parallel form: one restart segment per lane, all of the batch's tables (<= kMaxLaneTables) in LDS
 constexpr int kLaneLutBits = 11;
@@ -262,6 +264,24 @@ int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
 // jobs: pieces of at most a.chunk_strips strips of one MCU column, numbered image by image (job_prefix[i] = first job of image i)
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);
+// Stages 1 + 2 in one launch (fused.hip): producer wavefronts (the lane walk) and consumer wavefronts (stage 2's strip worker)
+// in one workgroup per CU that takes whole images.  fused_shape() says how such a launch would be cut — ok = false: it does not
+// apply (LDS) and the two launches stay.
+struct FusedShape {
+    bool ok;
+    int ipw;            // images per workgroup
+    int n_prod, lpw;    // producer wavefronts, lanes (restart segments) per producer wavefront
+    int n_cons;         // consumer wavefronts beside the producers (every wavefront is one once the producers are through)
+    int ring;           // bytes of stream window per lane
+    int ac_slot_bytes;  // one AC table in LDS (12-bit main level + its second-level tables)
+    int dbits;          // index bits of the DC tables in LDS
+};
+FusedShape fused_shape(int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, int n_images, int spi, int want_consumers);
+hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
+                        int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
+                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
+                        const ReconArgs &a, int hmax, int vmax, int spi, const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);
+// (lut13 of launch_fused: the tables with a 12-bit main level at stride shape.ac_slot_bytes)
 // Launch-geometry caches are per device: one process may hold contexts on several GPUs (mijpeg.h: one context per GPU per
 // thread), and a function attribute set on one device says nothing about the next.  (Racing first uses write the same values.)
 constexpr int kMaxDevices = 64;
