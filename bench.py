@@ -14,9 +14,11 @@ every rank decodes its own `--batch` images; the only cross-rank traffic is a gl
                                                          the ranks (1 250 per GPU at N = 8), each rank feeding its share
                                                          through a per-GPU image queue (strong scaling)
 
-Rank 0 prints ONE JSON line.  At N = 1 it also carries: `roofline` (+ `roofline_other_stage`), `cpu_baseline` (the C
-oracle on this host's cores + the reference's own timing from the build container), `progressive` (BASELINE
-configs[4]: 1024 x 1080p progressive), `without_restart_markers`, `host_bytes_to_device_pixels`.
+Rank 0 prints ONE JSON line.  At N = 1 it also carries: `roofline` (+ `roofline_other_stage`; `two_launches` when the step is
+one fused launch), `cpu_baseline` (the C oracle on this host's cores + the reference's own timing from the build
+container), `idct_only` (BASELINE configs[1]), `progressive` (BASELINE configs[4]: 1024 x 1080p progressive),
+`gpu_segmented`, `stage2_exact_only_ms`, `single_file_latency`, `mixed_content`, `without_restart_markers`,
+`host_bytes_to_device_pixels`.
 """
 import argparse
 import hashlib
@@ -260,6 +262,107 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
                     "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3)"}
 
 
+def idct_only_side(ctx, dev, torch, n_images: int = 256):
+    """BASELINE configs[1]: 256 synthetic 512x512 4:2:0 files, entropy decode on the HOST (here: the oracle's, outside any timing),
+    stage 2 alone on the GPU through the plan path of mj_idct_batch (mj_plan_write_coef + mj_plan_execute_stage2); all 256
+    images against the oracle."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    from tools import synth
+    w = h = 512
+    blob, offs = synth.synth_batch(n_images, 300000, w, h, 85, "420", 0)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n_images)]
+    oracle.decode(raws[0])
+    with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as ex:
+        dec = list(ex.map(oracle.decode, raws))
+    coef = np.concatenate([d["coef"] for d in dec])
+    prep = prepare_batch(raws, B.MJ_LAYOUT_XMAJOR, 0)
+    bc = prep.to_c()
+    bc.blob, bc.blob_mem = None, B.MJ_MEM_NONE
+    plan = B.Plan(ctx, bc, {"prep": prep, "n_images": n_images})
+    try:
+        plan.write_coef(coef)
+        d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        for _ in range(30):
+            plan.execute_stage2(0, d_rgb.data_ptr())
+        plan.sync()
+        _, s2 = plan.time_stages(50, d_rgb.data_ptr())
+        per = w * h * 3
+        host = d_rgb.cpu().numpy()
+        ok = all(np.array_equal(host[i * per:(i + 1) * per].reshape(w, h, 3), dec[i]["rgb"]) for i in range(n_images))
+    finally:
+        plan.close()
+    nbytes = n_images * ((w // 16) * (h // 16) * 6 * 128 + per)          # 1 572 864 B per image (SURVEY 8d)
+    gbs = nbytes / (s2 * 1e-3) / 1e9
+    return {"value": round(n_images * w * h / 1e6 / (s2 * 1e-3), 1), "unit": "MP/s", "stage2_ms": round(s2, 4),
+            "workload": f"{n_images} x 512x512 4:2:0 baseline JPEG, q85, Huffman decode on the host, dequant+IDCT+upsample+RGB on the GPU (BASELINE configs[1])",
+            "roofline": {"kernel": "k_reconstruct_fast (stage 2 alone)", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(s2, 4),
+                         "note": "128 B/block read + 3 B/pixel written = 1 572 864 B per 512x512 image; 0.4 GB per launch: a batch this small "
+                                 "ends before the chip's 3 072 wavefronts have each had two jobs, and its coefficients fit the 256 MB Infinity Cache"},
+            "parity": f"bit-exact vs oracle (all {n_images} images)" if ok else "MISMATCH"}
+
+
+def gpu_segmented_side(ctx, dev, torch, files, layout, d_ref):
+    """The headline step with the restart markers found ON THE GPU (k_scan_markers inside the timed step: the host reads headers
+    only — BatchDecoder's default route); output compared with the headline plan's on the device."""
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd import parse_jpeg
+    from pyjpegdecoder_amd.batch import prepare_batch
+    t0 = time.perf_counter()
+    prep = prepare_batch(files, layout, 0, [parse_jpeg(f, headers_only=True) for f in files])
+    host_s = time.perf_counter() - t0
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
+    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for _ in range(5):
+            plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        reps = 30
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        front, main = plan.time_execute(5, d_rgb.data_ptr())
+        ok = not plan.read(rgb=False)["status"].any() and bool(torch.equal(d_rgb, d_ref))
+        form = plan.stage1_form()
+    finally:
+        plan.close()
+    n = len(files)
+    return {"value": round(n * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 3),
+            "front_ms": round(front, 4), "main_ms": round(main, 4), "fused_launch": bool(form & B.MJ_FORM_FUSED),
+            "host_headers_only_parse_assemble_s": round(host_s, 2),
+            "parity": "identical to the headline plan's output (device-side compare), every image's status ok" if ok else "MISMATCH",
+            "note": "front = k_scan_markers + k_destuff (or stage 0+1 when the plan is not fused), main = the fused launch (or stage 2)"}
+
+
+def single_file_latency_side(raw, tmpdir):
+    """The reference's own call: JpegDecoder(path) on ONE 1080p file (jpeg_decoder.py:56-110) — parse, plan, decode, pixels on
+    the host; median of 7 after a warm-up."""
+    import numpy as np
+    from oracle import oracle
+    from pyjpegdecoder_amd import JpegDecoder
+    path = Path(tmpdir) / "one.jpg"
+    path.write_bytes(raw)
+    JpegDecoder(path)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        d = JpegDecoder(path)
+        ts.append(time.perf_counter() - t0)
+    ok = bool(np.array_equal(d.image_array, oracle.decode(raw)["rgb"]))
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": round(med * 1e3, 2), "unit": "ms", "higher_is_better": False, "min_ms": round(min(ts) * 1e3, 2),
+            "workload": "JpegDecoder(Path) on one 1920x1080 4:2:0 baseline file with DRI=120: file read, marker loop, plan, GPU decode, pixels to the host",
+            "parity": "bit-exact vs oracle" if ok else "MISMATCH"}
+
+
 def visible_gpus() -> int:
     """GPUs of this node, counted without initialising HIP (the launcher must stay a process that never touched the GPU): the
     KFD topology lists one node per agent, CPUs with simd_count 0.  Honours a ROCR/HIP_VISIBLE_DEVICES list.  -1 = unknown."""
@@ -434,6 +537,19 @@ def main():
     dt = max_over_ranks(dt, dev if (world > 1 and args.backend == "nccl") else None)
     images_all_ranks = int(sum_over_ranks(float(n_mine), dev if (world > 1 and args.backend == "nccl") else None))
 
+    # ---- per-launch times (HIP events on the launch stream) for the roofline objects, taken NOW: the parity check below leaves
+    # the GPU idle for seconds, and launches timed in the first second after such a pause came out 2-4x too long (clocks)
+    stage_times = None
+    if rank == 0 and not queue_mode:
+        plan.time_stages(2, d_rgb.data_ptr())           # (the stages' own kernels have not run yet when the step is one fused launch)
+        if plan.stage1_form() & B.MJ_FORM_FUSED:
+            front_ms, main_ms = plan.time_execute(10, d_rgb.data_ptr())
+        else:
+            front_ms = main_ms = None
+        stage_times = (front_ms, main_ms) + tuple(plan.time_stages(10, d_rgb.data_ptr()))
+        step()                                          # (the headline's own launch last: what the parity check looks at)
+        torch.cuda.synchronize()
+
     # ---- parity of what was just timed, outside the timed region.  One plan: EVERY distinct image of the rank's batch against
     # the oracle (a pool of host threads), every replica against its first instance on the device, every image's status.
     # Queue mode: first and last image of the share against the oracle, every plan's statuses. -------------------------------
@@ -517,12 +633,15 @@ def main():
                      "note": "outside the timed region; inputs are HBM-resident when timing starts"},
         }
 
-    # ---- roofline of the two stages: HIP events on the launch stream, algorithmic bytes per launch ----------------
+    # ---- roofline: HIP events on the launch stream, algorithmic bytes per launch ---------------------------
+    # A plan whose execute is ONE fused launch (stage 1's lane walk and stage 2's strip worker side by side, fused.hip):
+    # `roofline` is that launch — SURVEY 8d's end-to-end figure, E + 2 x 128 B/block + 3 B/pixel: the coefficients still go
+    # through memory, written by the walk and read back by the same CU —, `roofline_other_stage` what runs in front of it
+    # (stage 0), and `two_launches` the same plan's stages launched separately (mj_plan_execute_stage1 / _stage2), each
+    # with its own roofline: stage 2 alone is the kernel BASELINE.json's 40 % target is about.
     if rank == 0 and not queue_mode:
-        for _ in range(20):                     # the parity check above left the GPU idle for seconds: back to the clocks of the timed region
-            step()
-        torch.cuda.synchronize()
-        s1_ms, s2_ms = plan.time_stages(10, d_rgb.data_ptr())
+        fused = bool(plan.stage1_form() & B.MJ_FORM_FUSED)
+        front_ms, main_ms, s1_ms, s2_ms = stage_times
         copy_gbs = None
         try:                                    # second denominator SURVEY 8d asks for: a plain device-to-device copy here
             d_tmp = torch.empty_like(d_rgb)
@@ -551,7 +670,12 @@ def main():
             if td.get("sources_sha16") == sources_sha16():
                 for k, d in td["kernels"].items():
                     if "traffic_bytes_per_launch" in d:
-                        if "huffman" in k or "destuff" in k or "scan_markers" in k or "sync" in k or "vsegs" in k:
+                        if "fused" in k:
+                            traffic["fused"] = int(d["traffic_bytes_per_launch"])
+                        elif "destuff" in k or "scan_markers" in k:
+                            traffic["stage0"] = traffic.get("stage0", 0) + int(d["traffic_bytes_per_launch"])
+                            traffic["stage1"] = traffic.get("stage1", 0) + int(d["traffic_bytes_per_launch"])
+                        elif "huffman" in k or "sync" in k or "vsegs" in k:
                             traffic["stage1"] = traffic.get("stage1", 0) + int(d["traffic_bytes_per_launch"])
                         elif "reconstruct" in k:
                             traffic["stage2"] = int(d["traffic_bytes_per_launch"])
@@ -574,7 +698,23 @@ def main():
                   "stage1")
         r2 = roof("k_reconstruct_fast (stage 2: dequant+IDCT+upsample+colour)", s2_bytes, s2_ms,
                   "128 B/block read + 3 B/pixel written = 12 487 680 B per 1080p image", "stage2")
-        line["roofline"], line["roofline_other_stage"] = (r1, r2) if s1_ms >= s2_ms else (r2, r1)
+        if fused:
+            rf = roof("k_fused (ONE launch: stage 1's lane walk on 8 wavefronts per CU + stage 2's strip worker on the other 8, then on all 16; fused.hip)",
+                      s1_bytes + s2_bytes, main_ms,
+                      "SURVEY 8d's end-to-end figure: entropy bytes read + 128 B/block coefficients written and read back (a CU holds 272 "
+                      "restart segments in lock-step: their MCUs do not fit its LDS, so the blocks go through the coefficient store and come "
+                      "back through the same CU's L2 while the walk lasts) + 3 B/pixel written", "fused")
+            r0 = roof("k_destuff (stage 0: the bit reader's byte rules" + (", behind k_scan_markers" if args.segment == "gpu" else "") + ")",
+                      2 * ent_bytes, front_ms, "entropy-coded bytes read and the kept bytes written", "stage0")
+            line["roofline"], line["roofline_other_stage"] = rf, r0
+            # the same plan's stages as separate launches, timed the same way (HIP events, 10 launches each)
+            line["two_launches"] = {"stage01_ms": round(s1_ms, 4), "stage2_ms": round(s2_ms, 4), "sum_ms": round(s1_ms + s2_ms, 4),
+                                    "fused_ms": round(front_ms + main_ms, 4),
+                                    "roofline_stage2": r2, "roofline_stage01": r1,
+                                    "note": "mj_plan_execute_stage1 + _stage2 of the plan the headline ran as one launch; stage 2 alone is the "
+                                            "batched dequant+IDCT kernel of BASELINE.json's >= 40 % of HBM target"}
+        else:
+            line["roofline"], line["roofline_other_stage"] = (r1, r2) if s1_ms >= s2_ms else (r2, r1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(raws[:64])
@@ -584,7 +724,38 @@ def main():
                 line["pipelined"] = pipelined_side(ctx, dev, torch, prep, d_blob, plan, d_rgb)
             except Exception as exc:
                 line["pipelined"] = {"error": repr(exc)}
-            plan.close()
+        if plan is not None and args.segment == "host":
+            try:
+                line["gpu_segmented"] = gpu_segmented_side(ctx, dev, torch, files, layout, d_rgb)
+            except Exception as exc:
+                line["gpu_segmented"] = {"error": repr(exc)}
+            try:                                 # what the fp32 first level of stage 2 buys: the same batch through the exact-order kernel alone
+                prep_x = prepare_batch(files, layout, B.MJ_FLAG_EXACT_ONLY)
+                plan_x = B.Plan(ctx, prep_x.to_c(d_blob.data_ptr()), {"prep": prep_x, "n_images": args.batch})
+                d_rgb_x = torch.empty(plan_x.info.rgb_bytes, dtype=torch.uint8, device=dev)
+                plan_x.execute(stream, d_rgb_x.data_ptr())
+                plan_x.sync()
+                _, s2x = plan_x.time_stages(2, d_rgb_x.data_ptr())
+                same = bool(torch.equal(d_rgb_x, d_rgb))
+                plan_x.close()
+                del d_rgb_x
+                line["stage2_exact_only_ms"] = {"value": round(s2x, 3), "unit": "ms", "identical_output": same,
+                                                "note": "k_reconstruct (the reference's float64 summation order for every block, MJ_FLAG_EXACT_ONLY) on the headline batch; "
+                                                        "the headline's stage 2 is the fp32 first level with fp64 and exact-order levels behind it"}
+            except Exception as exc:
+                line["stage2_exact_only_ms"] = {"error": repr(exc)}
+        if plan is not None:
+            plan.close()                         # (its 6.4 GB coefficient store goes back to the context before the other batches come)
+        try:
+            line["idct_only"] = idct_only_side(ctx, dev, torch)
+        except Exception as exc:
+            line["idct_only"] = {"error": repr(exc)}
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                line["single_file_latency"] = single_file_latency_side(raws[0], td)
+        except Exception as exc:
+            line["single_file_latency"] = {"error": repr(exc)}
         try:
             line["mixed_content"] = mixed_content_side(ctx, dev, torch, layout, line["ms_per_step"])
         except Exception as exc:

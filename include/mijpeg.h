@@ -228,6 +228,11 @@ int mj_plan_read(mj_plan *plan, uint8_t *rgb_host, int16_t *coef_host, int16_t *
 /* Replace the plan's coefficient array (config 2: coefficients decoded elsewhere). mem = MJ_MEM_*. */
 int mj_plan_write_coef(mj_plan *plan, const int16_t *coef, int32_t mem);
 
+/* Test hook: every byte of the plan's coefficient store := byte_value (synchronous).  The parity tests poison the store in
+ * front of a fused execute: a reconstruction wavefront that read a block before its decoder wavefront had written it would
+ * show (a store that still holds the previous execute's blocks of the same files hides exactly that). */
+int mj_plan_fill_coef(mj_plan *plan, int byte_value);
+
 /* ---- one-shot conveniences ----------------------------------------------------------------------- */
 /* create + execute + sync + read + destroy; rgb_out/status_out host, coef_out may be NULL. */
 int mj_decode_baseline_batch(mj_context *ctx, const mj_batch *batch, uint8_t *rgb_out, int16_t *coef_out,
@@ -239,6 +244,10 @@ int mj_idct_batch(mj_context *ctx, const mj_batch *batch, const int16_t *coef, u
 /* Average device time (ms) of each stage's kernel over `iters` back-to-back launches on the plan's
  * stream, measured with HIP events recorded on that stream. */
 int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms);
+/* The same for the launches mj_plan_execute makes.  A plan whose execute is ONE fused launch (MJ_FORM_FUSED): front_ms = what
+ * runs in front of it (marker scan with MJ_FLAG_GPU_SEGMENT, stage 0), main_ms = the fused launch.  Any other plan: the two
+ * stages as mj_plan_time_stages reports them (front = stage 0+1, main = stage 2). */
+int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *front_ms, float *main_ms);
 
 /* Test and tuning switches, process-wide.  The defaults are what the library measured as best; the parity tests use the
  * switches to force every form of a stage through the same inputs, the probe scripts to sweep geometries.  The library does

@@ -26,8 +26,8 @@ EXPORTS = (
     "mj_create", "mj_destroy", "mj_last_error", "mj_version", "mj_context_wait_event",
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
-    "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option",
+    "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED = 0, 1, 2, 3, 16, 32, 64
 MJ_HOST_DECLINED = 1
@@ -124,6 +124,8 @@ def load_library():
     L.mj_decode_baseline_batch.argtypes = [vp, ctypes.POINTER(BatchC), vp, vp, vp]
     L.mj_idct_batch.argtypes = [vp, ctypes.POINTER(BatchC), vp, vp]
     L.mj_plan_time_stages.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.mj_plan_fill_coef.argtypes = [vp, ctypes.c_int]
+    L.mj_plan_time_execute.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.mj_host_idct_table.argtypes = [vp]
     L.mj_host_idct_table.restype = None
     L.mj_host_assemble.argtypes = [ctypes.POINTER(HostJobC)]
@@ -232,6 +234,10 @@ class Plan:
         assert coef.size == self.info.total_blocks * 64
         self.ctx.check(self.ctx.lib.mj_plan_write_coef(self.handle, _ptr(coef), MJ_MEM_HOST))
 
+    def fill_coef(self, byte_value: int):
+        """Test hook (mj_plan_fill_coef): poison the coefficient store."""
+        self.ctx.check(self.ctx.lib.mj_plan_fill_coef(self.handle, int(byte_value)))
+
     def read(self, rgb=True, coef=False, planes=False, idct=False):
         out = {}
         a_rgb = np.empty(self.info.rgb_bytes, dtype=np.uint8) if rgb else None
@@ -264,6 +270,12 @@ class Plan:
         s1, s2 = ctypes.c_float(), ctypes.c_float()
         self.ctx.check(self.ctx.lib.mj_plan_time_stages(self.handle, iters, rgb_device or None, ctypes.byref(s1), ctypes.byref(s2)))
         return s1.value, s2.value
+
+    def time_execute(self, iters: int = 10, rgb_device: int = 0):
+        """(front_ms, main_ms) of the launches execute() makes: a fused plan's stage 0 and fused launch, else the two stages."""
+        f, m = ctypes.c_float(), ctypes.c_float()
+        self.ctx.check(self.ctx.lib.mj_plan_time_execute(self.handle, iters, rgb_device or None, ctypes.byref(f), ctypes.byref(m)))
+        return f.value, m.value
 
     def close(self):
         if getattr(self, "handle", None):

@@ -503,6 +503,20 @@ __global__ void k_permute_blocks(const int16_t *__restrict__ src, int16_t *__res
         else dst[b * 64 + lane] = src[b * 64 + pos];
     }
 }
+// Small clears inside an execute (statuses, counters, the synchronisation form's records) are KERNELS, not hipMemsetAsync:
+// a re-executed plan replays a captured graph, and a memset node of a size that is no multiple of 16 bytes (1021 statuses)
+// was seen to write the byte value of an unrelated hipMemset issued between two replays (ROCm 7.0 runtime, MI355X; found
+// with the test hook that poisons the coefficient store: tests/test_gpu_parity.py::_decode_plan).  A kernel node carries
+// its value in its own arguments.
+__global__ void k_fill_words(uint32_t *__restrict__ p, uint32_t value, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
+}
+hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_t n_words) {
+    if (n_words <= 0) return hipSuccess;
+    const int64_t want = (n_words + 255) / 256;
+    hipLaunchKernelGGL(k_fill_words, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, static_cast<uint32_t *>(p), value, n_words);
+    return hipGetLastError();
+}
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
                                  int transposed) {
     if (n_blocks == 0) return hipSuccess;
@@ -1256,6 +1270,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if (const char *e = mj::opt("MJ_FUSED")) allow = atoi(e) != 0;
             if (const char *e = mj::opt("MJ_FUSED_CONSUMERS")) want_cons = atoi(e);
             const mj::DevImage &i0 = imgs[0];
+            // (not for restart segments of very different lengths, which the lane launch deals out by length: a fused launch
+            // walks them in blob order — whole images per workgroup — and its longest wave then sets the pace of everything;
+            // measured on bench.py's mixed content: 11.3 ms fused against 10.6 as two launches)
             const bool shape_ok = p->use_lanes && !p->use_sync && p->d_lut13 && p->seg_order_mode == 0 && p->uniform && !p->generic && !prog &&
                                   p->ncomp == 3 && (p->hmax == 1 || p->hmax == 2) && (p->vmax == 1 || p->vmax == 2) && !p->transposed &&
                                   p->layout == MJ_LAYOUT_XMAJOR && !(p->flags & (MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT)) &&
@@ -1438,7 +1455,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
     if (int rc = plan_ready(p, stream ? (hipStream_t)stream : ctx->stream)) return rc;
     if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data (stage 1 unavailable)");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
+    MJ_HIP(ctx, mj::launch_fill_words(s, p->d_status, 0u, p->n_images));
     if (p->progressive) {
         // scans accumulate into the coefficient store (:1029, :1225): start from zeros, then one launch per scan ordinal
         MJ_HIP(ctx, hipMemsetAsync(p->d_coef, 0, (size_t)p->info.total_blocks * 128, s));
@@ -1490,7 +1507,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
             // round 0 guesses, round 1.. start every chunk from its predecessor's exit state until no exit state changes
             // (typically the second true-state round changes nothing), then the pieces are decoded like restart segments
             const int cbits = p->sync_chunk_bytes * 8;
-            MJ_HIP(ctx, hipMemsetAsync(p->d_couts, 0xFF, (size_t)p->n_chunks * sizeof(mj::DevChunkOut), s));
+            MJ_HIP(ctx, mj::launch_fill_words(s, p->d_couts, 0xFFFFFFFFu, p->n_chunks * (int64_t)(sizeof(mj::DevChunkOut) / 4)));
             MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
                                               p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count, nullptr, p->sync_warm_bits));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
@@ -1499,7 +1516,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
             // nothing).  Whether they sufficed is decided on the device: k_build_vsegs marks the images whose chunk states
             // had not settled (MJ_ST_UNCONVERGED) and the caller decodes those again with MJ_FLAG_NO_SYNC.  No host
             // round trip: the execute is asynchronous and can be captured into a graph like every other form.
-            MJ_HIP(ctx, hipMemsetAsync(p->d_changed, 0, (size_t)(p->sync_rounds + 8) * sizeof(int32_t), s));
+            MJ_HIP(ctx, mj::launch_fill_words(s, p->d_changed, 0u, p->sync_rounds + 8));
             for (int round = 1; round <= p->sync_rounds; ++round) {
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
                                                   p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + round, p->d_wg_tabs_count, p->wg_slots_count,
@@ -1570,11 +1587,11 @@ static int stage2_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
         if (!p->d_rgb_tmp) MJ_HIP(ctx, ctx->cache.get((void **)&p->d_rgb_tmp, (size_t)p->info.rgb_bytes + 16));
         a.rgb = p->d_rgb_tmp;
     }
-    if (a.planes || a.idct_out) MJ_HIP(ctx, hipMemsetAsync(a.level_counts, 0, 3 * sizeof(unsigned long long), s));     // mj_plan_idct_levels
+    if (a.planes || a.idct_out) MJ_HIP(ctx, mj::launch_fill_words(s, a.level_counts, 0u, 6));     // mj_plan_idct_levels
     // the launch's ticket counter starts from zero whatever an earlier launch left behind (one that was aborted never drew its
     // last ticket).  The kernel still resets it itself at its end: the word is per PLAN, so a plan's executes must not overlap
     // (mijpeg.h) — two plans, or one plan's executes one after the other on any streams, are fine.
-    if (!p->generic && !a.exact_only) MJ_HIP(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), s));
+    if (!p->generic && !a.exact_only) MJ_HIP(ctx, mj::launch_fill_words(s, a.work_counter, 0u, 1));
     if (p->generic) {
         MJ_HIP(ctx, mj::launch_reconstruct_generic(s, a));
     } else if (a.exact_only) {
@@ -1596,7 +1613,7 @@ static int fused_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (int rc = plan_ready(p, s)) return rc;
     mj::ReconArgs a{};
     if (int rc = recon_args(p, rgb_device, a)) return rc;
-    MJ_HIP(ctx, hipMemsetAsync(p->d_status, 0, (size_t)p->n_images * sizeof(int32_t), s));
+    MJ_HIP(ctx, mj::launch_fill_words(s, p->d_status, 0u, p->n_images));
     if (p->n_jobs) MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
     MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
 #ifdef MJ_DIAGNOSTIC
@@ -1731,6 +1748,18 @@ int mj_plan_write_coef(mj_plan *p, const int16_t *coef, int32_t mem) {
     return MJ_OK;
 }
 
+int mj_plan_fill_coef(mj_plan *p, int byte_value) {
+    if (!p) return MJ_ERR_INVALID;
+    if (int rc = plan_ready(p)) return rc;
+    mj_context *ctx = p->ctx;
+    if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
+    if (getenv("MJ_DEBUG_FILL")) fprintf(stderr, "[fill] coef %p + %zu = %p, status %p, n_images %d\n", (void *)p->d_coef, (size_t)p->info.total_blocks * 128,
+                                         (void *)((char *)p->d_coef + (size_t)p->info.total_blocks * 128), (void *)p->d_status, p->n_images);
+    MJ_HIP(ctx, hipMemset(p->d_coef, byte_value & 0xFF, (size_t)p->info.total_blocks * 128));
+    MJ_HIP(ctx, hipDeviceSynchronize());
+    return MJ_OK;
+}
+
 int mj_decode_baseline_batch(mj_context *ctx, const mj_batch *batch, uint8_t *rgb_out, int16_t *coef_out,
                              int32_t *status_out) {
     mj_plan *p = nullptr;
@@ -1764,6 +1793,57 @@ int mj_plan_idct_levels(mj_plan *p, uint64_t counts[3]) {
     if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
     MJ_HIP(ctx, hipMemcpy(counts, p->d_job_prefix + p->n_images + 3, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MJ_OK;
+}
+
+int mj_plan_time_execute(mj_plan *p, int iters, uint8_t *rgb_device, float *front_ms, float *main_ms) {
+    if (!p || iters <= 0) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = ctx->stream;
+    if (!p->d_blob) return fail(ctx, MJ_ERR_INVALID, "plan has no entropy-coded data");
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    MJ_HIP(ctx, hipEventCreate(&ev.a));
+    MJ_HIP(ctx, hipEventCreate(&ev.b));
+    if (int rc = plan_ready(p, s)) return rc;
+    float ms = 0.f;
+    if (front_ms) *front_ms = 0.f;
+    if (main_ms) *main_ms = 0.f;
+    if (!p->use_fused) {                       // the two launches: front = stage 1 (with stage 0), main = stage 2
+        return mj_plan_time_stages(p, iters, rgb_device, front_ms, main_ms);
+    }
+    mj::ReconArgs a{};
+    if (int rc = recon_args(p, rgb_device, a)) return rc;
+    auto front = [&]() -> int {
+        MJ_HIP(ctx, mj::launch_fill_words(s, p->d_status, 0u, p->n_images));
+        if (p->n_jobs) MJ_HIP(ctx, mj::launch_scan_markers(s, p->d_blob, p->d_jobs, p->n_jobs, p->d_segs, p->d_status));
+        MJ_HIP(ctx, mj::launch_destuff(s, p->d_blob, p->d_segs, p->n_segs, p->d_stream, p->d_seg_bits));
+        return MJ_OK;
+    };
+    auto fused = [&]() -> int {
+        MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
+                                     p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->d_coef, p->d_status, a, p->hmax, p->vmax,
+                                     p->fused_spi, p->d_job_prefix, p->total_jobs, p->jobs_per_image));
+        return MJ_OK;
+    };
+    int rc = front();
+    if (rc == MJ_OK) rc = fused();
+    if (rc != MJ_OK) return rc;
+    MJ_HIP(ctx, hipEventRecord(ev.a, s));
+    for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = front();
+    MJ_HIP(ctx, hipEventRecord(ev.b, s));
+    MJ_HIP(ctx, hipEventSynchronize(ev.b));
+    MJ_HIP(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (front_ms) *front_ms = ms / iters;
+    if (rc != MJ_OK) return rc;
+    MJ_HIP(ctx, hipEventRecord(ev.a, s));
+    for (int i = 0; i < iters && rc == MJ_OK; ++i) rc = fused();
+    MJ_HIP(ctx, hipEventRecord(ev.b, s));
+    MJ_HIP(ctx, hipEventSynchronize(ev.b));
+    MJ_HIP(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
+    if (main_ms) *main_ms = ms / iters;
+    return rc != MJ_OK ? rc : mark_done(p, s);
 }
 
 int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms) {

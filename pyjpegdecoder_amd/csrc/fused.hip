@@ -236,7 +236,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
     if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
     FusedArgs F{};
     F.L = lanes13::Args{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                        coef, status, shape.lpw, 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits};
+                        coef, status, shape.lpw, 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi};
     F.R = a;
     F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
     F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;

@@ -80,6 +80,9 @@ struct Args {
     // plus the second-level tables the batch's codes need, lut13 holding the tables at this stride — and index bits of the DC
     // tables in LDS (taken out of lut11's 11-bit ones: every 2^(11 - dbits)-th entry, where its code is short enough)
     int ac_slot_bytes, dbits;
+    // fused.hip only: restart segments per workgroup (whole images: no multiple of the waves' lanes in general — the last
+    // lanes of a workgroup's last wave then have no segment)
+    int wg_segs;
 };
 
 // LDS bytes of `nw` waves of `lpw` lanes: tables, block rows, block addresses, stream windows — in this order from `smem`
@@ -157,12 +160,12 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     // lengths the host knows), mode 2 deals the list out one segment per wave and round, so that the long ones sit in
     // different waves, each beside short ones: a wave is as slow as the lock-step of its lanes, and a lane with a long
     // segment mostly sets its wave's pace alone.  Mode 1 (neighbours of the list share a wave) is there to be measured.
-    int64_t seg_id = ((int64_t)wg * nw + wave) * lpw + lane;
+    int64_t seg_id = FUSED ? (int64_t)wg * A.wg_segs + wave * lpw + lane : ((int64_t)wg * nw + wave) * lpw + lane;
     if (by_length) {
         const int64_t n_waves = (int64_t)n_wg * nw, rank = order_mode == 2 ? (int64_t)lane * n_waves + ((int64_t)wg * nw + wave) : seg_id;
         seg_id = (lane < lpw && rank < n_segs) ? by_length[rank] : n_segs;
     }
-    const bool have = lane < lpw && seg_id < n_segs;
+    const bool have = lane < lpw && seg_id < n_segs && (!FUSED || wave * lpw + lane < A.wg_segs);
     DevSegment sg = segs[(have && !vsegs) ? seg_id : 0];
     DevVSeg vs{};
     if (vsegs) {

@@ -299,6 +299,8 @@ inline int device_cus() {
 // MJ_LAYOUT_PLANAR_*: every image's interleaved pixels (x-major or row-major, as stage 2 wrote them) -> its three planes
 hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
                                           const uint8_t *interleaved, uint8_t *planar);
+// p[0 .. n_words) = value, as a kernel (why not hipMemsetAsync: api.hip)
+hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_t n_words);
 // 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
                                  int transposed);

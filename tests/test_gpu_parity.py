@@ -15,15 +15,15 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dec():
     from pyjpegdecoder_amd import BatchDecoder
-    d = BatchDecoder(device=0)
-    yield d
+    d = BatchDecoder(device=0, segment="host")          # (the host's restart segmentation: what most of these tests were written against;
+    yield d                                              # `dec_gs` and the default-decoder tests cover the GPU's)
     d.close()
 
 
 @pytest.fixture(scope="module")
 def dec_exact():
     from pyjpegdecoder_amd import BatchDecoder
-    d = BatchDecoder(device=0, exact_only=True)
+    d = BatchDecoder(device=0, exact_only=True, segment="host")
     yield d
     d.close()
 
@@ -31,7 +31,7 @@ def dec_exact():
 @pytest.fixture(scope="module")
 def dec_rm():
     from pyjpegdecoder_amd import BatchDecoder
-    d = BatchDecoder(device=0, layout="rowmajor")
+    d = BatchDecoder(device=0, layout="rowmajor", segment="host")
     yield d
     d.close()
 
@@ -1788,6 +1788,219 @@ def test_lane_form_waves_whose_lanes_use_different_ac_tables(dec, tune):
                 assert np.array_equal(out["rgb"][i * per_rgb:(i + 1) * per_rgb].reshape(W, H, 3), ref["rgb"]), i
     finally:
         plan.close()
+
+
+def test_default_decoder_takes_the_fast_host_route(monkeypatch):
+    """BatchDecoder() as a user gets it: restart markers found on the GPU and — in decode_device — headers read and the batch
+    assembled by the native front end (mj_host_assemble) for calls of 8 files or more, the Python marker loop for fewer and
+    for what the front end declines (a progressive file among them); every image against the oracle either way."""
+    torch = pytest.importorskip("torch")
+    import io
+    from PIL import Image
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import BatchDecoder, batch as batch_mod
+    calls = {"native": 0, "python": 0}
+    real_native, real_parse = batch_mod.prepare_batch_native, batch_mod.parse_jpeg
+
+    def native(*a, **kw):
+        calls["native"] += 1
+        return real_native(*a, **kw)
+
+    def parse(*a, **kw):
+        calls["python"] += 1
+        return real_parse(*a, **kw)
+    monkeypatch.setattr(batch_mod, "prepare_batch_native", native)
+    monkeypatch.setattr(batch_mod, "parse_jpeg", parse)
+    d = BatchDecoder(device=0)
+    try:
+        assert d.gpu_segment and d.native_host
+        files = [synth.synth_jpeg(900 + i, 320, 240, 85, "420", 20 if i % 2 else 0) for i in range(12)]
+        out = d.decode_device(files)
+        assert calls["native"] >= 1 and calls["python"] == 0
+        for f, t in zip(files, out):
+            assert np.array_equal(t.cpu().numpy(), oracle.decode(f)["rgb"])
+        host = d.decode(files)                                  # numpy out: headers in Python, markers on the GPU
+        for f, a in zip(files, host):
+            assert np.array_equal(a, oracle.decode(f)["rgb"])
+        calls["native"] = calls["python"] = 0
+        few = d.decode_device(files[:3])                        # a handful of files: segmented on the host
+        assert calls["native"] == 0 and calls["python"] == 3
+        for f, t in zip(files[:3], few):
+            assert np.array_equal(t.cpu().numpy(), oracle.decode(f)["rgb"])
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(77, 200, 120)).save(b, "JPEG", quality=80, progressive=True)
+        mixed = files[:9] + [b.getvalue()]
+        for f, t in zip(mixed, d.decode_device(mixed)):
+            assert np.array_equal(t.cpu().numpy(), oracle.decode(f)["rgb"])
+    finally:
+        d.close()
+
+
+# ---- stages 1 and 2 in one launch (fused.hip) ------------------------------------------------------------------------------
+def _fused_batch(ss, W, H, n, distinct, seed, ri=None, gpu_segment=False, layout=None, flags=0):
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd import parse_jpeg
+    from pyjpegdecoder_amd.batch import prepare_batch
+    mw = 16 if ss in ("420", "422") else 8
+    ri = (W + mw - 1) // mw if ri is None else ri
+    blob, offs = synth.synth_batch(distinct, seed, W, H, 85, ss, ri)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
+    files = [raws[(5 * i + i // distinct) % distinct] for i in range(n)]
+    layout = B.MJ_LAYOUT_XMAJOR if layout is None else layout
+    parsed = [parse_jpeg(f, headers_only=True) for f in files] if gpu_segment else None
+    return raws, files, prepare_batch(files, layout, flags, parsed)
+
+
+def _decode_plan(ctx, prep, n, torch, opts=()):
+    """(rgb on the device, statuses, stage1_form) of a plan's executes under library options: three of them — the second is
+    captured into a graph, the third replays it — each into its own zeroed buffer and each with the coefficient store
+    POISONED first (a fused launch's reconstruction wavefronts read what its decoder wavefronts have just written: a block
+    read too early must not find the previous execute's copy of itself); the three outputs must be one."""
+    from pyjpegdecoder_amd import _binding as B
+    for k, v in opts:
+        B.set_option(k, v)
+    try:
+        dev = torch.device("cuda", 0)
+        d_blob = torch.from_numpy(prep.blob).to(dev)
+        torch.cuda.synchronize()
+        plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+        try:
+            out = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            keep = None
+            for k, poison in enumerate((0x5A, 0xC3, 0x7E)):
+                out.zero_()
+                torch.cuda.synchronize()                # (the fill runs on torch's stream, the plan on the context's)
+                plan.fill_coef(poison)
+                plan.execute(0, out.data_ptr())
+                plan.sync()
+                if keep is None:
+                    keep = out.clone()
+                else:
+                    assert torch.equal(out, keep), f"execute {k} of the plan differs from its first"
+            return keep, plan.read(rgb=False)["status"], plan.stage1_form()
+        finally:
+            plan.close()
+    finally:
+        for k, _ in opts:
+            B.set_option(k, None)
+
+
+def test_fused_launch_config3_at_size_every_distinct_image(dec):
+    """BASELINE configs[2] through the ONE launch mj_plan_execute makes of it (fused.hip: lane-walk wavefronts and
+    reconstruction wavefronts in one workgroup per CU): 1024 x 1080p 4:2:0, one restart interval per MCU row.  Every distinct
+    image against the oracle, every copy against its first instance, and the whole output against the two launches'."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    W, H, n, distinct = 1920, 1080, 1024, 64
+    raws, files, prep = _fused_batch("420", W, H, n, distinct, 515100)
+    fused, st, form = _decode_plan(dec.ctx, prep, n, torch)
+    assert form & B.MJ_FORM_FUSED and form & 15 == B.MJ_FORM_LANES, form
+    assert not st.any()
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0")])
+    assert not form2 & B.MJ_FORM_FUSED and not st2.any()
+    per = W * H * 3
+    differ = (fused.view(n, per) != two.view(n, per)).any(dim=1).nonzero().flatten().tolist()
+    assert not differ, f"{len(differ)} images differ between the fused launch and the two launches, first {differ[:12]}"
+    imgs = fused.view(n, per)
+    first = {}
+    for i in range(n):
+        first.setdefault((5 * i + i // distinct) % distinct, i)
+    for i in range(n):
+        d = (5 * i + i // distinct) % distinct
+        if first[d] != i:
+            assert torch.equal(imgs[i], imgs[first[d]]), i
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        assert np.array_equal(imgs[first[d]].cpu().numpy().reshape(W, H, 3), want), d
+
+
+@pytest.mark.parametrize("ss,W,H,n,distinct", [("444", 640, 480, 1021, 12), ("422", 800, 608, 1300, 10), ("440", 512, 512, 700, 9), ("420", 1000, 700, 521, 7),
+                                                ("420", 1920, 1080, 1250, 5), ("444", 264, 200, 1500, 6)])
+def test_fused_launch_other_layouts_and_ragged_workgroups(dec, ss, W, H, n, distinct, tune):
+    """The fused launch on 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 batches whose image count is no multiple of the images per workgroup
+    (the last workgroup is short, some have one image), image sizes that are no multiple of the MCU or of a strip, with every
+    number of consumer wavefronts the option allows: each against the two launches byte for byte, the distinct files against
+    the oracle, with the restart markers found on the host and on the GPU."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    raws, files, prep = _fused_batch(ss, W, H, n, distinct, 77000 + W)
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0"), ("MJ_HUFFMAN", "lanes")])
+    assert not st2.any() and not form2 & B.MJ_FORM_FUSED
+    per = W * H * 3
+    imgs = two.view(n, per)
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        i = next(k for k in range(n) if (5 * k + k // distinct) % distinct == d)
+        assert np.array_equal(imgs[i].cpu().numpy().reshape(W, H, 3), want), d
+    for cons in (None, "1", "3", "8"):
+        opts = [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED_CONSUMERS", cons)] if cons else [])
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, opts)
+        assert form & B.MJ_FORM_FUSED, (form, cons)
+        assert not st.any() and torch.equal(fused, two), cons
+    _, _, prep_g = _fused_batch(ss, W, H, n, distinct, 77000 + W, gpu_segment=True)
+    fused, st, form = _decode_plan(dec.ctx, prep_g, n, torch, [("MJ_HUFFMAN", "lanes")])
+    assert form & B.MJ_FORM_FUSED and not st.any() and torch.equal(fused, two)
+
+
+def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
+    """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): a restart interval that is not
+    one MCU row, row-major pixels, seam outputs, the exact-order stage 2, restart segments of very different lengths (dealt out
+    by length), MJ_FUSED=0 — and whatever it is, the pixels are the oracle's."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from pyjpegdecoder_amd import _binding as B
+    W, H, n, distinct = 640, 480, 800, 5
+    for kind in ("half_rows", "two_rows", "rowmajor", "seams", "exact", "off"):
+        ri = {"half_rows": 20, "two_rows": 80}.get(kind)
+        layout = B.MJ_LAYOUT_ROWMAJOR if kind == "rowmajor" else None
+        flags = {"seams": B.MJ_FLAG_KEEP_IDCT, "exact": B.MJ_FLAG_EXACT_ONLY}.get(kind, 0)
+        raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000, ri=ri, layout=layout, flags=flags)
+        out, st, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED", "0")] if kind == "off" else []))
+        assert not form & B.MJ_FORM_FUSED, (kind, form)
+        assert not st.any()
+        got = out[:W * H * 3].cpu().numpy()
+        want = oracle.decode(files[0])["rgb"]
+        got = np.swapaxes(got.reshape(H, W, 3), 0, 1) if kind == "rowmajor" else got.reshape(W, H, 3)
+        assert np.array_equal(got, want), kind
+    raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000)
+    _, _, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")])
+    assert form & B.MJ_FORM_FUSED
+
+
+def test_fused_launch_damaged_files_do_not_stall_their_workgroup(dec, tune):
+    """Files of a fused batch with entropy-coded bytes overwritten (markers left where they are): the statuses are those of the
+    two launches, damaged files that still decode give the same pixels, every other image of the batch — the damaged files'
+    workgroup neighbours included — is untouched, and the launch returns (what the consumer wavefronts wait for is the
+    producers' progress, which does not depend on what the bytes say)."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, n, distinct = 640, 480, 800, 6
+    raws, files, _ = _fused_batch("420", W, H, n, distinct, 61000)
+    rng = np.random.default_rng(3)
+    files = list(files)
+    hurt = [3, 4, 257, 511, 799]
+    for i in hurt:
+        b = bytearray(files[i])
+        lo, done = len(b) // 3, 0
+        while done < 6:
+            pos = int(rng.integers(lo, len(b) - 4))
+            v = int(rng.integers(0, 255))
+            if 0xFF in (b[pos - 1], b[pos], b[pos + 1]) or v == b[pos]:
+                continue                                           # (no marker made, none unmade: the host's segmentation stands)
+            b[pos] = v
+            done += 1
+        files[i] = bytes(b)
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    two, st2, _ = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0"), ("MJ_HUFFMAN", "lanes")])
+    fused, st, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")])
+    assert form & B.MJ_FORM_FUSED
+    assert np.array_equal(st != 0, st2 != 0), (np.flatnonzero(st), np.flatnonzero(st2))
+    assert set(np.flatnonzero(st)) <= set(hurt) and B.MJ_ST_INTERNAL not in st
+    per = W * H * 3
+    a, b2 = fused.view(n, per), two.view(n, per)
+    good = torch.tensor([i for i in range(n) if st[i] == 0], device=a.device)
+    assert torch.equal(a[good], b2[good])
 
 
 # ---- sampling layouts outside the common ones (any factors 1..4 per component) ----------------------------------------

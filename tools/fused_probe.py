@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--segment", default="host", choices=["host", "gpu"])
+    ap.add_argument("--mixed", action="store_true", help="files of mixed content (bench.py's mixed_content family)")
     ap.add_argument("--lib", default=None, help="another build of the library (pyjpegdecoder_amd/libmijpeg_diag.so + MJ_DEBUG_FUSED=1: phase times)")
     ap.add_argument("exps", nargs="*", default=[""])
     args = ap.parse_args()
@@ -35,7 +36,10 @@ def main():
     from tools import synth
     dev = torch.device("cuda", 0)
     mcus_per_row = (args.width + (15 if args.subsampling in ("420", "422") else 7)) // (16 if args.subsampling in ("420", "422") else 8)
-    blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, mcus_per_row)
+    if args.mixed:
+        blob, offs = synth.synth_mixed_batch(args.distinct, 900000, args.width, args.height, args.subsampling, mcus_per_row)
+    else:
+        blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, mcus_per_row)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(args.distinct)]
     files = [raws[i % args.distinct] for i in range(args.batch)]
     if args.segment == "gpu":
@@ -62,18 +66,19 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / args.reps * 1e3
             st = plan.read(rgb=False)["status"]
+            parts = plan.time_execute(5, out.data_ptr())
         finally:
             plan.close()
             for k, _ in opts:
                 B.set_option(k, None)
-        return out, ms, form, st
-    ref, ms0, form0, st0 = run([("MJ_FUSED", "0")])
-    print(f"{'two launches (MJ_FUSED=0)':50s} form {form0:3d}  {ms0:7.3f} ms per step   statuses not ok: {int((st0 != 0).sum())}", flush=True)
+        return out, ms, form, st, parts
+    ref, ms0, form0, st0, parts0 = run([("MJ_FUSED", "0")])
+    print(f"{'two launches (MJ_FUSED=0)':50s} form {form0:3d}  {ms0:7.3f} ms per step ({parts0[0]:.3f} + {parts0[1]:.3f})   statuses not ok: {int((st0 != 0).sum())}", flush=True)
     for exp in args.exps:
         opts = [kv.split("=", 1) for kv in exp.split(",") if kv]
-        out, ms, form, st = run(opts)
+        out, ms, form, st, parts = run(opts)
         same = bool(torch.equal(out, ref))
-        print(f"{exp or 'default':50s} form {form:3d}  {ms:7.3f} ms per step   statuses not ok: {int((st != 0).sum())}   "
+        print(f"{exp or 'default':50s} form {form:3d}  {ms:7.3f} ms per step ({parts[0]:.3f} + {parts[1]:.3f})   statuses not ok: {int((st != 0).sum())}   "
               f"{'identical to the two launches' if same else 'DIFFERS from the two launches'}", flush=True)
         if not same:
             d = (out != ref).view(args.batch, -1).any(dim=1).nonzero().flatten()

@@ -23,7 +23,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    dec = {"host": BatchDecoder(0), "gpu": BatchDecoder(0, segment="gpu"), "rowmajor": BatchDecoder(0, layout="rowmajor")}
+    dec = {"host": BatchDecoder(0, segment="host"), "gpu": BatchDecoder(0, segment="gpu"), "rowmajor": BatchDecoder(0, layout="rowmajor")}
     bad = done = 0
     t0 = time.time()
     while done < n:
