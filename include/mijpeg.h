@@ -228,6 +228,15 @@ int mj_plan_read(mj_plan *plan, uint8_t *rgb_host, int16_t *coef_host, int16_t *
 /* Replace the plan's coefficient array (config 2: coefficients decoded elsewhere). mem = MJ_MEM_*. */
 int mj_plan_write_coef(mj_plan *plan, const int16_t *coef, int32_t mem);
 
+/* Test hook, host only (no GPU, no context): the form stage 1 would take for a batch with these restart-segment byte lengths —
+ * csrc/form_select.h's rule, the one mj_plan_create applies.  traits: 1 a table serves as DC and AC table, 2 segments not in blob
+ * order, 4 progressive, 8 a sampling layout outside the common five, 16 MJ_FLAG_GPU_SEGMENT, 32 ... with one segment per image,
+ * 64 a DC size above 15, 128 MJ_FLAG_NO_SYNC, 256 per-workgroup table lists do not fit.  force: MJ_HUFFMAN's value or NULL;
+ * forced_chunk: MJ_SYNC_CHUNK or 0.  out = { MJ_FORM_* (| MJ_FORM_WG_TABLES), chunk bytes, chunks, 1 if the segments would be
+ * dealt out by length }. */
+int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
+                         int32_t forced_chunk, int32_t out[4]);
+
 /* Test hook: every byte of the plan's coefficient store := byte_value (synchronous).  The parity tests poison the store in
  * front of a fused execute: a reconstruction wavefront that read a block before its decoder wavefront had written it would
  * show (a store that still holds the previous execute's blocks of the same files hides exactly that). */

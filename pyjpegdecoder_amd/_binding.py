@@ -27,7 +27,7 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED = 0, 1, 2, 3, 16, 32, 64
 MJ_HOST_DECLINED = 1
@@ -133,8 +133,22 @@ def load_library():
     L.mj_plan_idct_levels.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mj_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.mj_get_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32]
+    L.mj_debug_stage1_form.argtypes = [vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int32,
+                                       ctypes.POINTER(ctypes.c_int32)]
     _lib = L
     return L
+
+
+def stage1_form_rule(seg_len, blob_len=None, n_huff=4, traits=0, force=None, forced_chunk=0):
+    """mj_debug_stage1_form (host only): (MJ_FORM_*, chunk bytes, chunks, dealt out by length) for a batch whose restart
+    segments have these byte lengths — the rule mj_plan_create applies (csrc/form_select.h)."""
+    a = np.ascontiguousarray(seg_len, dtype=np.int32)
+    out = (ctypes.c_int32 * 4)()
+    rc = load_library().mj_debug_stage1_form(_ptr(a), a.size, int(a.sum()) + 4096 if blob_len is None else blob_len, n_huff, traits,
+                                             force.encode() if force else None, forced_chunk, out)
+    if rc != MJ_OK:
+        raise ValueError("mj_debug_stage1_form: bad arguments")
+    return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
 
 
 class UnknownOption(ValueError):

@@ -1,0 +1,124 @@
+// Which form stage 1 takes for a batch — the rule, apart from the plan that applies it (plan_create.hip), so that it can be
+// read in one place and tested without a GPU (mj_debug_stage1_form, tests/test_form_select.py).  Host-side, no HIP.
+//
+//   wave    one restart segment per wavefront (huffman.hip): small batches, tables in both roles, unusual sampling layouts
+//   lanes   one per lane (huffman_lanes13.hip / huffman_lanes.hip): from ~1000 segments on
+//   sync    long segments cut into self-synchronising chunks (huffman_sync.hip): files without restart markers, and
+//           batches of ordinary restart segments too small to fill the chip one per lane
+// The thresholds are measurements on MI355X (DESIGN.md §3 has the numbers behind each).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace mj {
+
+constexpr int kFormMaxLaneTables = 8;      // = kMaxLaneTables (mijpeg_internal.h): tables the lane forms hold in LDS at once
+
+struct FormInputs {
+    const int32_t *seg_len = nullptr;      // byte lengths of the batch's restart segments (with the GPU marker scan and one
+    int64_t n_segs = 0;                    // segment per image: the image's byte range, an upper bound)
+    uint64_t blob_len = 0;
+    int n_huff = 0;
+    bool both_roles = false;               // some table serves as DC and as AC table
+    bool ordered = true;                   // segments in ascending, non-overlapping blob order
+    bool progressive = false, generic = false;
+    bool gpu_segment = false;              // MJ_FLAG_GPU_SEGMENT: lengths unknown until the marker scan has run ...
+    bool one_seg_each = false;             // ... unless every image is one segment
+    bool dc_fits = true;                   // no DC size above 15 (the unified table format of the counting rounds)
+    bool no_sync = false;                  // MJ_FLAG_NO_SYNC
+    bool wg_lists_ok = true;               // more tables than LDS holds: the lane launch's per-workgroup table lists fit
+    const char *force = nullptr;           // MJ_HUFFMAN: wave | lanes | lanes11 | sync, or null
+    int forced_chunk = 0;                  // MJ_SYNC_CHUNK, 0 = choose
+};
+
+struct FormChoice {
+    bool many_tabs = false;                // more distinct tables than the lane forms hold: per-workgroup lists
+    bool lanes_ok = false;                 // the lane forms can take the batch at all
+    bool use_lanes = false;                // one segment per lane (before want_sync makes it true as well)
+    bool want_sync = false;                // chunks + synchronisation rounds (with many tables: still subject to the chunked launches' table lists)
+    int sync_chunk_bytes = 2048;
+    int64_t est_chunks = 0;
+    bool long_segs = false, few_segs = false;
+};
+
+inline FormChoice choose_stage1_form(const FormInputs &in) {
+    FormChoice c;
+    const char *force = in.force;
+    c.many_tabs = in.n_huff > kFormMaxLaneTables;
+    // (a table serving as DC and as AC table at once, or a stream beyond 32-bit offsets, stays with the wave form; stage 0
+    // places segment i's stream at dword (begin_i >> 2) + i, which needs the segments in blob order)
+    const bool fits32 = in.blob_len + 4 * (uint64_t)in.n_segs + 4096 < (1ull << 32);
+    c.lanes_ok = in.ordered && (!c.many_tabs || in.wg_lists_ok) && !in.both_roles && !in.progressive && !in.generic && fits32;
+    c.use_lanes = c.lanes_ok && in.n_segs >= 1024;       // measured crossover with the wave form: ~1000 segments
+    if (force && !strcmp(force, "wave")) c.use_lanes = false;
+    if (force && (!strcmp(force, "lanes") || !strcmp(force, "lanes11")) && c.lanes_ok) c.use_lanes = true;
+    int64_t total_len = 0;
+    int32_t longest = 0;
+    for (int64_t i = 0; i < in.n_segs; ++i) { total_len += in.seg_len[i]; longest = std::max(longest, in.seg_len[i]); }
+    if (in.forced_chunk) {
+        c.sync_chunk_bytes = in.forced_chunk;
+    } else {
+        // Chunk size by the amount of stream: small batches want many short chunks (a single 1080p image: 1.65 ms with
+        // 512-byte chunks, 3.0 ms with 2 KiB ones — six wavefronts' worth), big ones fewer long ones (the run-up in
+        // front of every chunk and the per-chunk records cost; 1024 images: 19.0 ms at 2 KiB, 20.2 ms at 512 bytes).
+        // Measured optimum: the shortest of 512 / 1024 / 2048 bytes that keeps the batch under ~330 000 chunks.
+        // ... and a single segment not in more than ~12 000 of them: wrongly guessed entry states are repaired one link
+        // of a chain per round, and chains grow with the chunks of a segment (one 24-megapixel image, 10 MB of
+        // stream: 5.4 ms with 512-byte chunks, 3.8 ms with 1 KiB).
+        c.sync_chunk_bytes = 2048;
+        for (int cb : {512, 1024})
+            if (total_len / cb <= 330000 && longest / cb <= 12000) { c.sync_chunk_bytes = cb; break; }
+    }
+    for (int64_t i = 0; i < in.n_segs; ++i) c.est_chunks += std::max(1, (in.seg_len[i] + c.sync_chunk_bytes - 1) / c.sync_chunk_bytes);
+    // Long segments (no DRI, or a very large restart interval) leave the chip empty at one lane each: chosen when segments
+    // average >= 32 KiB — or one is >= 64 KiB: in a batch that mixes files with and without restart markers, an image
+    // without them would otherwise be one lane's (or one wavefront's) serial walk, 220 ms for a 1080p file
+    c.long_segs = in.n_segs > 0 && (total_len / in.n_segs >= 32768 || longest >= 65536) && c.est_chunks >= 64;
+    // ... and so do small batches of ordinary restart segments: below ~20 000 segments the lane form cannot fill the
+    // chip (its time is one segment's serial walk, ~3.3 ms for a 1080p MCU row, however few there are), while chunks
+    // can (measured, 1080p with one restart interval per MCU row: 1 image 3.3 -> 1.4 ms, 32 images 3.9 -> 2.1 ms,
+    // 128 images 4.9 -> 3.8 ms, break-even at ~300 images = 20 000 segments).  Segments shorter than a few chunks
+    // gain nothing from being cut.
+    c.few_segs = in.n_segs > 0 && in.n_segs < 20000 && total_len / in.n_segs >= 2048 && c.est_chunks >= 64;
+    // (with many tables the synchronisation form needs its own two workgroup shapes to get by with their table lists;
+    // its lane launch runs over chunks, so the restart-segment shape that lanes_ok looked at does not matter for it)
+    const bool sync_shape_ok = in.ordered && !in.both_roles && !in.progressive && !in.generic && fits32;
+    // (with the GPU marker scan the segment lengths are not known at plan time: possible when every image is one segment)
+    c.want_sync = !in.no_sync && (c.many_tabs ? sync_shape_ok : c.lanes_ok) && (!in.gpu_segment || in.one_seg_each) && in.dc_fits &&
+                  ((force && !strcmp(force, "sync")) || (!force && (c.long_segs || c.few_segs)));
+    return c;
+}
+
+// Restart segments of very different lengths (longest > 1.25 x mean) are dealt out to the lane launch's waves by length
+// (huffman_lanes13.hip, MJ_SEG_ORDER): measured, 1024 x 1080p of mixed content 7.5 ms in blob order, 6.65 striped; files of
+// one kind 4.01 / 4.13 — so segments of similar length stay in blob order.
+inline bool spread_lengths(const int32_t *seg_len, int64_t n_segs) {
+    int64_t sum = 0;
+    int32_t top = 0;
+    for (int64_t i = 0; i < n_segs; ++i) { sum += seg_len[i]; top = std::max(top, seg_len[i]); }
+    return (int64_t)top * 4 * n_segs > 5 * sum;
+}
+
+// One launch for both stages (fused.hip) — the conditions apart from the LDS budget (fused_shape): the resolved-table lane
+// form in blob order on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files whose restart interval is ONE MCU ROW (a
+// producer wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
+// x-major pixels, no seam outputs, a stage-2 job = a whole MCU column.
+struct FusedInputs {
+    bool lanes_resolved = false;           // lane form (not sync) with the resolved tables, 12-bit copies built
+    int seg_order_mode = 0;
+    bool uniform = false, generic = false, progressive = false, transposed = false;
+    int ncomp = 3, hmax = 1, vmax = 1, layout = 0;
+    uint32_t flags = 0, seam_or_exact_flags = 0;
+    int restart_interval = 0, mcu_count_h = 0, mcu_count_v = 0, jobs_per_image = 0;
+    int64_t n_segs = 0, n_images = 0;
+};
+inline bool fused_applies(const FusedInputs &f) {
+    return f.lanes_resolved && f.seg_order_mode == 0 && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
+           (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && !f.transposed && f.layout == 0 &&
+           !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.jobs_per_image == f.mcu_count_h &&
+           f.n_segs == f.n_images * f.mcu_count_v;
+}
+
+}  // namespace mj

@@ -199,9 +199,8 @@ void dbg_fused_clear(uint8_t *dump) {
 
 
 // How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
-FusedShape fused_shape(int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, int n_images, int spi, int want_consumers) {
+FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, int n_images, int spi, int want_consumers) {
     FusedShape s{};
-    const int cus = device_cus();
     if (n_images < 1 || spi < 1) return s;
     s.ipw = (n_images + cus - 1) / cus;                        // whole images per workgroup, every workgroup resident at once
     const int lanes = s.ipw * spi;

@@ -1,0 +1,83 @@
+"""Which form stage 1 takes for a batch (csrc/form_select.h, through the host-only hook mj_debug_stage1_form): the rule as a
+table of cases — segment count x length x tables x traits -> form, chunk size — without a GPU."""
+import numpy as np
+import pytest
+
+from pyjpegdecoder_amd import _binding as B
+
+WAVE, LANES, SYNC, SCANS, WG = B.MJ_FORM_WAVE, B.MJ_FORM_LANES, B.MJ_FORM_SYNC, B.MJ_FORM_SCANS, B.MJ_FORM_WG_TABLES
+T_BOTH, T_UNORDERED, T_PROG, T_GENERIC, T_GPUSEG, T_ONESEG, T_DCBIG, T_NOSYNC, T_WGFAIL = 1, 2, 4, 8, 16, 32, 64, 128, 256
+
+
+def segs(n, length):
+    return np.full(n, length, dtype=np.int32)
+
+
+CASES = [
+    # name, segment lengths, kwargs, expected form, expected chunk bytes (None = do not care)
+    ("config 3: 1024 x 1080p, one MCU row per segment", segs(69632, 9800), {}, LANES, None),
+    ("one small file, three segments", segs(3, 700), {}, WAVE, None),
+    ("999 short segments: below the lane form's crossover", segs(999, 900), {}, WAVE, None),
+    ("1024 short segments: lanes (too short to cut)", segs(1024, 900), {}, LANES, None),
+    ("one 1080p file with a restart interval per row: too few lanes, chunks fill the chip", segs(68, 9800), {}, SYNC, 512),
+    ("128 such files", segs(68 * 128, 9800), {}, SYNC, 512),
+    ("300 such files: the lane form again", segs(68 * 300, 9800), {}, LANES, None),
+    ("one 1080p file without restart markers", segs(1, 660000), {}, SYNC, 512),
+    ("300 of them", segs(300, 660000), {}, SYNC, 1024),
+    ("1024 of them: fewer, longer chunks", segs(1024, 660000), {}, SYNC, 2048),
+    ("one 24-megapixel file: no more than ~12 000 chunks per segment", segs(1, 10_000_000), {}, SYNC, 1024),
+    ("a batch of restart segments with ONE long segment among them", np.concatenate([segs(69632, 9800), segs(1, 70000)]), {}, SYNC, None),
+    ("files without markers, NO_SYNC asked for (the serial fallback)", segs(256, 660000), dict(traits=T_NOSYNC), WAVE, None),
+    ("... in a batch large enough for lanes", segs(2000, 40000), dict(traits=T_NOSYNC), LANES, None),
+    ("a table in both roles: wave form whatever the size", segs(69632, 9800), dict(traits=T_BOTH), WAVE, None),
+    ("segments not in blob order", segs(69632, 9800), dict(traits=T_UNORDERED), WAVE, None),
+    ("unusual sampling layout", segs(69632, 9800), dict(traits=T_GENERIC), WAVE, None),
+    ("progressive", segs(10240, 60000), dict(traits=T_PROG), SCANS, None),
+    ("a stream beyond 32-bit offsets", segs(69632, 9800), dict(blob_len=(1 << 32) + 5), WAVE, None),
+    ("GPU marker scan, restart segments: lengths unknown, no chunks", segs(68 * 16, 0), dict(traits=T_GPUSEG), LANES, None),
+    ("GPU marker scan, one segment per image: the byte range bounds it", segs(64, 670000), dict(traits=T_GPUSEG | T_ONESEG), SYNC, 512),
+    ("GPU marker scan, few restart segments", segs(68, 0), dict(traits=T_GPUSEG), WAVE, None),
+    ("a DC size above 15: the counting rounds' format has no place for it", segs(256, 660000), dict(traits=T_DCBIG), WAVE, None),
+    ("67 tables (optimised files), restart segments, lists fit", segs(68 * 256, 9800), dict(n_huff=67), SYNC | WG, None),
+    ("... a full batch", segs(68 * 1024, 9800), dict(n_huff=67), LANES | WG, None),
+    ("... lists do not fit (many small files per workgroup)", segs(68 * 1024, 900), dict(n_huff=400, traits=T_WGFAIL), WAVE, None),
+    ("... no markers: chunks with per-workgroup lists", segs(256, 660000), dict(n_huff=70), SYNC | WG, None),
+    ("forced: wave", segs(69632, 9800), dict(force="wave"), WAVE, None),
+    ("forced: lanes on a small batch", segs(12, 800), dict(force="lanes"), LANES, None),
+    ("forced: lanes11 on a small batch", segs(12, 800), dict(force="lanes11"), LANES, None),
+    ("forced: lanes cannot override a table in both roles", segs(12, 800), dict(force="lanes", traits=T_BOTH), WAVE, None),
+    ("forced: sync on the benchmark", segs(69632, 9800), dict(force="sync"), SYNC, 2048),
+    ("forced: sync with a forced chunk", segs(64, 660000), dict(force="sync", forced_chunk=4096), SYNC, 4096),
+    ("forced: lanes keeps files without markers out of the chunks", segs(2000, 660000), dict(force="lanes"), LANES, None),
+    ("empty batch", segs(0, 0), {}, WAVE, None),
+]
+
+
+@pytest.mark.parametrize("name,seg_len,kw,form,chunk", CASES, ids=[c[0] for c in CASES])
+def test_stage1_form_rule(name, seg_len, kw, form, chunk):
+    got_form, got_chunk, n_chunks, _ = B.stage1_form_rule(seg_len, **kw)
+    assert got_form == form, (name, got_form)
+    if chunk is not None:
+        assert got_chunk == chunk, (name, got_chunk)
+        assert n_chunks == sum(max(1, -(-int(l) // got_chunk)) for l in seg_len)
+
+
+def test_chunk_size_keeps_the_batch_under_its_chunk_budget():
+    """The shortest of 512 / 1024 / 2048 bytes that keeps the batch under ~330 000 chunks and a segment under ~12 000."""
+    for n, length in ((1, 200_000), (64, 660_000), (256, 660_000), (300, 660_000), (1024, 660_000), (1, 5_000_000), (1, 13_000_000)):
+        _, chunk, n_chunks, _ = B.stage1_form_rule(segs(n, length))
+        assert chunk in (512, 1024, 2048)
+        if chunk > 512:
+            assert n * length // (chunk // 2) > 330000 or length // (chunk // 2) > 12000
+        if chunk < 2048:
+            assert n * length // chunk <= 330000 and length // chunk <= 12000
+
+
+def test_segments_are_dealt_out_by_length_only_when_they_differ():
+    rng = np.random.default_rng(0)
+    even = rng.integers(9000, 10500, 69632).astype(np.int32)
+    assert not B.stage1_form_rule(even)[3]
+    mixed = even.copy()
+    mixed[::50] = 30000
+    assert B.stage1_form_rule(mixed)[3]
+    assert not B.stage1_form_rule(segs(10, 5000))[3]
