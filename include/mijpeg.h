@@ -237,6 +237,12 @@ int mj_plan_write_coef(mj_plan *plan, const int16_t *coef, int32_t mem);
 int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
                          int32_t forced_chunk, int32_t out[4]);
 
+/* Test hook, host only: how a fused launch (MJ_FORM_FUSED) would be cut for a batch of n_images images of segments_per_image
+ * restart segments on a chip of `cus` CUs — out = { applies (LDS), images per workgroup, producer wavefronts, lanes per producer,
+ * consumer wavefronts beside them, bytes of LDS the producers take }. */
+int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
+                         int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[6]);
+
 /* Test hook: every byte of the plan's coefficient store := byte_value (synchronous).  The parity tests poison the store in
  * front of a fused execute: a reconstruction wavefront that read a block before its decoder wavefront had written it would
  * show (a store that still holds the previous execute's blocks of the same files hides exactly that). */

@@ -27,7 +27,7 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED = 0, 1, 2, 3, 16, 32, 64
 MJ_HOST_DECLINED = 1
@@ -149,6 +149,17 @@ def stage1_form_rule(seg_len, blob_len=None, n_huff=4, traits=0, force=None, for
     if rc != MJ_OK:
         raise ValueError("mj_debug_stage1_form: bad arguments")
     return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+
+
+def fused_shape_rule(n_images, segments_per_image, hmax=2, vmax=2, transposed=False, cus=256, n_ac=2, n_dc=2, ac_slot_bytes=17024,
+                     want_consumers=8):
+    """mj_debug_fused_shape (host only): dict(ok, images_per_wg, producers, lanes, consumers, producer_lds) of a fused launch."""
+    out = (ctypes.c_int32 * 6)()
+    L = load_library()
+    L.mj_debug_fused_shape.argtypes = [ctypes.c_int32] * 10 + [ctypes.POINTER(ctypes.c_int32)]
+    if L.mj_debug_fused_shape(cus, n_ac, n_dc, ac_slot_bytes, hmax, vmax, int(transposed), n_images, segments_per_image, want_consumers, out) != MJ_OK:
+        raise ValueError("mj_debug_fused_shape: bad arguments")
+    return dict(zip(("ok", "images_per_wg", "producers", "lanes", "consumers", "producer_lds"), (bool(out[0]),) + tuple(int(x) for x in out[1:])))
 
 
 class UnknownOption(ValueError):

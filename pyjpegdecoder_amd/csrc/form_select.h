@@ -104,7 +104,7 @@ inline bool spread_lengths(const int32_t *seg_len, int64_t n_segs) {
 // One launch for both stages (fused.hip) — the conditions apart from the LDS budget (fused_shape): the resolved-table lane
 // form in blob order on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files whose restart interval is ONE MCU ROW (a
 // producer wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
-// x-major pixels, no seam outputs, a stage-2 job = a whole MCU column.
+// interleaved pixels (x-major: a stage-2 job = a whole MCU column; row-major: pieces of an MCU row), no seam outputs.
 struct FusedInputs {
     bool lanes_resolved = false;           // lane form (not sync) with the resolved tables, 12-bit copies built
     int seg_order_mode = 0;
@@ -115,10 +115,12 @@ struct FusedInputs {
     int64_t n_segs = 0, n_images = 0;
 };
 inline bool fused_applies(const FusedInputs &f) {
+    // x-major: a stage-2 job is a whole MCU column (ready when every row of the image is past it); row-major (the strip worker
+    // runs on the transposed image): pieces of an MCU row, fused.hip cuts them itself
+    const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.jobs_per_image == f.mcu_count_h);
     return f.lanes_resolved && f.seg_order_mode == 0 && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
-           (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && !f.transposed && f.layout == 0 &&
-           !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.jobs_per_image == f.mcu_count_h &&
-           f.n_segs == f.n_images * f.mcu_count_v;
+           (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && layout_ok &&
+           !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.n_segs == f.n_images * f.mcu_count_v;
 }
 
 }  // namespace mj

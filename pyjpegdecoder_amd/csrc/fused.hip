@@ -59,18 +59,24 @@ struct FusedArgs {
     int32_t ipw;                           // images per workgroup
     int32_t spi;                           // restart segments (= MCU rows) per image
     int32_t n_images;
+    // row-major plans (the strip worker runs on the transposed image: its "columns" are the MCU ROWS): a job is a PIECE of one
+    // MCU row — `pieces` per row, each `piece_mcus` MCUs long (the last one shorter) —, ready when its row's wave is past it
+    int32_t pieces, piece_mcus, mcus_per_row;
 };
 
 typedef uint32_t __attribute__((address_space(3))) *lds_word;
 
 // Jobs of this workgroup's images from a ticket counter in LDS, column by column (ticket t = column t / images, image
-// t % images), each gated by the progress of the producer waves that hold the image's rows.
+// t % images), each gated by the progress of the producer waves that hold the image's rows.  BY_ROWS (row-major plans): piece
+// by piece instead (ticket t = piece t / rows, row t % rows of the workgroup's rows), gated by the one wave that holds the row.
+template <bool BY_ROWS>
 struct FusedSource {
     static constexpr bool kSingleJobs = true;      // a ticket = one job, and consecutive tickets are not consecutive jobs
     uint32_t ctrl;                         // LDS address of the control words
     uint32_t n_tickets;
     uint32_t images_here, image0;
     uint32_t jobs_per_image, lpw, spi;
+    uint32_t pieces, piece_mcus, mcus_per_row;      // BY_ROWS
     int32_t *status;
     int lane;
     __device__ __forceinline__ uint32_t draw() const {
@@ -80,13 +86,23 @@ struct FusedSource {
     }
     __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
     __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
-        const uint32_t m = ticket / images_here, j = ticket - m * images_here;
-        return (image0 + j) * jobs_per_image + m;
+        if constexpr (BY_ROWS) {
+            const uint32_t rows = images_here * spi, pc = ticket / rows, rr = ticket - pc * rows, j = rr / spi, row = rr - j * spi;
+            return (image0 + j) * jobs_per_image + row * pieces + pc;      // (job numbering of the strip worker: row by row, piece by piece)
+        } else {
+            const uint32_t m = ticket / images_here, j = ticket - m * images_here;
+            return (image0 + j) * jobs_per_image + m;
+        }
     }
     __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
     // complete MCUs of every row of the job's image > the job's column?
     __device__ __forceinline__ bool ready(uint32_t job) const {
         const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image, j = img - image0;
+        if constexpr (BY_ROWS) {           // MCUs complete in the row's wave >= where the piece ends
+            const uint32_t row = m / pieces, pc = m - row * pieces, w = (j * spi + row) / lpw;
+            const uint32_t done = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)done) >= min((pc + 1u) * piece_mcus, mcus_per_row);
+        }
         const uint32_t w0 = (j * spi) / lpw, w1 = (j * spi + spi - 1u) / lpw;
         uint32_t least = 0x7FFFFFFFu;
         for (uint32_t w = w0; w <= w1; ++w) {
@@ -109,7 +125,8 @@ struct FusedSource {
 
 }  // namespace
 
-template <int HS, int VS>
+// HS, VS: the sampling factors the strip worker sees (swapped for T, the transposed problem of row-major plans)
+template <int HS, int VS, bool T>
 __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     using G = rfast::FGeo<HS, VS, 3>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -120,15 +137,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     float4 *wts = reinterpret_cast<float4 *>(smem + kFusedLds - kFusedCtrl - G::WTS_BYTES);
     if (tid < kFusedCtrl / 4) ctrl[tid] = 0;
     lanes13::stage<true>(F.L, smem, tid, kFusedThreads, n_prod);
-    rfast::fill_weights<HS, VS, 3, false>(wts, tid, kFusedThreads);
+    rfast::fill_weights<HS, VS, 3, T>(wts, tid, kFusedThreads);
     __syncthreads();
 
-    FusedSource src;
+    FusedSource<T> src;
     src.ctrl = lanes13::lds_addr(ctrl);
     src.image0 = (uint32_t)blockIdx.x * (uint32_t)F.ipw;
     src.images_here = min((uint32_t)F.ipw, (uint32_t)F.n_images - src.image0);
     src.jobs_per_image = (uint32_t)F.jobs_per_image;
     src.n_tickets = src.images_here * src.jobs_per_image;
+    src.pieces = (uint32_t)F.pieces; src.piece_mcus = (uint32_t)F.piece_mcus; src.mcus_per_row = (uint32_t)F.mcus_per_row;
     src.lpw = (uint32_t)F.L.lpw;
     src.spi = (uint32_t)F.spi;
     src.lane = lane;
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
         const int k = wave < n_prod ? wave : wave - n_cons;
         my_lds = smem + k * G::WAVE_BYTES;
     }
-    rfast::strips_worker<HS, VS, 3, false, false>(F.R, F.job_prefix, F.total_jobs, F.jobs_per_image, my_lds, wts, lane, (int)blockIdx.x, wave, src);
+    rfast::strips_worker<HS, VS, 3, false, T>(F.R, F.job_prefix, F.total_jobs, F.jobs_per_image, my_lds, wts, lane, (int)blockIdx.x, wave, src);
 #ifdef MJ_DIAGNOSTIC
     if (lane == 0) atomicMax(dbg + 3, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -199,8 +217,9 @@ void dbg_fused_clear(uint8_t *dump) {
 
 
 // How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
-FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, int n_images, int spi, int want_consumers) {
+FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
     FusedShape s{};
+    if (transposed) std::swap(hmax, vmax);                     // the strip worker's geometry: that of the transposed image
     if (n_images < 1 || spi < 1) return s;
     s.ipw = (n_images + cus - 1) / cus;                        // whole images per workgroup, every workgroup resident at once
     const int lanes = s.ipw * spi;
@@ -228,17 +247,45 @@ FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax,
     return s;
 }
 
+}  // namespace mj
+
+extern "C" int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
+                                    int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[6]) {
+    if (!out) return MJ_ERR_INVALID;
+    const mj::FusedShape s = mj::fused_shape(cus, n_ac, n_dc, ac_slot_bytes, hmax, vmax, transposed != 0, n_images, segments_per_image, want_consumers);
+    out[0] = s.ok ? 1 : 0; out[1] = s.ipw; out[2] = s.n_prod; out[3] = s.lpw; out[4] = s.n_cons;
+    out[5] = s.ok ? (int32_t)mj::lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits) : 0;
+    return MJ_OK;
+}
+
+namespace mj {
+
 hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                         int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
-                        const ReconArgs &a, int hmax, int vmax, int spi, const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image) {
+                        const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
+                        int64_t total_jobs, int jobs_per_image) {
     if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
     FusedArgs F{};
     F.L = lanes13::Args{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                        coef, status, shape.lpw, 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi};
+                        coef, status, shape.lpw, transposed ? 1 : 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi};
     F.R = a;
     F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
     F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;
+    F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row;
+    if (transposed) {
+        // the strip worker's jobs on the transposed image are pieces of an MCU ROW of the original (its own numbering: row by
+        // row, piece by piece, `chunk_strips` strips each): about 20 MCUs per piece, so that the consumers work a piece behind
+        // the walk instead of a row behind it (an LDS ticket costs nothing: the stage-2 kernel's global counter wants big jobs)
+        const int tmw = 64 / (8 * vmax);                       // MCUs per strip (the worker's HS is the image's vmax)
+        const int strips = std::max(1, 20 / tmw);
+        const int spc = (mcus_per_row + tmw - 1) / tmw;
+        F.R.chunk_strips = strips;
+        F.pieces = (spc + strips - 1) / strips;
+        F.piece_mcus = strips * tmw;
+        F.jobs_per_image = spi * F.pieces;
+        F.total_jobs = (int64_t)a.n_images * F.jobs_per_image;
+    }
     const unsigned blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
     auto go = [&](auto kernel) {
         static bool attr_set[kMaxDevices] = {false};
@@ -248,11 +295,19 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFusedThreads), kFusedLds, stream, F);
     };
-    if (hmax == 2 && vmax == 2) go(k_fused<2, 2>);
-    else if (hmax == 2 && vmax == 1) go(k_fused<2, 1>);
-    else if (hmax == 1 && vmax == 2) go(k_fused<1, 2>);
-    else if (hmax == 1 && vmax == 1) go(k_fused<1, 1>);
-    else return hipErrorInvalidValue;
+    if (!transposed) {
+        if (hmax == 2 && vmax == 2) go(k_fused<2, 2, false>);
+        else if (hmax == 2 && vmax == 1) go(k_fused<2, 1, false>);
+        else if (hmax == 1 && vmax == 2) go(k_fused<1, 2, false>);
+        else if (hmax == 1 && vmax == 1) go(k_fused<1, 1, false>);
+        else return hipErrorInvalidValue;
+    } else {
+        if (hmax == 2 && vmax == 2) go(k_fused<2, 2, true>);
+        else if (hmax == 2 && vmax == 1) go(k_fused<1, 2, true>);
+        else if (hmax == 1 && vmax == 2) go(k_fused<2, 1, true>);
+        else if (hmax == 1 && vmax == 1) go(k_fused<1, 1, true>);
+        else return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -811,7 +811,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // everything; measured on bench.py's mixed content: 11.3 ms fused against 10.6 as two launches)
             const bool shape_ok = mj::fused_applies(fi);
             if (allow && want_cons > 0 && shape_ok && p->d_lut12) {
-                p->fused = mj::fused_shape(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, b->n_images, i0.mcu_count_v, want_cons);
+                p->fused = mj::fused_shape(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, p->transposed, b->n_images, i0.mcu_count_v, want_cons);
                 p->fused_spi = i0.mcu_count_v;
                 p->use_fused = p->fused.ok;
             }

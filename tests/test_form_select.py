@@ -81,3 +81,30 @@ def test_segments_are_dealt_out_by_length_only_when_they_differ():
     mixed[::50] = 30000
     assert B.stage1_form_rule(mixed)[3]
     assert not B.stage1_form_rule(segs(10, 5000))[3]
+
+
+def test_fused_launch_shapes():
+    """How a fused launch is cut (fused.hip: fused_shape): whole images per workgroup, every workgroup resident at once, 8
+    producer wavefronts of at most 64 lanes, as many consumers as the LDS left beside them holds (8 320 B each for 4:2:0)."""
+    c3 = B.fused_shape_rule(1024, 68)
+    assert c3 == dict(ok=True, images_per_wg=4, producers=8, lanes=34, consumers=8, producer_lds=c3["producer_lds"]) and c3["producer_lds"] <= 92 * 1024
+    c4 = B.fused_shape_rule(1250, 68)                   # config 4's share: 5 images per workgroup, 340 lanes
+    assert (c4["ok"], c4["images_per_wg"], c4["producers"], c4["lanes"]) == (True, 5, 8, 43) and 4 <= c4["consumers"] < 8
+    half = B.fused_shape_rule(512, 68)
+    assert (half["images_per_wg"], half["producers"], half["lanes"], half["consumers"]) == (2, 4, 34, 8)
+    one = B.fused_shape_rule(200, 68)
+    assert (one["images_per_wg"], one["producers"], one["lanes"]) == (1, 2, 34)
+    assert not B.fused_shape_rule(2048, 68)["ok"]       # 544 segments per workgroup: more than 8 x 64 lanes
+    assert not B.fused_shape_rule(1024, 135)["ok"]      # 2160p in rows: 540 lanes
+    assert B.fused_shape_rule(1024, 68, want_consumers=3)["consumers"] == 3
+    assert not B.fused_shape_rule(1024, 68, want_consumers=0)["ok"]
+    # three 13-bit-sized tables would not leave room: the budget is what decides
+    assert not B.fused_shape_rule(1024, 68, n_ac=3, ac_slot_bytes=37376)["ok"]
+    # row-major: the strip worker's geometry is the transposed image's (4:2:2 becomes 4:4:0 and back)
+    a, b = B.fused_shape_rule(1000, 45, hmax=2, vmax=1, transposed=True), B.fused_shape_rule(1000, 45, hmax=1, vmax=2)
+    assert a == b and a["ok"]
+    for n, spi in ((1024, 68), (1250, 68), (777, 30), (1021, 60), (64, 17)):
+        s = B.fused_shape_rule(n, spi)
+        if s["ok"]:
+            assert s["images_per_wg"] * 256 >= n and s["producers"] * s["lanes"] >= s["images_per_wg"] * spi
+            assert s["producers"] + s["consumers"] <= 16 and s["lanes"] <= 64

@@ -1942,17 +1942,43 @@ def test_fused_launch_other_layouts_and_ragged_workgroups(dec, ss, W, H, n, dist
     assert form & B.MJ_FORM_FUSED and not st.any() and torch.equal(fused, two)
 
 
+@pytest.mark.parametrize("ss,W,H,n,distinct", [("420", 1920, 1080, 1024, 16), ("420", 1000, 700, 521, 7), ("444", 640, 480, 1021, 12), ("422", 800, 608, 1300, 10),
+                                                ("440", 512, 512, 700, 9), ("420", 1920, 1080, 1250, 5)])
+def test_fused_launch_row_major(dec, ss, W, H, n, distinct, tune):
+    """Row-major plans (the strip worker runs on the transposed image): a fused launch's consumers take PIECES of MCU rows behind
+    the one producer wave that holds the row.  Against the two launches byte for byte (poisoned coefficient store, three
+    executes), the distinct files against the oracle, markers found on the host and on the GPU, 1..8 consumers."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    raws, files, prep = _fused_batch(ss, W, H, n, distinct, 88000 + W, layout=B.MJ_LAYOUT_ROWMAJOR)
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0"), ("MJ_HUFFMAN", "lanes")])
+    assert not st2.any() and not form2 & B.MJ_FORM_FUSED
+    per = W * H * 3
+    imgs = two.view(n, per)
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        i = next(k for k in range(n) if (5 * k + k // distinct) % distinct == d)
+        assert np.array_equal(np.swapaxes(imgs[i].cpu().numpy().reshape(H, W, 3), 0, 1), want), d
+    for cons in (None, "1", "5"):
+        opts = [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED_CONSUMERS", cons)] if cons else [])
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, opts)
+        assert form & B.MJ_FORM_FUSED, (form, cons)
+        assert not st.any() and torch.equal(fused, two), cons
+    _, _, prep_g = _fused_batch(ss, W, H, n, distinct, 88000 + W, gpu_segment=True, layout=B.MJ_LAYOUT_ROWMAJOR)
+    fused, st, form = _decode_plan(dec.ctx, prep_g, n, torch, [("MJ_HUFFMAN", "lanes")])
+    assert form & B.MJ_FORM_FUSED and not st.any() and torch.equal(fused, two)
+
+
 def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
     """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): a restart interval that is not
-    one MCU row, row-major pixels, seam outputs, the exact-order stage 2, restart segments of very different lengths (dealt out
+    one MCU row, planar pixels, seam outputs, the exact-order stage 2, restart segments of very different lengths (dealt out
     by length), MJ_FUSED=0 — and whatever it is, the pixels are the oracle's."""
     torch = pytest.importorskip("torch")
     from oracle import oracle
     from pyjpegdecoder_amd import _binding as B
     W, H, n, distinct = 640, 480, 800, 5
-    for kind in ("half_rows", "two_rows", "rowmajor", "seams", "exact", "off"):
+    for kind in ("half_rows", "two_rows", "planar", "seams", "exact", "off"):
         ri = {"half_rows": 20, "two_rows": 80}.get(kind)
-        layout = B.MJ_LAYOUT_ROWMAJOR if kind == "rowmajor" else None
+        layout = B.MJ_LAYOUT_PLANAR_XMAJOR if kind == "planar" else None
         flags = {"seams": B.MJ_FLAG_KEEP_IDCT, "exact": B.MJ_FLAG_EXACT_ONLY}.get(kind, 0)
         raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000, ri=ri, layout=layout, flags=flags)
         out, st, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED", "0")] if kind == "off" else []))
@@ -1960,7 +1986,7 @@ def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
         assert not st.any()
         got = out[:W * H * 3].cpu().numpy()
         want = oracle.decode(files[0])["rgb"]
-        got = np.swapaxes(got.reshape(H, W, 3), 0, 1) if kind == "rowmajor" else got.reshape(W, H, 3)
+        got = np.moveaxis(got.reshape(3, W, H), 0, 2) if kind == "planar" else got.reshape(W, H, 3)
         assert np.array_equal(got, want), kind
     raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000)
     _, _, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")])

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--segment", default="host", choices=["host", "gpu"])
+    ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--mixed", action="store_true", help="files of mixed content (bench.py's mixed_content family)")
     ap.add_argument("--lib", default=None, help="another build of the library (pyjpegdecoder_amd/libmijpeg_diag.so + MJ_DEBUG_FUSED=1: phase times)")
     ap.add_argument("exps", nargs="*", default=[""])
@@ -42,10 +43,11 @@ def main():
         blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, mcus_per_row)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(args.distinct)]
     files = [raws[i % args.distinct] for i in range(args.batch)]
+    layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
     if args.segment == "gpu":
-        prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0, [parse_jpeg(f, headers_only=True) for f in files])
+        prep = prepare_batch(files, layout, 0, [parse_jpeg(f, headers_only=True) for f in files])
     else:
-        prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+        prep = prepare_batch(files, layout, 0)
     ctx = B.Context(0)
     d_blob = torch.from_numpy(prep.blob).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
