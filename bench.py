@@ -240,6 +240,10 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         s1, s2 = plan.time_stages(5, d_rgb.data_ptr())
+        fused = bool(plan.stage1_form() & B.MJ_FORM_FUSED)
+        front, main = plan.time_execute(5, d_rgb.data_ptr()) if fused else (None, None)
+        plan.execute(stream, d_rgb.data_ptr())
+        torch.cuda.synchronize()
         ok = not plan.read(rgb=False)["status"].any()
         per = W * H * 3
         sizes = [len(r) for r in raws]
@@ -253,13 +257,16 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
         plan.close()
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 3),
             "stage01_ms": round(s1, 3), "stage2_ms": round(s2, 3), "vs_headline_ms_per_step": round(dt * 1e3 / headline_ms, 3),
+            "fused_launch": fused, "stage0_ms": None if front is None else round(front, 3), "fused_ms": None if main is None else round(main, 3),
             "workload": f"{n_images} x 1920x1080 4:2:0 baseline JPEG, DRI=120, {n_distinct} distinct files of mixed content "
                         "(quality 50..95, noise sigma 0..80 above / below a random split row)",
             "file_bytes": {"min": int(min(sizes)), "mean": int(sum(sizes) // len(sizes)), "max": int(max(sizes))},
             "restart_segment_bytes": {"mean": int(seg_len.mean()), "max": int(seg_len.max())},
             "parity": "bit-exact vs oracle (smallest and largest file)" if ok else "MISMATCH",
             "note": "stage 1 = one restart segment per lane: its launch lasts as long as the longest segment's serial walk, whatever "
-                    "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3)"}
+                    "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3); "
+                    "the step is ONE fused launch whose consumers take jobs from one pool across workgroups (stage01_ms / stage2_ms: the "
+                    "same plan's stages launched separately)"}
 
 
 def idct_only_side(ctx, dev, torch, n_images: int = 256):

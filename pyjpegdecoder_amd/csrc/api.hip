@@ -103,7 +103,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -339,12 +339,14 @@ static int fused_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
 #endif
     MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
                                  p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->d_coef, p->d_status, a, p->hmax, p->vmax,
-                                 p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image));
+                                 p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
+                                 p->d_by_length, p->d_holder, p->d_xwords));
 #ifdef MJ_DIAGNOSTIC
     if (dbg_fused) {
         (void)hipStreamSynchronize(s);
-        fprintf(stderr, "[diag fused] shape: %d images per workgroup, %d producers x %d lanes, %d consumers beside them\n", p->fused.ipw, p->fused.n_prod, p->fused.lpw, p->fused.n_cons);
-        mj::dbg_fused_report(ctx->d_dump, (p->n_images + p->fused.ipw - 1) / p->fused.ipw);
+        fprintf(stderr, "[diag fused] shape: %d workgroups, %d images each (0 = segments dealt out by length), %d producers x %d lanes, %d consumers beside them\n",
+                p->fused.n_wg, p->fused.ipw, p->fused.n_prod, p->fused.lpw, p->fused.n_cons);
+        mj::dbg_fused_report(ctx->d_dump, p->fused.n_wg);
     }
 #endif
     return MJ_OK;
@@ -541,7 +543,8 @@ int mj_plan_time_execute(mj_plan *p, int iters, uint8_t *rgb_device, float *fron
     auto fused = [&]() -> int {
         MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
                                      p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->d_coef, p->d_status, a, p->hmax, p->vmax,
-                                     p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image));
+                                     p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
+                                 p->d_by_length, p->d_holder, p->d_xwords));
         return MJ_OK;
     };
     int rc = front();

@@ -114,13 +114,16 @@ struct FusedInputs {
     int restart_interval = 0, mcu_count_h = 0, mcu_count_v = 0, jobs_per_image = 0;
     int64_t n_segs = 0, n_images = 0;
 };
-inline bool fused_applies(const FusedInputs &f) {
+// 0 = the two launches; 1 = fused, whole images per workgroup (segments in blob order); 2 = fused with the segments dealt out
+// by length (seg_order_mode 2: files of mixed content) — one pool of jobs, hand-off across workgroups.
+inline int fused_applies(const FusedInputs &f) {
     // x-major: a stage-2 job is a whole MCU column (ready when every row of the image is past it); row-major (the strip worker
     // runs on the transposed image): pieces of an MCU row, fused.hip cuts them itself
     const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.jobs_per_image == f.mcu_count_h);
-    return f.lanes_resolved && f.seg_order_mode == 0 && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
-           (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && layout_ok &&
-           !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.n_segs == f.n_images * f.mcu_count_v;
+    const bool ok = f.lanes_resolved && (f.seg_order_mode == 0 || f.seg_order_mode == 2) && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
+                    (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && layout_ok &&
+                    !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.n_segs == f.n_images * f.mcu_count_v;
+    return !ok ? 0 : (f.seg_order_mode == 2 ? 2 : 1);
 }
 
 }  // namespace mj

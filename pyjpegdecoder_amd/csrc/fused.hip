@@ -32,6 +32,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "mijpeg_internal.h"
@@ -62,6 +63,11 @@ struct FusedArgs {
     // row-major plans (the strip worker runs on the transposed image: its "columns" are the MCU ROWS): a job is a PIECE of one
     // MCU row — `pieces` per row, each `piece_mcus` MCUs long (the last one shorter) —, ready when its row's wave is past it
     int32_t pieces, piece_mcus, mcus_per_row;
+    // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
+    // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
+    uint32_t *x_counter;
+    uint32_t *x_progress;
+    const int32_t *x_holder;
 };
 
 typedef uint32_t __attribute__((address_space(3))) *lds_word;
@@ -123,10 +129,76 @@ struct FusedSource {
     }
 };
 
+// The same when the restart segments are dealt out by length (files of mixed content: the lane launch's striped order): a
+// workgroup's producers then walk segments of images all over the batch, so the jobs are ONE pool for the whole launch — a
+// global ticket counter, column by column over all images (BY_ROWS: piece by piece over all rows) — and a job is ready when
+// the progress words (global memory) of the waves that hold its image's rows say so.  The hand-off across CUs and XCDs is
+// MI355X_MICROARCH.md's: write-through (sc1) coefficient stores, drained (s_waitcnt vmcnt(0)) before the wave's sc1 progress
+// store; the consumer polls with sc1 loads, then ONE agent-scope acquire (invalidates its CU's vector L1), then plain loads.
+// Every workgroup of the launch is resident at once (one per CU, grid = CUs): a producer never waits, so nobody waits for a
+// wave that has not started.
+template <bool BY_ROWS>
+struct FusedSourceX {
+    static constexpr bool kSingleJobs = true;
+    uint32_t *counter;
+    const uint32_t *progress;
+    const int32_t *holder;
+    uint32_t n_tickets, n_images, jobs_per_image, spi;
+    uint32_t pieces, piece_mcus, mcus_per_row;
+    int32_t *status;
+    int lane;
+    __device__ __forceinline__ uint32_t draw() const {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
+    __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
+        if constexpr (BY_ROWS) {
+            const uint32_t rows = n_images * spi, pc = ticket / rows, rr = ticket - pc * rows, img = rr / spi, row = rr - img * spi;
+            return img * jobs_per_image + row * pieces + pc;
+        } else {
+            const uint32_t m = ticket / n_images, img = ticket - m * n_images;
+            return img * jobs_per_image + m;
+        }
+    }
+    __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
+    __device__ __forceinline__ bool ready(uint32_t job) const {
+        const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image;
+        bool behind = false;               // some row of the image (BY_ROWS: the job's row) is not past what the job needs
+        if constexpr (BY_ROWS) {
+            const uint32_t row = m / pieces, pc = m - row * pieces;
+            const uint32_t p = __hip_atomic_load(progress + holder[img * spi + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            behind = p < min((pc + 1u) * piece_mcus, mcus_per_row);
+        } else {
+            for (uint32_t r0 = 0; r0 < spi; r0 += 64u) {
+                const uint32_t row = r0 + (uint32_t)lane;
+                if (row < spi) {
+                    const uint32_t p = __hip_atomic_load(progress + holder[img * spi + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    behind = behind || p <= m;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(behind) != 0) return false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return true;
+    }
+    __device__ __forceinline__ void wait_ready(uint32_t job) const {
+        for (uint32_t spins = 0; !ready(job); ++spins) {
+            __builtin_amdgcn_s_sleep(16);
+            if (spins > (1u << 15)) {
+                if (lane == 0) atomicMax(status + job / jobs_per_image, MJ_ST_INTERNAL);
+                break;
+            }
+        }
+    }
+};
+
 }  // namespace
 
 // HS, VS: the sampling factors the strip worker sees (swapped for T, the transposed problem of row-major plans)
-template <int HS, int VS, bool T>
+// XWG: restart segments dealt out by length (FusedSourceX)
+template <int HS, int VS, bool T, bool XWG>
 __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     using G = rfast::FGeo<HS, VS, 3>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -140,14 +212,23 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     rfast::fill_weights<HS, VS, 3, T>(wts, tid, kFusedThreads);
     __syncthreads();
 
-    FusedSource<T> src;
-    src.ctrl = lanes13::lds_addr(ctrl);
-    src.image0 = (uint32_t)blockIdx.x * (uint32_t)F.ipw;
-    src.images_here = min((uint32_t)F.ipw, (uint32_t)F.n_images - src.image0);
-    src.jobs_per_image = (uint32_t)F.jobs_per_image;
-    src.n_tickets = src.images_here * src.jobs_per_image;
+    typename std::conditional<XWG, FusedSourceX<T>, FusedSource<T>>::type src;
+    const uint32_t ctrl_lds = lanes13::lds_addr(ctrl);
+    uint32_t image0 = 0;
+    if constexpr (XWG) {
+        src.counter = F.x_counter; src.progress = F.x_progress; src.holder = F.x_holder;
+        src.n_images = (uint32_t)F.n_images;
+        src.jobs_per_image = (uint32_t)F.jobs_per_image;
+        src.n_tickets = src.n_images * src.jobs_per_image;
+    } else {
+        src.ctrl = ctrl_lds;
+        src.image0 = image0 = (uint32_t)blockIdx.x * (uint32_t)F.ipw;
+        src.images_here = min((uint32_t)F.ipw, (uint32_t)F.n_images - src.image0);
+        src.jobs_per_image = (uint32_t)F.jobs_per_image;
+        src.n_tickets = src.images_here * src.jobs_per_image;
+        src.lpw = (uint32_t)F.L.lpw;
+    }
     src.pieces = (uint32_t)F.pieces; src.piece_mcus = (uint32_t)F.piece_mcus; src.mcus_per_row = (uint32_t)F.mcus_per_row;
-    src.lpw = (uint32_t)F.L.lpw;
     src.spi = (uint32_t)F.spi;
     src.lane = lane;
     src.status = F.L.status;
@@ -158,14 +239,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
 #endif
     unsigned char *my_lds;
     if (wave < n_prod) {
-        lanes13::walk<true, kFusedAB>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
+        lanes13::walk<XWG ? 2 : 1, kFusedAB>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
         __builtin_amdgcn_s_setprio(0);
 #ifdef MJ_DIAGNOSTIC
         if (lane == 0) {
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             atomicMin(dbg + 1, t);
             atomicMax(dbg + 2, t);
-            atomicMax(dbg + 4, (unsigned long long)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)src.ctrl);
+            if constexpr (!XWG) atomicMax(dbg + 4, (unsigned long long)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)ctrl_lds);
         }
 #endif
         if (lane == 0) __hip_atomic_fetch_add((lds_word)(uintptr_t)lanes13::lds_addr(ctrl + 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -175,10 +256,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
         my_lds = smem + kFusedLds - kFusedCtrl - G::WTS_BYTES - (wave - n_prod + 1) * G::WAVE_BYTES;
     } else {
         // phase 2: once every producer is through (their tables and rows are where these strips go)
-        for (uint32_t spins = 0; (int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(src.ctrl + 4u) < n_prod; ++spins) {
+        for (uint32_t spins = 0; (int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl_lds + 4u) < n_prod; ++spins) {
             __builtin_amdgcn_s_sleep(16);
             if (spins > (1u << 18)) {         // (cannot happen: see FusedSource::wait_ready)
-                if (lane == 0) atomicMax(F.L.status + src.image0, MJ_ST_INTERNAL);
+                if (lane == 0) atomicMax(F.L.status + image0, MJ_ST_INTERNAL);
                 return;
             }
         }
@@ -216,6 +297,25 @@ void dbg_fused_clear(uint8_t *dump) {
 #endif
 
 
+// LDS budget of a fused launch with `n_prod` producer wavefronts of `lpw` lanes: how many consumers fit beside them
+static bool fused_budget(FusedShape &s, int n_ac, int n_dc, int hmax, int vmax, int want_consumers) {
+    size_t wave_bytes, wts_bytes;
+    if (hmax == 2 && vmax == 2) { wave_bytes = rfast::FGeo<2, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 2, 3>::WTS_BYTES; }
+    else if (hmax == 2 && vmax == 1) { wave_bytes = rfast::FGeo<2, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 1, 3>::WTS_BYTES; }
+    else if (hmax == 1 && vmax == 2) { wave_bytes = rfast::FGeo<1, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 2, 3>::WTS_BYTES; }
+    else if (hmax == 1 && vmax == 1) { wave_bytes = rfast::FGeo<1, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 1, 3>::WTS_BYTES; }
+    else return false;
+    const size_t prod = lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits);
+    const size_t top = (size_t)kFusedLds - kFusedCtrl - wts_bytes;
+    if (prod > top) return false;
+    const int waves = kFusedThreads / 64;
+    int fit = (int)((top - prod) / wave_bytes);
+    fit = std::min(fit, waves - s.n_prod);
+    s.n_cons = std::max(0, std::min(fit, want_consumers));
+    if ((size_t)waves * wave_bytes > top) return false;      // phase 2: every wave a strip
+    return s.n_cons >= 1;
+}
+
 // How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
 FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
     FusedShape s{};
@@ -229,21 +329,28 @@ FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax,
     s.ring = 64;
     s.ac_slot_bytes = ac_slot_bytes;
     s.dbits = 8;                                                // (Annex K's DC codes of 9..11 bits — differences beyond +-255 in chroma, +-1023 in luma — take the canonical search)
-    size_t wave_bytes, wts_bytes;
-    if (hmax == 2 && vmax == 2) { wave_bytes = rfast::FGeo<2, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 2, 3>::WTS_BYTES; }
-    else if (hmax == 2 && vmax == 1) { wave_bytes = rfast::FGeo<2, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 1, 3>::WTS_BYTES; }
-    else if (hmax == 1 && vmax == 2) { wave_bytes = rfast::FGeo<1, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 2, 3>::WTS_BYTES; }
-    else if (hmax == 1 && vmax == 1) { wave_bytes = rfast::FGeo<1, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 1, 3>::WTS_BYTES; }
-    else return s;
-    const size_t prod = lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits);
-    const size_t top = (size_t)kFusedLds - kFusedCtrl - wts_bytes;
-    if (prod > top) return s;
-    const int waves = kFusedThreads / 64;
-    int fit = (int)((top - prod) / wave_bytes);
-    fit = std::min(fit, waves - s.n_prod);
-    s.n_cons = std::max(0, std::min(fit, want_consumers));
-    if ((size_t)(waves - s.n_cons) * wave_bytes + (size_t)s.n_cons * wave_bytes > top) return s;      // phase 2: every wave a strip
-    s.ok = s.n_cons >= 1;
+    s.n_wg = (n_images + s.ipw - 1) / s.ipw;
+    s.ok = fused_budget(s, n_ac, n_dc, hmax, vmax, want_consumers);
+    return s;
+}
+
+// ... with the restart segments dealt out by length (MODE 2 of the walk): no whole images per workgroup — one workgroup per CU,
+// the segments spread over all their producer wavefronts.
+FusedShape fused_shape_x(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers) {
+    FusedShape s{};
+    if (transposed) std::swap(hmax, vmax);
+    if (n_segs < 1 || cus < 1) return s;
+    const int64_t per_wg = (n_segs + cus - 1) / cus;
+    if (per_wg > 8 * 64) return s;
+    s.n_prod = (int)std::min<int64_t>(8, std::max<int64_t>(1, (per_wg + 33) / 34));
+    s.lpw = (int)((n_segs + (int64_t)cus * s.n_prod - 1) / ((int64_t)cus * s.n_prod));
+    s.ring = 64;
+    s.ac_slot_bytes = ac_slot_bytes;
+    s.dbits = 8;
+    s.xwg = true;
+    s.n_wg = cus;
+    s.ipw = 0;
+    s.ok = fused_budget(s, n_ac, n_dc, hmax, vmax, want_consumers);
     return s;
 }
 
@@ -264,11 +371,12 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                         int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
                         const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
-                        int64_t total_jobs, int jobs_per_image) {
+                        int64_t total_jobs, int jobs_per_image, const int32_t *by_length, const int32_t *holder, uint32_t *x_words) {
     if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
+    if (shape.xwg && (!by_length || !holder || !x_words)) return hipErrorInvalidValue;
     FusedArgs F{};
     F.L = lanes13::Args{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                        coef, status, shape.lpw, transposed ? 1 : 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi};
+                        coef, status, shape.lpw, transposed ? 1 : 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi, nullptr};
     F.R = a;
     F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
     F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;
@@ -286,7 +394,17 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         F.jobs_per_image = spi * F.pieces;
         F.total_jobs = (int64_t)a.n_images * F.jobs_per_image;
     }
-    const unsigned blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
+    unsigned blocks = 0;
+    if (shape.xwg) {
+        // the ticket counter (a line of its own) and the producers' progress words start from zero
+        const int64_t words = 32 + (int64_t)shape.n_wg * shape.n_prod;
+        if (hipError_t e = launch_fill_words(stream, x_words, 0u, words); e != hipSuccess) return e;
+        F.x_counter = x_words; F.x_progress = x_words + 32; F.x_holder = holder;
+        F.L.by_length = by_length; F.L.order_mode = 2; F.L.progress_global = F.x_progress;
+        blocks = (unsigned)shape.n_wg;
+    } else {
+        blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
+    }
     auto go = [&](auto kernel) {
         static bool attr_set[kMaxDevices] = {false};
         if (!attr_set[current_device()]) {
@@ -295,19 +413,21 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFusedThreads), kFusedLds, stream, F);
     };
+#define MJ_GO(H, V, TT) do { if (shape.xwg) go(k_fused<H, V, TT, true>); else go(k_fused<H, V, TT, false>); } while (0)
     if (!transposed) {
-        if (hmax == 2 && vmax == 2) go(k_fused<2, 2, false>);
-        else if (hmax == 2 && vmax == 1) go(k_fused<2, 1, false>);
-        else if (hmax == 1 && vmax == 2) go(k_fused<1, 2, false>);
-        else if (hmax == 1 && vmax == 1) go(k_fused<1, 1, false>);
+        if (hmax == 2 && vmax == 2) MJ_GO(2, 2, false);
+        else if (hmax == 2 && vmax == 1) MJ_GO(2, 1, false);
+        else if (hmax == 1 && vmax == 2) MJ_GO(1, 2, false);
+        else if (hmax == 1 && vmax == 1) MJ_GO(1, 1, false);
         else return hipErrorInvalidValue;
     } else {
-        if (hmax == 2 && vmax == 2) go(k_fused<2, 2, true>);
-        else if (hmax == 2 && vmax == 1) go(k_fused<1, 2, true>);
-        else if (hmax == 1 && vmax == 2) go(k_fused<2, 1, true>);
-        else if (hmax == 1 && vmax == 1) go(k_fused<1, 1, true>);
+        if (hmax == 2 && vmax == 2) MJ_GO(2, 2, true);
+        else if (hmax == 2 && vmax == 1) MJ_GO(1, 2, true);
+        else if (hmax == 1 && vmax == 2) MJ_GO(2, 1, true);
+        else if (hmax == 1 && vmax == 1) MJ_GO(1, 1, true);
         else return hipErrorInvalidValue;
     }
+#undef MJ_GO
     return hipGetLastError();
 }
 

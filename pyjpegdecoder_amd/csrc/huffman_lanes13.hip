@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(lanes13::Args A) {
     const int nw = (int)(blockDim.x >> 6);
     lanes13::stage<false>(A, smem, tid, (int)blockDim.x, nw);
     __syncthreads();
-    lanes13::walk<false>(A, smem, lane, wave, nw, (int)blockIdx.x, (int)gridDim.x, 0u);
+    lanes13::walk<0>(A, smem, lane, wave, nw, (int)blockIdx.x, (int)gridDim.x, 0u);
 }
 
 // LDS bytes of a launch with `nw` waves of `lpw` lanes
@@ -116,7 +116,7 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
         attr_set[current_device()] = true;
     }
     lanes13::Args A{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                    coef, status, lpw, transposed, vsegs, by_length, order_mode, ring, kLanes13SlotBytes, kLaneLutBits, 0};
+                    coef, status, lpw, transposed, vsegs, by_length, order_mode, ring, kLanes13SlotBytes, kLaneLutBits, 0, nullptr};
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, A);
 #ifdef MJ_X_STAMP
     if (getenv("MJ_X_REPORT")) {

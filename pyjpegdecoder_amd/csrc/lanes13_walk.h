@@ -83,6 +83,8 @@ struct Args {
     // fused.hip only: restart segments per workgroup (whole images: no multiple of the waves' lanes in general — the last
     // lanes of a workgroup's last wave then have no segment)
     int wg_segs;
+    // fused.hip, segments dealt out by length (MODE 2): a wave's progress word in global memory, at [workgroup * waves + wave]
+    uint32_t *progress_global;
 };
 
 // LDS bytes of `nw` waves of `lpw` lanes: tables, block rows, block addresses, stream windows — in this order from `smem`
@@ -118,11 +120,14 @@ __device__ __forceinline__ void stage(const Args &A, unsigned char *smem, int ti
     for (int i = tid; i < nw * wstride; i += nthreads) reinterpret_cast<uint32_t *>(rows0)[i] = 0;
 }
 
-// One wavefront's walk: wave `wave` of the `nw` of workgroup `wg` (of `n_wg`).  FUSED: the wave reports, in the LDS word at
-// `progress_addr`, how many MCUs of its lanes' segments are complete in memory (see the hook behind the AC loop).
+// One wavefront's walk: wave `wave` of the `nw` of workgroup `wg` (of `n_wg`).  MODE 0: the stage-1 kernel.  MODE 1 (fused.hip,
+// whole images per workgroup): the wave reports, in the LDS word at `progress_addr`, how many MCUs of its lanes' segments are
+// complete in memory (see the hook behind the AC loop).  MODE 2 (fused.hip, segments dealt out by length — any workgroup's
+// consumers may need this wave's blocks): the coefficient stores are write-through (sc1) and the report goes to
+// A.progress_global with an sc1 store — MI355X_MICROARCH.md's "sc1 stores, drained, then an sc1 flag" hand-off.
 // AB: index bits of the AC tables' main level (13; fused.hip: 12 — half the LDS, 1.5 % of the symbols instead of 0.4 % then take
 // the arithmetic step); their second-level tables have 2^(16 - AB) entries
-template <bool FUSED, int AB = 13>
+template <int MODE, int AB = 13>
 __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const int lane, const int wave, const int nw, const int wg, const int n_wg,
                                      const uint32_t progress_addr) {
     const uint32_t *__restrict__ stream = A.stream;
@@ -142,6 +147,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
 #ifdef MJ_DIAGNOSTIC
     const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    constexpr bool FUSED = MODE != 0;
     static_assert(FUSED || AB == 13, "the stage-1 kernel's tables are the 13-bit ones");
     const int aslot = FUSED ? A.ac_slot_bytes : kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
     uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][aslot / 4]
@@ -160,12 +166,12 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     // lengths the host knows), mode 2 deals the list out one segment per wave and round, so that the long ones sit in
     // different waves, each beside short ones: a wave is as slow as the lock-step of its lanes, and a lane with a long
     // segment mostly sets its wave's pace alone.  Mode 1 (neighbours of the list share a wave) is there to be measured.
-    int64_t seg_id = FUSED ? (int64_t)wg * A.wg_segs + wave * lpw + lane : ((int64_t)wg * nw + wave) * lpw + lane;
+    int64_t seg_id = MODE == 1 ? (int64_t)wg * A.wg_segs + wave * lpw + lane : ((int64_t)wg * nw + wave) * lpw + lane;
     if (by_length) {
         const int64_t n_waves = (int64_t)n_wg * nw, rank = order_mode == 2 ? (int64_t)lane * n_waves + ((int64_t)wg * nw + wave) : seg_id;
         seg_id = (lane < lpw && rank < n_segs) ? by_length[rank] : n_segs;
     }
-    const bool have = lane < lpw && seg_id < n_segs && (!FUSED || wave * lpw + lane < A.wg_segs);
+    const bool have = lane < lpw && seg_id < n_segs && (MODE != 1 || wave * lpw + lane < A.wg_segs);
     DevSegment sg = segs[(have && !vsegs) ? seg_id : 0];
     DevVSeg vs{};
     if (vsegs) {
@@ -597,7 +603,10 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 // and then the blocks through the same CU's vector cache: workgroup scope, nothing to invalidate.
                 if (b == 0) {
                     uint32_t t_prog;
-                    asm volatile("v_mov_b32 %0, %1\n\tds_write_b32 %2, %0" : "=&v"(t_prog) : "s"((uint32_t)m), "v"(progress_addr) : "memory");
+                    if constexpr (MODE == 1)
+                        asm volatile("v_mov_b32 %0, %1\n\tds_write_b32 %2, %0" : "=&v"(t_prog) : "s"((uint32_t)m), "v"(progress_addr) : "memory");
+                    else        // (write-through stores that have been waited for are in memory: the flag may follow)
+                        asm volatile("v_mov_b32 %0, %1\n\tglobal_store_dword %2, %0, off sc1" : "=&v"(t_prog) : "s"((uint32_t)m), "v"(A.progress_global + (wg * nw + wave)) : "memory");
                 }
             }
             {
@@ -634,7 +643,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 // LDS, one 16-byte store per lane
                 u32x4 fd, fh;
                 uint64_t fad;
-#define MJ_FLUSH8(it) \
+#define MJ_FLUSH8(it, SC) \
     "s_sub_u32 s42, %[lpw], " #it "*8\n\t"                                   \
     "v_cmpx_gt_u32 s42, %[fslot]\n\t"                                      \
     "ds_read_u16 v10, %[fa0] offset:" #it "*1056\n\t"                      \
@@ -652,17 +661,21 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     "v_lshl_or_b32 v12, v18, 16, v12\n\t"                                  \
     "v_lshl_or_b32 v13, v19, 16, v13\n\t"                                  \
     "v_lshl_add_u64 v[14:15], v[14:15], 0, %[dst]\n\t"                     \
-    "global_store_dwordx4 v[14:15], v[10:13], off\n\t"
-#define MJ_FLUSH_MORE(it) "s_cmp_le_u32 %[lpw], " #it "*8\n\ts_cbranch_scc1 L_fend%=\n\t" MJ_FLUSH8(it)
-                asm volatile(
-                    "s_mov_b64 s[40:41], exec\n\t"
-                    MJ_FLUSH8(0) MJ_FLUSH_MORE(1) MJ_FLUSH_MORE(2) MJ_FLUSH_MORE(3) MJ_FLUSH_MORE(4) MJ_FLUSH_MORE(5) MJ_FLUSH_MORE(6) MJ_FLUSH_MORE(7)
-                    "L_fend%=:\n\t"
-                    "s_mov_b64 exec, s[40:41]\n\t"
-                    : "=&{v[10:13]}"(fd), "=&{v[14:15]}"(fad), "=&{v[16:19]}"(fh)
-                    : [lpw] "s"(lpw), [fslot] "v"(fslot), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]), [fa3] "v"(fa[3]), [fa4] "v"(fa[4]),
-                      [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7]), [fb] "v"(fb_addr), [dst] "v"((uint64_t)(uintptr_t)dst0)
-                    : "memory", "vcc", "scc", "s40", "s41", "s42");
+    "global_store_dwordx4 v[14:15], v[10:13], off" SC "\n\t"
+#define MJ_FLUSH_MORE(it, SC) "s_cmp_le_u32 %[lpw], " #it "*8\n\ts_cbranch_scc1 L_fend%=\n\t" MJ_FLUSH8(it, SC)
+#define MJ_FLUSH_ALL(SC) \
+                asm volatile(                                                                                                                   \
+                    "s_mov_b64 s[40:41], exec\n\t"                                                                                               \
+                    MJ_FLUSH8(0, SC) MJ_FLUSH_MORE(1, SC) MJ_FLUSH_MORE(2, SC) MJ_FLUSH_MORE(3, SC) MJ_FLUSH_MORE(4, SC) MJ_FLUSH_MORE(5, SC)     \
+                    MJ_FLUSH_MORE(6, SC) MJ_FLUSH_MORE(7, SC)                                                                                   \
+                    "L_fend%=:\n\t"                                                                                                              \
+                    "s_mov_b64 exec, s[40:41]\n\t"                                                                                               \
+                    : "=&{v[10:13]}"(fd), "=&{v[14:15]}"(fad), "=&{v[16:19]}"(fh)                                                               \
+                    : [lpw] "s"(lpw), [fslot] "v"(fslot), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]), [fa3] "v"(fa[3]), [fa4] "v"(fa[4]), \
+                      [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7]), [fb] "v"(fb_addr), [dst] "v"((uint64_t)(uintptr_t)dst0)            \
+                    : "memory", "vcc", "scc", "s40", "s41", "s42")
+                if constexpr (MODE == 2) { MJ_FLUSH_ALL(" sc1"); } else { MJ_FLUSH_ALL(""); }
+#undef MJ_FLUSH_ALL
 #undef MJ_FLUSH8
 #undef MJ_FLUSH_MORE
             } else
@@ -676,7 +689,14 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 v.z = rd(4) | (rd(5) << 16);
                 v.w = rd(6) | (rd(7) << 16);
                 const int o = it * 8 + fslot;
-                if ((act_mask >> o) & 1) *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
+                if ((act_mask >> o) & 1) {
+                    if constexpr (MODE == 2) {
+                        const u32x4 vv = {v.x, v.y, v.z, v.w};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst0 + s_base[o]), "v"(vv) : "memory");
+                    } else {
+                        *reinterpret_cast<uint4 *>(dst0 + s_base[o]) = v;
+                    }
+                }
             }
             for (int i = lane; i < wstride / 4; i += 64) reinterpret_cast<uint4 *>(s_blk)[i] = make_uint4(0, 0, 0, 0);
 #ifdef MJ_X_STAMP
@@ -714,7 +734,11 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     }
     if constexpr (FUSED) {      // the last MCU's blocks: in memory before the wave says "everything"
         uint32_t t_prog;
-        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tds_write_b32 %1, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog) : "v"(progress_addr) : "memory");
+        if constexpr (MODE == 1)
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tds_write_b32 %1, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog) : "v"(progress_addr) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tglobal_store_dword %1, %0, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t_prog)
+                         : "v"(A.progress_global + (wg * nw + wave)) : "memory");
     }
 }
 

@@ -180,6 +180,8 @@ struct mj_plan {
     bool use_fused = false;
     mj::FusedShape fused{};
     int fused_spi = 0;                  // restart segments (= MCU rows) per image
+    int32_t *d_holder = nullptr;        // fused, segments dealt out by length: per segment, the progress word of the wave that walks it
+    uint32_t *d_xwords = nullptr;       // ... the launch's ticket counter (32 words: a line of its own) and the progress words
     // progressive batches: scans grouped by dependency level, one launch per level
     bool progressive = false;
     mj::DevProgScan *d_pscans = nullptr;

@@ -775,6 +775,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 p->use_sync = true;
             }
         }
+        std::vector<int32_t> by_length_order;      // restart segments, longest first (seg_order_mode != 0)
         if (p->use_lanes && !p->use_sync && p->d_lut13 && jobs.empty() && segs.size() > 1) {
             // the lane form deals restart segments out by length (huffman_lanes13.hip); MJ_SEG_ORDER = blob | binned | striped (tests, measurements)
             const char *e = mj::opt("MJ_SEG_ORDER");
@@ -783,7 +784,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             const bool spread = mj::spread_lengths(seg_len.data(), (int64_t)seg_len.size());
             p->seg_order_mode = (e && !strcmp(e, "blob")) ? 0 : ((e && !strcmp(e, "binned")) ? 1 : ((e && !strcmp(e, "striped")) || spread ? 2 : 0));
             if (p->seg_order_mode) {
-                std::vector<int32_t> ord(segs.size());
+                std::vector<int32_t> &ord = by_length_order;
+                ord.resize(segs.size());
                 for (size_t i = 0; i < segs.size(); ++i) ord[i] = (int32_t)i;
                 std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return segs[x].len > segs[y].len; });
                 if ((rc = upload(ctx, &p->d_by_length, ord.data(), ord.size())) != MJ_OK) return rc;
@@ -794,10 +796,10 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
             // x-major pixels, no seam outputs, a stage-2 job = a whole MCU column, and LDS left for at least one consumer
             // wavefront beside the producers.  MJ_FUSED=0 keeps the two launches; MJ_FUSED_CONSUMERS bounds the consumers.
-            int want_cons = 8;
+            int want_cons = 8, want_cons_x = 4;
             bool allow = true;
             if (const char *e = mj::opt("MJ_FUSED")) allow = atoi(e) != 0;
-            if (const char *e = mj::opt("MJ_FUSED_CONSUMERS")) want_cons = atoi(e);
+            if (const char *e = mj::opt("MJ_FUSED_CONSUMERS")) want_cons = want_cons_x = atoi(e);
             const mj::DevImage &i0 = imgs[0];
             mj::FusedInputs fi;
             fi.lanes_resolved = p->use_lanes && !p->use_sync && p->d_lut13 && p->d_lut12;
@@ -806,14 +808,30 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             fi.flags = p->flags; fi.seam_or_exact_flags = MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT;
             fi.restart_interval = i0.restart_interval; fi.mcu_count_h = i0.mcu_count_h; fi.mcu_count_v = i0.mcu_count_v;
             fi.jobs_per_image = p->jobs_per_image; fi.n_segs = (int64_t)segs.size(); fi.n_images = b->n_images;
-            // (not for restart segments of very different lengths, which the lane launch deals out by length — seg_order_mode:
-            // a fused launch walks them in blob order, whole images per workgroup, and its longest wave then sets the pace of
-            // everything; measured on bench.py's mixed content: 11.3 ms fused against 10.6 as two launches)
-            const bool shape_ok = mj::fused_applies(fi);
-            if (allow && want_cons > 0 && shape_ok && p->d_lut12) {
+            // Restart segments of very different lengths (dealt out by length, seg_order_mode 2: files of mixed content) in
+            // blob order — whole images per workgroup — would let the longest wave set the pace of everything (bench.py's mixed
+            // content: 11.3 ms fused that way against 10.6 as two launches): they keep their order, and the fused launch's
+            // consumers take their jobs from ONE pool, handed over across workgroups (mode 2).
+            const int mode = mj::fused_applies(fi);
+            if (allow && want_cons > 0 && mode == 1 && p->d_lut12) {
                 p->fused = mj::fused_shape(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, p->transposed, b->n_images, i0.mcu_count_v, want_cons);
                 p->fused_spi = i0.mcu_count_v;
                 p->use_fused = p->fused.ok;
+            } else if (allow && want_cons_x > 0 && mode == 2 && p->d_lut12 && p->d_by_length) {
+                // (four consumers, not eight: with segments of very different lengths the launch lasts as long as its longest
+                // wave's walk, and every consumer beside it slows that walk — bench.py's mixed content, launch: 2 consumers
+                // 9.4 ms, 3: 8.8, 4: 8.2, 5: 8.2, 6: 8.3, 8: 9.8; the two launches 10.2)
+                p->fused = mj::fused_shape_x(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, p->transposed, (int64_t)segs.size(), want_cons_x);
+                p->fused_spi = i0.mcu_count_v;
+                if (p->fused.ok) {
+                    // which progress word a segment's wave reports to: the walk deals rank r of the sorted list to wave r mod waves
+                    const int64_t n_waves = (int64_t)p->fused.n_wg * p->fused.n_prod;
+                    std::vector<int32_t> holder(segs.size());
+                    for (size_t r = 0; r < by_length_order.size(); ++r) holder[(size_t)by_length_order[r]] = (int32_t)((int64_t)r % n_waves);
+                    if ((rc = upload(ctx, &p->d_holder, holder.data(), holder.size())) != MJ_OK) return rc;
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_xwords, (size_t)(32 + n_waves) * sizeof(uint32_t)));
+                    p->use_fused = true;
+                }
             }
         }
         if ((rc = upload(ctx, &p->d_segs, segs.data(), segs.size())) != MJ_OK) return rc;

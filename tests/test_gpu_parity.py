@@ -1968,6 +1968,41 @@ def test_fused_launch_row_major(dec, ss, W, H, n, distinct, tune):
     assert form & B.MJ_FORM_FUSED and not st.any() and torch.equal(fused, two)
 
 
+@pytest.mark.parametrize("layout", ["xmajor", "rowmajor"])
+@pytest.mark.parametrize("W,H,n,distinct", [(1920, 1080, 1024, 32), (640, 480, 1021, 16)])
+def test_fused_launch_segments_dealt_out_by_length(dec, W, H, n, distinct, layout, tune):
+    """Files of MIXED content (restart segments that differ several-fold in length: the lane launch deals them out by length)
+    through the fused launch's second form: one pool of jobs for the whole launch, the hand-off across workgroups and XCDs
+    (write-through coefficient stores, progress words in global memory, an agent-scope acquire on the reading side).  Against
+    the two launches byte for byte — coefficient store poisoned before each of three executes —, every distinct file against
+    the oracle, 1..8 consumers."""
+    torch = pytest.importorskip("torch")
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    blob, offs = synth.synth_mixed_batch(distinct, 313100 + W, W, H, "420", (W + 15) // 16)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
+    files = [raws[(5 * i + i // distinct) % distinct] for i in range(n)]
+    lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    prep = prepare_batch(files, lay, 0)
+    base = [("MJ_HUFFMAN", "lanes"), ("MJ_SEG_ORDER", "striped")]
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, base + [("MJ_FUSED", "0")])
+    assert not st2.any() and not form2 & B.MJ_FORM_FUSED
+    per = W * H * 3
+    imgs = two.view(n, per)
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        i = next(k for k in range(n) if (5 * k + k // distinct) % distinct == d)
+        got = imgs[i].cpu().numpy()
+        got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
+        assert np.array_equal(got, want), d
+    for cons in (None, "1", "4"):
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, base + ([("MJ_FUSED_CONSUMERS", cons)] if cons else []))
+        assert form & B.MJ_FORM_FUSED, (form, cons)
+        assert not st.any(), np.unique(st)
+        differ = (fused.view(n, per) != imgs).any(dim=1).nonzero().flatten().tolist()
+        assert not differ, (cons, len(differ), differ[:10])
+
+
 def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
     """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): a restart interval that is not
     one MCU row, planar pixels, seam outputs, the exact-order stage 2, restart segments of very different lengths (dealt out
