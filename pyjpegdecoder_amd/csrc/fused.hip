@@ -65,9 +65,11 @@ struct FusedArgs {
     int32_t pieces, piece_mcus, mcus_per_row;
     // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
     // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
-    uint32_t *x_counter;
+    uint32_t *x_counter;                   // [0] tickets, [1] jobs given up, [2] the clean-up launch's tickets
     uint32_t *x_progress;
     const int32_t *x_holder;
+    uint32_t *x_left;                      // the jobs given up
+    int32_t x_patience;                    // polls (~2.5 us each) before a consumer gives a job up: 2000, MJ_FUSED_PATIENCE
 };
 
 typedef uint32_t __attribute__((address_space(3))) *lds_word;
@@ -118,7 +120,7 @@ struct FusedSource {
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > m;
     }
     // (bounded: ~0.3 s of sleeps; a producer never waits for anything, so the bound only guards the GPU against a defect here)
-    __device__ __forceinline__ void wait_ready(uint32_t job) const {
+    __device__ __forceinline__ bool wait_ready(uint32_t job) const {
         for (uint32_t spins = 0; !ready(job); ++spins) {
             __builtin_amdgcn_s_sleep(8);
             if (spins > (1u << 16)) {
@@ -126,6 +128,7 @@ struct FusedSource {
                 break;
             }
         }
+        return true;
     }
 };
 
@@ -145,6 +148,8 @@ struct FusedSourceX {
     const int32_t *holder;
     uint32_t n_tickets, n_images, jobs_per_image, spi;
     uint32_t pieces, piece_mcus, mcus_per_row;
+    uint32_t *left_count, *left_list;      // jobs given up: the clean-up launch's work
+    uint32_t patience;                     // polls before a job is given up
     int32_t *status;
     int lane;
     __device__ __forceinline__ uint32_t draw() const {
@@ -183,14 +188,22 @@ struct FusedSourceX {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         return true;
     }
-    __device__ __forceinline__ void wait_ready(uint32_t job) const {
+    // A job whose rows are walked by a workgroup that has NOT STARTED cannot become ready while this wave waits for it: every
+    // workgroup of the launch is resident at once only when the chip is the launch's alone, and another plan's kernel on
+    // another stream may hold CUs.  So the wait is bounded (~5 ms: beyond any wait between resident workgroups — a consumer
+    // that reaches the last columns of the batch's slowest image waits ~2 ms for them), and a job not ready by then is GIVEN UP:
+    // put on the list the clean-up launch behind this one works off (k_recon_leftover: by then every block is in memory), and
+    // the wave stops consuming — the tickets nobody draws are the clean-up launch's too.  Every wave therefore ends, resident
+    // or not, after one bounded wait at most.
+    __device__ __forceinline__ bool wait_ready(uint32_t job) const {
         for (uint32_t spins = 0; !ready(job); ++spins) {
             __builtin_amdgcn_s_sleep(16);
-            if (spins > (1u << 15)) {
-                if (lane == 0) atomicMax(status + job / jobs_per_image, MJ_ST_INTERNAL);
-                break;
+            if (spins >= patience) {
+                if (lane == 0) left_list[__hip_atomic_fetch_add(left_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = job;
+                return false;
             }
         }
+        return true;
     }
 };
 
@@ -217,6 +230,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     uint32_t image0 = 0;
     if constexpr (XWG) {
         src.counter = F.x_counter; src.progress = F.x_progress; src.holder = F.x_holder;
+        src.left_count = F.x_counter + 1; src.left_list = F.x_left; src.patience = (uint32_t)F.x_patience;
         src.n_images = (uint32_t)F.n_images;
         src.jobs_per_image = (uint32_t)F.jobs_per_image;
         src.n_tickets = src.n_images * src.jobs_per_image;
@@ -296,6 +310,55 @@ void dbg_fused_clear(uint8_t *dump) {
 }
 #endif
 
+
+// What a fused launch's consumers left undone (FusedSourceX::wait_ready): the jobs they gave up — a list — and the tickets
+// nobody drew after that.  The stage-2 kernel's geometry (four waves per workgroup, a strip each); nothing to do — the usual case —
+// costs a launch of workgroups that leave at once.
+template <bool BY_ROWS>
+struct LeftoverSource {
+    static constexpr bool kSingleJobs = true;
+    FusedSourceX<BY_ROWS> map;             // the fused launch's ticket -> job numbering
+    uint32_t *counter;
+    const uint32_t *list;
+    uint32_t n_left, first_undrawn, n_tickets;
+    int lane;
+    __device__ __forceinline__ uint32_t draw() const {
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
+    __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
+        return ticket < n_left ? list[ticket] : map.first_job(first_undrawn + (ticket - n_left));
+    }
+    __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
+    __device__ __forceinline__ bool ready(uint32_t) const { return true; }
+    __device__ __forceinline__ bool wait_ready(uint32_t) const { return true; }
+};
+
+template <int HS, int VS, bool T>
+__global__ __launch_bounds__(256, 3) void k_recon_leftover(FusedArgs F) {
+    using G = rfast::FGeo<HS, VS, 3>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t n_left = __hip_atomic_load(F.x_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t all = (uint32_t)F.n_images * (uint32_t)F.jobs_per_image;
+    const uint32_t drawn = min(__hip_atomic_load(F.x_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), all);
+    if (n_left == 0 && drawn == all) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (G::SUB) {
+        rfast::fill_weights<HS, VS, 3, T>(reinterpret_cast<float4 *>(smem + 4 * G::WAVE_BYTES), tid, 256);
+        __syncthreads();
+    }
+    LeftoverSource<T> src;
+    src.map.n_images = (uint32_t)F.n_images; src.map.jobs_per_image = (uint32_t)F.jobs_per_image; src.map.spi = (uint32_t)F.spi;
+    src.map.pieces = (uint32_t)F.pieces; src.map.piece_mcus = (uint32_t)F.piece_mcus; src.map.mcus_per_row = (uint32_t)F.mcus_per_row;
+    src.counter = F.x_counter + 2; src.list = F.x_left; src.n_left = n_left; src.first_undrawn = drawn;
+    src.n_tickets = n_left + (all - drawn);
+    src.lane = lane;
+    rfast::strips_worker<HS, VS, 3, false, T>(F.R, nullptr, F.total_jobs, F.jobs_per_image, smem + wave * G::WAVE_BYTES,
+                                              reinterpret_cast<const float4 *>(smem + 4 * G::WAVE_BYTES), lane, (int)blockIdx.x, wave, src);
+}
 
 // LDS budget of a fused launch with `n_prod` producer wavefronts of `lpw` lanes: how many consumers fit beside them
 static bool fused_budget(FusedShape &s, int n_ac, int n_dc, int hmax, int vmax, int want_consumers) {
@@ -400,6 +463,9 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         const int64_t words = 32 + (int64_t)shape.n_wg * shape.n_prod;
         if (hipError_t e = launch_fill_words(stream, x_words, 0u, words); e != hipSuccess) return e;
         F.x_counter = x_words; F.x_progress = x_words + 32; F.x_holder = holder;
+        F.x_left = x_words + 32 + (int64_t)shape.n_wg * shape.n_prod;
+        F.x_patience = 2000;
+        if (const char *e = opt("MJ_FUSED_PATIENCE")) F.x_patience = atoi(e);
         F.L.by_length = by_length; F.L.order_mode = 2; F.L.progress_global = F.x_progress;
         blocks = (unsigned)shape.n_wg;
     } else {
@@ -428,6 +494,24 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         else return hipErrorInvalidValue;
     }
 #undef MJ_GO
+    if (shape.xwg) {      // the clean-up launch: the jobs given up (none, when the chip was this launch's alone)
+        auto left = [&](auto kernel, size_t lds) {
+            hipLaunchKernelGGL(kernel, dim3(3 * device_cus()), dim3(256), lds, stream, F);
+        };
+#define MJ_LEFT(H, V, TT) left(k_recon_leftover<H, V, TT>, rfast::FGeo<H, V, 3>::LDS_BYTES)
+        if (!transposed) {
+            if (hmax == 2 && vmax == 2) MJ_LEFT(2, 2, false);
+            else if (hmax == 2 && vmax == 1) MJ_LEFT(2, 1, false);
+            else if (hmax == 1 && vmax == 2) MJ_LEFT(1, 2, false);
+            else MJ_LEFT(1, 1, false);
+        } else {
+            if (hmax == 2 && vmax == 2) MJ_LEFT(2, 2, true);
+            else if (hmax == 2 && vmax == 1) MJ_LEFT(1, 2, true);
+            else if (hmax == 1 && vmax == 2) MJ_LEFT(2, 1, true);
+            else MJ_LEFT(1, 1, true);
+        }
+#undef MJ_LEFT
+    }
     return hipGetLastError();
 }
 

@@ -829,7 +829,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     std::vector<int32_t> holder(segs.size());
                     for (size_t r = 0; r < by_length_order.size(); ++r) holder[(size_t)by_length_order[r]] = (int32_t)((int64_t)r % n_waves);
                     if ((rc = upload(ctx, &p->d_holder, holder.data(), holder.size())) != MJ_OK) return rc;
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_xwords, (size_t)(32 + n_waves) * sizeof(uint32_t)));
+                    // (the ticket counters, the progress words, and room for every job on the list of jobs given up)
+                    const int64_t jobs_cap = (int64_t)b->n_images * std::max<int64_t>(p->jobs_per_image, (int64_t)i0.mcu_count_v * i0.mcu_count_h);
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_xwords, (size_t)(32 + n_waves + jobs_cap) * sizeof(uint32_t)));
                     p->use_fused = true;
                 }
             }

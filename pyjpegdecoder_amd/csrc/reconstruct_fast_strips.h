@@ -311,7 +311,7 @@ struct TicketSource {
     __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const { return ticket * jpt; }
     __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t n_jobs) const { return min(n_jobs, (ticket + 1) * jpt); }
     __device__ __forceinline__ bool ready(uint32_t) const { return true; }
-    __device__ __forceinline__ void wait_ready(uint32_t) const {}
+    __device__ __forceinline__ bool wait_ready(uint32_t) const { return true; }      // (false: the job was given up and the wave ends)
 };
 
 // One wavefront's share of a launch.  `wave_lds`: FGeo::WAVE_BYTES of LDS of its own (strip, scratch, quantisation tables);
@@ -430,7 +430,7 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
   for (;;) {        // (gated sources only come round again: a job whose blocks were not there yet when its turn to be fetched came)
-    src.wait_ready(job);
+    if (!src.wait_ready(job)) return;     // (gated across workgroups: the job was given up to the clean-up launch, and so is the rest)
     fetch_first(job_of(job), cw);
     bool stalled = false;
     if constexpr (!SEAMS) {

@@ -1995,12 +1995,61 @@ def test_fused_launch_segments_dealt_out_by_length(dec, W, H, n, distinct, layou
         got = imgs[i].cpu().numpy()
         got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
         assert np.array_equal(got, want), d
-    for cons in (None, "1", "4"):
-        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, base + ([("MJ_FUSED_CONSUMERS", cons)] if cons else []))
-        assert form & B.MJ_FORM_FUSED, (form, cons)
+    # (MJ_FUSED_PATIENCE: polls before a consumer gives a job up to the clean-up launch and ends — what keeps the launch from
+    # waiting for a workgroup that another plan's kernel keeps off the chip.  0 = every job that is not ready at once, and every
+    # ticket its wave would have drawn after it: nearly the whole batch goes through the clean-up launch; 3 = some of it)
+    for extra in ([], [("MJ_FUSED_CONSUMERS", "1")], [("MJ_FUSED_CONSUMERS", "8")], [("MJ_FUSED_PATIENCE", "0")], [("MJ_FUSED_PATIENCE", "3")]):
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, base + extra)
+        assert form & B.MJ_FORM_FUSED, (form, extra)
         assert not st.any(), np.unique(st)
         differ = (fused.view(n, per) != imgs).any(dim=1).nonzero().flatten().tolist()
-        assert not differ, (cons, len(differ), differ[:10])
+        assert not differ, (extra, len(differ), differ[:10])
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_fused_launches_of_several_plans_at_once(dec, mixed, tune):
+    """Three plans' fused launches in flight together, each on a stream of its own: a fused launch wants a CU's whole LDS, so
+    the launches' workgroups find their CUs at different times.  Whole images per workgroup: no workgroup waits for another.
+    Segments dealt out by length (mixed content): a consumer may wait for a workgroup that has not started — its patience is
+    bounded, what it gives up goes through the clean-up launch, and every launch ends with the right pixels."""
+    torch = pytest.importorskip("torch")
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, n, distinct = 1920, 1080, 1024, 12
+    if mixed:
+        blob, offs = synth.synth_mixed_batch(distinct, 424242, W, H, "420", 120)
+    else:
+        blob, offs = synth.synth_batch(distinct, 424242, W, H, 85, "420", 120)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
+    files = [raws[(5 * i + i // distinct) % distinct] for i in range(n)]
+    prep = prepare_batch(files, B.MJ_LAYOUT_XMAJOR, 0)
+    ref, st, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0")])
+    assert not st.any() and not form & B.MJ_FORM_FUSED
+    dev = torch.device("cuda", 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    torch.cuda.synchronize()
+    plans = [B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n}) for _ in range(3)]
+    try:
+        assert all(p.stage1_form() & B.MJ_FORM_FUSED for p in plans)
+        outs = [torch.zeros(plans[0].info.rgb_bytes, dtype=torch.uint8, device=dev) for _ in plans]
+        streams = [torch.cuda.Stream(device=dev) for _ in plans]
+        torch.cuda.synchronize()
+        for rnd in range(4):
+            for p in plans:
+                p.fill_coef(0x33 + rnd)
+            for p, o, s_ in zip(plans, outs, streams):
+                p.execute(s_.cuda_stream, o.data_ptr())
+            for p in plans:
+                p.sync()
+            for k, (p, o) in enumerate(zip(plans, outs)):
+                assert not p.read(rgb=False)["status"].any(), (rnd, k)
+                assert torch.equal(o, ref), (rnd, k)
+                o.zero_()
+            torch.cuda.synchronize()
+    finally:
+        for p in plans:
+            p.close()
 
 
 def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
