@@ -277,6 +277,8 @@ int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *f
  *   MJ_STAGE2_CHUNK   1..4096 strips per stage-2 job
  *   MJ_FUSED          0 | 1  (0 = mj_plan_execute always launches the stages separately)
  *   MJ_FUSED_CONSUMERS 0..8  reconstruction wavefronts beside the lane walk of a fused launch (as many as LDS allows)
+ *   MJ_FUSED_LUMA13   0 | 1  component 0's AC table of a fused launch with a 13-bit main level (default: only where the segments are
+ *                     dealt out by length) or with 12 bits like the others
  *   MJ_FUSED_PATIENCE 0..1000000  polls before a consumer of a fused launch whose jobs cross workgroups gives a job up to the
  *                     clean-up launch (2000; 0: every job that is not ready at once — the tests' way into that path)
  * Returns MJ_ERR_INVALID for a name that is none of these AND for a value outside the range or word list given here (a probe

@@ -48,7 +48,6 @@ namespace {
 constexpr int kFusedLds = 160 * 1024;
 constexpr int kFusedCtrl = 128;            // control words at the very top of LDS: ticket, producers done, progress per producer wave
 constexpr int kFusedThreads = 1024;        // 16 wavefronts = 4 per SIMD, 128 registers each: 8 producers and up to 8 consumers beside them
-constexpr int kFusedAB = 12;               // main-level index bits of the AC tables in LDS (lanes13_walk.h)
 
 struct FusedArgs {
     lanes13::Args L;                       // the stage-1 launch (lpw = lanes per producer wave)
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
 #endif
     unsigned char *my_lds;
     if (wave < n_prod) {
-        lanes13::walk<XWG ? 2 : 1, kFusedAB>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
+        lanes13::walk<XWG ? 2 : 1>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
         __builtin_amdgcn_s_setprio(0);
 #ifdef MJ_DIAGNOSTIC
         if (lane == 0) {
@@ -361,14 +360,14 @@ __global__ __launch_bounds__(256, 3) void k_recon_leftover(FusedArgs F) {
 }
 
 // LDS budget of a fused launch with `n_prod` producer wavefronts of `lpw` lanes: how many consumers fit beside them
-static bool fused_budget(FusedShape &s, int n_ac, int n_dc, int hmax, int vmax, int want_consumers) {
+static bool fused_budget(FusedShape &s, int n_dc, int hmax, int vmax, int want_consumers) {
     size_t wave_bytes, wts_bytes;
     if (hmax == 2 && vmax == 2) { wave_bytes = rfast::FGeo<2, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 2, 3>::WTS_BYTES; }
     else if (hmax == 2 && vmax == 1) { wave_bytes = rfast::FGeo<2, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 1, 3>::WTS_BYTES; }
     else if (hmax == 1 && vmax == 2) { wave_bytes = rfast::FGeo<1, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 2, 3>::WTS_BYTES; }
     else if (hmax == 1 && vmax == 1) { wave_bytes = rfast::FGeo<1, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 1, 3>::WTS_BYTES; }
     else return false;
-    const size_t prod = lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits);
+    const size_t prod = lanes13::lds_bytes(s.ac_total_bytes, n_dc, s.n_prod, s.lpw, s.ring, s.dbits);
     const size_t top = (size_t)kFusedLds - kFusedCtrl - wts_bytes;
     if (prod > top) return false;
     const int waves = kFusedThreads / 64;
@@ -380,7 +379,7 @@ static bool fused_budget(FusedShape &s, int n_ac, int n_dc, int hmax, int vmax, 
 }
 
 // How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
-FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
+FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
     FusedShape s{};
     if (transposed) std::swap(hmax, vmax);                     // the strip worker's geometry: that of the transposed image
     if (n_images < 1 || spi < 1) return s;
@@ -390,16 +389,16 @@ FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax,
     s.n_prod = std::min(8, std::max(1, (lanes + 33) / 34));
     s.lpw = (lanes + s.n_prod - 1) / s.n_prod;
     s.ring = 64;
-    s.ac_slot_bytes = ac_slot_bytes;
+    s.ac_total_bytes = ac_total_bytes;
     s.dbits = 8;                                                // (Annex K's DC codes of 9..11 bits — differences beyond +-255 in chroma, +-1023 in luma — take the canonical search)
     s.n_wg = (n_images + s.ipw - 1) / s.ipw;
-    s.ok = fused_budget(s, n_ac, n_dc, hmax, vmax, want_consumers);
+    s.ok = fused_budget(s, n_dc, hmax, vmax, want_consumers);
     return s;
 }
 
 // ... with the restart segments dealt out by length (MODE 2 of the walk): no whole images per workgroup — one workgroup per CU,
 // the segments spread over all their producer wavefronts.
-FusedShape fused_shape_x(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers) {
+FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers) {
     FusedShape s{};
     if (transposed) std::swap(hmax, vmax);
     if (n_segs < 1 || cus < 1) return s;
@@ -408,12 +407,12 @@ FusedShape fused_shape_x(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hma
     s.n_prod = (int)std::min<int64_t>(8, std::max<int64_t>(1, (per_wg + 33) / 34));
     s.lpw = (int)((n_segs + (int64_t)cus * s.n_prod - 1) / ((int64_t)cus * s.n_prod));
     s.ring = 64;
-    s.ac_slot_bytes = ac_slot_bytes;
+    s.ac_total_bytes = ac_total_bytes;
     s.dbits = 8;
     s.xwg = true;
     s.n_wg = cus;
     s.ipw = 0;
-    s.ok = fused_budget(s, n_ac, n_dc, hmax, vmax, want_consumers);
+    s.ok = fused_budget(s, n_dc, hmax, vmax, want_consumers);
     return s;
 }
 
@@ -422,9 +421,9 @@ FusedShape fused_shape_x(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hma
 extern "C" int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
                                     int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[6]) {
     if (!out) return MJ_ERR_INVALID;
-    const mj::FusedShape s = mj::fused_shape(cus, n_ac, n_dc, ac_slot_bytes, hmax, vmax, transposed != 0, n_images, segments_per_image, want_consumers);
+    const mj::FusedShape s = mj::fused_shape(cus, n_ac * ac_slot_bytes, n_dc, hmax, vmax, transposed != 0, n_images, segments_per_image, want_consumers);
     out[0] = s.ok ? 1 : 0; out[1] = s.ipw; out[2] = s.n_prod; out[3] = s.lpw; out[4] = s.n_cons;
-    out[5] = s.ok ? (int32_t)mj::lanes13::lds_bytes(n_ac, n_dc, s.n_prod, s.lpw, s.ring, s.ac_slot_bytes, s.dbits) : 0;
+    out[5] = s.ok ? (int32_t)mj::lanes13::lds_bytes(s.ac_total_bytes, n_dc, s.n_prod, s.lpw, s.ring, s.dbits) : 0;
     return MJ_OK;
 }
 
@@ -432,14 +431,16 @@ namespace mj {
 
 hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
-                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
+                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, const int ac_off[4], const int ac_bits[4],
+                        int16_t *coef, int32_t *status,
                         const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
                         int64_t total_jobs, int jobs_per_image, const int32_t *by_length, const int32_t *holder, uint32_t *x_words) {
     if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
     if (shape.xwg && (!by_length || !holder || !x_words)) return hipErrorInvalidValue;
     FusedArgs F{};
     F.L = lanes13::Args{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                        coef, status, shape.lpw, transposed ? 1 : 0, nullptr, nullptr, 0, shape.ring, shape.ac_slot_bytes, shape.dbits, shape.ipw * spi, nullptr};
+                        coef, status, shape.lpw, transposed ? 1 : 0, nullptr, nullptr, 0, shape.ring, shape.ac_total_bytes, shape.dbits,
+                        {ac_off[0], ac_off[1], ac_off[2], ac_off[3]}, {ac_bits[0], ac_bits[1], ac_bits[2], ac_bits[3]}, shape.ipw * spi, nullptr};
     F.R = a;
     F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
     F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_huffman_lanes13(lanes13::Args A) {
 }
 
 // LDS bytes of a launch with `nw` waves of `lpw` lanes
-static size_t lds13(int n_ac, int n_dc, int nw, int lpw, int kRing = 128) { return lanes13::lds_bytes(n_ac, n_dc, nw, lpw, kRing); }
+static size_t lds13(int n_ac, int n_dc, int nw, int lpw, int kRing = 128) { return lanes13::lds_bytes(n_ac * kLanes13SlotBytes, n_dc, nw, lpw, kRing); }
 
 bool lanes13_fits(int n_ac, int n_dc) { return n_ac >= 1 && n_ac <= 3 && n_dc >= 1 && n_dc <= 4 && lds13(n_ac, n_dc, 4, 8, 64) <= 160 * 1024; }
 
@@ -116,7 +116,7 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
         attr_set[current_device()] = true;
     }
     lanes13::Args A{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
-                    coef, status, lpw, transposed, vsegs, by_length, order_mode, ring, kLanes13SlotBytes, kLaneLutBits, 0, nullptr};
+                    coef, status, lpw, transposed, vsegs, by_length, order_mode, ring, n_ac * kLanes13SlotBytes, kLaneLutBits, {0, 0, 0, 0}, {13, 13, 13, 13}, 0, nullptr};
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, A);
 #ifdef MJ_X_STAMP
     if (getenv("MJ_X_REPORT")) {

@@ -79,7 +79,9 @@ struct Args {
     // fused.hip only (the stage-1 kernel keeps the constants): bytes of one AC table in LDS — its main table of 2^AB entries
     // plus the second-level tables the batch's codes need, lut13 holding the tables at this stride — and index bits of the DC
     // tables in LDS (taken out of lut11's 11-bit ones: every 2^(11 - dbits)-th entry, where its code is short enough)
-    int ac_slot_bytes, dbits;
+    int ac_total_bytes, dbits;
+    // ... the AC tables lie back to back in lut13 and in LDS: byte offset and main-level index bits (12 or 13) per LDS slot
+    int ac_off[4], ac_bits[4];
     // fused.hip only: restart segments per workgroup (whole images: no multiple of the waves' lanes in general — the last
     // lanes of a workgroup's last wave then have no segment)
     int wg_segs;
@@ -88,9 +90,9 @@ struct Args {
 };
 
 // LDS bytes of `nw` waves of `lpw` lanes: tables, block rows, block addresses, stream windows — in this order from `smem`
-__host__ __device__ inline size_t lds_bytes(int n_ac, int n_dc, int nw, int lpw, int kRing, int ac_slot_bytes = kASlotBytes, int dbits = kDBits) {
+__host__ __device__ inline size_t lds_bytes(int ac_total_bytes, int n_dc, int nw, int lpw, int kRing, int dbits = kDBits) {
     const int wstride = (lpw * kRow + 3) & ~3;
-    return (((size_t)n_ac * ac_slot_bytes + ((size_t)n_dc << dbits) * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw + 8) * 8 + 127) & ~(size_t)127) +
+    return (((size_t)ac_total_bytes + ((size_t)n_dc << dbits) * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw + 8) * 8 + 127) & ~(size_t)127) +
            (size_t)nw * lpw * kRing;
 }
 
@@ -98,12 +100,12 @@ __host__ __device__ inline size_t lds_bytes(int n_ac, int n_dc, int nw, int lpw,
 template <bool FUSED>
 __device__ __forceinline__ void stage(const Args &A, unsigned char *smem, int tid, int nthreads, int nw) {
     const int n_ac = A.n_ac, n_dc = A.n_dc;
-    const int aslot = FUSED ? A.ac_slot_bytes : kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
-    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][aslot / 4]
-    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * aslot);                // [n_dc][dsize]
+    const int ac_total = FUSED ? A.ac_total_bytes : n_ac * kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
+    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // the AC tables, back to back
+    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)ac_total);                    // [n_dc][dsize]
     const int wstride = (A.lpw * kRow + 3) & ~3;
-    unsigned char *rows0 = smem + (size_t)n_ac * aslot + (size_t)n_dc * dsize * 2;
-    for (int i = tid; i < n_ac * (aslot / 16); i += nthreads)
+    unsigned char *rows0 = smem + (size_t)ac_total + (size_t)n_dc * dsize * 2;
+    for (int i = tid; i < ac_total / 16; i += nthreads)
         reinterpret_cast<uint4 *>(s_ac)[i] = reinterpret_cast<const uint4 *>(A.lut13)[i];
     for (int s = 0; s < n_dc; ++s) {
         const int t = (int)((A.dc_tab_pk >> (8 * s)) & 0xFF);
@@ -125,9 +127,9 @@ __device__ __forceinline__ void stage(const Args &A, unsigned char *smem, int ti
 // complete in memory (see the hook behind the AC loop).  MODE 2 (fused.hip, segments dealt out by length — any workgroup's
 // consumers may need this wave's blocks): the coefficient stores are write-through (sc1) and the report goes to
 // A.progress_global with an sc1 store — MI355X_MICROARCH.md's "sc1 stores, drained, then an sc1 flag" hand-off.
-// AB: index bits of the AC tables' main level (13; fused.hip: 12 — half the LDS, 1.5 % of the symbols instead of 0.4 % then take
-// the arithmetic step); their second-level tables have 2^(16 - AB) entries
-template <int MODE, int AB = 13>
+// Index bits of an AC table's main level: 13 — or, in a fused launch, what A.ac_bits says for its LDS slot (12: half the LDS,
+// 1.5 % of the benchmark's symbols instead of 0.4 % then take the arithmetic step); its second-level tables have 2^(16 - bits) entries
+template <int MODE>
 __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const int lane, const int wave, const int nw, const int wg, const int n_wg,
                                      const uint32_t progress_addr) {
     const uint32_t *__restrict__ stream = A.stream;
@@ -148,19 +150,18 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr bool FUSED = MODE != 0;
-    static_assert(FUSED || AB == 13, "the stage-1 kernel's tables are the 13-bit ones");
-    const int aslot = FUSED ? A.ac_slot_bytes : kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
-    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // [n_ac][aslot / 4]
-    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)n_ac * aslot);                // [n_dc][dsize]
+    const int ac_total = FUSED ? A.ac_total_bytes : n_ac * kASlotBytes, dbits = FUSED ? A.dbits : kDBits, dsize = 1 << dbits;
+    uint32_t *s_ac = reinterpret_cast<uint32_t *>(smem);                                         // the AC tables, back to back
+    uint16_t *s_dc = reinterpret_cast<uint16_t *>(smem + (size_t)ac_total);                    // [n_dc][dsize]
     // (the flush moves blocks eight at a time and may read up to seven rows and positions past a wave's last: the next wave's,
     // or the slack behind the last wave's — never stored)
     const int lpw2 = lpw;
     const int wstride = (lpw2 * kRow + 3) & ~3;                                                  // dwords per wave, 16-byte multiple
-    unsigned char *rows0 = smem + (size_t)n_ac * aslot + (size_t)n_dc * dsize * 2;
+    unsigned char *rows0 = smem + (size_t)ac_total + (size_t)n_dc * dsize * 2;
     uint32_t *s_blk = reinterpret_cast<uint32_t *>(rows0) + wave * wstride;
     uint64_t *s_base = reinterpret_cast<uint64_t *>(rows0 + (size_t)nw * wstride * 4 + 8 * kRow * 4) + wave * lpw2;
     // per-lane window on the lane's stream: kRing bytes, the stream's bytes at their offsets modulo kRing (see the bit reader)
-    unsigned char *rings0 = smem + (((size_t)n_ac * aslot + (size_t)n_dc * dsize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127);
+    unsigned char *rings0 = smem + (((size_t)ac_total + (size_t)n_dc * dsize * 2 + (size_t)nw * wstride * 4 + 8 * kRow * 4 + (size_t)(nw * lpw2 + 8) * 8 + 127) & ~(size_t)127);
 
     // Which segment a lane takes.  Without a length list: the segments in blob order.  With one (restart segments whose
     // lengths the host knows), mode 2 deals the list out one segment per wave and round, so that the long ones sit in
@@ -350,7 +351,11 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 pB = ok ? mybase : lastB;                                      // position of the last coefficient written; lastB = lane is done
             }
             // ---- AC (:833-866): until every lane is at its end of block.  See the header for the entry formats.
-            const uint32_t lutb = ac_base + (uint32_t)acs * (uint32_t)aslot;
+            // (where the block's AC table sits and how wide its main level is: wave-uniform, in registers for the asm)
+            const uint32_t lutb = ac_base + (FUSED ? (uint32_t)(acs == 0 ? A.ac_off[0] : (acs == 1 ? A.ac_off[1] : (acs == 2 ? A.ac_off[2] : A.ac_off[3])))
+                                                   : (uint32_t)acs * (uint32_t)kASlotBytes);
+            const uint32_t ab_v = FUSED ? (uint32_t)(acs == 0 ? A.ac_bits[0] : (acs == 1 ? A.ac_bits[1] : (acs == 2 ? A.ac_bits[2] : A.ac_bits[3]))) : 13u;
+            const uint32_t ash_v = 32u - ab_v, sb_v = 16u - ab_v;
             uint32_t e_last = 0xFFu;                 // the lane's latest entry; 0xFF = "nothing a correction below could use"
 #ifdef MJ_X_STAMP
             const uint64_t dbg_a0 = __builtin_amdgcn_s_memtime();
@@ -556,7 +561,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                       , [di] "+v"(dbg_iter), [d0] "+v"(dbg_d[0]), [d1] "+v"(dbg_d[1]), [d2] "+v"(dbg_d[2]), [d3] "+v"(dbg_d[3]), [d4] "+v"(dbg_d[4]), [d5] "+v"(dbg_d[5]), [d6] "+v"(dbg_d[6]), [d7] "+v"(dbg_w[0]), [d8] "+v"(dbg_w[1]), [d9] "+v"(dbg_w[2])
 #endif
                     : [lastB] "v"(lastB), [storeB] "v"(storeB), [lutb] "v"(lutb), [sbase] "s"(streamb), [c7f] "v"(c7f),
-                      [ash] "n"(32 - AB), [abits] "n"(AB), [sbits] "n"(16 - AB),
+                      [ash] "v"(ash_v), [abits] "v"(ab_v), [sbits] "v"(sb_v),
                       [ring] "v"(ringbase), [c124] "v"(c124), [c112] "v"(c112), [c96] "v"(c96), [rl] "s"(ring_lanes), [rot] "v"(rot)
                     : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72");
 #undef MJ_REFILL13

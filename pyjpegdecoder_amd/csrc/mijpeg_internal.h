@@ -273,20 +273,21 @@ struct FusedShape {
     int n_prod, lpw;    // producer wavefronts, lanes (restart segments) per producer wavefront
     int n_cons;         // consumer wavefronts beside the producers (every wavefront is one once the producers are through)
     int ring;           // bytes of stream window per lane
-    int ac_slot_bytes;  // one AC table in LDS (12-bit main level + its second-level tables)
+    int ac_total_bytes; // the AC tables in LDS, back to back (12-bit main levels — 13 where the plan says so — + their second-level tables)
     int dbits;          // index bits of the DC tables in LDS
     bool xwg;           // restart segments dealt out by length: one pool of jobs for the launch, hand-off across workgroups
     int n_wg;           // ... workgroups of such a launch (= CUs: all resident at once)
 };
-FusedShape fused_shape_x(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers);
-FusedShape fused_shape(int cus, int n_ac, int n_dc, int ac_slot_bytes, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers);
+FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers);
+FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers);
 hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
-                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, int16_t *coef, int32_t *status,
+                        int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, const int ac_off[4], const int ac_bits[4],
+                        int16_t *coef, int32_t *status,
                         const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
                         int64_t total_jobs, int jobs_per_image, const int32_t *by_length = nullptr, const int32_t *holder = nullptr,
                         uint32_t *x_words = nullptr);
-// (lut13 of launch_fused: the tables with a 12-bit main level at stride shape.ac_slot_bytes)
+// (lut13 of launch_fused: the plan's fused tables, back to back — ac_off / ac_bits per LDS slot)
 // Launch-geometry caches are per device: one process may hold contexts on several GPUs (mijpeg.h: one context per GPU per
 // thread), and a function attribute set on one device says nothing about the next.  (Racing first uses write the same values.)
 constexpr int kMaxDevices = 64;

@@ -131,8 +131,8 @@ struct mj_plan {
     int32_t *d_by_length = nullptr;     // restart segments, longest first (how the lane form deals them out to its waves)
     int seg_order_mode = 0;
     uint32_t *d_lut13 = nullptr;        // [n_ac13][8192]
-    uint32_t *d_lut12 = nullptr;        // the same with a 12-bit main level, [n_ac13][lut12_slot_bytes / 4] (fused launches)
-    int lut12_slot_bytes = 0;
+    uint32_t *d_lut12 = nullptr;        // a fused launch's AC tables: back to back, 12-bit main levels (13 where it says so)
+    int lutf_off[4] = {0, 0, 0, 0}, lutf_bits[4] = {12, 12, 12, 12}, lutf_total = 0;   // ... byte offset and index bits per LDS slot, bytes in all
     int n_ac13 = 0, n_dc13 = 0;
     uint64_t ac_slot_pk = 0, dc_slot_pk = 0, dc_tab_pk = 0;
     // batches with more tables than LDS holds (files with their own optimised tables): per workgroup, the tables its

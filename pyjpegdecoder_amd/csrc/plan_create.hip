@@ -77,41 +77,50 @@ int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 
 }
 
 
-// Resolved AC tables (huffman_lanes13.hip's entry format) with AB index bits for every table of the batch used as an AC table:
-// per table a main level of 2^AB entries — the FINISHED symbol wherever code + value bits fit the index (jpeg_decoder.py:834-866 and
-// bin_twos_complement :1636-1646 evaluated here), else what the arithmetic step needs — and second-level tables of 2^(16 - AB)
-// entries for the prefixes of longer codes.  fixed_slot_bytes: the stride of a table in `out` (0 = as small as the batch's codes
-// allow: main level + the largest number of second-level tables any table needs; slot_bytes returns it).  false: does not fit.
-bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint64_t ac_pk, int n_ac, int AB, int fixed_slot_bytes,
-                           std::vector<uint32_t> &out, int &slot_bytes) {
-    const int AS = 1 << AB, SUB = 1 << (16 - AB);
-    const int res_limit = AB;
-    int max_sub = 1;
-    if (fixed_slot_bytes) {
-        max_sub = (fixed_slot_bytes / 4 - AS) / SUB;
-    } else {
-        for (int t = 0; t < b->n_huff; ++t) {
-            if (role[t] != 2) continue;
-            std::vector<char> seen(AS, 0);
-            int n = 1, code = 0, k = 0;
-            for (int l = 1; l <= 16; ++l) {
-                code <<= 1;
-                for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
-                    if (code >= (1 << l) || l <= AB) continue;
-                    const int prefix = code >> (l - AB);
-                    if (!seen[prefix]) { seen[prefix] = 1; ++n; }
-                }
-            }
-            max_sub = std::max(max_sub, n);
-        }
-    }
-    const int SLOT = fixed_slot_bytes ? fixed_slot_bytes / 4 : ((AS + max_sub * SUB) * 4 + 15) / 16 * 4;
-    if ((size_t)SLOT * 4 > 65535u) return false;                // (second-level tables are addressed by a 16-bit byte offset)
-    slot_bytes = SLOT * 4;
-    out.assign((size_t)n_ac * SLOT, 0xFFFFFFFFu);
+// Resolved AC tables (huffman_lanes13.hip's entry format) for every table of the batch used as an AC table, table (LDS slot) s with
+// ab_of_slot[s] index bits: a main level of 2^AB entries — the FINISHED symbol wherever code + value bits fit the index
+// (jpeg_decoder.py:834-866 and bin_twos_complement :1636-1646 evaluated here), else what the arithmetic step needs — and second-level
+// tables of 2^(16 - AB) entries for the prefixes of longer codes.  fixed_slot_bytes: the stride of a table in `out` (the stage-1
+// kernel's), or 0: back to back, each as small as its codes allow (a fused launch's).  slot_off / total_bytes: where each lies.
+// false: does not fit.
+bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint64_t ac_pk, int n_ac, const int ab_of_slot[4], int fixed_slot_bytes,
+                           std::vector<uint32_t> &out, int slot_off[4], int &total_bytes) {
+    if (n_ac > 4) return false;
+    int subs_of_slot[4] = {1, 1, 1, 1}, words_of_slot[4] = {0, 0, 0, 0};
     for (int t = 0; t < b->n_huff; ++t) {
         if (role[t] != 2) continue;
-        uint32_t *tab = out.data() + (size_t)((ac_pk >> (8 * t)) & 0xFF) * SLOT;
+        const int slot = (int)((ac_pk >> (8 * t)) & 0xFF), AB = ab_of_slot[slot], AS = 1 << AB, SUB = 1 << (16 - AB);
+        if (fixed_slot_bytes) {
+            subs_of_slot[slot] = (fixed_slot_bytes / 4 - AS) / SUB;
+            words_of_slot[slot] = fixed_slot_bytes / 4;
+            continue;
+        }
+        std::vector<char> seen(AS, 0);
+        int n = 1, code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            code <<= 1;
+            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
+                if (code >= (1 << l) || l <= AB) continue;
+                const int prefix = code >> (l - AB);
+                if (!seen[prefix]) { seen[prefix] = 1; ++n; }
+            }
+        }
+        subs_of_slot[slot] = n;
+        words_of_slot[slot] = ((AS + n * SUB) * 4 + 15) / 16 * 4;
+    }
+    int at = 0;
+    for (int sl = 0; sl < n_ac; ++sl) {
+        if ((size_t)words_of_slot[sl] * 4 > 65535u) return false;        // (second-level tables are addressed by a 16-bit byte offset)
+        slot_off[sl] = at * 4;
+        at += words_of_slot[sl];
+    }
+    total_bytes = at * 4;
+    out.assign((size_t)at, 0xFFFFFFFFu);
+    for (int t = 0; t < b->n_huff; ++t) {
+        if (role[t] != 2) continue;
+        const int slot = (int)((ac_pk >> (8 * t)) & 0xFF), AB = ab_of_slot[slot], AS = 1 << AB, SUB = 1 << (16 - AB);
+        const int SLOT = words_of_slot[slot], max_sub = subs_of_slot[slot];
+        uint32_t *tab = out.data() + slot_off[slot] / 4;
         // second-level tables behind the main one: for the 16 - AB bits that follow an AB-bit prefix of longer codes;
         // table 0 = "no such code" (where every other unset main entry points as well)
         int n_sub = 1;
@@ -140,7 +149,7 @@ bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint
                     if ((m & 0xC0FFu) != 0xC000u) continue;       // a shorter code owns the prefix (over-subscribed table)
                     uint32_t *sub = tab + ((m >> 16) / 4);
                     put(sub, ((uint32_t)code << (16 - l)) & (uint32_t)(SUB - 1), 1u << (16 - l), open_entry);
-                } else if (hv == 0 ? l <= res_limit : l + size <= res_limit) {
+                } else if (hv == 0 ? l <= AB : l + size <= AB) {
                     const int n = hv == 0 ? 0 : size, rest = AB - l - n;
                     for (uint32_t vb = 0; vb < (1u << n); ++vb) {
                         // bin_twos_complement (:1636-1646): leading 1 = the value itself, leading 0 = value - (2^n - 1)
@@ -612,16 +621,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 if (f13 && !strcmp(f13, "lanes11")) ok13 = false;
                 if (ok13 && mj::lanes13_fits(n_ac, n_dc)) {
                     std::vector<uint32_t> l13;
-                    int slot_bytes = 0;
-                    if (!build_resolved_tables(b, role, ac_pk, n_ac, 13, mj::kLanes13SlotBytes, l13, slot_bytes)) goto no_lanes13;
+                    const int ab13[4] = {13, 13, 13, 13};
+                    int off13[4] = {0, 0, 0, 0}, total13 = 0;
+                    if (!build_resolved_tables(b, role, ac_pk, n_ac, ab13, mj::kLanes13SlotBytes, l13, off13, total13)) goto no_lanes13;
                     if ((rc = upload(ctx, &p->d_lut13, l13.data(), l13.size())) != MJ_OK) return rc;
                     p->n_ac13 = n_ac; p->n_dc13 = n_dc;
                     p->ac_slot_pk = ac_pk; p->dc_slot_pk = dc_pk; p->dc_tab_pk = dct_pk;
-                    // the same tables with a 12-bit main level, as small as the batch's codes allow: what a fused launch keeps in
-                    // LDS beside its reconstruction wavefronts' strips (fused.hip)
-                    std::vector<uint32_t> l12;
-                    if (build_resolved_tables(b, role, ac_pk, n_ac, 12, 0, l12, p->lut12_slot_bytes))
-                        if ((rc = upload(ctx, &p->d_lut12, l12.data(), l12.size())) != MJ_OK) return rc;
+                    // (a fused launch keeps smaller copies in LDS beside its reconstruction wavefronts' strips: built when the plan
+                    // turns out to be one, below)
                 }
             no_lanes13:;
             }
@@ -796,13 +803,15 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
             // x-major pixels, no seam outputs, a stage-2 job = a whole MCU column, and LDS left for at least one consumer
             // wavefront beside the producers.  MJ_FUSED=0 keeps the two launches; MJ_FUSED_CONSUMERS bounds the consumers.
-            int want_cons = 8, want_cons_x = 4;
+            int want_cons = 8, want_cons_x = 6;
             bool allow = true;
             if (const char *e = mj::opt("MJ_FUSED")) allow = atoi(e) != 0;
             if (const char *e = mj::opt("MJ_FUSED_CONSUMERS")) want_cons = want_cons_x = atoi(e);
+            int luma13 = -1;                                     // MJ_FUSED_LUMA13: 0 / 1 overrides which form keeps component 0's table at 13 bits
+            if (const char *e = mj::opt("MJ_FUSED_LUMA13")) luma13 = atoi(e);
             const mj::DevImage &i0 = imgs[0];
             mj::FusedInputs fi;
-            fi.lanes_resolved = p->use_lanes && !p->use_sync && p->d_lut13 && p->d_lut12;
+            fi.lanes_resolved = p->use_lanes && !p->use_sync && p->d_lut13 && p->n_ac13 <= 4;
             fi.seg_order_mode = p->seg_order_mode; fi.uniform = p->uniform; fi.generic = p->generic; fi.progressive = prog;
             fi.transposed = p->transposed; fi.ncomp = p->ncomp; fi.hmax = p->hmax; fi.vmax = p->vmax; fi.layout = p->layout;
             fi.flags = p->flags; fi.seam_or_exact_flags = MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT;
@@ -813,15 +822,39 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // content: 11.3 ms fused that way against 10.6 as two launches): they keep their order, and the fused launch's
             // consumers take their jobs from ONE pool, handed over across workgroups (mode 2).
             const int mode = mj::fused_applies(fi);
-            if (allow && want_cons > 0 && mode == 1 && p->d_lut12) {
-                p->fused = mj::fused_shape(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, p->transposed, b->n_images, i0.mcu_count_v, want_cons);
-                p->fused_spi = i0.mcu_count_v;
-                p->use_fused = p->fused.ok;
-            } else if (allow && want_cons_x > 0 && mode == 2 && p->d_lut12 && p->d_by_length) {
-                // (four consumers, not eight: with segments of very different lengths the launch lasts as long as its longest
-                // wave's walk, and every consumer beside it slows that walk — bench.py's mixed content, launch: 2 consumers
-                // 9.4 ms, 3: 8.8, 4: 8.2, 5: 8.2, 6: 8.3, 8: 9.8; the two launches 10.2)
-                p->fused = mj::fused_shape_x(mj::device_cus(), p->n_ac13, p->n_dc13, p->lut12_slot_bytes, p->hmax, p->vmax, p->transposed, (int64_t)segs.size(), want_cons_x);
+            // A fused launch's AC tables: a 12-bit main level (half the LDS of the stage-1 kernel's 13 bits) and second-level tables
+            // sized to the batch's codes.  With the segments dealt out by length (mode 2) the table of component 0 keeps 13 bits
+            // where four consumers still fit beside it: the long segments of such batches are the ones with large coefficients,
+            // whose symbols a 12-bit table finishes least often, and the launch lasts as long as their walk.
+            // (0 = built and uploaded, 1 = such tables cannot be built — no fused launch then —, negative = an API error)
+            auto fused_tables = [&](bool luma13) -> int {
+                int ab[4] = {12, 12, 12, 12};
+                if (luma13) ab[(p->ac_slot_pk >> (8 * imgs[0].tab_index[imgs[0].blk_ac_slot[0]])) & 0xFF] = 13;
+                std::vector<uint32_t> lf;
+                if (!build_resolved_tables(b, role, p->ac_slot_pk, p->n_ac13, ab, 0, lf, p->lutf_off, p->lutf_total)) return 1;
+                for (int sl = 0; sl < 4; ++sl) p->lutf_bits[sl] = ab[sl];
+                if (p->d_lut12) { ctx->cache.put(p->d_lut12); p->d_lut12 = nullptr; }
+                return upload(ctx, &p->d_lut12, lf.data(), lf.size());
+            };
+            if (allow && want_cons > 0 && mode == 1) {
+                if ((rc = fused_tables(luma13 == 1)) < 0) return rc;
+                if (rc == 0) {
+                    p->fused = mj::fused_shape(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, b->n_images, i0.mcu_count_v, want_cons);
+                    p->fused_spi = i0.mcu_count_v;
+                    p->use_fused = p->fused.ok;
+                }
+            } else if (allow && want_cons_x > 0 && mode == 2 && p->d_by_length) {
+                if ((rc = fused_tables(luma13 != 0)) < 0) return rc;
+                if (rc == 0) p->fused = mj::fused_shape_x(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, (int64_t)segs.size(), want_cons_x);
+                if (rc == 1 || !p->fused.ok || p->fused.n_cons < std::min(want_cons_x, 4)) {       // (no room for them beside a 13-bit table: 12 bits all round)
+                    if ((rc = fused_tables(false)) < 0) return rc;
+                    p->fused = mj::FusedShape{};
+                    if (rc == 0) p->fused = mj::fused_shape_x(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, (int64_t)segs.size(), want_cons_x);
+                }
+                // (six consumers — all that fit beside a 13-bit table — not eight: with segments of very different lengths the launch
+                // lasts as long as its longest wave's walk, and every consumer beside it slows that walk.  bench.py's mixed content,
+                // ms per step: 12-bit tables all round 2 consumers 10.2, 4: 8.9, 6: 9.1, 8: 10.5; component 0's table at 13 bits
+                // 4: 8.1-8.4, 5: 7.8-7.9, 6: 7.6-7.8; the two launches 10.4)
                 p->fused_spi = i0.mcu_count_v;
                 if (p->fused.ok) {
                     // which progress word a segment's wave reports to: the walk deals rank r of the sorted list to wave r mod waves
