@@ -200,6 +200,8 @@ int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
 #define MJ_FORM_SCANS     3
 #define MJ_FORM_WG_TABLES 16
 #define MJ_FORM_RESOLVED  32
+#define MJ_FORM_COUNT_RESOLVED 128   /* MJ_FORM_SYNC: the counting walks run on resolved tables with a repair work list
+                                        (huffman_sync.hip: k_count) instead of the classic rounds */
 #define MJ_FORM_FUSED     64   /* mj_plan_execute runs stages 1 and 2 as ONE launch (fused.hip): lane-walk wavefronts and
                                   reconstruction wavefronts side by side in one workgroup per CU.  Uniform x-major batches of
                                   4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 files with one restart interval per MCU row and the resolved
@@ -237,6 +239,13 @@ int mj_plan_write_coef(mj_plan *plan, const int16_t *coef, int32_t mem);
 int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
                          int32_t forced_chunk, int32_t out[4]);
 
+/* Test hook, host only: the tables the counting walks of MJ_FORM_SYNC look symbols up in (csrc/huffman_sync.hip: k_count), as
+ * mj_plan_create builds them for a batch with these n_huff <= 8 tables — roles[t] 1 = DC table, 2 = AC table —, wbits index bits.
+ * *tab_bytes = bytes from one table to the next; out (may be NULL) receives n_huff * tab_bytes / 4 words.  MJ_ERR_UNSUPPORTED:
+ * such a batch takes the classic rounds (a table in both roles, a DC size above 15, tables too large). */
+int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_t *roles, int32_t wbits, uint32_t *out, int64_t cap_words,
+                          int32_t *tab_bytes);
+
 /* Test hook, host only: how a fused launch (MJ_FORM_FUSED) would be cut for a batch of n_images images of segments_per_image
  * restart segments on a chip of `cus` CUs — out = { applies (LDS), images per workgroup, producer wavefronts, lanes per producer,
  * consumer wavefronts beside them, bytes of LDS the producers take }. */
@@ -269,7 +278,11 @@ int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *f
  * NOT read them from the environment (a stray variable must not change how a production decode runs).  Read when a plan is
  * created (forms, orders, chunk sizes) or when it executes (lane geometry).  value NULL or "" = back to the default.
  *   MJ_HUFFMAN        wave | lanes | lanes11 | sync   stage-1 form              MJ_SEG_ORDER     blob | binned | striped
- *   MJ_SYNC_ROUNDS    0..64  repair rounds           MJ_SYNC_CHUNK   256..65536 bytes   MJ_SYNC_WARM   run-up bytes
+ *   MJ_SYNC_ROUNDS    0..64  repair rounds (classic) / chunks a repair lane may walk on (resolved); 0 = no repairs
+ *   MJ_SYNC_CHUNK     256..65536 bytes   MJ_SYNC_WARM   run-up bytes in front of every chunk (half a chunk)
+ *   MJ_SYNC_COUNT     classic | resolved   the counting walks of MJ_FORM_SYNC: the round-3 kernel and its repair rounds, or the
+ *                     walk on resolved tables with a repair work list (default wherever the batch allows: <= 8 tables, one role each)
+ *   MJ_SYNC_BITS      10..13  index bits of those tables (12, fewer if LDS asks for it)
  *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
  *   MJ_PROG_SPLIT     0 | 1 | 2  refining AC scans as scout + parts: never | while the chip has wave slots for it | always
  *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)

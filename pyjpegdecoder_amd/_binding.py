@@ -27,9 +27,9 @@ EXPORTS = (
     "mj_plan_create", "mj_plan_destroy", "mj_plan_get_info", "mj_plan_image_offsets",
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
-    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape",
+    "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape", "mj_debug_count_tables",
 )
-MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED = 0, 1, 2, 3, 16, 32, 64
+MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED, MJ_FORM_COUNT_RESOLVED = 0, 1, 2, 3, 16, 32, 64, 128
 MJ_HOST_DECLINED = 1
 
 
@@ -149,6 +149,33 @@ def stage1_form_rule(seg_len, blob_len=None, n_huff=4, traits=0, force=None, for
     if rc != MJ_OK:
         raise ValueError("mj_debug_stage1_form: bad arguments")
     return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+
+
+def count_tables(huff_specs, roles, wbits=12):
+    """mj_debug_count_tables (host only): (words, tab_bytes) — the synchronisation form's counting tables for these tables
+    (list of (bits[16], vals) pairs; roles: 1 = DC, 2 = AC) — or None where such a batch takes the classic rounds."""
+    L = load_library()
+    n = len(huff_specs)
+    arr = (HuffSpecC * n)()
+    for i, (bits, vals) in enumerate(huff_specs):
+        for j in range(16):
+            arr[i].bits[j] = int(bits[j])
+        for j, v in enumerate(vals):
+            arr[i].vals[j] = int(v)
+    r = (ctypes.c_int32 * n)(*[int(x) for x in roles])
+    tb = ctypes.c_int32(0)
+    L.mj_debug_count_tables.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.POINTER(ctypes.c_int32)]
+    rc = L.mj_debug_count_tables(ctypes.byref(arr), n, ctypes.byref(r), wbits, None, 0, ctypes.byref(tb))
+    if rc == MJ_ERR_UNSUPPORTED:
+        return None
+    if rc != MJ_OK:
+        raise ValueError("mj_debug_count_tables: bad arguments")
+    out = np.zeros(n * tb.value // 4, dtype=np.uint32)
+    rc = L.mj_debug_count_tables(ctypes.byref(arr), n, ctypes.byref(r), wbits, _ptr(out), out.size, ctypes.byref(tb))
+    if rc != MJ_OK:
+        raise ValueError("mj_debug_count_tables: bad arguments")
+    return out, tb.value
 
 
 def fused_shape_rule(n_images, segments_per_image, hmax=2, vmax=2, transposed=False, cus=256, n_ac=2, n_dc=2, ac_slot_bytes=17024,

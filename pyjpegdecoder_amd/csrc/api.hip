@@ -103,7 +103,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_lutc, p->d_sync_items, p->d_seg_chunk0, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -114,7 +114,8 @@ int mj_plan_stage1_form(const mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
     if (p->progressive) return MJ_FORM_SCANS;
     const int base = p->use_sync ? MJ_FORM_SYNC : (p->use_lanes ? MJ_FORM_LANES : MJ_FORM_WAVE);
-    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0) | (p->use_fused ? MJ_FORM_FUSED : 0);
+    return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0) | (p->use_fused ? MJ_FORM_FUSED : 0) |
+           (p->use_sync && p->d_lutc ? MJ_FORM_COUNT_RESOLVED : 0);
 }
 
 int mj_plan_get_info(const mj_plan *p, mj_plan_info *info) {
@@ -224,24 +225,30 @@ static int stage1_impl(mj_plan *p, void *stream) {
             // round 0 guesses, round 1.. start every chunk from its predecessor's exit state until no exit state changes
             // (typically the second true-state round changes nothing), then the pieces are decoded like restart segments
             const int cbits = p->sync_chunk_bytes * 8;
-            MJ_HIP(ctx, mj::launch_fill_words(s, p->d_couts, 0xFFFFFFFFu, p->n_chunks * (int64_t)(sizeof(mj::DevChunkOut) / 4)));
-            MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
-                                              p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count, nullptr, p->sync_warm_bits));
             uint64_t *in = p->d_stateA, *out = p->d_stateB;
-            // repair rounds: a fixed number, queued without looking (a chain of wrongly guessed entry states gets one link
-            // shorter per round; after round 0's run-up nearly every guess is right and the second repair round changes
-            // nothing).  Whether they sufficed is decided on the device: k_build_vsegs marks the images whose chunk states
-            // had not settled (MJ_ST_UNCONVERGED) and the caller decodes those again with MJ_FLAG_NO_SYNC.  No host
-            // round trip: the execute is asynchronous and can be captured into a graph like every other form.
-            MJ_HIP(ctx, mj::launch_fill_words(s, p->d_changed, 0u, p->sync_rounds + 8));
-            for (int round = 1; round <= p->sync_rounds; ++round) {
-                MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
-                                                  p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + round, p->d_wg_tabs_count, p->wg_slots_count,
-                                                  round >= 2 ? p->d_changed + round - 1 : nullptr, p->sync_warm_bits));
-                std::swap(in, out);
+            if (p->d_lutc) {
+                // resolved tables: one walk over every chunk, the list of wrong guesses, their repair — three launches
+                MJ_HIP(ctx, mj::launch_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_lutc, p->lutc_tab_bytes, p->n_huff, p->lutc_bits,
+                                             p->d_chunks, p->n_chunks, cbits, p->sync_warm_bits, p->d_stateA, p->d_couts, p->d_sync_items, p->d_changed, p->sync_rounds));
+            } else {
+                MJ_HIP(ctx, mj::launch_fill_words(s, p->d_couts, 0xFFFFFFFFu, p->n_chunks * (int64_t)(sizeof(mj::DevChunkOut) / 4)));
+                MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,
+                                                  p->d_chunks, p->n_chunks, cbits, nullptr, p->d_stateA, p->d_couts, p->d_changed, p->d_wg_tabs_count, p->wg_slots_count, nullptr, p->sync_warm_bits));
+                // repair rounds: a fixed number, queued without looking (a chain of wrongly guessed entry states gets one link
+                // shorter per round; after round 0's run-up nearly every guess is right and the second repair round changes
+                // nothing).  Whether they sufficed is decided on the device: k_build_vsegs marks the images whose chunk states
+                // had not settled (MJ_ST_UNCONVERGED) and the caller decodes those again with MJ_FLAG_NO_SYNC.  No host
+                // round trip: the execute is asynchronous and can be captured into a graph like every other form.
+                MJ_HIP(ctx, mj::launch_fill_words(s, p->d_changed, 0u, p->sync_rounds + 8));
+                for (int round = 1; round <= p->sync_rounds; ++round) {
+                    MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u,
+                                                      p->n_huff, p->d_chunks, p->n_chunks, cbits, in, out, p->d_couts, p->d_changed + round, p->d_wg_tabs_count, p->wg_slots_count,
+                                                      round >= 2 ? p->d_changed + round - 1 : nullptr, p->sync_warm_bits));
+                    std::swap(in, out);
+                }
             }
-            MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->n_chunks, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,
-                                               in, p->d_status));
+            MJ_HIP(ctx, mj::launch_build_vsegs(s, p->d_chunks, p->d_seg_chunk0, p->n_segs, p->d_couts, p->d_segs, p->d_seg_bits, p->d_images, p->d_vsegs,
+                                               in, cbits, p->d_status));
             if (p->d_lut13)
                 MJ_HIP(ctx, mj::launch_huffman_lanes13(s, p->d_stream, p->d_seg_bits, p->d_segs, p->n_chunks, p->d_images, p->d_huff, p->d_lut11,
                                                        p->d_lut13, p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk,

@@ -60,16 +60,17 @@ inline FormChoice choose_stage1_form(const FormInputs &in) {
     if (in.forced_chunk) {
         c.sync_chunk_bytes = in.forced_chunk;
     } else {
-        // Chunk size by the amount of stream: small batches want many short chunks (a single 1080p image: 1.65 ms with
-        // 512-byte chunks, 3.0 ms with 2 KiB ones — six wavefronts' worth), big ones fewer long ones (the run-up in
-        // front of every chunk and the per-chunk records cost; 1024 images: 19.0 ms at 2 KiB, 20.2 ms at 512 bytes).
-        // Measured optimum: the shortest of 512 / 1024 / 2048 bytes that keeps the batch under ~330 000 chunks.
-        // ... and a single segment not in more than ~12 000 of them: wrongly guessed entry states are repaired one link
-        // of a chain per round, and chains grow with the chunks of a segment (one 24-megapixel image, 10 MB of
-        // stream: 5.4 ms with 512-byte chunks, 3.8 ms with 1 KiB).
+        // Chunk size by the amount of stream: small batches want many short chunks (a single 1080p image: 0.71 ms with
+        // 256-byte chunks, 0.74 with 512, 1.14 with 1 KiB — too few wavefronts), big ones fewer long ones (the run-up in
+        // front of every chunk and the per-chunk records cost; 1024 images: 11.5 ms at 2 KiB, 12.6 ms at 1 KiB; 256
+        // images: 3.43 / 3.26 / 3.74 at 512 / 1024 / 1536; 64 images: 1.38 / 1.34 / 1.70 at 256 / 512 / 1024; 16: 0.94 / 1.06
+        // at 256 / 512).  The shortest of 256 / 512 / 1024 / 2048 bytes that keeps the batch under ~50 000 chunks (256)
+        // or ~330 000 (the others)
+        // ... and a single segment not in more than ~12 000 of them (one 24-megapixel image, 10 MB of stream, round 4:
+        // 5.4 ms with 512-byte chunks, 3.8 ms with 1 KiB).
         c.sync_chunk_bytes = 2048;
-        for (int cb : {512, 1024})
-            if (total_len / cb <= 330000 && longest / cb <= 12000) { c.sync_chunk_bytes = cb; break; }
+        for (int cb : {256, 512, 1024})
+            if (total_len / cb <= (cb == 256 ? 50000 : 330000) && longest / cb <= 12000) { c.sync_chunk_bytes = cb; break; }
     }
     for (int64_t i = 0; i < in.n_segs; ++i) c.est_chunks += std::max(1, (in.seg_len[i] + c.sync_chunk_bytes - 1) / c.sync_chunk_bytes);
     // Long segments (no DRI, or a very large restart interval) leave the chip empty at one lane each: chosen when segments

@@ -190,9 +190,16 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
                              const DevChunk *chunks, int64_t n_chunks, int cbits, const uint64_t *entry, uint64_t *exit_out,
                              DevChunkOut *outs, int32_t *changed, const int32_t *wg_tabs = nullptr, int wg_slots = 0, const int32_t *prev_changed = nullptr,
                              int warm_bits = -1);   // wg_tabs: per 256 chunks; warm_bits: run-up in front of every chunk, -1 = half a chunk
-hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, int64_t n_chunks, const DevChunkOut *outs,
+// the same on resolved tables (lutc: n_tabs tables of tab_bytes each, wbits index bits: plan_create.hip's build_count_tables): the first
+// walk over every chunk, then — max_links > 0 — the list of chunks whose entry state was guessed wrong (items: 16 bytes per
+// chunk, *n_items) and their repair, each lane walking on for at most max_links chunks.  exit_state / outs as above.
+hipError_t launch_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, const DevImage *images,
+                        const uint32_t *lutc, int tab_bytes, int n_tabs, int wbits, const DevChunk *chunks, int64_t n_chunks, int cbits,
+                        int warm_bits, uint64_t *exit_state, DevChunkOut *outs, void *items, int32_t *n_items, int max_links);
+// seg_chunk0[s] = the first chunk of restart segment s (n_segs + 1 entries)
+hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, const int32_t *seg_chunk0, int64_t n_segs, const DevChunkOut *outs,
                               const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs,
-                              const uint64_t *final_exit, int32_t *status);
+                              const uint64_t *final_exit, int cbits, int32_t *status);
 hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const DevSegment *segs, const DevPiece *pieces,
                                  int64_t n_pieces, int32_t *kept, uint32_t *out_stream, int32_t *seg_bits);
 // lut11: (len << 8 | symbol) for tables used as DC tables, (len << 11 | run << 4 | size, EOB = run 64) for AC tables

@@ -155,6 +155,10 @@ struct mj_plan {
     uint64_t *d_stateA = nullptr, *d_stateB = nullptr;
     mj::DevChunkOut *d_couts = nullptr;
     mj::DevVSeg *d_vsegs = nullptr;
+    int32_t *d_seg_chunk0 = nullptr;    // [n_segs + 1] first chunk of every restart segment
+    uint32_t *d_lutc = nullptr;         // the counting walks' resolved tables (k_count), or null: the classic rounds (k_sync_count)
+    int lutc_tab_bytes = 0, lutc_bits = 0;
+    void *d_sync_items = nullptr;       // the repair launch's work list (16 bytes per chunk); its counter is d_changed[0]
     hipGraphExec_t graph_exec = nullptr;   // captured launches of one execute (see mj_plan_execute)
     hipStream_t graph_stream = nullptr;
     uint8_t *graph_rgb = nullptr;

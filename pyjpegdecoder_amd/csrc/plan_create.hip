@@ -170,9 +170,104 @@ bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint
     return true;
 }
 
+// Every table of a batch of at most 8 as the counting walks of the synchronisation form want it (huffman_sync.hip: k_count): all
+// with W index bits, `tab_bytes` apart.  A 32-bit entry: bits consumed — code AND value — (0..5) | run + 1, 128 = end of block
+// (8..15) | DC tables: the EXTENDed difference (16..30; jpeg_decoder.py:818-820, bin_twos_complement :1636-1646) — finished
+// wherever the code fits the index (AC tables: counting does not look at AC values) or code + value bits do (DC tables).  Bit 31
+// = not finished: bit 30 set = a code longer than the index, (0..15) the byte offset of the second-level table (2^(16 - W)
+// entries for the bits behind the index) for its prefix; else the open form, which second-level tables hold throughout: code
+// length (0..4; 0 = no such code) | run + 1 / 128 (8..15) | size (16..19).  false: does not fit (or a DC size above 15).
+bool build_count_tables(const mj_batch *b, const std::vector<int> &role, int W, std::vector<uint32_t> &out, int &tab_bytes) {
+    if (b->n_huff > 8) return false;
+    const int AS = 1 << W, SUB = 1 << (16 - W);
+    auto walk_codes = [&](const mj_huff_spec &spec, auto &&f) {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            code <<= 1;
+            for (int i = 0; i < spec.bits[l - 1] && k < 256; ++i, ++k, ++code)
+                if (code < (1 << l)) f(l, code, (int)spec.vals[k]);
+        }
+    };
+    int max_words = AS + SUB;
+    for (int t = 0; t < b->n_huff; ++t) {
+        if (role[t] != 1 && role[t] != 2) return false;
+        std::vector<char> seen((size_t)AS, 0);
+        int n = 1;
+        walk_codes(b->huff[t], [&](int l, int code, int) {
+            if (l > W && !seen[(size_t)(code >> (l - W))]) { seen[(size_t)(code >> (l - W))] = 1; ++n; }
+        });
+        max_words = std::max(max_words, AS + n * SUB);
+    }
+    tab_bytes = (max_words * 4 + 15) / 16 * 16;
+    if (tab_bytes > 65535) return false;
+    const int TW = tab_bytes / 4;
+    out.assign((size_t)b->n_huff * TW, 0xFFFFFFFFu);
+    for (int t = 0; t < b->n_huff; ++t) {
+        uint32_t *tab = out.data() + (size_t)t * TW;
+        const bool is_dc = role[t] == 1;
+        int n_sub = 1;                                            // table 0 = "no such code"
+        for (int i = 0; i < SUB; ++i) tab[AS + i] = 0x80000000u;
+        bool ok = true;
+        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
+            for (uint32_t f = 0; f < count; ++f)
+                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
+        };
+        walk_codes(b->huff[t], [&](int l, int code, int hv) {
+            const int run = is_dc ? 0 : hv >> 4, size = is_dc ? hv : (hv & 15);
+            if (size > 15) { ok = false; return; }
+            const bool eob = !is_dc && hv == 0;
+            const uint32_t adv = eob ? 128u : (uint32_t)(run + 1);
+            const uint32_t open_entry = 0x80000000u | ((uint32_t)size << 16) | (adv << 8) | (uint32_t)l;
+            if (l > W) {
+                uint32_t &m = tab[(uint32_t)code >> (l - W)];
+                if (m == 0xFFFFFFFFu) {                           // first long code under this prefix: a new table
+                    for (int j = 0; j < SUB; ++j) tab[AS + n_sub * SUB + j] = 0xFFFFFFFFu;
+                    m = 0xC0000000u | (uint32_t)((AS + n_sub * SUB) * 4);
+                    ++n_sub;
+                }
+                if ((m & 0xC0000000u) != 0xC0000000u) return;     // a shorter code owns the prefix (over-subscribed table)
+                put(tab + (m & 0xFFFFu) / 4, ((uint32_t)code << (16 - l)) & (uint32_t)(SUB - 1), 1u << (16 - l), open_entry);
+            } else if (!is_dc) {
+                put(tab, (uint32_t)code << (W - l), 1u << (W - l), (adv << 8) | (uint32_t)(l + size));
+            } else if (l + size <= W) {
+                const int rest = W - l - size;
+                for (uint32_t vb = 0; vb < (1u << size); ++vb) {
+                    const int val = size == 0 ? 0 : ((vb >> (size - 1)) ? (int)vb : (int)vb - ((1 << size) - 1));
+                    put(tab, (((uint32_t)code << size) | vb) << rest, 1u << rest, (((uint32_t)val & 0x7FFFu) << 16) | (adv << 8) | (uint32_t)(l + size));
+                }
+            } else {
+                put(tab, (uint32_t)code << (W - l), 1u << (W - l), open_entry);
+            }
+        });
+        if (!ok) return false;
+        for (int i = 0; i < AS; ++i)
+            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x80000000u;       // no such code
+        for (int i = AS; i < TW; ++i)
+            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x80000000u;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_t *roles, int32_t wbits, uint32_t *out, int64_t cap_words,
+                          int32_t *tab_bytes) {
+    if (!huff || !roles || !tab_bytes || n_huff < 1 || n_huff > 8 || wbits < 10 || wbits > 13) return MJ_ERR_INVALID;
+    mj_batch b{};
+    b.n_huff = n_huff; b.huff = huff;
+    std::vector<int> role(roles, roles + n_huff);
+    std::vector<uint32_t> t;
+    int tb = 0;
+    if (!build_count_tables(&b, role, wbits, t, tb)) return MJ_ERR_UNSUPPORTED;
+    *tab_bytes = tb;
+    if (out) {
+        if ((int64_t)t.size() > cap_words) return MJ_ERR_INVALID;
+        memcpy(out, t.data(), t.size() * 4);
+    }
+    return MJ_OK;
+}
 
 int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
                          int32_t forced_chunk, int32_t out[4]) {
@@ -769,6 +864,30 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_couts, ck.size() * sizeof(mj::DevChunkOut) + 16));
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
                 MJ_HIP(ctx, ctx->cache.get((void **)&p->d_changed, (size_t)(p->sync_rounds + 8) * sizeof(int32_t)));   // [0]: round 0's, [r]: repair round r's count of changed exit states
+                {   // first chunk of every restart segment: k_build_vsegs runs one workgroup per segment
+                    std::vector<int32_t> c0(segs.size() + 1, 0);
+                    for (size_t i = 0; i < segs.size(); ++i) c0[i + 1] = c0[i] + std::max(1, (segs[i].len + cb - 1) / cb);
+                    if ((rc = upload(ctx, &p->d_seg_chunk0, c0.data(), c0.size())) != MJ_OK) return rc;
+                }
+                // the counting walks on resolved tables (huffman_sync.hip: k_count) where the batch is of the everyday kind: at most
+                // 8 tables, one role each, MCUs of at most 8 blocks; MJ_SYNC_COUNT = classic | resolved (tests, measurements)
+                {
+                    const char *e = mj::opt("MJ_SYNC_COUNT");
+                    bool ok = !(e && !strcmp(e, "classic")) && !many_tabs && !both_roles && b->n_huff <= 8;
+                    for (const mj::DevImage &im : imgs) ok = ok && im.blocks_per_mcu <= 8 && im.ncomp <= 3;
+                    int wb = 12;
+                    if (const char *w = mj::opt("MJ_SYNC_BITS")) wb = atoi(w);
+                    for (; ok && wb >= 10; --wb) {
+                        std::vector<uint32_t> lc;
+                        int tb = 0;
+                        if (!build_count_tables(b, role, wb, lc, tb)) { ok = false; break; }
+                        if ((size_t)tb * (size_t)b->n_huff > 150 * 1024) continue;             // a narrower index fits
+                        if ((rc = upload(ctx, &p->d_lutc, lc.data(), lc.size())) != MJ_OK) return rc;
+                        p->lutc_tab_bytes = tb; p->lutc_bits = wb;
+                        MJ_HIP(ctx, ctx->cache.get((void **)&p->d_sync_items, ck.size() * 16 + 16));
+                        break;
+                    }
+                }
                 // stage 0 of long segments runs piece by piece (16 KiB of source bytes per wavefront)
                 std::vector<mj::DevPiece> pcs;
                 for (size_t i = 0; i < segs.size(); ++i) {

@@ -19,10 +19,11 @@ CASES = [
     ("one small file, three segments", segs(3, 700), {}, WAVE, None),
     ("999 short segments: below the lane form's crossover", segs(999, 900), {}, WAVE, None),
     ("1024 short segments: lanes (too short to cut)", segs(1024, 900), {}, LANES, None),
-    ("one 1080p file with a restart interval per row: too few lanes, chunks fill the chip", segs(68, 9800), {}, SYNC, 512),
+    ("one 1080p file with a restart interval per row: too few lanes, chunks fill the chip", segs(68, 9800), {}, SYNC, 256),
     ("128 such files", segs(68 * 128, 9800), {}, SYNC, 512),
     ("300 such files: the lane form again", segs(68 * 300, 9800), {}, LANES, None),
-    ("one 1080p file without restart markers", segs(1, 660000), {}, SYNC, 512),
+    ("one 1080p file without restart markers", segs(1, 660000), {}, SYNC, 256),
+    ("64 of them", segs(64, 660000), {}, SYNC, 512),
     ("300 of them", segs(300, 660000), {}, SYNC, 1024),
     ("1024 of them: fewer, longer chunks", segs(1024, 660000), {}, SYNC, 2048),
     ("one 24-megapixel file: no more than ~12 000 chunks per segment", segs(1, 10_000_000), {}, SYNC, 1024),
@@ -63,14 +64,17 @@ def test_stage1_form_rule(name, seg_len, kw, form, chunk):
 
 
 def test_chunk_size_keeps_the_batch_under_its_chunk_budget():
-    """The shortest of 512 / 1024 / 2048 bytes that keeps the batch under ~330 000 chunks and a segment under ~12 000."""
-    for n, length in ((1, 200_000), (64, 660_000), (256, 660_000), (300, 660_000), (1024, 660_000), (1, 5_000_000), (1, 13_000_000)):
+    """The shortest of 256 / 512 / 1024 / 2048 bytes that keeps the batch under ~50 000 chunks (256) or ~330 000 (the others) and a
+    segment under ~12 000."""
+    budget = lambda chunk: 50000 if chunk == 256 else 330000
+    for n, length in ((1, 200_000), (16, 660_000), (20, 660_000), (64, 660_000), (256, 660_000), (300, 660_000), (1024, 660_000), (1, 5_000_000),
+                      (1, 13_000_000)):
         _, chunk, n_chunks, _ = B.stage1_form_rule(segs(n, length))
-        assert chunk in (512, 1024, 2048)
-        if chunk > 512:
-            assert n * length // (chunk // 2) > 330000 or length // (chunk // 2) > 12000
+        assert chunk in (256, 512, 1024, 2048)
+        if chunk > 256:
+            assert n * length // (chunk // 2) > budget(chunk // 2) or length // (chunk // 2) > 12000
         if chunk < 2048:
-            assert n * length // chunk <= 330000 and length // chunk <= 12000
+            assert n * length // chunk <= budget(chunk) and length // chunk <= 12000
 
 
 def test_segments_are_dealt_out_by_length_only_when_they_differ():

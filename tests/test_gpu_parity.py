@@ -1311,6 +1311,70 @@ def test_sync_rounds_that_do_not_settle_fall_back_to_the_serial_walk(dec, monkey
         plan.close()
 
 
+def _sync_plan_statuses(dec, raws):
+    """One plan over `raws`, one execute, no fallback layer: (stage-1 form, per-image statuses)."""
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    prep = prepare_batch(raws, B.MJ_LAYOUT_XMAJOR, 0)
+    plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": len(raws)})
+    try:
+        form = plan.stage1_form()
+        plan.execute()
+        plan.sync()
+        return form, plan.read(rgb=False)["status"].copy()
+    finally:
+        plan.close()
+
+
+@pytest.mark.parametrize("count,bits", [(None, None), ("resolved", "10"), ("resolved", "13"), ("classic", None)])
+def test_sync_counting_walks_classic_and_resolved(dec, count, bits, tune):
+    """The counting walks of the synchronisation form exist twice: the round-3 kernel with its repair rounds (MJ_SYNC_COUNT=classic:
+    what batches with more than eight tables, or a table in both roles, still take) and the walk on resolved tables with a repair
+    work list (round 5, the default).  The same mixed batch of files without restart markers — three sampling layouts in one
+    plan each — through both, with small chunks (many chunks per
+    file, many wrong guesses) and every index width: every status ok without the fallback layer, every image the oracle's."""
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    tune("MJ_HUFFMAN", "sync")
+    tune("MJ_SYNC_CHUNK", "256")
+    tune("MJ_SYNC_COUNT", count)
+    tune("MJ_SYNC_BITS", bits)
+    for k, ss in enumerate(("420", "444", "grey", "422")):                 # (a plan holds one sampling layout)
+        raws = [synth.synth_jpeg(900 + 10 * k + i, 320 + 48 * i, 240 + 16 * (i % 3), (85, 60, 95)[i % 3], ss, 0, 10.0 + 5 * (i % 3)) for i in range(4)]
+        form, status = _sync_plan_statuses(dec, raws)
+        assert form & 15 == B.MJ_FORM_SYNC
+        assert bool(form & B.MJ_FORM_COUNT_RESOLVED) == (count != "classic")
+        assert not status.any(), (ss, status)
+        for i, (raw, img) in enumerate(zip(raws, dec.decode(raws))):
+            assert np.array_equal(img, oracle.decode(raw)["rgb"]), (ss, i)
+
+
+def test_sync_repair_lanes_walk_on_where_an_exit_state_changes(dec, tune):
+    """No run-up at all and tiny chunks: nearly every chunk's entry state is guessed wrong, and a quarter of the old walks had not
+    found their way by the end of their chunk either — the repair launch's lanes then start from a state that is itself wrong, and
+    the lane in front, whose chunk now leaves in another state, has to walk on into theirs (huffman_sync.hip: k_count<true>).
+    Every image still settles inside one execute (statuses ok without the fallback layer) and equals the oracle's; with the walk-on
+    switched off (MJ_SYNC_ROUNDS=1: one chunk per lane) the device reports what did not settle instead of a wrong image."""
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    tune("MJ_HUFFMAN", "sync")
+    tune("MJ_SYNC_CHUNK", "256")
+    tune("MJ_SYNC_WARM", "0")
+    raws = [synth.synth_jpeg(7000 + i, 640, 480, 85, "420", 0, 12.0) for i in range(6)]
+    form, status = _sync_plan_statuses(dec, raws)
+    assert form & B.MJ_FORM_COUNT_RESOLVED
+    assert not status.any(), status
+    for i, (raw, img) in enumerate(zip(raws, dec.decode(raws))):
+        assert np.array_equal(img, oracle.decode(raw)["rgb"]), i
+    tune("MJ_SYNC_ROUNDS", "1")
+    _, status = _sync_plan_statuses(dec, raws)
+    assert set(np.unique(status)) <= {0, B.MJ_ST_UNCONVERGED} and (status == B.MJ_ST_UNCONVERGED).any(), status
+    for i, (raw, img) in enumerate(zip(raws, dec.decode(raws))):          # ... and the host layer decodes those again, exactly
+        assert np.array_equal(img, oracle.decode(raw)["rgb"]), i
+
+
 @pytest.mark.parametrize("layout", ["planar", "planar_rowmajor"])
 def test_planar_layouts(layout):
     """MJ_LAYOUT_PLANAR_*: the components of the reference's image_array (:1373-1386) as three planes per image — every

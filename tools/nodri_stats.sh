@@ -1,11 +1,12 @@
 #!/bin/bash
-# per-kernel totals of one no-DRI batch (files without restart markers: the synchronisation form):  bash tools/nodri_stats.sh [batch] [lib]
+# per-kernel totals of one no-DRI batch (files without restart markers: the synchronisation form):  bash tools/nodri_stats.sh [batch] [lib] [NAME=VALUE,...]
 R=${GRAFT_REPO_ROOT:-$PWD}
 N=${1:-256}
 LIB=${2:-$R/pyjpegdecoder_amd/libmijpeg.so}
+EXP=${3:-}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_nd
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nd -- python3 $R/tools/stage_probe.py --lib $LIB --ri 0 --batch $N --warm 2 --iters 4 "" > /tmp/prof_nd.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_nd -- python3 $R/tools/stage_probe.py --lib $LIB --ri 0 --batch $N --warm 2 --iters 4 "$EXP" > /tmp/prof_nd.log 2>&1
 grep stage0 /tmp/prof_nd.log
 python3 - <<'PY'
 import csv,glob

@@ -63,8 +63,15 @@ def main():
         for _ in range(args.warm):
             plan.execute(torch.cuda.current_stream().cuda_stream, d_rgb.data_ptr())
         torch.cuda.synchronize()
+        import time
+        st = torch.cuda.current_stream().cuda_stream
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            plan.execute(st, d_rgb.data_ptr())
+        torch.cuda.synchronize()
+        step = (time.perf_counter() - t0) / args.iters * 1e3
         s1, s2 = plan.time_stages(args.iters, d_rgb.data_ptr())
-        print(f"{exp or 'default':50s} stage0+1 {s1:7.3f} ms   stage2 {s2:7.3f} ms", flush=True)
+        print(f"{exp or 'default':50s} stage0+1 {s1:7.3f} ms   stage2 {s2:7.3f} ms   step {step:7.3f} ms", flush=True)
         plan.close()
         for k in api_opts:
             B.set_option(k, None)
