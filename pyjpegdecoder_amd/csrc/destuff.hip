@@ -17,32 +17,33 @@
 namespace mj {
 
 namespace {
-constexpr int kRing = 512;     // staging bytes per wave: < 256 left over + <= 256 new
+constexpr int kTile = 1024;    // k_destuff: source bytes per turn, sixteen per lane
+constexpr int kStage = 2 * kTile + 64;   // its staging bytes per wave: < 1024 left over + <= 1024 new (+ the reach of a 16-byte write)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+
+// bit 7 of every byte that is 0xFF: the low seven bits all set (their sum with 1 carries into bit 7, never beyond) and bit 7 set
+__device__ __forceinline__ uint32_t ff_flags(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u; }
+// flags (bit 7 of each byte) of the first n bytes of dword number i of a lane's sixteen
+__device__ __forceinline__ uint32_t valid_flags(int nv, int i) {
+    const int n = nv - 4 * i;
+    return n >= 4 ? 0x80808080u : (n <= 0 ? 0u : (0x80808080u >> (8 * (4 - n))));
 }
 
-__global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blob, const DevSegment *__restrict__ segs,
-                                                 int64_t n_segs, uint32_t *__restrict__ stream,
-                                                 int32_t *__restrict__ seg_bits) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kRing];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
-    if (seg >= n_segs) return;                                  // wave-uniform; no block barriers below
-    uint8_t *stage = s_stage[wave];
-    const int64_t begin = segs[seg].begin;
-    const int len = __builtin_amdgcn_readfirstlane(segs[seg].len);
-    const int64_t abase = begin & ~(int64_t)3;
-    const int lead = (int)(begin - abase);
-    const int span = lead + len;                                // bytes from abase to the segment's end
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(blob + abase);
-    uint32_t *out = stream + (begin >> 2) + seg;
-
-    int fill = 0, base = 0, total = 0;                          // wave-uniform: staged bytes, ring origin, kept bytes
-    uint32_t carry = 0;                                         // 1 = the next valid byte is dropped
+// The byte rules for the `len` source bytes at `src` the slow way — four bytes per lane and turn, a two-state transfer function per
+// lane, a scalar fix-up over the lanes whose output state depends on their input state: any content, any alignment —, kept bytes
+// appended to the staging buffer at `fill`.  Returns the number kept; `carry` (1 = the next byte is dropped) goes in and out.
+template <bool STORE>
+__device__ __forceinline__ int destuff_range_slow(const uint8_t *src_bytes, int len, uint8_t *stage, int fill, uint32_t &carry, int lane) {
+    const uint64_t addr = reinterpret_cast<uint64_t>(src_bytes);
+    const int lead = (int)(addr & 3u);
+    const int span = lead + len;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(addr & ~(uint64_t)3);
+    int total = 0;
     for (int c0 = 0; c0 < span; c0 += 256) {
-        const int p = c0 + 4 * lane;                            // this lane's first byte, relative to abase
+        const int p = c0 + 4 * lane;                            // this lane's first byte, relative to the aligned base
         const uint32_t w = p < span ? src[p >> 2] : 0u;
-        // valid bytes of the dword: lead <= p + i < span
         uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 1, vm = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -73,34 +74,137 @@ __global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blo
         const int cnt = __builtin_popcount(keep);
         const uint64_t b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
         const uint64_t below = (1ull << lane) - 1;
-        int pos = base + fill + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below) +
-                  4 * __builtin_popcountll(b2 & below);
+        int pos = fill + total + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below) + 4 * __builtin_popcountll(b2 & below);
         const int tot = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+        if constexpr (STORE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if ((keep >> i) & 1) {
-                stage[pos & (kRing - 1)] = (uint8_t)(w >> (8 * i));
-                ++pos;
+            for (int i = 0; i < 4; ++i) {
+                if ((keep >> i) & 1) {
+                    stage[pos] = (uint8_t)(w >> (8 * i));
+                    ++pos;
+                }
             }
         }
-        fill += tot;
         total += tot;
+        // (a lane that holds no valid byte passes its input state on: A and B differ there, V excludes it, S carries through)
         carry = carry_out;
-        if (fill >= 256) {                                       // one full 256-byte line, coalesced
-            const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
-            out[lane] = __builtin_bswap32(d);
-            out += 64;
-            base = (base + 256) & (kRing - 1);
-            fill -= 256;
+    }
+    return total;
+}
+// Round 5: sixteen bytes per lane and turn.  In entropy-coded data an 0xFF is followed by its stuffed 0x00, never by another 0xFF,
+// so the sequential rule degenerates: dropped = the byte behind an 0xFF.  A turn takes 1 KiB of the segment: each lane flags its 0xFF
+// bytes with three integer operations per dword, the flags moved up one byte (across dwords with v_alignbit, across lanes with a
+// DPP shift, across turns with a carry) are the dropped bytes; a lane takes its (at most three) dropped bytes out of its
+// sixteen in registers, fills up from its successor's first bytes, and writes SIXTEEN bytes at its byte offset in the staging
+// buffer — gfx950's LDS takes a 16-byte access at any byte address (tools/unaligned_lds_probe.hip), and where two lanes' writes
+// overlap they carry the same bytes.  A turn in which some dropped byte is itself an 0xFF (fill bytes in front of a marker,
+// damaged data), or a lane has more than three, goes through the slow step above.  Instructions per source byte: 0.11 against
+// 0.4; the kernel had been bound by instruction issue (0.52 ms per 1024 x 1080p, 1.3 TB/s each way).
+// One turn: the `tile_len` (<= 1 KiB) source bytes at `src`, kept bytes to the staging buffer at `fill` (STORE) or only counted.
+template <bool STORE>
+__device__ __forceinline__ int destuff_tile(const uint8_t *src, int tile_len, uint8_t *stage, int fill, uint32_t &carry, int lane) {
+    const int p = 16 * lane;
+    const int nv = min(16, max(0, tile_len - p));           // this lane's bytes that belong to the range
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (nv == 16) {
+        w = *reinterpret_cast<const u32x4_u *>(src + p);
+    } else if (nv > 0) {                                    // the range's last lane: byte by byte (nothing is read behind it)
+        for (int i = 0; i < nv; ++i) w[i >> 2] |= (uint32_t)src[p + i] << (8 * (i & 3));
+    }
+    uint32_t F[4], D[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F[i] = ff_flags(w[i]) & valid_flags(nv, i);
+    // the flags one byte up: the byte behind an 0xFF
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)(carry << 31), (int)F[3], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    D[0] = __builtin_amdgcn_alignbit(F[0], prev, 24);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) D[i] = __builtin_amdgcn_alignbit(F[i], F[i - 1], 24);
+    uint32_t both = 0;
+    int drops = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        D[i] &= valid_flags(nv, i);
+        both |= D[i] & F[i];
+        drops += __builtin_popcount(D[i]);
+    }
+    if (__builtin_amdgcn_ballot_w64(both != 0u || drops > 3) != 0) return destuff_range_slow<STORE>(src, tile_len, stage, fill, carry, lane);
+    // the state behind the range: its last byte an 0xFF (kept: a dropped one would have sent the turn the slow way)
+    const int last_lane = (tile_len - 1) >> 4;
+    const uint32_t lastF = (uint32_t)__builtin_amdgcn_readlane((int)F[((tile_len - 1) >> 2) & 3], last_lane);
+    // (F[] is an array in registers: select by the wave-uniform index of the last byte's dword)
+    carry = (lastF >> (8 * ((tile_len - 1) & 3) + 7)) & 1u;
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64(drops & 1), b1 = __builtin_amdgcn_ballot_w64(drops & 2);
+    const int kept = tile_len - (__builtin_popcountll(b0) + 2 * __builtin_popcountll(b1));
+    if constexpr (STORE) {
+        const uint64_t below = (1ull << lane) - 1;
+        const int drops_before = __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
+        int nk = nv;
+        while (__builtin_amdgcn_ballot_w64(drops > 0) != 0) {             // the highest dropped byte of each lane that has one: out
+            if (drops > 0) {
+                int q = 0;                                               // its index, 0..15
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q = D[i] ? 4 * i + ((31 - __builtin_clz(D[i])) >> 3) : q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t up = i < 3 ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 8) : (w[3] >> 8);    // the sixteen bytes moved down by one
+                    const int n = q - 4 * i;                                                                     // bytes of this dword in front of q
+                    const uint32_t low = n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << (8 * n)) - 1u));
+                    w[i] = (w[i] & low) | (up & ~low);
+                    if (4 * i <= q && q < 4 * i + 4) D[i] &= ~(0x80u << (8 * (q & 3)));
+                }
+                --drops;
+                --nk;
+            }
+        }
+        // behind its own bytes a lane writes its successor's first ones: what the successor writes there itself
+        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+        if (nk < 16 && nk >= 13) {
+            const int sh = 8 * (nk - 12);
+            w[3] = (w[3] & ((1u << sh) - 1u)) | (next << sh);
+        }
+        if (nv > 0) *reinterpret_cast<u32x4_u *>(stage + fill + min(p, tile_len) - drops_before) = w;
+    }
+    return kept;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_destuff(const uint8_t *__restrict__ blob, const DevSegment *__restrict__ segs,
+                                                 int64_t n_segs, uint32_t *__restrict__ stream,
+                                                 int32_t *__restrict__ seg_bits) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kStage];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t seg = (int64_t)blockIdx.x * 4 + wave;
+    if (seg >= n_segs) return;                                  // wave-uniform; no block barriers below
+    uint8_t *stage = s_stage[wave];
+    const int64_t begin = segs[seg].begin;
+    const int len = __builtin_amdgcn_readfirstlane(segs[seg].len);
+    const uint8_t *src = blob + begin;
+    uint32_t *out = stream + (begin >> 2) + seg;
+
+    int fill = 0, total = 0;                                    // wave-uniform: staged bytes, kept bytes
+    uint32_t carry = 0;                                         // 1 = the next byte is dropped
+    for (int t0 = 0; t0 < len; t0 += kTile) {
+        const int kept = destuff_tile<true>(src + t0, min(kTile, len - t0), stage, fill, carry, lane);
+        fill += kept;
+        total += kept;
+        if (fill >= kTile) {                                     // 1 KiB of stream, coalesced: sixteen bytes per lane
+            u32x4 d = *reinterpret_cast<const u32x4 *>(stage + 16 * lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = __builtin_bswap32(d[i]);
+            *reinterpret_cast<u32x4_u *>(out + 4 * lane) = d;
+            out += kTile / 4;
+            fill -= kTile;
+            if (16 * lane < fill) {                              // what is left moves to the front
+                const u32x4 r = *reinterpret_cast<const u32x4 *>(stage + kTile + 16 * lane);
+                *reinterpret_cast<u32x4 *>(stage + 16 * lane) = r;
+            }
         }
     }
     // tail: zero-pad to a whole dword; nothing is written past it (the next dword belongs to the next segment)
-    if (lane < 4) stage[(base + fill + lane) & (kRing - 1)] = 0;
+    if (lane < 4) stage[fill + lane] = 0;
     const int n_dw = (fill + 3) >> 2;
-    if (lane < n_dw) {
-        const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
-        out[lane] = __builtin_bswap32(d);
-    }
+    for (int i = lane; i < n_dw; i += 64) out[i] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(stage + 4 * i));
     if (lane == 0) seg_bits[seg] = total * 8;
 }
 
@@ -145,7 +249,7 @@ __global__ __launch_bounds__(256) void k_destuff_pieces(const uint8_t *__restric
                                                         const DevPiece *__restrict__ pieces, int64_t n_pieces,
                                                         int32_t *__restrict__ kept, uint32_t *__restrict__ stream,
                                                         int32_t *__restrict__ seg_bits) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][kStage];      // (the counting launch stages only what its slow turns write)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t pi = (int64_t)blockIdx.x * 4 + wave;
@@ -162,10 +266,7 @@ __global__ __launch_bounds__(256) void k_destuff_pieces(const uint8_t *__restric
 
     const int64_t begin = seg_begin + p_off;
     const int len = empty ? 0 : p_end - p_off;
-    const int64_t abase = begin & ~(int64_t)3;
-    const int lead = (int)(begin - abase);
-    const int span = lead + len;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(blob + abase);
+    const uint8_t *src = blob + begin;
 
     // where this piece's bytes go: behind everything the segment's earlier pieces keep
     int o = 0;
@@ -177,63 +278,34 @@ __global__ __launch_bounds__(256) void k_destuff_pieces(const uint8_t *__restric
         o = __builtin_amdgcn_readfirstlane(part);
     }
     uint32_t *out = stream + (seg_begin >> 2) + pc.seg + (o >> 2);
-    int fill = o & 3, base = 0, total = 0;                       // the first o & 3 ring bytes stand for the predecessor's
+    int fill = o & 3, total = 0;                                 // the first o & 3 staged bytes stand for the predecessor's
     uint32_t head_mask = (0xFu << (o & 3)) & 0xFu;               // ... bytes of the first dword, which are not ours to write
     uint32_t carry = (p_off > 0 && !empty) ? carry_in_at(blob, seg_begin, begin, lane) : 0u;
 
-    for (int c0 = 0; c0 < span; c0 += 256) {
-        const int p = c0 + 4 * lane;
-        const uint32_t w = p < span ? src[p >> 2] : 0u;
-        uint32_t k0 = 0, k1 = 0, s0 = 0, s1 = 1, vm = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool valid = p + i >= lead && p + i < span;
-            const bool isff = ((w >> (8 * i)) & 0xFFu) == 0xFFu;
-            vm |= valid ? 1u << i : 0u;
-            k0 |= (valid && !s0) ? 1u << i : 0u;
-            k1 |= (valid && !s1) ? 1u << i : 0u;
-            s0 = valid ? (s0 ? 0u : (uint32_t)isff) : s0;
-            s1 = valid ? (s1 ? 0u : (uint32_t)isff) : s1;
-        }
-        const uint64_t A = __ballot(s0 != 0), B = __ballot(s1 != 0);
-        const uint64_t V = __ballot(vm != 0);
-        uint64_t S = (A << 1) | carry;
-        uint32_t carry_out = (uint32_t)(A >> 63);
-        uint64_t dep = (A ^ B) & V;
-        while (dep) {
-            const int L = __builtin_ctzll(dep);
-            dep &= dep - 1;
-            const uint32_t ov = (uint32_t)((((S >> L) & 1) ? B : A) >> L) & 1u;
-            if (L == 63) carry_out = ov;
-            else S = (S & ~(2ull << L)) | ((uint64_t)ov << (L + 1));
-        }
-        const uint32_t keep = ((S >> lane) & 1) ? k1 : k0;
-        const int cnt = __builtin_popcount(keep);
-        const uint64_t b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-        const int tot = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+    for (int t0 = 0; t0 < len; t0 += kTile) {
+        const int got = destuff_tile<WRITE>(src + t0, min(kTile, len - t0), stage, fill, carry, lane);
+        total += got;
         if constexpr (WRITE) {
-            const uint64_t below = (1ull << lane) - 1;
-            int pos = base + fill + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below) +
-                      4 * __builtin_popcountll(b2 & below);
+            fill += got;
+            if (fill >= kTile) {                                 // 1 KiB of stream, coalesced
+                if (head_mask != 0xFu) {                         // (the piece's first: its first dword is shared)
+                    for (int i = lane; i < kTile / 4; i += 64)
+                        store_stream_dword(out + i, *reinterpret_cast<const uint32_t *>(stage + 4 * i), i == 0 ? head_mask : 0xFu);
+                    head_mask = 0xFu;
+                } else {
+                    u32x4 d = *reinterpret_cast<const u32x4 *>(stage + 16 * lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if ((keep >> i) & 1) {
-                    stage[pos & (kRing - 1)] = (uint8_t)(w >> (8 * i));
-                    ++pos;
+                    for (int i = 0; i < 4; ++i) d[i] = __builtin_bswap32(d[i]);
+                    *reinterpret_cast<u32x4_u *>(out + 4 * lane) = d;
+                }
+                out += kTile / 4;
+                fill -= kTile;
+                if (16 * lane < fill) {                          // what is left moves to the front
+                    const u32x4 r = *reinterpret_cast<const u32x4 *>(stage + kTile + 16 * lane);
+                    *reinterpret_cast<u32x4 *>(stage + 16 * lane) = r;
                 }
             }
-            fill += tot;
-            if (fill >= 256) {                                   // one full 256-byte line, coalesced
-                const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
-                store_stream_dword(out + lane, d, lane == 0 ? head_mask : 0xFu);
-                head_mask = 0xFu;
-                out += 64;
-                base = (base + 256) & (kRing - 1);
-                fill -= 256;
-            }
         }
-        total += tot;
-        carry = carry_out;
     }
     if constexpr (!WRITE) {
         if (lane == 0) kept[pi] = total;
@@ -241,13 +313,12 @@ __global__ __launch_bounds__(256) void k_destuff_pieces(const uint8_t *__restric
         // tail: the segment's last piece zero-pads to a whole dword; any other piece leaves the rest of its last dword to
         // its successor
         const int rem = fill & 3;
-        if (last && lane < 4) stage[(base + fill + lane) & (kRing - 1)] = 0;
+        if (last && lane < 4) stage[fill + lane] = 0;
         const int n_dw = (fill + 3) >> 2;
-        if (lane < n_dw) {
-            const uint32_t d = *reinterpret_cast<const uint32_t *>(stage + ((base + 4 * lane) & (kRing - 1)));
-            uint32_t mask = lane == 0 ? head_mask : 0xFu;
-            if (lane == n_dw - 1 && rem != 0 && !last) mask &= (1u << rem) - 1u;
-            store_stream_dword(out + lane, d, mask);
+        for (int i = lane; i < n_dw; i += 64) {
+            uint32_t mask = i == 0 ? head_mask : 0xFu;
+            if (i == n_dw - 1 && rem != 0 && !last) mask &= (1u << rem) - 1u;
+            store_stream_dword(out + i, *reinterpret_cast<const uint32_t *>(stage + 4 * i), mask);
         }
         if (last && lane == 0) seg_bits[pc.seg] = (o + total) * 8;
     }
