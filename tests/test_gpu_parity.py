@@ -1813,6 +1813,47 @@ def test_value_sizes_up_to_15_and_bursts_of_unresolved_entries(dec, form, tune):
         assert np.array_equal(img[8 * b:8 * b + 8], ref["rgb"][8 * b:8 * b + 8]), b
 
 
+@pytest.mark.parametrize("form", ["lanes", "wave", "sync"])
+def test_streams_dense_with_0xff_bytes(dec, form, tune):
+    """Stage 0 (csrc/destuff.hip) takes sixteen source bytes per lane and turn and assumes what entropy-coded data guarantees — an
+    0xFF is followed by its stuffed 0x00 — with the general step behind it for turns that break the assumption or hold more than
+    three dropped bytes in one lane's sixteen.  A hand-written stream whose value bits are runs of ones, in four stretches of
+    different density: lanes with one, two and three stuffed bytes to take out in registers, turns that go the slow way, 0xFF as
+    the last byte of a turn (the carry into the next), through the restart-segment kernel (lanes, wave) and the piece-wise one
+    (sync) — coefficients and pixels against the oracle."""
+    from oracle import oracle
+    from pyjpegdecoder_amd import parse_jpeg
+    rng = np.random.default_rng(5)
+
+    def block(density):
+        out, k = [], 1
+        while k < 60:
+            if rng.random() < density:
+                size = int(rng.integers(6, 11))
+                out.append((0, size, (1 << size) - 1))
+                k += 1
+            else:
+                run, size = int(rng.integers(0, 3)), int(rng.integers(1, 4))
+                out.append((run, size, int(rng.integers(0, 1 << size))))
+                k += run + 1
+        return out + [(0, 0, None)]
+    blocks = [block(d) for d in [0.02] * 250 + [0.15] * 250 + [0.9] * 100 + [0.05] * 200]
+    raw = _craft_grey_stream(8 * len(blocks), blocks)
+    sc = parse_jpeg(raw).scans[0]
+    ff = np.frombuffer(raw[sc.entropy_start:sc.entropy_end], dtype=np.uint8) == 0xFF
+    n = ff.size // 1024 * 1024
+    per_lane = ff[:n].reshape(-1, 64, 16).sum(axis=2)                     # 0xFF bytes per lane and turn
+    worst = per_lane.max(axis=1)
+    assert (worst <= 3).sum() >= 8 and (worst > 3).sum() >= 8             # turns of both kinds
+    assert all((per_lane[worst <= 3] == k).sum() >= 10 for k in (1, 2, 3))
+    assert ff[1023:n:1024].sum() >= 2                                     # an 0xFF as a turn's last byte
+    ref = oracle.decode(raw)
+    tune("MJ_HUFFMAN", form)
+    (img,), (seam,) = dec.decode([raw], return_seams=True)
+    assert np.array_equal(seam["coef"], ref["coef"])
+    assert np.array_equal(img, ref["rgb"])
+
+
 def test_lane_form_waves_whose_lanes_use_different_ac_tables(dec, tune):
     """A batch of >= 1024 restart segments from files that assign the batch's three AC tables to their components in four
     different ways (the Annex-K pair as it is, swapped, and a third table on luma or on Cb): consecutive segments — the lanes of
