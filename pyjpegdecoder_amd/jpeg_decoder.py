@@ -99,6 +99,23 @@ class JpegDecoder():
             del self.raw_file
             del self._arr
 
+    # `huffman_tables` (:61): {destination: {codeword string: value}} as the reference holds it.  Nothing on the decode path reads
+    # the strings (the GPU tables are built from BITS / HUFFVAL), and writing them out costs more than the whole decode of a
+    # 1080p file (0.5 of 2.2 ms), so a DHT only notes its tables and the dict is filled in — in place — when it is looked at.
+    @property
+    def huffman_tables(self):
+        pending = self.__dict__.get("_pending_tables")
+        if pending:
+            for dest, spec in pending.items():
+                self._huffman_tables[dest] = dict(spec.tree)
+            pending.clear()
+        return self._huffman_tables
+
+    @huffman_tables.setter
+    def huffman_tables(self, value):
+        self._huffman_tables = value
+        self._pending_tables = {}
+
     # -- the reference's handlers (:112-652, :1368-1390): same names, same argument, same effect on the attributes ------
     def start_of_frame(self, data: bytes) -> None:
         """SOF0 / SOF2 (:112-247): scan mode, dimensions, components, sampling, quantisation table ids."""
@@ -114,7 +131,7 @@ class JpegDecoder():
         """DHT (:249-390): the tables as the reference's {codeword string: value} dicts; BITS/HUFFVAL kept for the GPU LUTs."""
         for dest, spec in parse_huffman_segment(data).items():
             self._parsed.huffman[dest] = spec
-            self.huffman_tables[dest] = dict(spec.tree)
+            self._pending_tables[dest] = spec              # the codeword strings are built when somebody looks (`huffman_tables`)
             self._say(f"Parsed Huffman table - ID: {dest & 0x0F} ({'DC' if dest >> 4 == 0 else 'AC'})")
         self.file_header += len(data)
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r05a'
-TAG=${1:-r05a}
+# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r05b'
+TAG=${1:-r05b}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1
@@ -14,5 +14,8 @@ bash "$R/tools/layout_sweep.sh" > /dev/null 2>&1
 ( cd "$R" && timeout 300 python3 tools/prog_batch_probe.py 16 256 512 768 1024 2048 > "$O/prog_sweep_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 300 python3 tools/e2e_probe.py > "$O/e2e_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 600 python3 bench.py --gpus 2 --share-gpu --steps 20 --warmup 3 --no-cpu-baseline --no-progressive > "$O/bench_gpus2_sharegpu_$TAG.json" 2> "$O/bench_gpus2_sharegpu_$TAG.err" )
+( cd "$R" && bash tools/nodri_stats.sh 256 > "$O/nodri_stats_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 300 python3 tools/stage_probe.py --ri 0 --batch 1 --distinct 1 "" > "$O/nodri_sizes_$TAG.txt" 2>&1; for n in 16 64 256 1024; do timeout 300 python3 tools/stage_probe.py --ri 0 --batch $n --distinct 16 "" MJ_SYNC_COUNT=classic 2>&1 | tail -2 | sed "s/^/$n files: /" >> "$O/nodri_sizes_$TAG.txt"; done )
+( cd "$R" && timeout 200 python3 tools/single_file_probe.py 120 > "$O/single_file_$TAG.txt" 2>&1 )
 ( cd "$R" && { [ -x tools/step_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm tools/step_probe.hip -o tools/step_probe.bin; } && timeout 300 ./tools/step_probe.bin > "$O/step_probe_$TAG.txt" 2>&1 )
 ls "$O" | tail -20

@@ -29,7 +29,7 @@ def per_kernel(pattern):
     for f in glob.glob(str(src / pattern / "*" / "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if any(w in k for w in ("huffman", "reconstruct", "progressive", "destuff", "scan_markers", "sync", "vsegs", "planes", "fused")):
+            if any(w in k for w in ("huffman", "reconstruct", "progressive", "destuff", "scan_markers", "sync", "vsegs", "planes", "fused", "count")):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
