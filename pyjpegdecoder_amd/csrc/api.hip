@@ -103,7 +103,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_lut9p, p->d_canon, p->d_nzmask, p->d_lutc, p->d_sync_items, p->d_seg_chunk0, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_lutc, p->d_sync_items, p->d_seg_chunk0, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -181,7 +181,6 @@ static int stage1_impl(mj_plan *p, void *stream) {
         // step - L, so a refining scan follows one band behind what it refines instead of waiting for the whole scan.
         MJ_HIP(ctx, hipMemsetAsync(p->d_pstates, 0xFF, (size_t)p->n_psegs * sizeof(mj::DevProgState), s));
         if (p->n_split) MJ_HIP(ctx, hipMemsetAsync(p->d_psubs, 0xFF, (size_t)p->n_split * 2 * mj::kProgSub * sizeof(mj::DevProgSub), s));
-        if (p->prog_lanes) MJ_HIP(ctx, hipMemsetAsync(p->d_nzmask, 0, (size_t)p->info.total_blocks * 8, s));
         const bool fast = p->prog_fast;
         const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
         if (fast)       // stage 0 for every segment: what progressive_fast.hip's walks read
@@ -189,13 +188,9 @@ static int stage1_impl(mj_plan *p, void *stream) {
         if (p->prog_banded) {
             for (int step = 0; step < p->prog_steps; ++step) {
                 if (fast)
-                    MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)(p->prog_lanes ? p->prog_lane_off : p->prog_rest_off), p->d_pscans, p->d_images,
+                    MJ_HIP(ctx, mj::launch_progressive_fast(s, p->d_stream, p->d_seg_bits, p->d_psegs, (int)p->prog_rest_off, p->d_pscans, p->d_images,
                                                             p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates, step,
                                                             p->prog_rows_per_band, (int)p->n_split, p->d_psubs, p->prog_parts));
-                if (p->prog_lanes)      // the AC scans: one segment per lane
-                    MJ_HIP(ctx, mj::launch_progressive_lanes(s, p->d_stream, p->d_seg_bits, p->d_psegs + p->prog_lane_off, (int)(p->prog_rest_off - p->prog_lane_off),
-                                                             p->d_pscans, p->d_images, p->d_lut9p, p->d_canon, p->d_coef, p->d_nzmask, p->d_status, tr,
-                                                             p->d_pstates + p->prog_lane_off, step, p->prog_rows_per_band));
                 const int64_t r0 = fast ? p->prog_rest_off : 0;
                 MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(p->n_psegs - r0), p->d_pscans, p->d_images, p->d_huff,
                                                         p->d_coef, p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates + r0, step,

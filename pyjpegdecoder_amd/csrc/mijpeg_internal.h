@@ -152,14 +152,6 @@ hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, 
                                    int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
                                    DevProgState *states, int step, int rows_per_band, int n_split = 0, DevProgSub *subs = nullptr, int parts = 1);
-// one AC scan segment per lane (progressive_lanes.hip): lut9 = per table 512 entries (len << 8 | symbol, 0 = longer than nine bits),
-// canon = per table kProgCanonBytes: uint16 limit[16], int16 base[16], uint8 vals[256]; nzmask = per coefficient block the zig-zag
-// positions that are non-zero (zeroed with the coefficient store at the start of an execute)
-constexpr int kProgCanonBytes = 320;
-hipError_t launch_progressive_lanes(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevProgSeg *segs, int n_segs,
-                                    const DevProgScan *scans, const DevImage *images, const uint16_t *lut9, const uint8_t *canon,
-                                    int16_t *coef, uint64_t *nzmask, int32_t *status, int transposed, DevProgState *states, int step,
-                                    int rows_per_band);
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,

@@ -201,11 +201,6 @@ struct mj_plan {
     int64_t prog_rest_off = 0;               // banded: d_psegs[prog_rest_off..] are the segments of the scans progressive.hip walks
     mj::DevProgSub *d_psubs = nullptr;       // [n_split][2][kProgSub]: by segment, two sets (even and odd bands)
     int prog_parts = 4;                      // ... parts per band
-    bool prog_lanes = false;                 // banded: the AC scans' segments are d_psegs[prog_lane_off..prog_rest_off), one per LANE (progressive_lanes.hip)
-    int64_t prog_lane_off = 0;
-    uint16_t *d_lut9p = nullptr;             // ... their 9-bit LUTs and canonical code books per table, the blocks' non-zero masks
-    uint8_t *d_canon = nullptr;
-    uint64_t *d_nzmask = nullptr;
     int64_t n_split = 0;                     // banded: d_psegs[0..n_split) are the segments of the scans walked as scout + parts
     // (one launch per dependency level only — MJ_PROG_BANDS=0; the band pipeline orders d_psegs by length instead)
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs

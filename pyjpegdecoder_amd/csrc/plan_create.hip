@@ -460,17 +460,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (const char *e = mj::opt("MJ_PROG_SPLIT")) split_mode = atoi(e);
         if (const char *e = mj::opt("MJ_PROG_PARTS")) p->prog_parts = std::min(std::max(atoi(e), 1), mj::kProgSub);
         if (!p->prog_fast || !p->prog_banded) split_mode = 0;
-        // One AC scan segment per LANE instead of per wavefront (progressive_lanes.hip) for large batches: from ~1 000 files on the
-        // wavefront walks run out of instruction issue and the batch time grows with the batch.  MJ_PROG_LANES: 0 never, 1 from
-        // 512 images on (the default), 2 always (the tests).  Not with MJ_FLAG_SPEC_REFINE (T.81's refinement reads the old value).
-        {
-            int mode = 1;
-            if (const char *e = mj::opt("MJ_PROG_LANES")) mode = atoi(e);
-            p->prog_lanes = p->prog_fast && p->prog_banded && !(b->flags & MJ_FLAG_SPEC_REFINE) && (mode >= 2 || (mode == 1 && b->n_images >= 512));
-            for (int k = 0; k < b->n_scans && p->prog_lanes; ++k)
-                if (b->scans[k].ss > 0 && b->scans[k].n_comp != 1) p->prog_lanes = false;       // (refused below anyway)
-            if (p->prog_lanes) split_mode = 0;
-        }
         std::vector<char> split_of(b->n_scans, 0);
         if (split_mode) {
             // ... and while the chip has wave slots for it: past that the added work — a split scan is walked one and a half
@@ -615,20 +604,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 auto rest = [&](const mj::DevProgSeg &g) { return kind_of(b->scans[g.scan]) == 3; };
                 // (in front of them all the split scans' segments: the kernel finds their parts by position)
                 auto split = [&](const mj::DevProgSeg &g) { return pscans[g.scan].split != 0; };
-                // (with one AC scan segment per lane: the wavefront walks' segments — DC scans —, then the lanes' in the order that
-                // makes a wavefront the same scan of 64 consecutive images — same kind of walk, same number of blocks —, then the rest)
-                auto by_lane = [&](const mj::DevProgSeg &g) { const int kd = kind_of(b->scans[g.scan]); return p->prog_lanes && (kd == 1 || kd == 2); };
-                std::vector<int> first_scan_of(b->n_images, -1);
-                for (int k = b->n_scans - 1; k >= 0; --k) first_scan_of[b->scans[k].image] = k;
                 std::stable_sort(psegs.begin(), psegs.end(), [&](const mj::DevProgSeg &x, const mj::DevProgSeg &y) {
                     if (rest(x) != rest(y)) return rest(y);
-                    if (by_lane(x) != by_lane(y)) return by_lane(y);
-                    if (by_lane(x)) {
-                        const int px = x.scan - first_scan_of[b->scans[x.scan].image], py = y.scan - first_scan_of[b->scans[y.scan].image];
-                        if (px != py) return px < py;
-                        if (x.mcu0 != y.mcu0) return x.mcu0 < y.mcu0;
-                        return b->scans[x.scan].image < b->scans[y.scan].image;
-                    }
                     if (split(x) != split(y)) return split(x);
                     return x.len > y.len;
                 });
@@ -636,11 +613,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 while (p->n_split < (int64_t)psegs.size() && split(psegs[p->n_split])) ++p->n_split;
                 p->prog_rest_off = 0;
                 while (p->prog_rest_off < (int64_t)psegs.size() && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
-                p->prog_lane_off = p->prog_rest_off;
-                if (p->prog_lanes) {
-                    p->prog_lane_off = 0;
-                    while (p->prog_lane_off < p->prog_rest_off && !by_lane(psegs[p->prog_lane_off])) ++p->prog_lane_off;
-                }
             }
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
             p->prog_steps = n_bands + n_ord - 1;
@@ -1071,35 +1043,6 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     }
                 }
                 if ((rc = upload(ctx, &p->d_lut11p, lp.data(), lp.size())) != MJ_OK) return rc;
-                if (p->prog_lanes) {
-                    // per table what a lane keeps in LDS: the 9-bit LUT (every fourth entry of the 11-bit one, where the code
-                    // fits), and the canonical code book — per length the left-aligned upper limit of its codes (lengths
-                    // without codes repeat their predecessor's), first symbol minus first code, then the symbol values
-                    std::vector<uint16_t> l9((size_t)b->n_huff * 512, 0);
-                    std::vector<uint8_t> cn((size_t)b->n_huff * mj::kProgCanonBytes, 0);
-                    for (int t = 0; t < b->n_huff; ++t) {
-                        for (int i = 0; i < 512; ++i) {
-                            const uint16_t e = lp[(size_t)t * LS + ((size_t)i << (mj::kProgLutBits - 9))];
-                            l9[(size_t)t * 512 + i] = (e >> 8) <= 9 ? e : (uint16_t)0;
-                        }
-                        uint16_t *lim = reinterpret_cast<uint16_t *>(cn.data() + (size_t)t * mj::kProgCanonBytes);
-                        int16_t *base = reinterpret_cast<int16_t *>(lim + 16);
-                        uint8_t *vals = reinterpret_cast<uint8_t *>(base + 16);
-                        int code = 0, k = 0;
-                        for (int l = 1; l <= 16; ++l) {
-                            code <<= 1;
-                            base[l - 1] = (int16_t)(k - code);
-                            const int n = b->huff[t].bits[l - 1];
-                            code += n; k += n;
-                            const int64_t upper = (int64_t)code << (16 - l);
-                            lim[l - 1] = (uint16_t)std::min<int64_t>(upper, 65535);
-                        }
-                        for (int i = 0; i < 256; ++i) vals[i] = b->huff[t].vals[i];
-                    }
-                    if ((rc = upload(ctx, &p->d_lut9p, l9.data(), l9.size())) != MJ_OK) return rc;
-                    if ((rc = upload(ctx, &p->d_canon, cn.data(), cn.size())) != MJ_OK) return rc;
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_nzmask, (size_t)blk * 8 + 16));
-                }
             }
             if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
             if (p->n_split)     // by segment (the first n_split of them), two sets: even and odd bands

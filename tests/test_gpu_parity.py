@@ -1175,8 +1175,7 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
 
 
-@pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none",
-                                  "lanes", "lanes_three_rows"])
+@pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none"])
 def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
     launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, one MCU row per
@@ -1190,9 +1189,7 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
            "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"},
            # (round 4) every refining AC scan walked as scout + parts (by default only those with 1 KiB or more per band), or none
            "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_three_rows": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3"},
-           "split_none": {"MJ_PROG_SPLIT": "0"},
-           # (round 5) one AC scan segment per LANE (progressive_lanes.hip: what batches of 512 files and more take)
-           "lanes": {"MJ_PROG_LANES": "2"}, "lanes_three_rows": {"MJ_PROG_LANES": "2", "MJ_PROG_ROWS": "3"}}[form]
+           "split_none": {"MJ_PROG_SPLIT": "0"}}[form]
     for k, v in env.items():
         tune(k, v)
     names = prog_names()
