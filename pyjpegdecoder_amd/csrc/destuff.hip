@@ -62,7 +62,13 @@ __device__ __forceinline__ int destuff_range_slow(const uint8_t *src_bytes, int 
         // order, the lanes whose output does depend on it (rare: an 0xFF in the first byte, runs of 0xFF)
         uint64_t S = (A << 1) | carry;
         uint32_t carry_out = (uint32_t)(A >> 63);
-        uint64_t dep = (A ^ B) & V;
+        // (a lane that holds no byte of the range passes its input state on — A = 0, B = 1 there —, so it is one of these: a range
+        // that starts off a dword boundary ends in a turn of one dword, and the state behind its last byte has to come through
+        // the 63 empty lanes behind it.  Round 5, found by bench.py's 256-image parity check: the rule here used to skip such
+        // lanes — right as long as empty lanes only followed the END of a segment, wrong for a range in the middle of one whose
+        // last byte is an 0xFF.)
+        uint64_t dep = A ^ B;
+        (void)V;
         while (dep) {
             const int L = __builtin_ctzll(dep);
             dep &= dep - 1;
@@ -86,7 +92,6 @@ __device__ __forceinline__ int destuff_range_slow(const uint8_t *src_bytes, int 
             }
         }
         total += tot;
-        // (a lane that holds no valid byte passes its input state on: A and B differ there, V excludes it, S carries through)
         carry = carry_out;
     }
     return total;
