@@ -229,7 +229,8 @@ static int stage1_impl(mj_plan *p, void *stream) {
             if (p->d_lutc) {
                 // resolved tables: one walk over every chunk, the list of wrong guesses, their repair — three launches
                 MJ_HIP(ctx, mj::launch_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_lutc, p->lutc_tab_bytes, p->n_huff, p->lutc_bits,
-                                             p->d_chunks, p->n_chunks, cbits, p->sync_warm_bits, p->d_stateA, p->d_couts, p->d_sync_items, p->d_changed, p->sync_rounds));
+                                             p->d_chunks, p->n_chunks, cbits, p->sync_warm_bits, p->d_stateA, p->d_couts, p->d_sync_items, p->d_changed, p->sync_rounds,
+                                             reinterpret_cast<int32_t *>(p->d_stateB)));
             } else {
                 MJ_HIP(ctx, mj::launch_fill_words(s, p->d_couts, 0xFFFFFFFFu, p->n_chunks * (int64_t)(sizeof(mj::DevChunkOut) / 4)));
                 MJ_HIP(ctx, mj::launch_sync_count(s, p->d_stream, p->d_seg_bits, p->d_segs, p->d_images, p->d_huff, p->d_lut11u, p->n_huff,

@@ -99,11 +99,11 @@ __device__ __forceinline__ int destuff_range_slow(const uint8_t *src_bytes, int 
 // Round 5: sixteen bytes per lane and turn.  In entropy-coded data an 0xFF is followed by its stuffed 0x00, never by another 0xFF,
 // so the sequential rule degenerates: dropped = the byte behind an 0xFF.  A turn takes 1 KiB of the segment: each lane flags its 0xFF
 // bytes with three integer operations per dword, the flags moved up one byte (across dwords with v_alignbit, across lanes with a
-// DPP shift, across turns with a carry) are the dropped bytes; a lane takes its (at most three) dropped bytes out of its
+// DPP shift, across turns with a carry) are the dropped bytes; a lane takes its (at most seven) dropped bytes out of its
 // sixteen in registers, fills up from its successor's first bytes, and writes SIXTEEN bytes at its byte offset in the staging
 // buffer — gfx950's LDS takes a 16-byte access at any byte address (tools/unaligned_lds_probe.hip), and where two lanes' writes
 // overlap they carry the same bytes.  A turn in which some dropped byte is itself an 0xFF (fill bytes in front of a marker,
-// damaged data), or a lane has more than three, goes through the slow step above.  Instructions per source byte: 0.11 against
+// damaged data), or a lane has more than seven, goes through the slow step above.  Instructions per source byte: 0.11 against
 // 0.4; the kernel had been bound by instruction issue (0.52 ms per 1024 x 1080p, 1.3 TB/s each way).
 // One turn: the `tile_len` (<= 1 KiB) source bytes at `src`, kept bytes to the staging buffer at `fill` (STORE) or only counted.
 template <bool STORE>
@@ -132,17 +132,17 @@ __device__ __forceinline__ int destuff_tile(const uint8_t *src, int tile_len, ui
         both |= D[i] & F[i];
         drops += __builtin_popcount(D[i]);
     }
-    if (__builtin_amdgcn_ballot_w64(both != 0u || drops > 3) != 0) return destuff_range_slow<STORE>(src, tile_len, stage, fill, carry, lane);
+    if (__builtin_amdgcn_ballot_w64(both != 0u || drops > 7) != 0) return destuff_range_slow<STORE>(src, tile_len, stage, fill, carry, lane);
     // the state behind the range: its last byte an 0xFF (kept: a dropped one would have sent the turn the slow way)
     const int last_lane = (tile_len - 1) >> 4;
     const uint32_t lastF = (uint32_t)__builtin_amdgcn_readlane((int)F[((tile_len - 1) >> 2) & 3], last_lane);
     // (F[] is an array in registers: select by the wave-uniform index of the last byte's dword)
     carry = (lastF >> (8 * ((tile_len - 1) & 3) + 7)) & 1u;
-    const uint64_t b0 = __builtin_amdgcn_ballot_w64(drops & 1), b1 = __builtin_amdgcn_ballot_w64(drops & 2);
-    const int kept = tile_len - (__builtin_popcountll(b0) + 2 * __builtin_popcountll(b1));
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64(drops & 1), b1 = __builtin_amdgcn_ballot_w64(drops & 2), b2 = __builtin_amdgcn_ballot_w64(drops & 4);
+    const int kept = tile_len - (__builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2));
     if constexpr (STORE) {
         const uint64_t below = (1ull << lane) - 1;
-        const int drops_before = __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
+        const int drops_before = __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below) + 4 * __builtin_popcountll(b2 & below);
         int nk = nv;
         while (__builtin_amdgcn_ballot_w64(drops > 0) != 0) {             // the highest dropped byte of each lane that has one: out
             if (drops > 0) {
@@ -161,11 +161,15 @@ __device__ __forceinline__ int destuff_tile(const uint8_t *src, int tile_len, ui
                 --nk;
             }
         }
-        // behind its own bytes a lane writes its successor's first ones: what the successor writes there itself
-        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-        if (nk < 16 && nk >= 13) {
-            const int sh = 8 * (nk - 12);
-            w[3] = (w[3] & ((1u << sh) - 1u)) | (next << sh);
+        // behind its own bytes (nine at least) a lane writes its successor's first ones: what the successor writes there itself
+        const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+        const uint32_t next1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[1], 0x130, 0xF, 0xF, false);
+        if (nk < 16 && nk >= 9) {
+            const int sh = 8 * (nk - 8);
+            const uint64_t mine = ((uint64_t)w[3] << 32) | w[2], fill_in = ((uint64_t)next1 << 32) | next0;
+            const uint64_t both_halves = sh ? (mine & ((1ull << sh) - 1ull)) | (fill_in << sh) : fill_in;
+            w[2] = (uint32_t)both_halves;
+            w[3] = (uint32_t)(both_halves >> 32);
         }
         if (nv > 0) *reinterpret_cast<u32x4_u *>(stage + fill + min(p, tile_len) - drops_before) = w;
     }

@@ -309,6 +309,7 @@ struct CountArgs {
     const DevChunk *chunks; int64_t n_chunks; int32_t cbits, warm;
     uint64_t *exit_state; DevChunkOut *outs;
     const SyncItem *items; const int32_t *n_items; int32_t max_links;
+    int32_t *owner;            // repair launch: per chunk, the first chunk of the leftmost walk that has taken it
 };
 
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
@@ -444,7 +445,18 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
         my_entry = pack_state(pos, (int)(b8 >> 3), (int)k);
     }
     int links = 0;
+    const int32_t origin = (int32_t)c;                  // (repair) where this lane's walk started
     for (;;) {
+        if constexpr (REPAIR) {
+            // A chunk may be walked by several lanes of this launch — its own, from the state its predecessor USED to leave, and
+            // lanes that walk on into it from further left because their chunk now leaves differently.  Truth travels from left
+            // to right: the walk that started furthest left wins, whenever the others finish.  A lane takes a chunk before it
+            // walks it (atomic minimum of the walks' first chunks) and writes its record only if nobody from further left has
+            // taken it meanwhile.  (Without this the order of two such writes was left to the launch's timing — fine alone on the
+            // chip, not under other streams' kernels: a sharded queue's plans, two in flight per rank, showed it as one image in
+            // a few hundred executes coming back MJ_ST_UNCONVERGED.)
+            if (have) __hip_atomic_fetch_min(A.owner + c, origin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         blocks = 0; mx = 0; bnd_blocks = 0; acc01 = 0; acc2 = 0; bd01 = 0; bd2 = 0;
         bnd_pos = (b8 == 0 && k == 0 && pos < final_limit) ? pos : ~0u;      // entered at an MCU boundary
         if (__builtin_amdgcn_ballot_w64(pos < final_limit) != 0) {
@@ -456,6 +468,7 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
         }
         const uint64_t ex = pack_state(pos, (int)(b8 >> 3), (int)k);
         uint64_t old_exit = ex;
+        bool mine = true;
         if (have) {
             DevChunkOut o;
             o.entry = mx > 192u ? ~0ull : my_entry;
@@ -465,15 +478,17 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
             o.dc_bnd[0] = (int16_t)bd01; o.dc_bnd[1] = (int16_t)(bd01 >> 16); o.dc_bnd[2] = (int16_t)bd2;
             o.dc_sum[0] = (int16_t)acc01; o.dc_sum[1] = (int16_t)(acc01 >> 16); o.dc_sum[2] = (int16_t)acc2;
             if constexpr (REPAIR) {
-                // A chunk may be written by several lanes of this launch, on different CUs and XCDs, a chunk's walk apart — the one
-                // that walked from the true state last.  "Last" has to mean last in time: device-scope loads and write-through
-                // stores (a plain store stays in its XCD's L2 until the launch ends, and the write-backs come in any order).
-                old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
-                uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
+                // Writes of different lanes to one chunk have to land in memory in the order they are made: device-scope loads and
+                // write-through stores (a plain store stays in its XCD's L2 until the launch ends, and the write-backs come in any order).
+                mine = __hip_atomic_load(A.owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= origin;
+                if (mine) {
+                    old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
+                    uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else {
                 A.outs[c] = o;
                 A.exit_state[c] = ex;
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
         // The chunk leaves in the state it left in before (nearly always: the old walk had found its way inside the chunk): the next
         // chunk's record was computed from that state, or is being computed from it by its own lane right now.  Else this lane
         // walks on: whatever the next chunk's record says, or its lane writes — a chunk's walk earlier than this one — is void.
-        bool go = have && ex != old_exit && links < A.max_links && c + 1 < A.n_chunks;
+        bool go = have && mine && ex != old_exit && links < A.max_links && c + 1 < A.n_chunks;
         if (go) go = A.chunks[c + 1].seg == ch.seg && (uint64_t)(ch.j + 1) * cbits < nbits;
         have = go;
         if (go) { ++c; ++ch.j; ++links; my_entry = ex; final_limit = chunk_limit(ch.j); }
@@ -496,9 +511,10 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
 // state to start from.
 __global__ void k_sync_scan(const DevChunk *__restrict__ chunks, int64_t n_chunks, const DevChunkOut *__restrict__ outs,
                             const uint64_t *__restrict__ exit_state, const int32_t *__restrict__ seg_bits, int cbits,
-                            SyncItem *__restrict__ items, int32_t *__restrict__ n_items) {
+                            SyncItem *__restrict__ items, int32_t *__restrict__ n_items, int32_t *__restrict__ owner) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool add = c < n_chunks;
+    if (add) owner[c] = 0x7FFFFFFF;                   // nobody has taken the chunk yet (k_count<true>)
     uint64_t e = 0;
     if (add) {
         const DevChunk ch = chunks[c];
@@ -523,9 +539,10 @@ __global__ void k_sync_scan(const DevChunk *__restrict__ chunks, int64_t n_chunk
 
 hipError_t launch_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, const DevImage *images,
                         const uint32_t *lutc, int tab_bytes, int n_tabs, int wbits, const DevChunk *chunks, int64_t n_chunks, int cbits,
-                        int warm_bits, uint64_t *exit_state, DevChunkOut *outs, void *items, int32_t *n_items, int max_links) {
+                        int warm_bits, uint64_t *exit_state, DevChunkOut *outs, void *items, int32_t *n_items, int max_links, int32_t *owner) {
     if (n_chunks == 0) return hipSuccess;
     CountArgs A{};
+    A.owner = owner;
     A.stream = dstream; A.seg_bits = seg_bits; A.segs = segs; A.images = images;
     A.lutc = lutc; A.tab_bytes = tab_bytes; A.n_tabs = n_tabs; A.wbits = wbits;
     // the run-up in front of every chunk: half a chunk.  A wrong guess costs one lane of the repair launch, whose duration is one
@@ -550,7 +567,7 @@ hipError_t launch_count(hipStream_t stream, const uint32_t *dstream, const int32
     if (max_links > 0) {
         if (hipError_t e = launch_fill_words(stream, n_items, 0u, 1); e != hipSuccess) return e;
         hipLaunchKernelGGL(k_sync_scan, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream, chunks, n_chunks, outs, exit_state, seg_bits,
-                           cbits, reinterpret_cast<SyncItem *>(items), n_items);
+                           cbits, reinterpret_cast<SyncItem *>(items), n_items, owner);
         // (four wavefronts per workgroup = one per SIMD: each still runs alone, and the tables are in LDS four times sooner)
         hipLaunchKernelGGL(k_count<true>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), lds, stream, A);
     }

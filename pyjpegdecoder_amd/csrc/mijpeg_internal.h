@@ -192,10 +192,11 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
                              int warm_bits = -1);   // wg_tabs: per 256 chunks; warm_bits: run-up in front of every chunk, -1 = half a chunk
 // the same on resolved tables (lutc: n_tabs tables of tab_bytes each, wbits index bits: plan_create.hip's build_count_tables): the first
 // walk over every chunk, then — max_links > 0 — the list of chunks whose entry state was guessed wrong (items: 16 bytes per
-// chunk, *n_items) and their repair, each lane walking on for at most max_links chunks.  exit_state / outs as above.
+// chunk, *n_items) and their repair, each lane walking on for at most max_links chunks (owner: 4 bytes per chunk of scratch).
+// exit_state / outs as above.
 hipError_t launch_count(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs, const DevImage *images,
                         const uint32_t *lutc, int tab_bytes, int n_tabs, int wbits, const DevChunk *chunks, int64_t n_chunks, int cbits,
-                        int warm_bits, uint64_t *exit_state, DevChunkOut *outs, void *items, int32_t *n_items, int max_links);
+                        int warm_bits, uint64_t *exit_state, DevChunkOut *outs, void *items, int32_t *n_items, int max_links, int32_t *owner);
 // seg_chunk0[s] = the first chunk of restart segment s (n_segs + 1 entries)
 hipError_t launch_build_vsegs(hipStream_t stream, const DevChunk *chunks, const int32_t *seg_chunk0, int64_t n_segs, const DevChunkOut *outs,
                               const DevSegment *segs, const int32_t *seg_bits, const DevImage *images, DevVSeg *vsegs,

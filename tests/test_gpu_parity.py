@@ -1375,6 +1375,48 @@ def test_sync_repair_lanes_walk_on_where_an_exit_state_changes(dec, tune):
         assert np.array_equal(img, oracle.decode(raw)["rgb"]), i
 
 
+def test_sync_form_plans_on_concurrent_streams_always_settle(dec):
+    """Several small plans of files without restart markers, each on a stream of its own, executed side by side again and again
+    (a sharded queue's ranks sharing a GPU do exactly this).  Small batches mean 256-byte chunks with a 128-byte run-up: a
+    third of the guesses are wrong and in every image a few old walks had not found their way by the end of their chunk, so the
+    repair launch's lanes walk on into chunks that other lanes — started from a stale state — are writing too.  Which write
+    stands must not depend on when the workgroups of the launch get to run (huffman_sync.hip: the walk from furthest left takes
+    the chunk): every execute of every plan has to settle on the device — no MJ_ST_UNCONVERGED, no fallback — and give the
+    oracle's pixels."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    dev = torch.device("cuda", 0)
+    plans = []
+    try:
+        for k in range(4):
+            raws = [synth.synth_jpeg(8800 + 10 * k + i, 480 + 32 * k, 320 + 16 * i, 85, "420", 0, 14.0) for i in range(6)]
+            prep = prepare_batch(raws, B.MJ_LAYOUT_XMAJOR, 0)
+            d_blob = torch.from_numpy(prep.blob).to(dev)
+            plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(raws), "blob": d_blob})
+            assert plan.stage1_form() & 15 == B.MJ_FORM_SYNC and plan.stage1_form() & B.MJ_FORM_COUNT_RESOLVED
+            plans.append((plan, raws, torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev)))
+        for it in range(60):
+            for plan, _, rgb, st in plans:
+                plan.execute(st.cuda_stream, rgb.data_ptr())
+            for plan, _, _, _ in plans:
+                plan.sync()
+            for k, (plan, _, _, _) in enumerate(plans):
+                status = plan.read(rgb=False)["status"]
+                assert not status.any(), (it, k, status)
+        for plan, raws, rgb, _ in plans:
+            flat, off = rgb.cpu().numpy(), 0
+            for raw in raws:
+                want = oracle.decode(raw)["rgb"]
+                assert np.array_equal(flat[off:off + want.size].reshape(want.shape), want)
+                off += want.size
+    finally:
+        for plan, _, _, _ in plans:
+            plan.close()
+
+
 @pytest.mark.parametrize("layout", ["planar", "planar_rowmajor"])
 def test_planar_layouts(layout):
     """MJ_LAYOUT_PLANAR_*: the components of the reference's image_array (:1373-1386) as three planes per image — every
