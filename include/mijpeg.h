@@ -201,7 +201,8 @@ int mj_plan_get_info(const mj_plan *plan, mj_plan_info *info);
 #define MJ_FORM_WG_TABLES 16
 #define MJ_FORM_RESOLVED  32
 #define MJ_FORM_COUNT_RESOLVED 128   /* MJ_FORM_SYNC: the counting walks run on resolved tables with a repair work list
-                                        (huffman_sync.hip: k_count) instead of the classic rounds */
+                                        (huffman_sync.hip: k_count) instead of the classic rounds; MJ_FORM_SCANS: the first AC
+                                        scans are walked in self-synchronising chunks (progressive_chunks.hip) */
 #define MJ_FORM_FUSED     64   /* mj_plan_execute runs stages 1 and 2 as ONE launch (fused.hip): lane-walk wavefronts and
                                   reconstruction wavefronts side by side in one workgroup per CU.  Uniform x-major batches of
                                   4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 files with one restart interval per MCU row and the resolved
@@ -286,6 +287,8 @@ int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *f
  *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
  *   MJ_PROG_SPLIT     0 | 1 | 2  refining AC scans as scout + parts: never | while the chip has wave slots for it | always
  *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)
+ *   MJ_PROG_CHUNKS    0 | 1 | 2  the first AC scans of progressive files in self-synchronising chunks, one per lane, in front of the
+ *                     band pipeline: never | from 2 048 images on | always;  MJ_PROG_CHUNK  128..65536 bytes per chunk (512)
  *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64 (the 11-bit lane form reads 1 as 2)   MJ_LANES_RING  64 | 128
  *   MJ_STAGE2_CHUNK   1..4096 strips per stage-2 job
  *   MJ_FUSED          0 | 1  (0 = mj_plan_execute always launches the stages separately)

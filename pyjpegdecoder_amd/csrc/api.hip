@@ -103,7 +103,7 @@ void mj_plan_destroy(mj_plan *p) {
         else (void)hipHostFree(p->arena.base);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_lutc, p->d_sync_items, p->d_seg_chunk0, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
+    void *ptrs[] = {p->d_blob_owned, p->d_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut13, p->d_lut12, p->d_by_length, p->d_holder, p->d_xwords, p->d_wg_tabs_lanes, p->d_wg_tabs_count, p->d_stream, p->d_seg_bits, p->d_jobs, p->d_lut11u, p->d_acsegs, p->d_pc_chunks, p->d_pc_tabs, p->d_pc_exit, p->d_pc_outs, p->d_pc_items, p->d_pc_owner, p->d_pc_vsegs, p->d_lutc, p->d_sync_items, p->d_seg_chunk0, p->d_chunks, p->d_stateA, p->d_stateB, p->d_couts, p->d_vsegs, p->d_changed, p->d_pieces, p->d_piece_kept, p->d_pscans, p->d_psegs, p->d_pstates, p->d_psubs, p->d_prog_dsegs, p->d_lut11p, p->d_qt, p->d_mcu_prefix, p->d_job_prefix, p->d_tmp_coef, p->d_coef,
                     p->d_rgb, p->d_rgb_tmp, p->d_planes, p->d_idct, p->d_status};
     for (void *q : ptrs)
         if (q) p->ctx->cache.put(q);
@@ -112,7 +112,7 @@ void mj_plan_destroy(mj_plan *p) {
 
 int mj_plan_stage1_form(const mj_plan *p) {
     if (!p) return MJ_ERR_INVALID;
-    if (p->progressive) return MJ_FORM_SCANS;
+    if (p->progressive) return MJ_FORM_SCANS | (p->prog_chunks ? MJ_FORM_COUNT_RESOLVED : 0);
     const int base = p->use_sync ? MJ_FORM_SYNC : (p->use_lanes ? MJ_FORM_LANES : MJ_FORM_WAVE);
     return base | (p->d_wg_tabs_lanes ? MJ_FORM_WG_TABLES : 0) | (p->use_lanes && p->d_lut13 ? MJ_FORM_RESOLVED : 0) | (p->use_fused ? MJ_FORM_FUSED : 0) |
            (p->use_sync && p->d_lutc ? MJ_FORM_COUNT_RESOLVED : 0);
@@ -185,6 +185,10 @@ static int stage1_impl(mj_plan *p, void *stream) {
         const int spec = (p->flags & MJ_FLAG_SPEC_REFINE) ? 1 : 0, tr = p->transposed ? 1 : 0;
         if (fast)       // stage 0 for every segment: what progressive_fast.hip's walks read
             MJ_HIP(ctx, mj::launch_destuff_pieces(s, p->d_blob, p->d_prog_dsegs, p->d_pieces, p->n_pieces, p->d_piece_kept, p->d_stream, p->d_seg_bits));
+        if (p->prog_chunks)     // the first AC scans, chunk by chunk, before the band pipeline starts
+            MJ_HIP(ctx, mj::launch_progressive_chunks(s, p->d_stream, p->d_seg_bits, p->d_acsegs, p->n_acsegs, p->d_pc_tabs, p->d_lut11p, p->d_pc_chunks, p->n_pc_chunks,
+                                                      p->pc_chunk_bytes * 8, p->d_pc_exit, p->d_pc_outs, p->d_pc_items, p->d_pc_owner + p->n_pc_chunks, p->d_pc_owner,
+                                                      p->d_pc_vsegs, p->d_images, p->d_coef, p->d_status, tr, p->sync_rounds));
         if (p->prog_banded) {
             for (int step = 0; step < p->prog_steps; ++step) {
                 if (fast)
@@ -192,7 +196,7 @@ static int stage1_impl(mj_plan *p, void *stream) {
                                                             p->d_huff, p->d_lut11p, p->d_coef, p->d_status, spec, tr, p->d_pstates, step,
                                                             p->prog_rows_per_band, (int)p->n_split, p->d_psubs, p->prog_parts));
                 const int64_t r0 = fast ? p->prog_rest_off : 0;
-                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(p->n_psegs - r0), p->d_pscans, p->d_images, p->d_huff,
+                MJ_HIP(ctx, mj::launch_progressive_scan(s, p->d_blob, p->d_psegs + r0, (int)(p->n_psegs_wave - r0), p->d_pscans, p->d_images, p->d_huff,
                                                         p->d_coef, p->d_status, spec | (fast ? 2 : 0), tr, p->d_pstates + r0, step,
                                                         p->prog_rows_per_band));
             }

@@ -152,6 +152,24 @@ hipError_t launch_progressive_fast(hipStream_t stream, const uint32_t *dstream, 
                                    int n_segs, const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    const uint16_t *lut11p, int16_t *coef, int32_t *status, int spec_refine, int transposed,
                                    DevProgState *states, int step, int rows_per_band, int n_split = 0, DevProgSub *subs = nullptr, int parts = 1);
+// The first AC scans of large progressive batches, cut into chunks (progressive_chunks.hip): one restart segment of such a scan
+struct DevAcSeg {
+    int32_t image;                // the image (status, geometry)
+    int32_t comp;                 // the scan's component
+    int32_t ss, se, al;
+    int32_t table;                // index of the scan's AC table in the batch
+    int32_t stream_slot;          // the segment's number in stage 0's stream buffer (seg_bits index)
+    int32_t stream_dw;            // its first dword there: (begin >> 2) + stream_slot
+    int32_t first_blk, n_blk;     // blocks of the scan (its own raster): the segment's first, how many
+    int32_t mcu_count_h;          // blocks per row of the scan
+    int32_t last;                 // the scan's last restart segment
+    int32_t chunk0, n_chunks;     // its chunks in the (padded) chunk list
+};
+constexpr int kProgCanonBytes = 320;     // per table behind its 9-bit LUT (512 x uint16: len << 8 | symbol): uint16 limit[16], int16 base[16], uint8 vals[256]
+hipError_t launch_progressive_chunks(hipStream_t stream, const uint32_t *dstream, const int32_t *seg_bits, const DevAcSeg *segs, int n_segs,
+                                     const uint8_t *tabs, const uint16_t *lut11p, const DevChunk *chunks, int64_t n_chunks, int cbits, uint64_t *exit_state,
+                                     DevChunkOut *outs, void *items, int32_t *n_items, int32_t *owner, DevVSeg *vsegs, const DevImage *images,
+                                     int16_t *coef, int32_t *status, int transposed, int max_links);
 hipError_t launch_progressive_scan(hipStream_t stream, const uint8_t *blob, const DevProgSeg *segs, int n_segs,
                                    const DevProgScan *scans, const DevImage *images, const DevHuff *huff,
                                    int16_t *coef, int32_t *status, int spec_refine, int transposed, DevProgState *states,

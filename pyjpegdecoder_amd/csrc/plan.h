@@ -201,6 +201,20 @@ struct mj_plan {
     int64_t prog_rest_off = 0;               // banded: d_psegs[prog_rest_off..] are the segments of the scans progressive.hip walks
     mj::DevProgSub *d_psubs = nullptr;       // [n_split][2][kProgSub]: by segment, two sets (even and odd bands)
     int prog_parts = 4;                      // ... parts per band
+    // the first AC scans of large batches in chunks (progressive_chunks.hip): d_psegs[n_psegs_wave..] are theirs, no wavefront walk takes them
+    bool prog_chunks = false;
+    int pc_chunk_bytes = 512;
+    int64_t n_psegs_wave = 0;
+    mj::DevAcSeg *d_acsegs = nullptr;
+    int n_acsegs = 0;
+    mj::DevChunk *d_pc_chunks = nullptr;
+    int64_t n_pc_chunks = 0;
+    uint8_t *d_pc_tabs = nullptr;
+    uint64_t *d_pc_exit = nullptr;
+    mj::DevChunkOut *d_pc_outs = nullptr;
+    void *d_pc_items = nullptr;
+    int32_t *d_pc_owner = nullptr;
+    mj::DevVSeg *d_pc_vsegs = nullptr;
     int64_t n_split = 0;                     // banded: d_psegs[0..n_split) are the segments of the scans walked as scout + parts
     // (one launch per dependency level only — MJ_PROG_BANDS=0; the band pipeline orders d_psegs by length instead)
     std::vector<int64_t> ordinal_seg_off;   // [n_ordinals + 1] into d_psegs

@@ -460,6 +460,19 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         if (const char *e = mj::opt("MJ_PROG_SPLIT")) split_mode = atoi(e);
         if (const char *e = mj::opt("MJ_PROG_PARTS")) p->prog_parts = std::min(std::max(atoi(e), 1), mj::kProgSub);
         if (!p->prog_fast || !p->prog_banded) split_mode = 0;
+        // The first AC scans of very large batches are cut into self-synchronising chunks and walked one chunk per LANE before the
+        // band pipeline starts (progressive_chunks.hip): they are a third of the wavefront walks' work, which the chip runs out of
+        // instruction issue for — from ~1 800 files on; below that a batch lasts as long as one image's chain through its last
+        // refinement, and the pass in front of the pipeline (4.5 ms per 1 024 files) only adds to it.  1080p, libjpeg's script, ms per
+        // batch without / with: 1 024 files 66.9 / 71.8, 1 536: 79.6 / 84.0, 2 048: 104.2 / 93.5, 3 072: 154.6 / 141.0, 4 096: 204.9 /
+        // 184.1 (profiles/r05_progressive_chunks.txt).  MJ_PROG_CHUNKS: 0 never, 1 from 2 048 images on (the default), 2 always (tests).
+        {
+            int mode = 1;
+            if (const char *e = mj::opt("MJ_PROG_CHUNKS")) mode = atoi(e);
+            p->prog_chunks = p->prog_fast && p->prog_banded && !(b->flags & MJ_FLAG_NO_SYNC) && (mode >= 2 || (mode == 1 && b->n_images >= 2048));
+            if (const char *e = mj::opt("MJ_PROG_CHUNK")) p->pc_chunk_bytes = atoi(e);
+        }
+        auto chunked = [&](int k) { return p->prog_chunks && b->scans[k].ss > 0 && b->scans[k].ah == 0 && b->scans[k].n_comp == 1; };
         std::vector<char> split_of(b->n_scans, 0);
         if (split_mode) {
             // ... and while the chip has wave slots for it: past that the added work — a split scan is walked one and a half
@@ -498,6 +511,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 int lvl = 0;
                 for (int j = k - 1; j >= 0 && b->scans[j].image == sd.image; --j) {
                     const mj_scan_desc &pj = b->scans[j];
+                    if (chunked(j)) continue;                 // (complete before the band pipeline starts)
                     bool comp_overlap = false;
                     for (int a1 = 0; a1 < sd.n_comp && a1 < 3; ++a1)
                         for (int a2 = 0; a2 < pj.n_comp && a2 < 3; ++a2) comp_overlap |= sd.comp[a1] == pj.comp[a2];
@@ -507,7 +521,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 ordinal_of[k] = lvl;
             }
             (void)seen;
-            n_ord = std::max(n_ord, ordinal_of[k] + 1 + (want_split(k) ? 1 : 0));
+            if (chunked(k)) ordinal_of[k] = 0;
+            else n_ord = std::max(n_ord, ordinal_of[k] + 1 + (want_split(k) ? 1 : 0));
             const mj_image_desc &d = b->images[sd.image];
             const mj::DevImage &im = imgs[sd.image];
             mj::DevProgScan ps{};
@@ -604,18 +619,25 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 auto rest = [&](const mj::DevProgSeg &g) { return kind_of(b->scans[g.scan]) == 3; };
                 // (in front of them all the split scans' segments: the kernel finds their parts by position)
                 auto split = [&](const mj::DevProgSeg &g) { return pscans[g.scan].split != 0; };
+                // (and behind everything the segments of the first AC scans that are walked in chunks: no wavefront walk takes them)
+                auto in_chunks = [&](const mj::DevProgSeg &g) { return chunked(g.scan); };
                 std::stable_sort(psegs.begin(), psegs.end(), [&](const mj::DevProgSeg &x, const mj::DevProgSeg &y) {
+                    if (in_chunks(x) != in_chunks(y)) return in_chunks(y);
+                    if (in_chunks(x)) return false;           // (among themselves: as they come — by image, scan, restart segment)
                     if (rest(x) != rest(y)) return rest(y);
                     if (split(x) != split(y)) return split(x);
                     return x.len > y.len;
                 });
                 p->n_split = 0;
                 while (p->n_split < (int64_t)psegs.size() && split(psegs[p->n_split])) ++p->n_split;
+                p->n_psegs_wave = 0;
+                while (p->n_psegs_wave < (int64_t)psegs.size() && !in_chunks(psegs[p->n_psegs_wave])) ++p->n_psegs_wave;
                 p->prog_rest_off = 0;
-                while (p->prog_rest_off < (int64_t)psegs.size() && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
+                while (p->prog_rest_off < p->n_psegs_wave && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
             }
+            if (!p->prog_banded) p->n_psegs_wave = (int64_t)psegs.size();
             const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
-            p->prog_steps = n_bands + n_ord - 1;
+            p->prog_steps = n_bands + std::max(n_ord, 1) - 1;
         }
     }
     p->mcus_per_image = (int32_t)(mcu / b->n_images);
@@ -1043,6 +1065,58 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     }
                 }
                 if ((rc = upload(ctx, &p->d_lut11p, lp.data(), lp.size())) != MJ_OK) return rc;
+                if (p->prog_chunks && p->n_psegs_wave < (int64_t)psegs.size()) {
+                    // the chunked first AC scans (progressive_chunks.hip): their segments, the chunk list — padded to whole wavefronts
+                    // per segment, so that a wavefront's lanes share a table —, and per table the 9-bit LUT + canonical code book
+                    const int cb = std::min(std::max(p->pc_chunk_bytes, 128), 65536) & ~3;
+                    p->pc_chunk_bytes = cb;
+                    std::vector<mj::DevAcSeg> as;
+                    std::vector<mj::DevChunk> ck;
+                    for (size_t i = (size_t)p->n_psegs_wave; i < psegs.size(); ++i) {
+                        const mj::DevProgSeg &g = psegs[i];
+                        const mj::DevProgScan &ps = pscans[g.scan];
+                        mj::DevAcSeg a{};
+                        a.image = ps.image; a.comp = ps.comp[0]; a.ss = ps.ss; a.se = ps.se; a.al = ps.al; a.table = ps.ac_tab[0];
+                        a.stream_slot = g.stream_slot; a.stream_dw = (int32_t)((g.begin >> 2) + g.stream_slot);
+                        a.first_blk = g.mcu0; a.n_blk = g.n_mcu; a.mcu_count_h = ps.mcu_count_h; a.last = g.last;
+                        a.chunk0 = (int32_t)ck.size();
+                        a.n_chunks = std::max(1, (g.len + cb - 1) / cb);
+                        for (int j = 0; j < a.n_chunks; ++j) ck.push_back(mj::DevChunk{(int32_t)as.size(), j});
+                        while (ck.size() % 64) ck.push_back(mj::DevChunk{-1, 0});
+                        as.push_back(a);
+                    }
+                    std::vector<uint8_t> tb((size_t)b->n_huff * (1024 + mj::kProgCanonBytes), 0);
+                    for (int t = 0; t < b->n_huff; ++t) {
+                        uint16_t *l9 = reinterpret_cast<uint16_t *>(tb.data() + (size_t)t * (1024 + mj::kProgCanonBytes));
+                        for (int i = 0; i < 512; ++i) {
+                            const uint16_t e = lp[(size_t)t * LS + ((size_t)i << (mj::kProgLutBits - 9))];
+                            l9[i] = (e >> 8) <= 9 ? e : (uint16_t)0;
+                        }
+                        uint16_t *lim = l9 + 512;
+                        int16_t *base = reinterpret_cast<int16_t *>(lim + 16);
+                        uint8_t *vals = reinterpret_cast<uint8_t *>(base + 16);
+                        int code = 0, k = 0;
+                        for (int l = 1; l <= 16; ++l) {
+                            code <<= 1;
+                            base[l - 1] = (int16_t)(k - code);
+                            const int n = b->huff[t].bits[l - 1];
+                            code += n; k += n;
+                            lim[l - 1] = (uint16_t)std::min<int64_t>((int64_t)code << (16 - l), 65535);
+                        }
+                        for (int i = 0; i < 256; ++i) vals[i] = b->huff[t].vals[i];
+                    }
+                    p->n_acsegs = (int)as.size(); p->n_pc_chunks = (int64_t)ck.size();
+                    if ((rc = upload(ctx, &p->d_acsegs, as.data(), as.size())) != MJ_OK) return rc;
+                    if ((rc = upload(ctx, &p->d_pc_chunks, ck.data(), ck.size())) != MJ_OK) return rc;
+                    if ((rc = upload(ctx, &p->d_pc_tabs, tb.data(), tb.size())) != MJ_OK) return rc;
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_exit, ck.size() * 8 + 16));
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_outs, ck.size() * sizeof(mj::DevChunkOut) + 16));
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_items, ck.size() * 16 + 16));
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_owner, ck.size() * 4 + 64));      // (+ the work list's counter behind it)
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
+                } else {
+                    p->prog_chunks = false;
+                }
             }
             if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
             if (p->n_split)     // by segment (the first n_split of them), two sets: even and odd bands

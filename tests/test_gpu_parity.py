@@ -1175,7 +1175,8 @@ def test_progressive_randomised_sweep(dec, dec_rm):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), i
 
 
-@pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none"])
+@pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none",
+                                  "chunks", "chunks_small", "chunks_split_all"])
 def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
     launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, one MCU row per
@@ -1189,7 +1190,12 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
            "general_walk_levels": {"MJ_PROG_FAST": "0", "MJ_PROG_BANDS": "0"},
            # (round 4) every refining AC scan walked as scout + parts (by default only those with 1 KiB or more per band), or none
            "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_three_rows": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3"},
-           "split_none": {"MJ_PROG_SPLIT": "0"}}[form]
+           "split_none": {"MJ_PROG_SPLIT": "0"},
+           # (round 5) the first AC scans cut into self-synchronising chunks, one per lane (progressive_chunks.hip: what batches of
+           # 512 files and more take), with the default 512-byte chunks, with tiny ones (many wrong guesses, many repairs), and
+           # beside split refining scans
+           "chunks": {"MJ_PROG_CHUNKS": "2"}, "chunks_small": {"MJ_PROG_CHUNKS": "2", "MJ_PROG_CHUNK": "128"},
+           "chunks_split_all": {"MJ_PROG_CHUNKS": "2", "MJ_PROG_SPLIT": "2", "MJ_PROG_CHUNK": "256"}}[form]
     for k, v in env.items():
         tune(k, v)
     names = prog_names()
@@ -1212,6 +1218,60 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
         assert np.array_equal(img, ref), (form, i)
     for i, (img, ref) in enumerate(zip(dec_rm.decode(files), refs)):
         assert np.array_equal(np.swapaxes(img, 0, 1), ref), (form, i)
+    if form.startswith("chunks"):          # ... and on the device itself: no image may have needed the host layer's second decode
+        from pyjpegdecoder_amd import _binding as B
+        from pyjpegdecoder_amd.batch import prepare_batch
+        for i, f in enumerate(files + [load_golden(n)[0] for n in names]):
+            prep = prepare_batch([f], B.MJ_LAYOUT_XMAJOR, 0)
+            plan = B.Plan(dec.ctx, prep.to_c(), {"prep": prep, "n_images": 1})
+            try:
+                assert plan.stage1_form() & B.MJ_FORM_COUNT_RESOLVED, (form, i)
+                plan.execute()
+                plan.sync()
+                assert plan.read(rgb=False)["status"][0] == 0, (form, i)
+            finally:
+                plan.close()
+
+
+def test_progressive_batches_of_2048_files_take_the_chunked_first_scans(dec):
+    """From 2 048 images on a progressive plan walks its first AC scans in chunks, one per lane, in front of the band pipeline
+    (progressive_chunks.hip; below that the wavefront walks are faster: profiles/r05_progressive_chunks.txt).  2 048 small files
+    (16 distinct ones, optimised tables each, one with restart intervals): the plan says so, every status is ok, every distinct
+    image is the oracle's and every copy its first instance's; 2 047 files keep the wavefront walks."""
+    Image = pytest.importorskip("PIL.Image")
+    torch = pytest.importorskip("torch")
+    import io
+    from oracle import oracle
+    from tools import synth
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.batch import prepare_batch
+    W, H, nd = 96, 64, 16
+    raws = []
+    for i in range(nd):
+        kw = dict(quality=(60, 85, 95)[i % 3], subsampling=2, progressive=True)
+        if i == 5:
+            kw["restart_marker_rows"] = 1
+        b = io.BytesIO()
+        Image.fromarray(synth.synth_rgb(91000 + i, W, H, 5.0 + 3 * (i % 5))).save(b, "JPEG", **kw)
+        raws.append(b.getvalue())
+    dev = torch.device("cuda", 0)
+    for n, want_chunks in ((2048, True), (2047, False)):
+        prep = prepare_batch([raws[i % nd] for i in range(n)], B.MJ_LAYOUT_XMAJOR, 0)
+        d_blob = torch.from_numpy(prep.blob).to(dev)
+        plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+        try:
+            form = plan.stage1_form()
+            assert form & 15 == B.MJ_FORM_SCANS and bool(form & B.MJ_FORM_COUNT_RESOLVED) == want_chunks, (n, form)
+            d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            plan.execute(0, d_rgb.data_ptr())
+            plan.sync()
+            assert not plan.read(rgb=False)["status"].any()
+            imgs = d_rgb[:n // nd * nd * W * H * 3].view(n // nd, nd, W * H * 3)
+            for i in range(nd):
+                assert np.array_equal(imgs[0, i].cpu().numpy().reshape(W, H, 3), oracle.decode(raws[i])["rgb"]), (n, i)
+            assert bool((imgs == imgs[0]).all()), n
+        finally:
+            plan.close()
 
 
 # ---- round 2: boundary and fallbacks ---------------------------------------------------------------------------------

@@ -38,7 +38,8 @@ print("made %d files + oracle answers in %.1f s" % (len(files), time.time() - t0
 bad = 0
 forms = {"bands": {}, "two-row bands": {"MJ_PROG_ROWS": "2"}, "levels": {"MJ_PROG_BANDS": "0"}, "general walk": {"MJ_PROG_FAST": "0"},
          "split scans": {"MJ_PROG_SPLIT": "2"}, "split, 3 rows, 3 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3", "MJ_PROG_PARTS": "3"},
-         "split, 7 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_PARTS": "7"}}
+         "split, 7 parts": {"MJ_PROG_SPLIT": "2", "MJ_PROG_PARTS": "7"},
+         "chunks": {"MJ_PROG_CHUNKS": "2"}, "chunks of 128 B, split": {"MJ_PROG_CHUNKS": "2", "MJ_PROG_CHUNK": "128", "MJ_PROG_SPLIT": "2"}}
 for name, env in forms.items():
     for k, v in env.items():
         _B.set_option(k, v)
