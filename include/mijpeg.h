@@ -285,7 +285,8 @@ int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *f
  *                     walk on resolved tables with a repair work list (default wherever the batch allows: <= 8 tables, one role each)
  *   MJ_SYNC_BITS      10..13  index bits of those tables (12, fewer if LDS asks for it)
  *   MJ_PROG_BANDS     0 | 1   MJ_PROG_ROWS  frame MCU rows per band   MJ_PROG_FAST  0 | 1 (0 = the general scan walk only)
- *   MJ_PROG_SPLIT     0 | 1 | 2  refining AC scans as scout + parts: never | while the chip has wave slots for it | always
+ *   MJ_PROG_SPLIT     0 | 1 | 2 | 3  refining AC scans as scout + parts: never | by the size of the batch (all of them, then only each
+ *                     image's largest with two parts, then none) | always | each image's largest
  *   MJ_PROG_PARTS     1..8  parts per band of a split scan (4)
  *   MJ_PROG_CHUNKS    0 | 1 | 2  the first AC scans of progressive files in self-synchronising chunks, one per lane, in front of the
  *                     band pipeline: never | from 2 048 images on | always;  MJ_PROG_CHUNK  128..65536 bytes per chunk (512)

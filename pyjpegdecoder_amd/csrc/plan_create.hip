@@ -487,14 +487,27 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 for (int g = 0; g < sd.n_segments; ++g) bytes += b->seg_end[sd.first_segment + g] - b->seg_begin[sd.first_segment + g];
                 if (split_mode >= 2 || bytes / n_bands >= 1024) cand.push_back({-bytes, k});
             }
-            // All of them if their scouts and parts find a wave slot at once, else none.  (libjpeg's script, 1080p: 512 files
-            // 56.2 ms split / 73.2 not, 768: 69.3 / 76.7, 1024: 92.1 / 78.6, 1536: 135 / 94.  Only each image's largest scan where
-            // those fit: 1024 files 79.5, 1536 116.  As many images as fit: worse than either, 99.7 at 1024.)
+            // All of them while their scouts and parts leave a fifth of the chip's wave slots free; past that only each image's
+            // LARGEST refining scan — the last luma refinement, the one a batch waits for — with two parts per band, up to ~1 100
+            // images; past that none.  (libjpeg's script, 1080p, ms per batch, round 5: all split with four parts / largest only with
+            // two / none: 384 files 47.4 / 47.8 / 61.3, 512: 48.2 / 48.0 / 61.9, 640: 53.2 / 53.0 / 63.1, 768: 61.3 / 54.0 / 64.8,
+            // 896: 65.8 / 61.6 / 66.0, 1 024: 81.5 / 66.2 / 66.7, 1 536: 117 / 99.7 / 79.6.  As many images as fit: worse than
+            // either, 99.7 at 1 024.)  MJ_PROG_SPLIT: 0 none, 1 this rule, 2 all, 3 the largest of each image.
             const int64_t slots = (int64_t)mj::device_cus() * 32;
             int64_t need_all = 0;
             for (auto &c : cand) need_all += (int64_t)b->scans[c.second].n_segments * (1 + p->prog_parts);
-            if (split_mode >= 2 || need_all <= slots)
+            const bool parts_given = mj::opt("MJ_PROG_PARTS") != nullptr;
+            const bool all = split_mode == 2 || (split_mode == 1 && need_all <= slots * 4 / 5);
+            const bool largest = split_mode == 3 || (split_mode == 1 && !all && (int64_t)b->n_images * 3 <= slots * 2 / 5);
+            if (all) {
                 for (auto &c : cand) split_of[c.second] = 1;
+            } else if (largest) {
+                std::vector<int64_t> best(b->n_images, 0);
+                std::vector<int> which(b->n_images, -1);
+                for (auto &c : cand) { const int im = b->scans[c.second].image; if (-c.first > best[im]) { best[im] = -c.first; which[im] = c.second; } }
+                for (int i = 0; i < b->n_images; ++i) if (which[i] >= 0) split_of[which[i]] = 1;
+                if (!parts_given) p->prog_parts = 2;
+            }
         }
         auto want_split = [&](int k) { return split_of[k] != 0; };
         std::vector<int> ordinal_of(b->n_scans, 0);

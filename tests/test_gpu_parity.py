@@ -1176,7 +1176,7 @@ def test_progressive_randomised_sweep(dec, dec_rm):
 
 
 @pytest.mark.parametrize("form", ["levels", "two_row_bands", "general_walk", "general_walk_levels", "split_all", "split_all_three_rows", "split_none",
-                                  "chunks", "chunks_small", "chunks_split_all"])
+                                  "split_largest", "chunks", "chunks_small", "chunks_split_all"])
 def test_progressive_launch_forms(dec, dec_rm, form, tune):
     """The progressive stage 1 has two walks (the stream walks of progressive_fast.hip; progressive.hip's general one) and two
     launch schedules (band pipeline; one launch per dependency level).  The default — stream walks, one MCU row per
@@ -1191,6 +1191,8 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
            # (round 4) every refining AC scan walked as scout + parts (by default only those with 1 KiB or more per band), or none
            "split_all": {"MJ_PROG_SPLIT": "2"}, "split_all_three_rows": {"MJ_PROG_SPLIT": "2", "MJ_PROG_ROWS": "3"},
            "split_none": {"MJ_PROG_SPLIT": "0"},
+           # (round 5) only each image's largest refining scan split, two parts per band (what 700-1 100 files take)
+           "split_largest": {"MJ_PROG_SPLIT": "3"},
            # (round 5) the first AC scans cut into self-synchronising chunks, one per lane (progressive_chunks.hip: what batches of
            # 512 files and more take), with the default 512-byte chunks, with tiny ones (many wrong guesses, many repairs), and
            # beside split refining scans
