@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r05d'
-TAG=${1:-r05d}
+# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r05e'
+TAG=${1:-r05e}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1
