@@ -114,7 +114,7 @@ def test_option_values_are_validated_and_readable(lib):
             assert B.get_option("MJ_LANES_PER_WAVE") == "34"
         for name, good, bad in (("MJ_HUFFMAN", "lanes11", "lanes12"), ("MJ_SEG_ORDER", "striped", "sorted"), ("MJ_LANES_RING", "64", "96"),
                                 ("MJ_SYNC_CHUNK", "1024", "1022"), ("MJ_SYNC_ROUNDS", "0", "65"), ("MJ_PROG_PARTS", "8", "9"),
-                                ("MJ_PROG_SPLIT", "2", "3"), ("MJ_LANES_WAVES", "16", "17")):
+                                ("MJ_PROG_SPLIT", "3", "4"), ("MJ_LANES_WAVES", "16", "17")):
             B.set_option(name, good)
             assert B.get_option(name) == good
             with pytest.raises(ValueError):
