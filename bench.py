@@ -202,7 +202,7 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             "algorithmic_bytes_per_step": int(s1_bytes), "stage1_ms": round(s1, 3),
             "note": "entropy bytes + per scan 2 B x (Se-Ss+1) per covered block (x2 for refining scans: read-modify-write); "
                     "serial-walk (instruction issue) bound, quoted against HBM as SURVEY 8d asks; launches per step and their "
-                    "average durations: profiles/r04d_progressive_kernel_stats.csv"}
+                    "average durations: profiles/r05e_progressive_kernel_stats.csv"}
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
             "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3), "roofline": roof,
             "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
