@@ -1235,6 +1235,45 @@ def test_progressive_launch_forms(dec, dec_rm, form, tune):
                 plan.close()
 
 
+def test_progressive_chunks_damaged_streams_end_like_the_wavefront_walks(dec, tune):
+    """A damaged first AC scan in the chunked form: whatever the counting walks make of it — records that do not fit together
+    (MJ_ST_UNCONVERGED: the host layer decodes the image again with the wavefront walks), a code that does not exist, a run past
+    the block — the caller sees what it sees without chunks: the same exception class, or the same pixels."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from tools import synth
+    from pyjpegdecoder_amd import JpegError, parse_jpeg
+    b = io.BytesIO()
+    Image.fromarray(synth.synth_rgb(7711, 320, 240, 20.0)).save(b, "JPEG", quality=85, subsampling=2, progressive=True)
+    raw = b.getvalue()
+    scans = [sc for sc in parse_jpeg(raw).scans if sc.spectral_start > 0 and sc.bit_high == 0]
+    assert len(scans) >= 3
+    rng = np.random.default_rng(31)
+
+    def outcome():
+        try:
+            return ("image", dec.decode([bytes(buf)])[0])
+        except JpegError as exc:
+            return ("error", type(exc).__name__)
+    for trial in range(16):
+        buf = bytearray(raw)
+        sc = scans[trial % len(scans)]
+        for _ in range(int(rng.integers(1, 3))):
+            at = int(rng.integers(sc.entropy_start + 4, sc.entropy_end - 4))
+            v = int(rng.integers(0, 255))
+            buf[at] = v if v != 0xFF and buf[at - 1] != 0xFF else buf[at]      # (no new markers: the segmentation stays the file's)
+        tune("MJ_PROG_CHUNKS", "0")
+        want = outcome()
+        tune("MJ_PROG_CHUNKS", "2")
+        tune("MJ_PROG_CHUNK", ("128", "512")[trial % 2])
+        got = outcome()
+        assert got[0] == want[0], (trial, got[0], want)
+        if got[0] == "image":
+            assert np.array_equal(got[1], want[1]), trial
+        else:
+            assert got[1] == want[1], (trial, got, want)
+
+
 def test_progressive_batches_of_2048_files_take_the_chunked_first_scans(dec):
     """From 2 048 images on a progressive plan walks its first AC scans in chunks, one per lane, in front of the band pipeline
     (progressive_chunks.hip; below that the wavefront walks are faster: profiles/r05_progressive_chunks.txt).  2 048 small files
