@@ -381,11 +381,9 @@ def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, s
         count_v = (p.image_height // sh) + (0 if p.image_height % sh == 0 else 1)
         p.array_width, p.array_height, p.array_depth = sw * count_h, sh * count_v, len(comps)
         gpu_scan = headers_only and p.scan_mode == "baseline_dct" and components_amount == len(comps) and p.image_height > 0
-        if not gpu_scan:
-            p.scan_amount = p.raw[scan.entropy_start:].count(SOS) + 1
-            say(f"Number of scans: {p.scan_amount}")
+        first_scan = not gpu_scan
     else:
-        gpu_scan = False
+        gpu_scan = first_scan = False
 
     scan.restart_interval = p.restart_interval
     scan.huffman = dict(p.huffman)
@@ -395,6 +393,25 @@ def _start_of_scan(p: ParsedJpeg, data: bytes, data_pos: int, arr: np.ndarray, s
         scan.entropy_end = len(p.raw)
         scan.segment_offsets = None
         return scan
-    scan.entropy_end = find_entropy_end(arr, scan.entropy_start)
-    scan.segment_offsets = find_restart_segments(arr, scan.entropy_start, scan.entropy_end)
+    # One pass over the 0xFF bytes behind the scan header gives the number of scans (the first scan announces it, :624-637: the
+    # SOS markers from here on), the end of the entropy-coded data (find_entropy_end) and the restart segments
+    # (find_restart_segments) — three passes and a copy of the file's tail before round 5, a fifth of JpegDecoder(path)'s time.
+    start = scan.entropy_start
+    ff = np.flatnonzero(arr[start:-1] == 0xFF) + start
+    nxt = arr[ff + 1] if ff.size else ff
+    if first_scan:
+        p.scan_amount = int(np.count_nonzero(nxt == 0xDA)) + 1
+        say(f"Number of scans: {p.scan_amount}")
+    end = int(arr.size)
+    if ff.size:
+        hits = ff[(nxt != 0x00) & ((nxt < 0xD0) | (nxt > 0xD7)) & (nxt != 0xFF)]
+        if hits.size:
+            end = int(hits[0])
+    scan.entropy_end = end
+    rst = ff[(nxt >= 0xD0) & (nxt <= 0xD7) & (ff < end - 1)] if ff.size else ff
+    offs = np.empty(rst.size + 2, dtype=np.int64)
+    offs[0] = start
+    offs[1:-1] = rst + 2
+    offs[-1] = end
+    scan.segment_offsets = offs
     return scan
