@@ -48,6 +48,45 @@ def sources_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def images_not_matching_the_oracle(raws, fetch, layout_name: str = "xmajor", w: int = W, h: int = H, workers=None):
+    """Every file of `raws` decoded by the oracle on a pool of host threads (the C oracle runs outside the GIL) and compared with
+    what the GPU left: fetch(i) -> that image's bytes as a flat uint8 array.  Returns the indices that differ.  Checker only:
+    called after the timed regions."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    if not raws:
+        return []
+    oracle.decode(raws[0])                            # (builds the oracle's tables before the threads start)
+
+    def one(i):
+        ref = oracle.decode(raws[i])["rgb"]
+        got = fetch(i)
+        got = got.reshape(ref.shape) if layout_name == "xmajor" else np.swapaxes(got.reshape((h, w) + ref.shape[2:]), 0, 1)
+        return None if np.array_equal(got, ref) else i
+    with ThreadPoolExecutor(max_workers=workers or max(1, min(os.cpu_count() or 1, 32))) as ex:
+        return sorted(i for i in ex.map(one, range(len(raws))) if i is not None)
+
+
+def timed_executes(torch, plan, stream, out_ptr, reps: int, warm_s: float = 1.0, warm_min: int = 3):
+    """Seconds per plan.execute over `reps` back-to-back executes, after at least `warm_s` seconds of them: a plan that has just
+    been created starts on a chip that idled through its host-side preparation, and launches timed in the first second after
+    such a pause came out long (the clock ramps; round 5's gpu_segmented object: 7.13 ms per step against 6.04 of kernels)."""
+    t0 = time.perf_counter()
+    n = 0
+    while n < warm_min or time.perf_counter() - t0 < warm_s:
+        plan.execute(stream, out_ptr)
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.execute(stream, out_ptr)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
 def cpu_baseline(raws, budget_s: float = 20.0):
     """The CPU oracle (bit-exact restatement of the reference path) timed on this host, one thread, then all cores."""
     import ctypes
@@ -105,10 +144,11 @@ def pipelined_side(ctx, dev, torch, prep, d_blob, plan, d_rgb, depth: int = 3, r
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     try:
         torch.cuda.synchronize()
-        for _ in range(2):
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 1.0:                     # (a second of it first: see timed_executes)
             for q, o, st in zip(plans, outs, streams):
                 q.execute(st.cuda_stream, o.data_ptr())
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(rounds):
             for q, o, st in zip(plans, outs, streams):
@@ -122,7 +162,9 @@ def pipelined_side(ctx, dev, torch, prep, d_blob, plan, d_rgb, depth: int = 3, r
     n = plan.info.total_pixels
     return {"value": round(n / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 3), "plans_in_flight": depth,
             "steps": rounds * depth, "parity": "every plan's output identical to the headline plan's" if ok else "MISMATCH",
-            "note": "the headline step issued round-robin on separate plans and streams, inputs shared, outputs separate; not `value`"}
+            "note": "the headline step issued round-robin on separate plans and streams, inputs shared, outputs separate; not `value`. "
+                    "A fused launch takes every CU's whole LDS, so a context's fused launches take turns (an event chain, api.hip): "
+                    "plans in flight cost nothing and gain nothing on the kernels — what overlaps is the host side (plan creation, uploads)"}
 
 
 def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8):
@@ -146,21 +188,18 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
     plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n_images})
     d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    per = W * H * 3
+
+    def bad_of(m):          # every distinct file among the first m images against the oracle
+        nd = min(m, n_distinct)
+        return images_not_matching_the_oracle(raws[:nd], lambda i: d_rgb[i * per:(i + 1) * per].cpu().numpy())
     try:
+        dt = timed_executes(torch, plan, stream, d_rgb.data_ptr(), 3, warm_s=0.3, warm_min=1)
+        s1, s2 = plan.time_stages(1, d_rgb.data_ptr())
         plan.execute(stream, d_rgb.data_ptr())
         torch.cuda.synchronize()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            plan.execute(stream, d_rgb.data_ptr())
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        s1, s2 = plan.time_stages(1, d_rgb.data_ptr())
-        ok = not plan.read(rgb=False)["status"].any()
-        per = W * H * 3
-        host = d_rgb[:2 * per].cpu().numpy()
-        for i in (0, 1):
-            ok = ok and np.array_equal(host[i * per:(i + 1) * per].reshape(W, H, 3), oracle.decode(files[i])["rgb"])
+        bad = bad_of(n_images)
+        ok = not plan.read(rgb=False)["status"].any() and not bad
     finally:
         plan.close()
     # the same files in smaller batches: below ~900 files the plan walks the luma refinements as scout + parts
@@ -172,17 +211,11 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
         d_blob_m = torch.from_numpy(prep_m.blob).to(dev)
         plan_m = B.Plan(ctx, prep_m.to_c(d_blob_m.data_ptr()), {"prep": prep_m, "n_images": m})
         try:
-            plan_m.execute(stream, d_rgb.data_ptr())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                plan_m.execute(stream, d_rgb.data_ptr())
-            torch.cuda.synchronize()
-            dt_m = (time.perf_counter() - t0) / 3
-            ok_m = not plan_m.read(rgb=False)["status"].any()
-            ok_m = ok_m and bool(np.array_equal(d_rgb[:W * H * 3].cpu().numpy().reshape(W, H, 3), oracle.decode(files[0])["rgb"]))
+            dt_m = timed_executes(torch, plan_m, stream, d_rgb.data_ptr(), 3, warm_s=0.3, warm_min=1)
+            bad_m = bad_of(m)
+            ok_m = not plan_m.read(rgb=False)["status"].any() and not bad_m
             smaller.append({"images": m, "ms_per_step": round(dt_m * 1e3, 2), "value": round(m * W * H / 1e6 / dt_m, 1),
-                            "parity": "bit-exact vs oracle (image 0)" if ok_m else "MISMATCH"})
+                            "parity": f"bit-exact vs oracle (all {min(m, n_distinct)} distinct files)" if ok_m else f"MISMATCH (files {bad_m[:8]})"})
         finally:
             plan_m.close()
     # algorithmic bytes of the scan walks: the entropy-coded bytes once, plus for every scan the coefficients it covers —
@@ -202,14 +235,14 @@ def progressive_side(ctx, dev, torch, n_images: int = 1024, n_distinct: int = 8)
             "algorithmic_bytes_per_step": int(s1_bytes), "stage1_ms": round(s1, 3),
             "note": "entropy bytes + per scan 2 B x (Se-Ss+1) per covered block (x2 for refining scans: read-modify-write); "
                     "serial-walk (instruction issue) bound, quoted against HBM as SURVEY 8d asks; launches per step and their "
-                    "average durations: profiles/r05e_progressive_kernel_stats.csv"}
+                    "average durations: profiles/r06*_progressive_kernel_stats.csv"}
     return {"value": round(n_images * W * H / 1e6 / dt, 1), "unit": "MP/s", "ms_per_step": round(dt * 1e3, 2),
             "stage1_ms": round(s1, 2), "stage2_ms": round(s2, 3), "roofline": roof,
             "workload": f"{n_images} x 1920x1080 4:2:0 progressive JPEG (Pillow/libjpeg default scan script, q85, {n_distinct} distinct), "
                         "scan-by-scan entropy decode + the ordinary stage 2 (BASELINE configs[4])",
             "entropy_bytes_per_image": int(sum(map(len, raws)) // n_distinct),
             "smaller_batches": smaller,
-            "parity": "bit-exact vs oracle (images 0 and 1)" if ok else "MISMATCH"}
+            "parity": f"bit-exact vs oracle (all {n_distinct} distinct files), every image's status ok" if ok else f"MISMATCH (files {bad[:8]})"}
 
 
 def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 1024, n_distinct: int = 256):
@@ -230,28 +263,20 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
     d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     try:
-        for _ in range(3):
-            plan.execute(stream, d_rgb.data_ptr())
-        torch.cuda.synchronize()
-        reps = 20
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            plan.execute(stream, d_rgb.data_ptr())
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = timed_executes(torch, plan, stream, d_rgb.data_ptr(), 20)
         s1, s2 = plan.time_stages(5, d_rgb.data_ptr())
         fused = bool(plan.stage1_form() & B.MJ_FORM_FUSED)
         front, main = plan.time_execute(5, d_rgb.data_ptr()) if fused else (None, None)
         plan.execute(stream, d_rgb.data_ptr())
         torch.cuda.synchronize()
-        ok = not plan.read(rgb=False)["status"].any()
         per = W * H * 3
         sizes = [len(r) for r in raws]
-        for i in (int(np.argmin(sizes)), int(np.argmax(sizes))):
-            got = d_rgb[i * per:(i + 1) * per].cpu().numpy()
-            want = oracle.decode(raws[i])["rgb"]
-            got = got.reshape(want.shape) if layout == B.MJ_LAYOUT_XMAJOR else np.swapaxes(got.reshape(H, W, 3), 0, 1)
-            ok = ok and np.array_equal(got, want)
+        bad = images_not_matching_the_oracle(raws, lambda i: d_rgb[i * per:(i + 1) * per].cpu().numpy(),
+                                             "xmajor" if layout == B.MJ_LAYOUT_XMAJOR else "rowmajor")
+        imgs = d_rgb[:n_images * per].view(n_images, per)
+        same = all(bool(torch.equal(imgs[k * n_distinct:min(n_images, (k + 1) * n_distinct)], imgs[:min(n_distinct, n_images - k * n_distinct)]))
+                   for k in range(1, (n_images + n_distinct - 1) // n_distinct))
+        ok = not plan.read(rgb=False)["status"].any() and not bad and same
         seg_len = np.asarray(prep.seg_end, dtype=np.int64) - np.asarray(prep.seg_begin, dtype=np.int64)
     finally:
         plan.close()
@@ -262,7 +287,8 @@ def mixed_content_side(ctx, dev, torch, layout, headline_ms, n_images: int = 102
                         "(quality 50..95, noise sigma 0..80 above / below a random split row)",
             "file_bytes": {"min": int(min(sizes)), "mean": int(sum(sizes) // len(sizes)), "max": int(max(sizes))},
             "restart_segment_bytes": {"mean": int(seg_len.mean()), "max": int(seg_len.max())},
-            "parity": "bit-exact vs oracle (smallest and largest file)" if ok else "MISMATCH",
+            "parity": (f"bit-exact vs oracle: all {n_distinct} distinct files, every replica identical to its first instance, every image's status ok"
+                       if ok else f"MISMATCH (files {bad[:8]})"),
             "note": "stage 1 = one restart segment per lane: its launch lasts as long as the longest segment's serial walk, whatever "
                     "the others hold; segments are dealt out by length so that long ones sit in different waves (DESIGN.md section 3); "
                     "the step is ONE fused launch whose consumers take jobs from one pool across workgroups (stage01_ms / stage2_ms: the "
@@ -327,15 +353,7 @@ def gpu_segmented_side(ctx, dev, torch, files, layout, d_ref):
     d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     try:
-        for _ in range(5):
-            plan.execute(stream, d_rgb.data_ptr())
-        torch.cuda.synchronize()
-        reps = 30
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            plan.execute(stream, d_rgb.data_ptr())
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = timed_executes(torch, plan, stream, d_rgb.data_ptr(), 60)
         front, main = plan.time_execute(5, d_rgb.data_ptr())
         ok = not plan.read(rgb=False)["status"].any() and bool(torch.equal(d_rgb, d_ref))
         form = plan.stage1_form()
@@ -392,22 +410,22 @@ def visible_gpus() -> int:
 
 def launch_ranks(n_ranks: int, argv, share_gpu: bool, script=None) -> int:
     """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
-    --nproc-per-node N bench.py <same arguments>` as a child (rendezvous on 127.0.0.1, a free port), pass its stdout — rank 0's
-    one JSON line — through, return its exit code."""
-    import socket
+    --nproc-per-node N bench.py <same arguments>` as a child (c10d rendezvous on 127.0.0.1, port chosen by the store itself), pass
+    its stdout — rank 0's one JSON line — through, return its exit code."""
     import subprocess
+    import uuid
     have = visible_gpus()
     if not share_gpu and 0 <= have < n_ranks:
         print(f"bench.py: --gpus {n_ranks} but this node shows {have} GPU(s); --share-gpu runs every rank on cuda:0 (self-test)",
               file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script or Path(__file__).resolve())] + list(argv)
+    # the rendezvous store binds port 0 itself (c10d backend) and the agent hands the ranks an address and a port of its own
+    # choosing: no port is picked here by bind-and-close, which another process could take before the store binds it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", f"--rdzv-id={uuid.uuid4()}", "--local-addr", "127.0.0.1",
+           str(script or Path(__file__).resolve())] + list(argv)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -503,10 +521,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     if queue_mode:
-        queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank)
+        # (across_passes: a pass — the rank's share of one job — hands over to the next without draining the GPU: the next
+        # pass's plan is created while this pass's kernels run, as the next job's would be in a service; the fence drains)
+        queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank, across_passes=True)
         torch.cuda.synchronize()
         host_prep_s, h2d_s = time.perf_counter() - t0, None
-        step = queue.run
+
+        def step():
+            queue.run(wait=False)
         plan = None
     else:
         # host side of the path: header parse + restart segmentation (Python, not timed as "step")
@@ -528,6 +550,8 @@ def main():
             plan.execute(stream, d_rgb.data_ptr())
 
     def fence():
+        if queue_mode:
+            queue.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -549,8 +573,13 @@ def main():
     stage_times = None
     if rank == 0 and not queue_mode:
         plan.time_stages(2, d_rgb.data_ptr())           # (the stages' own kernels have not run yet when the step is one fused launch)
+        launch_clock = None
         if plan.stage1_form() & B.MJ_FORM_FUSED:
             front_ms, main_ms = plan.time_execute(10, d_rgb.data_ptr())
+            try:                                        # the shader clock the chip held during the last of those launches (power-limited)
+                launch_clock = ctx.launch_clock()
+            except Exception:
+                pass
         else:
             front_ms = main_ms = None
         stage_times = (front_ms, main_ms) + tuple(plan.time_stages(10, d_rgb.data_ptr()))
@@ -559,33 +588,33 @@ def main():
 
     # ---- parity of what was just timed, outside the timed region.  One plan: EVERY distinct image of the rank's batch against
     # the oracle (a pool of host threads), every replica against its first instance on the device, every image's status.
-    # Queue mode: first and last image of the share against the oracle, every plan's statuses. -------------------------------
+    # Queue mode: every distinct image of rank 0's first and last plan against the oracle, every plan's statuses. -------------
     parity = "unchecked"
     per = W * H * 3
 
-    def as_reference_order(got, ref):
-        got = got.reshape(ref.shape if args.layout == "xmajor" else (H, W, 3))
-        return got if args.layout == "xmajor" else np.swapaxes(got, 0, 1)
     if queue_mode:
         status_bad = queue.bad
-        k_last = len(queue.batches) - 1
-        n_last = queue.batches[k_last][3]
-        got_last = queue.out_tensor(queue.slot_of(k_last))[(n_last - 1) * per:n_last * per].cpu().numpy()
-        queue.run(first=0, count=1)                           # image 0: decode the first batch once more
-        got_first = queue.out_tensor(0)[:per].cpu().numpy()
         if rank == 0:
-            from oracle import oracle
+            # rank 0's first and last plan once more, every distinct image of each against the oracle (the timed passes' statuses
+            # are in status_bad); a plan's images are the share's files in order
             ok = status_bad == 0
-            for i, got in ((0, got_first), (n_mine - 1, got_last)):
-                ref = oracle.decode(files[i])["rgb"]
-                ok = ok and np.array_equal(as_reference_order(got, ref), ref)
-            parity = "bit-exact vs oracle (first and last image of rank 0's share), every plan's statuses ok" if ok else "MISMATCH"
+            checked, bad_q = 0, []
+            for kb in sorted({0, len(queue.batches) - 1}):
+                queue.run(first=kb, count=1)
+                out_t = queue.out_tensor(queue.slot_of(kb))
+                base = kb * args.queue_batch
+                idx = sorted({(base + i) % distinct: i for i in range(queue.batches[kb][3])}.values())     # one position per distinct file
+                bad_k = images_not_matching_the_oracle([files[base + i] for i in idx],
+                                                       lambda t, idx=idx, out_t=out_t: out_t[idx[t] * per:(idx[t] + 1) * per].cpu().numpy(), args.layout)
+                checked += len(idx)
+                bad_q += [base + idx[t] for t in bad_k]
+            ok = ok and not bad_q and queue.bad == status_bad
+            parity = (f"bit-exact vs oracle: every distinct image of rank 0's first and last plan ({checked} images), every plan's statuses ok"
+                      if ok else f"MISMATCH (images {bad_q[:8]}, plans with a status not ok: {queue.bad})")
     else:
         out = plan.read(rgb=False)
         status_bad = int(np.count_nonzero(out["status"]))
         if rank == 0:
-            from concurrent.futures import ThreadPoolExecutor
-            from oracle import oracle
             n_chk = distinct if args.parity_images <= 0 else min(distinct, args.parity_images)
             ok = status_bad == 0
             imgs = d_rgb[:args.batch * per].view(args.batch, per)
@@ -593,15 +622,7 @@ def main():
                 m = min(distinct, args.batch - k * distinct)
                 ok = ok and bool(torch.equal(imgs[k * distinct:k * distinct + m], imgs[:m]))
             t0 = time.perf_counter()
-            oracle.decode(raws[0])                               # (builds the oracle's tables before the threads start)
-            bad_imgs = []
-
-            def check(i):
-                ref = oracle.decode(raws[i])["rgb"]
-                if not np.array_equal(as_reference_order(imgs[i].cpu().numpy(), ref), ref):
-                    bad_imgs.append(i)
-            with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as ex:
-                list(ex.map(check, range(n_chk)))
+            bad_imgs = images_not_matching_the_oracle(raws[:n_chk], lambda i: imgs[i].cpu().numpy(), args.layout)
             ok = ok and not bad_imgs
             parity = (f"bit-exact vs oracle: all {n_chk} distinct images of the batch ({time.perf_counter() - t0:.1f} s of oracle time on host threads), "
                       f"every replica identical to its first instance (device-side compare), every image's status ok") if ok else \
@@ -650,18 +671,8 @@ def main():
         fused = bool(plan.stage1_form() & B.MJ_FORM_FUSED)
         front_ms, main_ms, s1_ms, s2_ms = stage_times
         copy_gbs = None
-        try:                                    # second denominator SURVEY 8d asks for: a plain device-to-device copy here
-            d_tmp = torch.empty_like(d_rgb)
-            d_tmp.copy_(d_rgb)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                d_tmp.copy_(d_rgb)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = round(2 * d_rgb.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del d_tmp
+        try:            # second denominator SURVEY 8d asks for: what a plain device-to-device copy achieves here (16 B per lane, util_kernels.hip)
+            copy_gbs = round(ctx.copy_rate_gbs(1 << 31, 5), 1)
         except Exception:
             pass
         ent_bytes = plan.info.entropy_bytes
@@ -713,6 +724,11 @@ def main():
                       "back through the same CU's L2 while the walk lasts) + 3 B/pixel written", "fused")
             r0 = roof("k_destuff (stage 0: the bit reader's byte rules" + (", behind k_scan_markers" if args.segment == "gpu" else "") + ")",
                       2 * ent_bytes, front_ms, "entropy-coded bytes read and the kept bytes written", "stage0")
+            if launch_clock and launch_clock[0] > 0:
+                rf["shader_clock_mhz"] = round(launch_clock[0], 0)
+                rf["launch_ms_seen_by_workgroup_0"] = round(launch_clock[1], 4)
+                rf["clock_note"] = ("shader-clock counter / 100 MHz counter between the start and the end of the launch's workgroup 0, in this "
+                                    "process, for the last of the launches avg_launch_ms averages: the launch is power-limited, its time follows this clock")
             line["roofline"], line["roofline_other_stage"] = rf, r0
             # the same plan's stages as separate launches, timed the same way (HIP events, 10 launches each)
             line["two_launches"] = {"stage01_ms": round(s1_ms, 4), "stage2_ms": round(s2_ms, 4), "sum_ms": round(s1_ms + s2_ms, 4),
@@ -783,22 +799,17 @@ def main():
             d_blob2 = torch.from_numpy(prep2.blob).to(dev)
             plan2 = B.Plan(ctx, prep2.to_c(d_blob2.data_ptr()), {"prep": prep2, "n_images": nb})
             d_rgb2 = d_rgb[:plan2.info.rgb_bytes]
-            for _ in range(3):
-                plan2.execute(stream, d_rgb2.data_ptr())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                plan2.execute(stream, d_rgb2.data_ptr())
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t0) / 10
-            want = oracle.decode(raws2[0])["rgb"]
+            dt2 = timed_executes(torch, plan2, stream, d_rgb2.data_ptr(), 10, warm_s=0.5)
             st2 = plan2.read(rgb=False)["status"]
-            ok2 = not st2.any() and np.array_equal(d_rgb2[:W * H * 3].cpu().numpy().reshape((W, H, 3) if args.layout == "xmajor" else (H, W, 3)),
-                                 want if args.layout == "xmajor" else np.swapaxes(want, 0, 1))
+            bad2 = images_not_matching_the_oracle(raws2, lambda i: d_rgb2[i * W * H * 3:(i + 1) * W * H * 3].cpu().numpy(), args.layout)
+            imgs2 = d_rgb2[:nb * W * H * 3].view(nb, W * H * 3)
+            same2 = all(bool(torch.equal(imgs2[k * nd:(k + 1) * nd], imgs2[:nd])) for k in range(1, nb // nd))
+            ok2 = not st2.any() and not bad2 and same2
             line["without_restart_markers"] = {"value": round(nb * W * H / 1e6 / dt2, 1), "unit": "MP/s", "ms_per_step": round(dt2 * 1e3, 3),
                                                "workload": f"{nb} x 1920x1080 4:2:0 baseline JPEG, q85, no DRI (one segment per image)",
                                                "images_not_ok": int((st2 != 0).sum()),
-                                               "parity": "bit-exact vs oracle (image 0), every image's status ok" if ok2 else "MISMATCH"}
+                                               "parity": (f"bit-exact vs oracle: all {nd} distinct files, every replica identical to its first instance, every image's status ok"
+                                                          if ok2 else f"MISMATCH (files {bad2[:8]})")}
             plan2.close()
         except Exception as exc:
             line["without_restart_markers"] = {"error": repr(exc)}

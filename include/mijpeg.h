@@ -274,6 +274,16 @@ int mj_plan_time_stages(mj_plan *plan, int iters, uint8_t *rgb_device, float *st
  * stages as mj_plan_time_stages reports them (front = stage 0+1, main = stage 2). */
 int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *front_ms, float *main_ms);
 
+/* The plain device-to-device copy the rooflines are held against (SURVEY 8d's second denominator): `bytes` (a multiple of 16)
+ * copied `iters` times between two buffers of the context's own by a kernel that moves sixteen bytes per lane; average
+ * device time per copy in ms (HIP events on the context's stream).  2 * bytes / ms = the chip's achieved copy rate. */
+int mj_device_copy_rate(mj_context *ctx, int64_t bytes, int iters, float *ms_per_copy);
+/* The shader clock (MHz) the chip held during the context's latest fused launch (MJ_FORM_FUSED) and that launch's duration as
+ * its first workgroup saw it: the launch leaves the shader-clock counter and the 100 MHz counter at its start and end.  The
+ * launch is power-limited on MI355X, so a time without its clock does not compare across boards.  Zeros: no fused launch yet.
+ * Call after the launch has completed (mj_plan_sync). */
+int mj_context_launch_clock(mj_context *ctx, float *shader_mhz, float *launch_ms);
+
 /* Test and tuning switches, process-wide.  The defaults are what the library measured as best; the parity tests use the
  * switches to force every form of a stage through the same inputs, the probe scripts to sweep geometries.  The library does
  * NOT read them from the environment (a stray variable must not change how a production decode runs).  Read when a plan is

@@ -28,6 +28,7 @@ EXPORTS = (
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
     "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape", "mj_debug_count_tables",
+    "mj_device_copy_rate", "mj_context_launch_clock",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED, MJ_FORM_COUNT_RESOLVED = 0, 1, 2, 3, 16, 32, 64, 128
 MJ_HOST_DECLINED = 1
@@ -239,6 +240,20 @@ class Context:
         """Everything queued on the context's stream from now on runs after `hip_event` (a hipEvent_t handle, e.g.
         ``torch.cuda.Event.cuda_event``) has happened."""
         self.check(self.lib.mj_context_wait_event(self.handle, hip_event))
+
+    def copy_rate_gbs(self, nbytes: int = 1 << 31, iters: int = 5) -> float:
+        """mj_device_copy_rate: GB/s (read + written) of a plain 16-bytes-per-lane device copy of `nbytes`."""
+        ms = ctypes.c_float()
+        self.lib.mj_device_copy_rate.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        self.check(self.lib.mj_device_copy_rate(self.handle, int(nbytes), int(iters), ctypes.byref(ms)))
+        return 2.0 * (int(nbytes) & ~15) / (ms.value * 1e-3) / 1e9
+
+    def launch_clock(self):
+        """mj_context_launch_clock: (shader MHz held during the latest fused launch, that launch's ms as workgroup 0 saw it)."""
+        mhz, ms = ctypes.c_float(), ctypes.c_float()
+        self.lib.mj_context_launch_clock.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        self.check(self.lib.mj_context_launch_clock(self.handle, ctypes.byref(mhz), ctypes.byref(ms)))
+        return mhz.value, ms.value
 
     def close(self):
         if getattr(self, "handle", None):

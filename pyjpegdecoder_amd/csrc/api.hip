@@ -48,6 +48,7 @@ int mj_create(int device_id, mj_context **out) {
     MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     MJ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking));
     MJ_HIP(nullptr, hipHostMalloc((void **)&ctx->h_word, 64, hipHostMallocDefault));
+    MJ_HIP(nullptr, hipEventCreateWithFlags(&ctx->fused_done, hipEventDisableTiming));
     std::vector<double> tt(64 * 64);
     build_idct_tt(tt.data());
     MJ_HIP(nullptr, hipMalloc((void **)&ctx->d_idct_tt, tt.size() * sizeof(double)));
@@ -76,6 +77,7 @@ void mj_destroy(mj_context *ctx) {
     ctx->cache.trim(0);
     for (auto &a : ctx->free_arenas) (void)hipHostFree(a.base);
     if (ctx->h_word) (void)hipHostFree(ctx->h_word);
+    if (ctx->fused_done) (void)hipEventDestroy(ctx->fused_done);
     if (ctx->d_idct_tt) (void)hipFree(ctx->d_idct_tt);
     if (ctx->d_dump) (void)hipFree(ctx->d_dump);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -372,8 +374,25 @@ static int execute_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
     return rc;
 }
 
+static int execute_launches(mj_plan *p, void *stream, uint8_t *rgb_device);
+
 int mj_plan_execute(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (!p) return MJ_ERR_INVALID;
+    mj_context *ctx = p->ctx;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const bool fused = p->use_fused && p->d_blob;
+    // fused launches of one context take turns (plan.h): outside any graph — the wait and the record bracket whatever this
+    // execute submits, replayed or not
+    if (fused && ctx->fused_stream && ctx->fused_stream != s) MJ_HIP(ctx, hipStreamWaitEvent(s, ctx->fused_done, 0));
+    const int rc = execute_launches(p, stream, rgb_device);
+    if (fused && rc == MJ_OK) {
+        MJ_HIP(ctx, hipEventRecord(ctx->fused_done, s));
+        ctx->fused_stream = s;
+    }
+    return rc;
+}
+
+static int execute_launches(mj_plan *p, void *stream, uint8_t *rgb_device) {
     if (int rc = plan_ready(p, stream ? (hipStream_t)stream : p->ctx->stream)) return rc;
     mj_context *ctx = p->ctx;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -484,8 +503,6 @@ int mj_plan_fill_coef(mj_plan *p, int byte_value) {
     if (int rc = plan_ready(p)) return rc;
     mj_context *ctx = p->ctx;
     if (p->done_valid) MJ_HIP(ctx, hipEventSynchronize(p->done));
-    if (getenv("MJ_DEBUG_FILL")) fprintf(stderr, "[fill] coef %p + %zu = %p, status %p, n_images %d\n", (void *)p->d_coef, (size_t)p->info.total_blocks * 128,
-                                         (void *)((char *)p->d_coef + (size_t)p->info.total_blocks * 128), (void *)p->d_status, p->n_images);
     MJ_HIP(ctx, hipMemset(p->d_coef, byte_value & 0xFF, (size_t)p->info.total_blocks * 128));
     MJ_HIP(ctx, hipDeviceSynchronize());
     return MJ_OK;
@@ -576,6 +593,42 @@ int mj_plan_time_execute(mj_plan *p, int iters, uint8_t *rgb_device, float *fron
     MJ_HIP(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
     if (main_ms) *main_ms = ms / iters;
     return rc != MJ_OK ? rc : mark_done(p, s);
+}
+
+int mj_context_launch_clock(mj_context *ctx, float *shader_mhz, float *launch_ms) {
+    if (!ctx) return MJ_ERR_INVALID;
+    unsigned long long w[4] = {0, 0, 0, 0};
+    MJ_HIP(ctx, hipSetDevice(ctx->device));
+    MJ_HIP(ctx, hipMemcpy(w, ctx->d_dump + mj::kDumpClockWords, sizeof(w), hipMemcpyDeviceToHost));
+    const bool have = w[3] > w[1] && w[2] > w[0];
+    if (shader_mhz) *shader_mhz = have ? (float)((double)(w[2] - w[0]) / (double)(w[3] - w[1]) * 100.0) : 0.f;
+    if (launch_ms) *launch_ms = have ? (float)((double)(w[3] - w[1]) * 1e-5) : 0.f;
+    return MJ_OK;
+}
+
+int mj_device_copy_rate(mj_context *ctx, int64_t bytes, int iters, float *ms_per_copy) {
+    if (!ctx || bytes < 16 || iters <= 0 || !ms_per_copy) return MJ_ERR_INVALID;
+    MJ_HIP(ctx, hipSetDevice(ctx->device));
+    bytes &= ~(int64_t)15;
+    struct Bufs {
+        mj_context *c; void *a = nullptr, *b = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Bufs() { if (a) c->cache.put(a); if (b) c->cache.put(b); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } h{ctx};
+    MJ_HIP(ctx, ctx->cache.get(&h.a, (size_t)bytes));
+    MJ_HIP(ctx, ctx->cache.get(&h.b, (size_t)bytes));
+    MJ_HIP(ctx, hipEventCreate(&h.e0));
+    MJ_HIP(ctx, hipEventCreate(&h.e1));
+    hipStream_t s = ctx->stream;
+    MJ_HIP(ctx, mj::launch_fill_words(s, h.a, 0x01020304u, bytes / 4));
+    for (int i = 0; i < 3; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes));      // warm
+    MJ_HIP(ctx, hipEventRecord(h.e0, s));
+    for (int i = 0; i < iters; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes));
+    MJ_HIP(ctx, hipEventRecord(h.e1, s));
+    MJ_HIP(ctx, hipEventSynchronize(h.e1));
+    float ms = 0.f;
+    MJ_HIP(ctx, hipEventElapsedTime(&ms, h.e0, h.e1));
+    *ms_per_copy = ms / iters;
+    return MJ_OK;
 }
 
 int mj_plan_time_stages(mj_plan *p, int iters, uint8_t *rgb_device, float *stage1_ms, float *stage2_ms) {

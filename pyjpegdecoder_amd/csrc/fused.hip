@@ -73,6 +73,13 @@ struct FusedArgs {
 
 typedef uint32_t __attribute__((address_space(3))) *lds_word;
 
+// The waits of a fused launch are for wavefronts that never wait themselves (a producer walks its segments and ends), so
+// they always end; what bounds them only guards the GPU against a defect in this file.  The bound is WALL-CLOCK time (the
+// 100 MHz counter), not a number of polls: a walk's length grows with the row (8K-16K pixel rows at high quality: tens of
+// milliseconds) and a resident wave may be held up by another process's kernels while the poller goes on counting.
+constexpr unsigned long long kFusedGuardTicks = 200000000ull;      // 2 s
+__device__ __forceinline__ bool guard_expired(unsigned long long t0) { return __builtin_amdgcn_s_memrealtime() - t0 > kFusedGuardTicks; }
+
 // Jobs of this workgroup's images from a ticket counter in LDS, column by column (ticket t = column t / images, image
 // t % images), each gated by the progress of the producer waves that hold the image's rows.  BY_ROWS (row-major plans): piece
 // by piece instead (ticket t = piece t / rows, row t % rows of the workgroup's rows), gated by the one wave that holds the row.
@@ -118,11 +125,13 @@ struct FusedSource {
         }
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > m;
     }
-    // (bounded: ~0.3 s of sleeps; a producer never waits for anything, so the bound only guards the GPU against a defect here)
+    // (bounded by kFusedGuardTicks: on expiry the image is marked MJ_ST_INTERNAL — its blocks were not there — and the wave goes on)
     __device__ __forceinline__ bool wait_ready(uint32_t job) const {
-        for (uint32_t spins = 0; !ready(job); ++spins) {
+        if (ready(job)) return true;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (!ready(job)) {
             __builtin_amdgcn_s_sleep(8);
-            if (spins > (1u << 16)) {
+            if (guard_expired(t0)) {
                 if (lane == 0) atomicMax(status + job / jobs_per_image, MJ_ST_INTERNAL);
                 break;
             }
@@ -250,6 +259,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(F.R.dump + (3u << 20)) + (size_t)(blockIdx.x & 1023) * 8;
     if (tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // workgroup 0 leaves the shader clock and the 100 MHz clock at its start and end: what frequency the chip held under THIS
+    // launch (the launch runs the board into its power cap; mj_context_launch_clock, bench.py's `clock_mhz`)
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(F.R.dump + kDumpClockWords);
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = __builtin_amdgcn_s_memrealtime(); }
     unsigned char *my_lds;
     if (wave < n_prod) {
         lanes13::walk<XWG ? 2 : 1>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
@@ -268,12 +281,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
         // beside the producers from the start: a strip of its own under the weights, above everything the producers use
         my_lds = smem + kFusedLds - kFusedCtrl - G::WTS_BYTES - (wave - n_prod + 1) * G::WAVE_BYTES;
     } else {
-        // phase 2: once every producer is through (their tables and rows are where these strips go)
-        for (uint32_t spins = 0; (int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl_lds + 4u) < n_prod; ++spins) {
-            __builtin_amdgcn_s_sleep(16);
-            if (spins > (1u << 18)) {         // (cannot happen: see FusedSource::wait_ready)
-                if (lane == 0) atomicMax(F.L.status + image0, MJ_ST_INTERNAL);
-                return;
+        // phase 2: once every producer is through (their tables and rows are where these strips go).  Idle wavefronts and
+        // producers that are through early wait here for the whole walk, however long the rows are; should the guard ever
+        // expire the wave simply ends — the jobs it would have taken are drawn by the others, nothing is lost and no status is set
+        {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while ((int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl_lds + 4u) < n_prod) {
+                __builtin_amdgcn_s_sleep(16);
+                if (guard_expired(t0)) return;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -281,6 +296,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
         my_lds = smem + k * G::WAVE_BYTES;
     }
     rfast::strips_worker<HS, VS, 3, false, T>(F.R, F.job_prefix, F.total_jobs, F.jobs_per_image, my_lds, wts, lane, (int)blockIdx.x, wave, src);
+    if (blockIdx.x == 0 && lane == 0) {      // (every wave of workgroup 0 as it ends: the latest stamp stands)
+        atomicMax(clk + 2, (unsigned long long)__builtin_amdgcn_s_memtime());
+        atomicMax(clk + 3, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
 #ifdef MJ_DIAGNOSTIC
     if (lane == 0) atomicMax(dbg + 3, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -473,11 +492,10 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
     }
     auto go = [&](auto kernel) {
-        static bool attr_set[kMaxDevices] = {false};
-        if (!attr_set[current_device()]) {
+        static OncePerDevice attr_once;
+        attr_once.run([&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
-            attr_set[current_device()] = true;
-        }
+        });
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFusedThreads), kFusedLds, stream, F);
     };
 #define MJ_GO(H, V, TT) do { if (shape.xwg) go(k_fused<H, V, TT, true>); else go(k_fused<H, V, TT, false>); } while (0)

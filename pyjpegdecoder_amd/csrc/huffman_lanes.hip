@@ -447,12 +447,11 @@ hipError_t launch_huffman_lanes(hipStream_t stream, const uint32_t *dstream, con
     const int64_t blocks = (n_segs + 4 * lpw_run - 1) / (4 * lpw_run);
     const int lpw2_run = (lpw_run + 1) & ~1, wstride_run = (lpw2_run * kBlkStride + 3) & ~3;
     const size_t lds = (size_t)n_slots * kLSize * 2 + (size_t)4 * wstride_run * 4 + (size_t)4 * lpw2_run * 8 + 16 + (size_t)n_slots * kLongInts * 4;
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[current_device()]) {
+    static OncePerDevice attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[current_device()] = true;
-    }
+    });
     if (wg_tabs)
         hipLaunchKernelGGL(k_huffman_lanes<true>, dim3((unsigned)blocks), dim3(256), lds, stream, dstream, seg_bits, segs, n_segs, images,
                            huff, lut11, n_slots, coef, status, lpw_run, transposed, vsegs, wg_tabs);

@@ -110,11 +110,10 @@ hipError_t launch_huffman_lanes13(hipStream_t stream, const uint32_t *dstream, c
     }
     if (const char *e = opt("MJ_LANES_RING")) { const int v = atoi(e); if ((v == 64 || v == 128) && lds13(n_ac, n_dc, nw, lpw, v) <= 160 * 1024) ring = v; }
     const size_t lds = lds13(n_ac, n_dc, nw, lpw, ring);
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[current_device()]) {
+    static OncePerDevice attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_huffman_lanes13), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[current_device()] = true;
-    }
+    });
     lanes13::Args A{dstream, seg_bits, segs, n_segs, images, huff, lut11, lut13, n_ac, n_dc, ac_slot_pk, dc_slot_pk, dc_tab_pk,
                     coef, status, lpw, transposed, vsegs, by_length, order_mode, ring, n_ac * kLanes13SlotBytes, kLaneLutBits, {0, 0, 0, 0}, {13, 13, 13, 13}, 0, nullptr};
     hipLaunchKernelGGL(k_huffman_lanes13, dim3((unsigned)blocks), dim3(64 * nw), lds, stream, A);

@@ -469,29 +469,47 @@ __global__ __launch_bounds__(1024) void k_count(CountArgs A) {
         const uint64_t ex = pack_state(pos, (int)(b8 >> 3), (int)k);
         uint64_t old_exit = ex;
         bool mine = true;
+        DevChunkOut o{};
         if (have) {
-            DevChunkOut o;
             o.entry = mx > 192u ? ~0ull : my_entry;
             o.blocks = (int32_t)blocks;
             o.bnd_pos = bnd_pos < final_limit ? (int32_t)bnd_pos : -1;
             o.bnd_blocks = (int32_t)bnd_blocks;
             o.dc_bnd[0] = (int16_t)bd01; o.dc_bnd[1] = (int16_t)(bd01 >> 16); o.dc_bnd[2] = (int16_t)bd2;
             o.dc_sum[0] = (int16_t)acc01; o.dc_sum[1] = (int16_t)(acc01 >> 16); o.dc_sum[2] = (int16_t)acc2;
-            if constexpr (REPAIR) {
-                // Writes of different lanes to one chunk have to land in memory in the order they are made: device-scope loads and
-                // write-through stores (a plain store stays in its XCD's L2 until the launch ends, and the write-backs come in any order).
-                mine = __hip_atomic_load(A.owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= origin;
-                if (mine) {
-                    old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
-                    uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
+            if constexpr (!REPAIR) {
                 A.outs[c] = o;
                 A.exit_state[c] = ex;
+            }
+        }
+        if constexpr (REPAIR) {
+            // Writes of different lanes to one chunk have to land in memory in the order they are made: device-scope loads and
+            // write-through stores (a plain store stays in its XCD's L2 until the launch ends, and the write-backs come in any order).
+            // And "am I still the leftmost taker?" + the record's four words + the exit state are ONE step per chunk: a lane holds
+            // the chunk's lock (A.owner[n_chunks + c]) while it looks and writes.  Without it a lane that had looked before a walk
+            // from further left took the chunk, and was then held up (wavefronts are pre-empted when queues are oversubscribed),
+            // could land its words behind the winner's — in part: a record with one walk's entry state and the other's counts
+            // passes k_build_vsegs' entry == exit test.  (A lane never waits with the lock taken, and the loop is the SIMT form:
+            // whoever gets the lock does its writing and lets go in the same turn, lanes of one wavefront included.)
+            bool pending = have;
+            while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+                if (pending) {
+                    int32_t *lock = A.owner + A.n_chunks + c;
+                    int32_t expect = 0;
+                    if (__hip_atomic_compare_exchange_strong(lock, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        mine = __hip_atomic_load(A.owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= origin;
+                        if (mine) {
+                            old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
+                            uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __hip_atomic_store(lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        pending = false;
+                    }
+                }
             }
         }
         if constexpr (!REPAIR) break;
@@ -514,7 +532,7 @@ __global__ void k_sync_scan(const DevChunk *__restrict__ chunks, int64_t n_chunk
                             SyncItem *__restrict__ items, int32_t *__restrict__ n_items, int32_t *__restrict__ owner) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool add = c < n_chunks;
-    if (add) owner[c] = 0x7FFFFFFF;                   // nobody has taken the chunk yet (k_count<true>)
+    if (add) { owner[c] = 0x7FFFFFFF; owner[n_chunks + c] = 0; }      // nobody has taken the chunk yet, nobody holds its lock (k_count<true>)
     uint64_t e = 0;
     if (add) {
         const DevChunk ch = chunks[c];
@@ -552,12 +570,11 @@ hipError_t launch_count(hipStream_t stream, const uint32_t *dstream, const int32
     A.chunks = chunks; A.n_chunks = n_chunks; A.cbits = cbits; A.warm = warm_bits >= 0 ? warm_bits : cbits / 2;
     A.exit_state = exit_state; A.outs = outs; A.items = reinterpret_cast<const SyncItem *>(items); A.n_items = n_items; A.max_links = max_links;
     const size_t lds = (size_t)n_tabs * (size_t)tab_bytes;
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[current_device()]) {
+    static OncePerDevice attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[current_device()] = true;
-    }
+    });
     // the first walk: every chunk, one workgroup per CU and as few waves of workgroups as that allows, all equally full
     const int64_t cus = device_cus();
     const int64_t waves_of_wgs = (n_chunks + cus * 1024 - 1) / (cus * 1024);
@@ -664,12 +681,11 @@ hipError_t launch_sync_count(hipStream_t stream, const uint32_t *dstream, const 
     if (wg_tabs) n_huff = wg_slots;                             // table slots in LDS
     const size_t lds = (size_t)n_huff * kLSize * 2 + 16 + kMaxWgTables * 4 + (size_t)n_huff * kLongInts * 4;
     const dim3 grid((unsigned)((n_chunks + 255) / 256));
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[current_device()]) {                          // 16 table slots: just over the 64 KiB default
+    static OncePerDevice attr_once;
+    attr_once.run([&] {                          // 16 table slots: just over the 64 KiB default
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[current_device()] = true;
-    }
+    });
     const int warm = warm_bits >= 0 ? warm_bits : cbits / 2;   // run-up in front of every chunk (swept: half a chunk is best; MJ_SYNC_WARM is read once, when the plan is created)
     if (entry)
         hipLaunchKernelGGL(k_sync_count<false>, grid, dim3(256), lds, stream, dstream, seg_bits, segs, images, huff, lut11u, n_huff,

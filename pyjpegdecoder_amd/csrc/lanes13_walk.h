@@ -642,6 +642,11 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
             const uint64_t act_mask = __ballot(in_mcu);
             const uint32_t blk_byte = (uint32_t)(m * bpm + b) * 128u;    // same for every lane (same layout)
             unsigned char *dst0 = reinterpret_cast<unsigned char *>(coef) + blk_byte + fpart * 16;
+#ifdef MJ_X_SPARSE_ST    // probe (holes in the store): rows 4..7 of every chroma block are not written — what a half-block store could save on the write side
+            const int fslot_x = (comp != 0 && fpart >= 4) ? fslot + 4096 : fslot;
+#else
+            const int fslot_x = fslot;
+#endif
             if (act_mask == full_mask) {
                 // every lane of the wave has a block (all but a segment's last rounds): by hand — per eight blocks eight 16-bit
                 // reads and four packs (a d16 load clears the other half of its register on this chip), the block's address from
@@ -676,7 +681,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                     "L_fend%=:\n\t"                                                                                                              \
                     "s_mov_b64 exec, s[40:41]\n\t"                                                                                               \
                     : "=&{v[10:13]}"(fd), "=&{v[14:15]}"(fad), "=&{v[16:19]}"(fh)                                                               \
-                    : [lpw] "s"(lpw), [fslot] "v"(fslot), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]), [fa3] "v"(fa[3]), [fa4] "v"(fa[4]), \
+                    : [lpw] "s"(lpw), [fslot] "v"(fslot_x), [fa0] "v"(fa[0]), [fa1] "v"(fa[1]), [fa2] "v"(fa[2]), [fa3] "v"(fa[3]), [fa4] "v"(fa[4]), \
                       [fa5] "v"(fa[5]), [fa6] "v"(fa[6]), [fa7] "v"(fa[7]), [fb] "v"(fb_addr), [dst] "v"((uint64_t)(uintptr_t)dst0)            \
                     : "memory", "vcc", "scc", "s40", "s41", "s42")
                 if constexpr (MODE == 2) { MJ_FLUSH_ALL(" sc1"); } else { MJ_FLUSH_ALL(""); }
@@ -694,7 +699,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 v.z = rd(4) | (rd(5) << 16);
                 v.w = rd(6) | (rd(7) << 16);
                 const int o = it * 8 + fslot;
-                if ((act_mask >> o) & 1) {
+                if (((act_mask >> o) & 1) && fslot_x == fslot) {
                     if constexpr (MODE == 2) {
                         const u32x4 vv = {v.x, v.y, v.z, v.w};
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst0 + s_base[o]), "v"(vv) : "memory");

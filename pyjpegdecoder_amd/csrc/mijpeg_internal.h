@@ -1,5 +1,7 @@
 // Internal device/host structures of libmijpeg.so (gfx950 only).
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -249,6 +251,9 @@ int set_opt(const char *name, const char *value);
 int get_opt(const char *name, char *out, int cap);
 
 constexpr size_t kStage2DumpBytes = 4096 * 1024;    // 1 KiB per workgroup of the largest persistent grid
+// (MI355X: at most 768 workgroups use their KiB; two small areas further up have other uses)
+constexpr size_t kDumpZeroLine = 0x180000;          // 16 bytes that stay zero (variant builds -DMJ_X_SPARSE_LD read them)
+constexpr size_t kDumpClockWords = 0x1C0000;        // 4 x u64: shader-clock / 100 MHz stamps of the latest fused launch's workgroup 0 (mj_context_launch_clock)
 struct ReconArgs {
     const DevImage *images;
     int32_t n_images;
@@ -315,22 +320,37 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
                         uint32_t *x_words = nullptr);
 // (lut13 of launch_fused: the plan's fused tables, back to back — ac_off / ac_bits per LDS slot)
 // Launch-geometry caches are per device: one process may hold contexts on several GPUs (mijpeg.h: one context per GPU per
-// thread), and a function attribute set on one device says nothing about the next.  (Racing first uses write the same values.)
+// thread), and a function attribute set on one device says nothing about the next.  Contexts on two threads may make a
+// kernel's FIRST launch at the same moment: the per-device flags are std::once_flag (OncePerDevice), the cached integers atomics.
 constexpr int kMaxDevices = 64;
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < kMaxDevices ? d : 0; }
-inline int device_cus() {
-    static int cus[kMaxDevices] = {0};
-    const int d = current_device();
-    if (cus[d] == 0) {
-        int c = 0;
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c < 1) c = 256;
-        cus[d] = c;
+struct OncePerDevice {
+    std::once_flag flag[kMaxDevices];
+    template <class F> void run(F &&fn) { std::call_once(flag[current_device()], fn); }
+};
+struct IntPerDevice {         // 0 = not known yet; racing first uses compute and store the same value
+    std::atomic<int> v[kMaxDevices];
+    IntPerDevice() { for (auto &x : v) x.store(0, std::memory_order_relaxed); }
+    template <class F> int get(F &&compute) {
+        std::atomic<int> &x = v[current_device()];
+        int r = x.load(std::memory_order_relaxed);
+        if (r == 0) { r = compute(); x.store(r, std::memory_order_relaxed); }
+        return r;
     }
-    return cus[d];
+};
+inline int device_cus() {
+    static IntPerDevice cus;
+    return cus.get([] {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || c < 1) c = 256;
+        return c;
+    });
 }
 // MJ_LAYOUT_PLANAR_*: every image's interleaved pixels (x-major or row-major, as stage 2 wrote them) -> its three planes
 hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
                                           const uint8_t *interleaved, uint8_t *planar);
+// dst[0 .. bytes) = src[0 .. bytes), sixteen bytes per lane (bytes a multiple of 16): the plain copy the rooflines are held against
+hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes);
 // p[0 .. n_words) = value, as a kernel (why not hipMemsetAsync: api.hip)
 hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_t n_words);
 // 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]

@@ -95,6 +95,12 @@ struct mj_context {
     double *d_idct_tt = nullptr;   // [u*8+v][x*8+y], the reference's InverseDCT.idct_table transposed
     uint8_t *d_dump = nullptr;     // stage 2's dump lines (mj::kStage2DumpBytes)
     bool no_graph = false;         // MJ_NO_GRAPH at context creation: never replay captured graphs
+    // Fused launches (fused.hip) of one context take turns: a fused workgroup wants a CU's whole LDS, so two plans' fused
+    // launches on two streams cannot share the chip — left to the hardware queues they interleave workgroup by workgroup and
+    // both finish later than one after the other would (three plans in flight: 6.58 ms per step against 5.74, round 5).  An
+    // execute that contains a fused launch waits — its stream does, not the host — for the context's previous one.
+    hipEvent_t fused_done = nullptr;
+    hipStream_t fused_stream = nullptr;     // where the latest fused execute went (null: none yet)
     DevBufferCache cache;
     std::string err;
 };

@@ -1125,7 +1125,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_exit, ck.size() * 8 + 16));
                     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_outs, ck.size() * sizeof(mj::DevChunkOut) + 16));
                     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_items, ck.size() * 16 + 16));
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_owner, ck.size() * 4 + 64));      // (+ the work list's counter behind it)
+                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_owner, ck.size() * 8 + 128));     // (+ the work list's counter behind it, + a lock word per chunk behind that)
                     MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
                 } else {
                     p->prog_chunks = false;

@@ -216,25 +216,38 @@ __global__ __launch_bounds__(256) void k_pc_count(PcArgs A) {
         const uint64_t ex = pc_state(rd.pos, k);
         uint64_t old_exit = ex;
         bool mine = true;
+        DevChunkOut o{};
         if (have) {
-            DevChunkOut o{};
             o.entry = damaged ? ~0ull : my_entry;            // (a record no chunk's state matches: the image goes to the wavefront walks)
             o.blocks = blocks;
             o.bnd_pos = bnd_pos < limit ? (int32_t)bnd_pos : -1;
             o.bnd_blocks = bnd_blocks;
-            if constexpr (REPAIR) {
-                mine = __hip_atomic_load(A.owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= origin;
-                if (mine) {
-                    old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
-                    uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
+            if constexpr (!REPAIR) {
                 A.outs[c] = o;
                 A.exit_state[c] = ex;
+            }
+        }
+        if constexpr (REPAIR) {
+            // look ("still the leftmost taker?") and write under the chunk's lock, A.owner[n_chunks + 16 + c]: huffman_sync.hip, k_count
+            bool pending = have;
+            while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+                if (pending) {
+                    int32_t *lock = A.owner + A.n_chunks + 16 + c;
+                    int32_t expect = 0;
+                    if (__hip_atomic_compare_exchange_strong(lock, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        mine = __hip_atomic_load(A.owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= origin;
+                        if (mine) {
+                            old_exit = __hip_atomic_load(A.exit_state + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint64_t *w = reinterpret_cast<const uint64_t *>(&o);
+                            uint64_t *dst = reinterpret_cast<uint64_t *>(A.outs + c);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) __hip_atomic_store(dst + q, w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(A.exit_state + c, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __hip_atomic_store(lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        pending = false;
+                    }
+                }
             }
         }
         if constexpr (!REPAIR) break;
@@ -256,6 +269,7 @@ __global__ void k_pc_scan(const DevChunk *__restrict__ chunks, int64_t n_chunks,
     uint64_t e = 0;
     if (add) {
         owner[c] = 0x7FFFFFFF;
+        owner[n_chunks + 16 + c] = 0;                 // (the chunk's lock: behind the owners and the work list's counter)
         const DevChunk ch = chunks[c];
         add = ch.seg >= 0 && ch.j > 0 && (int64_t)ch.j * cbits < seg_bits[segs[ch.seg >= 0 ? ch.seg : 0].stream_slot];
         if (add) {
@@ -413,11 +427,10 @@ hipError_t launch_progressive_chunks(hipStream_t stream, const uint32_t *dstream
                                      DevChunkOut *outs, void *items, int32_t *n_items, int32_t *owner, DevVSeg *vsegs, const DevImage *images,
                                      int16_t *coef, int32_t *status, int transposed, int max_links) {
     if (n_chunks == 0 || n_segs == 0) return hipSuccess;
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[current_device()]) {
+    static OncePerDevice attr_once;
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pc_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[current_device()] = true;
-    }
+    });
     PcArgs A{};
     A.stream = dstream; A.seg_bits = seg_bits; A.segs = segs; A.tabs = tabs; A.lut11p = lut11p; A.chunks = chunks; A.n_chunks = n_chunks;
     A.cbits = cbits; A.warm = cbits / 2; A.exit_state = exit_state; A.outs = outs;

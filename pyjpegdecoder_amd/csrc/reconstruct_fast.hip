@@ -73,14 +73,12 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
     if (total_jobs == 0) return hipSuccess;
     // persistent grid = at most what the chip can hold at once; its waves draw the jobs from a.work_counter
     auto launch = [&](auto kernel) {
-        static int resident_of[kMaxDevices] = {0};     // per instantiation and device
-        int &resident = resident_of[current_device()];
-        if (resident == 0) {
+        static IntPerDevice resident_of;               // per instantiation and device
+        const int resident = resident_of.get([&] {
             int per_cu = 0;
-            const int cus = device_cus();
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
-            resident = per_cu * cus;
-        }
+            return per_cu * device_cus();
+        });
         const int64_t want = ((total_jobs + a.jobs_per_ticket - 1) / a.jobs_per_ticket + 3) / 4;      // one ticket per wave at least
         const unsigned blocks = (unsigned)(want < resident ? want : resident);
 #ifdef MJ_DIAGNOSTIC      // occupancy experiment: MJ_LDS_PAD bytes of unused LDS per workgroup

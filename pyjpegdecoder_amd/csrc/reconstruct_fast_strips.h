@@ -400,6 +400,10 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
         for (int r = 0; r < G::ROUNDS; ++r) {
             const int bt = min(r * 8 + grp, G::NBT - 1);        // (groups past the strip's last block repeat it: never stored)
             const int k = bt / G::NB, b = bt - k * G::NB;
+#ifdef MJ_X_SPARSE_LD   // probe (wrong pixels): rows 4..7 of every chroma block are not fetched — what a half-block store could save on the read side
+            if (NC == 3 && b >= G::NBY && j >= 4) cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(a.dump + kDumpZeroLine));
+            else
+#endif
             cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(jo.cfirst + __mul24(k < nv ? k : 0, jo.row_elems) + b * 64 + j * 8));
             asm volatile("" ::: "memory");     // keep the loads in round order: the waits in front of the rounds count on it
         }
@@ -665,7 +669,13 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
             if (nv == G::TMW) {
 #pragma unroll
                 for (int r = 0; r < G::ROUNDS; ++r) {
+#ifdef MJ_X_SPARSE_LD
+                    const int bt_x = min(r * 8 + grp, G::NBT - 1), b_x = bt_x - (bt_x / G::NB) * G::NB;
+                    const unsigned char *src_x = (NC == 3 && b_x >= G::NBY && j >= 4) ? a.dump + kDumpZeroLine : cn + voff[r];
+                    cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(src_x));
+#else
                     cw[r] = MJ_COEF_LOAD(reinterpret_cast<const uint4 *>(cn + voff[r]));
+#endif
                     asm volatile("" ::: "memory");
                 }
             } else {                                 // the column's last strip has fewer MCUs: the missing ones repeat the first

@@ -32,6 +32,25 @@ hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_
     hipLaunchKernelGGL(k_fill_words, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, static_cast<uint32_t *>(p), value, n_words);
     return hipGetLastError();
 }
+// The copy SURVEY 8d's second denominator asks for ("what a plain device-to-device copy achieves here"): every lane moves 16
+// bytes per instruction, a wavefront 1 KiB of consecutive addresses, four loads in flight per lane, a grid that fills the chip
+// eight workgroups deep.  (torch's uint8 copy_ moved 2.1 TB/s on this chip — below what the decode kernels themselves move.)
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes) {
+    if (bytes <= 0) return hipSuccess;
+    const int64_t n16 = bytes / 16, want = (n16 + 1023) / 1024;
+    const int64_t cap = (int64_t)device_cus() * 8;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
                                  int transposed) {
     if (n_blocks == 0) return hipSuccess;

@@ -5,8 +5,10 @@ The reference decodes one file per ``JpegDecoder(path)`` call (jpeg_decoder.py:5
 node of GPUs is sharded by image (``sharding.shard``) and each rank feeds ITS GPU from this queue — no collective on the
 data path.  The share's files are assembled and uploaded once (inputs resident in HBM), cut into batches of
 ``batch_size`` images; ``run()`` makes one pass: plan k is created and queued on stream ``k % depth`` into output slot
-``k % depth``, then — before slot ``k % depth`` is used again — plan ``k - depth`` is collected (synchronised, its
-per-image status read, destroyed: where a consumer takes the pixels from HBM).
+``k % depth`` — the plan is created first (host work beside the kernels in flight), then, before slot ``k % depth`` is used
+again, plan ``k - depth`` is collected (synchronised, its per-image status read, destroyed: where a consumer takes the
+pixels from HBM).  Statuses are kept per batch (``statuses``): images whose synchronisation rounds had not settled are
+decoded again through the serial walk, an internal error raises, corrupt files are counted and named.
 
 Why a queue and not one plan per batch back to back: stage 1 lasts as long as ONE restart segment's serial walk however
 few segments a plan holds, so a plan of a few hundred images leaves most of the chip idle, and plan creation
@@ -50,65 +52,128 @@ class TorchBackend:
 
 class DeviceImageQueue:
     """``files``: this rank's share (a list of file bytes).  ``depth`` plans are in flight at once, each on its own stream
-    and with its own output buffer."""
+    and with its own output buffer.
+
+    ``across_passes=True`` keeps ``depth`` slots even when the share is fewer batches than that, so that with
+    ``run(wait=False)`` the plan of the next pass (the next job's files, in a service) is created — host work — while the
+    current pass's kernels run; ``drain()`` collects what is still in flight."""
 
     def __init__(self, ctx, files: Sequence[bytes], batch_size: int, layout: int, depth: int = 2, device=None, backend=None,
-                 prepare: Optional[Callable] = None, on_collect: Optional[Callable] = None):
+                 prepare: Optional[Callable] = None, on_collect: Optional[Callable] = None, across_passes: bool = False):
         if batch_size < 1 or depth < 1:
             raise ValueError("batch_size and depth must be at least 1")
         if prepare is None:
             from .batch import prepare_batch as prepare
         self.backend = backend if backend is not None else TorchBackend(ctx, device)
         self.layout = layout
+        self._prepare = prepare
         self.batches = []                 # (prep, device blob handle, device blob pointer, images)
+        self._files = []                  # per batch, its files (only looked at again when a batch has to be decoded another way)
         for i in range(0, len(files), batch_size):
             part = files[i:i + batch_size]
             prep = prepare(part, layout, 0)
             handle, ptr = self.backend.upload(prep.blob)
             self.batches.append((prep, handle, ptr, len(part)))
+            self._files.append(part)
         cap = max((sum(w * h * nc for (w, h, nc) in b[0].shapes) for b in self.batches), default=0)
-        self.depth = max(1, min(depth, len(self.batches)))
+        self.depth = max(1, depth if across_passes else min(depth, len(self.batches)))
         self.out = [self.backend.empty(cap) for _ in range(self.depth)]           # (handle, pointer) per slot
         self.streams = [self.backend.stream() for _ in range(self.depth)]        # (handle, raw stream) per slot
         self.n_images = len(files)
         self.bad = 0                      # plans with an image whose status was not MJ_ST_OK, over every run() so far
+        self.statuses = {}                # batch number -> per-image status array of its latest decode (MJ_ST_*; all zero = fine)
         self.collected: List[int] = []    # batch numbers in the order they were collected (the latest run())
-        # called as on_collect(batch number, slot, plan) when a plan's pixels are in HBM, before the plan is destroyed
+        # called as on_collect(batch number, slot, plan) when a plan's pixels are in HBM, before the plan is destroyed;
+        # statuses[batch number] then says which of its images (if any) are not valid
         self.on_collect = on_collect
+        self._flying = []                 # (batch number, plan), oldest first — across run() calls with wait=False
+        self._seq = 0                     # plans submitted since the queue last ran dry: plan number `seq` uses slot seq % depth
+        self._slot = {}                   # batch number -> slot of its latest submission
 
     def slot_of(self, k: int) -> int:
-        return k % self.depth
+        """The slot batch k's latest decode went to (k % depth for a pass that started with nothing in flight)."""
+        return self._slot.get(k, k % self.depth)
 
     def out_tensor(self, slot: int):
         """The output buffer of a slot (the backend's handle: a ``torch.uint8`` tensor with the default backend)."""
         return self.out[slot][0]
 
+    def _again_without_sync(self, k: int):
+        """Batch k once more through the serial walk (MJ_FLAG_NO_SYNC), into the same slot: some image's synchronisation
+        rounds had not settled (files without restart markers; BatchDecoder does the same per image).  Returns the statuses."""
+        from . import _binding as B
+        prep = self._prepare(self._files[k], self.layout, B.MJ_FLAG_NO_SYNC)
+        handle, ptr = self.backend.upload(prep.blob)
+        plan = self.backend.make_plan(prep, ptr, len(self._files[k]))
+        try:
+            slot = self.slot_of(k)
+            plan.execute(self.streams[slot][1], self.out[slot][1])
+            plan.sync()
+            return plan.read(rgb=False)["status"]
+        finally:
+            plan.close()
+            del handle
+
     def _collect(self, k: int, plan):
         try:
             plan.sync()
-            self.bad += int(plan.read(rgb=False)["status"].any())
+            status = plan.read(rgb=False)["status"]
+            if status.any():
+                from . import _binding as B
+                if (status == B.MJ_ST_UNCONVERGED).any():
+                    status = self._again_without_sync(k)
+                if (status == B.MJ_ST_INTERNAL).any():          # not the files' fault: nothing of this batch can be trusted
+                    from .errors import BackendError
+                    raise BackendError(f"batch {k}: a fused launch gave up waiting for its decoder wavefronts (internal error)")
+            self.statuses[k] = status
+            self.bad += int(status.any())
             self.collected.append(k)
             if self.on_collect is not None:
                 self.on_collect(k, self.slot_of(k), plan)
         finally:
             plan.close()
 
-    def run(self, first: int = 0, count: Optional[int] = None):
-        """One pass over the share (or over ``count`` batches from batch ``first``); returns when every batch's pixels are
-        in HBM.  Batch k's pixels are in ``out_tensor(slot_of(k))`` until batch k + depth overwrites them."""
-        self.collected = []
+    def run(self, first: int = 0, count: Optional[int] = None, wait: bool = True):
+        """One pass over the share (or over ``count`` batches from batch ``first``).  ``wait=True``: returns when every
+        batch's pixels are in HBM; batch k's pixels are in ``out_tensor(slot_of(k))`` until ``depth`` more plans have been
+        submitted.  ``wait=False``: returns with up to ``depth`` plans still in flight — the next ``run()`` goes on from
+        there (its first plan is created while they run), ``drain()`` collects them."""
+        if not self._flying:
+            self.collected = []
+            self._seq = first
         last = len(self.batches) if count is None else min(len(self.batches), first + count)
-        flying = []                       # (batch number, plan), oldest first
         try:
             for k in range(first, last):
                 prep, _, ptr, n = self.batches[k]
-                if len(flying) == self.depth:            # slot k % depth is still in use by plan k - depth
-                    self._collect(*flying.pop(0))
+                # the plan first (host work, beside the kernels in flight), then — if the slot is still in use by the plan
+                # submitted `depth` plans ago — that plan's collection, then the launch
                 plan = self.backend.make_plan(prep, ptr, n)
-                flying.append((k, plan))
-                plan.execute(self.streams[self.slot_of(k)][1], self.out[self.slot_of(k)][1])
-            while flying:
-                self._collect(*flying.pop(0))
-        finally:
-            for _, plan in flying:        # (an exception on the way: nothing of this pass stays alive)
+                try:
+                    if len(self._flying) == self.depth:
+                        self._collect(*self._flying.pop(0))
+                except BaseException:
+                    plan.close()
+                    raise
+                slot = self._seq % self.depth
+                self._seq += 1
+                self._slot[k] = slot
+                self._flying.append((k, plan))
+                plan.execute(self.streams[slot][1], self.out[slot][1])
+            if wait:
+                self.drain()
+        except BaseException:
+            for _, plan in self._flying:  # (an exception on the way: nothing of this pass stays alive)
                 plan.close()
+            self._flying = []
+            raise
+
+    def drain(self):
+        """Collect every plan still in flight (after ``run(wait=False)``)."""
+        try:
+            while self._flying:
+                self._collect(*self._flying.pop(0))
+        except BaseException:
+            for _, plan in self._flying:
+                plan.close()
+            self._flying = []
+            raise

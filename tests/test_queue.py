@@ -13,8 +13,8 @@ class _Prep:
 
 
 class _Plan:
-    def __init__(self, log, k, n, bad=False, fail_execute=False):
-        self.log, self.k, self.n, self.bad, self.fail_execute = log, k, n, bad, fail_execute
+    def __init__(self, log, k, n, bad=False, fail_execute=False, code=2):
+        self.log, self.k, self.n, self.bad, self.fail_execute, self.code = log, k, n, bad, fail_execute, code
         self.closed = False
 
     def execute(self, stream, out):
@@ -28,7 +28,7 @@ class _Plan:
     def read(self, rgb=True):
         st = np.zeros(self.n, dtype=np.int32)
         if self.bad:
-            st[-1] = 2
+            st[-1] = self.code
         return {"status": st}
 
     def close(self):
@@ -38,8 +38,8 @@ class _Plan:
 
 
 class _Backend:
-    def __init__(self, bad=(), fail=()):
-        self.log, self.bad, self.fail = [], set(bad), set(fail)
+    def __init__(self, bad=(), fail=(), code=2):
+        self.log, self.bad, self.fail, self.code = [], set(bad), set(fail), code
         self.n_up = self.n_out = self.n_streams = self.made = 0
         self.plans = []
 
@@ -57,8 +57,8 @@ class _Backend:
         return ("stream", self.n_streams), 70 + self.n_streams
 
     def make_plan(self, prep, ptr, n):
-        k = ptr - 1001                      # the batch whose blob this is
-        p = _Plan(self.log, k, n, bad=k in self.bad, fail_execute=k in self.fail)
+        k = ptr - 1001                      # the batch whose blob this is (a blob uploaded later: a batch decoded once more)
+        p = _Plan(self.log, k, n, bad=k in self.bad, fail_execute=k in self.fail, code=self.code)
         self.plans.append(p)
         return p
 
@@ -117,3 +117,52 @@ def test_status_counting_callbacks_and_cleanup_after_a_failure():
     assert all(p.closed for p in be2.plans)                         # nothing of the pass stays alive
     with pytest.raises(ValueError):
         DeviceImageQueue(None, _files(4), 0, 0, backend=_Backend(), prepare=_prepare)
+
+
+def test_passes_overlap_when_asked_to_and_drain_collects_the_rest():
+    """across_passes + run(wait=False): the next pass's plan is created (host work) before the previous pass's plan is waited
+    for — config 4's share is ONE 1 250-image plan per pass, whose creation would otherwise sit between two passes' kernels."""
+    be = _Backend()
+    q = DeviceImageQueue(None, _files(4), 4, 0, depth=2, backend=be, prepare=_prepare, across_passes=True)
+    assert len(q.batches) == 1 and q.depth == 2 and be.n_out == 2
+    for _ in range(3):
+        q.run(wait=False)
+    ex = [i for i, e in enumerate(be.log) if e[0] == "execute"]
+    sy = [i for i, e in enumerate(be.log) if e[0] == "sync"]
+    assert len(ex) == 3 and len(sy) == 1                           # two plans in flight, the first pass collected for its slot
+    assert ex[1] < sy[0] < ex[2]                                   # pass 1 was queued before pass 0 was waited for
+    assert [be.log[i][2:] for i in ex] == [(71, 5001), (72, 5002), (71, 5001)]     # slots in turn
+    assert q.slot_of(0) == 0                                       # the latest decode of batch 0 went to slot 0
+    assert len(be.plans) == 3 and [p.closed for p in be.plans] == [True, False, False]
+    q.drain()
+    assert all(p.closed for p in be.plans) and q.collected == [0, 0, 0] and q.bad == 0
+    q.run()                                                        # (and a waiting pass afterwards starts from slot 0 again)
+    assert be.log[-3][0] == "execute" and be.log[-3][2:] == (71, 5001) and all(p.closed for p in be.plans)
+
+
+def test_statuses_are_kept_unsettled_images_go_round_again_and_internal_errors_raise():
+    from pyjpegdecoder_amd import _binding as B
+    from pyjpegdecoder_amd.errors import BackendError
+    be = _Backend(bad={1})
+    q = DeviceImageQueue(None, _files(8), 4, 0, depth=2, backend=be, prepare=_prepare)
+    q.run()
+    assert q.bad == 1 and not q.statuses[0].any() and q.statuses[1].tolist() == [0, 0, 0, 2]      # which image of which batch
+    # MJ_ST_UNCONVERGED: the batch is decoded once more with MJ_FLAG_NO_SYNC into the same slot; what that decode says stands
+    flags_seen = []
+
+    def prepare(files, layout, flags):
+        flags_seen.append(flags)
+        return _Prep(files)
+    be = _Backend(bad={1}, code=B.MJ_ST_UNCONVERGED)
+    q = DeviceImageQueue(None, _files(8), 4, 0, depth=2, backend=be, prepare=prepare)
+    q.run()
+    assert flags_seen == [0, 0, B.MJ_FLAG_NO_SYNC]
+    redo = be.plans[-1]                                             # (its blob was uploaded third: the stand-in calls it batch 2)
+    assert redo.closed and ("execute", redo.k, 72, 5002) in be.log  # batch 1's stream and slot
+    assert q.bad == 0 and not q.statuses[1].any()
+    # MJ_ST_INTERNAL is not a property of a file: it raises, and nothing stays alive
+    be = _Backend(bad={0}, code=B.MJ_ST_INTERNAL)
+    q = DeviceImageQueue(None, _files(8), 4, 0, depth=2, backend=be, prepare=_prepare)
+    with pytest.raises(BackendError):
+        q.run()
+    assert all(p.closed for p in be.plans)
