@@ -248,10 +248,10 @@ int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_
                           int32_t *tab_bytes);
 
 /* Test hook, host only: how a fused launch (MJ_FORM_FUSED) would be cut for a batch of n_images images of segments_per_image
- * restart segments on a chip of `cus` CUs — out = { applies (LDS), images per workgroup, producer wavefronts, lanes per producer,
- * consumer wavefronts beside them, bytes of LDS the producers take }. */
+ * restart segments on a chip of `cus` CUs — out = { applies (LDS), images per workgroup and pass, producer wavefronts, lanes per
+ * producer, consumer wavefronts beside them, bytes of LDS the producers take, passes per workgroup, workgroups }. */
 int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
-                         int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[6]);
+                         int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[8]);
 
 /* Test hook: every byte of the plan's coefficient store := byte_value (synchronous).  The parity tests poison the store in
  * front of a fused execute: a reconstruction wavefront that read a block before its decoder wavefront had written it would

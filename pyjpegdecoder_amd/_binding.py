@@ -181,13 +181,15 @@ def count_tables(huff_specs, roles, wbits=12):
 
 def fused_shape_rule(n_images, segments_per_image, hmax=2, vmax=2, transposed=False, cus=256, n_ac=2, n_dc=2, ac_slot_bytes=17024,
                      want_consumers=8):
-    """mj_debug_fused_shape (host only): dict(ok, images_per_wg, producers, lanes, consumers, producer_lds) of a fused launch."""
-    out = (ctypes.c_int32 * 6)()
+    """mj_debug_fused_shape (host only): dict(ok, images_per_wg [and pass], producers, lanes, consumers, producer_lds, passes,
+    workgroups) of a fused launch."""
+    out = (ctypes.c_int32 * 8)()
     L = load_library()
     L.mj_debug_fused_shape.argtypes = [ctypes.c_int32] * 10 + [ctypes.POINTER(ctypes.c_int32)]
     if L.mj_debug_fused_shape(cus, n_ac, n_dc, ac_slot_bytes, hmax, vmax, int(transposed), n_images, segments_per_image, want_consumers, out) != MJ_OK:
         raise ValueError("mj_debug_fused_shape: bad arguments")
-    return dict(zip(("ok", "images_per_wg", "producers", "lanes", "consumers", "producer_lds"), (bool(out[0]),) + tuple(int(x) for x in out[1:])))
+    return dict(zip(("ok", "images_per_wg", "producers", "lanes", "consumers", "producer_lds", "passes", "workgroups"),
+                    (bool(out[0]),) + tuple(int(x) for x in out[1:])))
 
 
 class UnknownOption(ValueError):

@@ -378,8 +378,15 @@ class BatchDecoder:
         self.gpu_segment_min_files = gpu_segment_min_files
         self._staging: Optional[np.ndarray] = None
 
+    def _gpu_segment_for(self, files: Sequence[bytes]) -> bool:
+        """segment="gpu" applies from `gpu_segment_min_files` files per call on, or from 4 MiB of files on (see __init__)."""
+        return self.gpu_segment and (len(files) >= self.gpu_segment_min_files or sum(map(len, files)) > (4 << 20))
+
     def plan(self, files: Sequence[bytes], flags: int = 0, blob_device_ptr: int = 0):
-        parsed = [parse_jpeg(f, headers_only=True) for f in files] if self.gpu_segment else None
+        """(prepared batch, plan) for files of ONE kind.  Like decode(), a handful of files is segmented on the host (the plan
+        then knows the segment lengths and can take the chunked stage-1 form); from `gpu_segment_min_files` files on the GPU
+        finds the markers, and a caller that executes such a plan itself handles MJ_ST_TAIL (a file the scan handed back)."""
+        parsed = [parse_jpeg(f, headers_only=True) for f in files] if self._gpu_segment_for(files) else None
         if parsed is not None and not all(p.headers_only for p in parsed):
             parsed = None                       # progressive / multi-scan files: host segmentation for the whole batch
         prep = prepare_batch(files, self.layout, flags | self.base_flags, parsed)
@@ -403,7 +410,7 @@ class BatchDecoder:
 
     def decode(self, files: Sequence[bytes], return_seams: bool = False):
         """Decode files that may mix sampling layouts (one plan per layout)."""
-        gpu_segment = self.gpu_segment and (len(files) >= self.gpu_segment_min_files or sum(map(len, files)) > (4 << 20))
+        gpu_segment = self._gpu_segment_for(files)
         parsed = [parse_jpeg(f, headers_only=gpu_segment) for f in files]
         groups: Dict[tuple, List[int]] = {}
         for i, p in enumerate(parsed):
@@ -473,7 +480,7 @@ class BatchDecoder:
         parsed: Dict[int, ParsedJpeg] = {}
         work: List[Tuple[List[int], Optional[PreparedBatch]]] = []
         rest: List[int] = []
-        gpu_segment = self.gpu_segment and (len(files) >= self.gpu_segment_min_files or sum(map(len, files)) > (4 << 20))
+        gpu_segment = self._gpu_segment_for(files)
         if gpu_segment and self.native_host:
             prep = prepare_batch_native(files, self.layout, self.base_flags, staging=self._staging_for(files))
             if isinstance(prep, PreparedBatch):                   # the everyday case: one pass, one plan

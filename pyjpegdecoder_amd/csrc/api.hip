@@ -353,7 +353,7 @@ static int fused_impl(mj_plan *p, void *stream, uint8_t *rgb_device) {
 #endif
     MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
                                  p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->lutf_off, p->lutf_bits, p->d_coef, p->d_status, a, p->hmax, p->vmax,
-                                 p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
+                                 p->transposed, p->fused_spi, p->h_images[0].restart_interval, p->h_images[0].mcu_count_h, p->h_images[0].mcu_count_v, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
                                  p->d_by_length, p->d_holder, p->d_xwords));
 #ifdef MJ_DIAGNOSTIC
     if (dbg_fused) {
@@ -572,7 +572,7 @@ int mj_plan_time_execute(mj_plan *p, int iters, uint8_t *rgb_device, float *fron
     auto fused = [&]() -> int {
         MJ_HIP(ctx, mj::launch_fused(s, p->fused, p->d_stream, p->d_seg_bits, p->d_segs, p->n_segs, p->d_images, p->d_huff, p->d_lut11, p->d_lut12,
                                      p->n_ac13, p->n_dc13, p->ac_slot_pk, p->dc_slot_pk, p->dc_tab_pk, p->lutf_off, p->lutf_bits, p->d_coef, p->d_status, a, p->hmax, p->vmax,
-                                     p->transposed, p->fused_spi, p->h_images[0].mcu_count_h, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
+                                     p->transposed, p->fused_spi, p->h_images[0].restart_interval, p->h_images[0].mcu_count_h, p->h_images[0].mcu_count_v, p->d_job_prefix, p->total_jobs, p->jobs_per_image,
                                  p->d_by_length, p->d_holder, p->d_xwords));
         return MJ_OK;
     };

@@ -103,27 +103,39 @@ inline bool spread_lengths(const int32_t *seg_len, int64_t n_segs) {
 }
 
 // One launch for both stages (fused.hip) — the conditions apart from the LDS budget (fused_shape): the resolved-table lane
-// form in blob order on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files whose restart interval is ONE MCU ROW (a
-// producer wave that is through MCU m has then finished column m of all its rows, which is the consumers' unit of work),
-// interleaved pixels (x-major: a stage-2 job = a whole MCU column; row-major: pieces of an MCU row), no seam outputs.
+// form on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files that all have the SAME restart interval, interleaved
+// pixels, no seam outputs.  A consumer's job is ready when the producer waves that hold its MCUs are past them (fused.hip works
+// that out per MCU, so any interval is correct); what the rule keeps out is where that would be late:
+//   x-major (a job = a whole MCU column of an image): the interval must divide the MCU row — one row (the benchmark's files),
+//     half a row, a third ... —: then column m is the (m mod interval)-th MCU of every segment that holds a piece of it.  With
+//     several rows per segment a column would only be complete when every segment is in its LAST row: no overlap left;
+//   row-major (a job = a piece of one MCU row): any interval — a piece waits for its own segment(s) only.
 struct FusedInputs {
     bool lanes_resolved = false;           // lane form (not sync) with the resolved tables, 12-bit copies built
     int seg_order_mode = 0;
     bool uniform = false, generic = false, progressive = false, transposed = false;
+    bool same_interval = true;             // every image of the batch has image 0's restart interval
     int ncomp = 3, hmax = 1, vmax = 1, layout = 0;
     uint32_t flags = 0, seam_or_exact_flags = 0;
     int restart_interval = 0, mcu_count_h = 0, mcu_count_v = 0, jobs_per_image = 0;
     int64_t n_segs = 0, n_images = 0;
 };
+// restart segments per image (0: no restart interval)
+inline int64_t fused_segments_per_image(const FusedInputs &f) {
+    return f.restart_interval > 0 ? ((int64_t)f.mcu_count_h * f.mcu_count_v + f.restart_interval - 1) / f.restart_interval : 0;
+}
 // 0 = the two launches; 1 = fused, whole images per workgroup (segments in blob order); 2 = fused with the segments dealt out
 // by length (seg_order_mode 2: files of mixed content) — one pool of jobs, hand-off across workgroups.
 inline int fused_applies(const FusedInputs &f) {
-    // x-major: a stage-2 job is a whole MCU column (ready when every row of the image is past it); row-major (the strip worker
-    // runs on the transposed image): pieces of an MCU row, fused.hip cuts them itself
+    // x-major: a stage-2 job is a whole MCU column; row-major (the strip worker runs on the transposed image): pieces of an MCU
+    // row, fused.hip cuts them itself
     const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.jobs_per_image == f.mcu_count_h);
+    const int64_t spi = fused_segments_per_image(f);
+    const bool interval_ok = f.same_interval && spi >= 1 && spi <= 512 && f.n_segs == f.n_images * spi &&
+                             (f.transposed || f.mcu_count_h % f.restart_interval == 0);
     const bool ok = f.lanes_resolved && (f.seg_order_mode == 0 || f.seg_order_mode == 2) && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
                     (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && layout_ok &&
-                    !(f.flags & f.seam_or_exact_flags) && f.restart_interval == f.mcu_count_h && f.n_segs == f.n_images * f.mcu_count_v;
+                    !(f.flags & f.seam_or_exact_flags) && interval_ok;
     return !ok ? 0 : (f.seg_order_mode == 2 ? 2 : 1);
 }
 

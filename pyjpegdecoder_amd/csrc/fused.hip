@@ -54,14 +54,16 @@ struct FusedArgs {
     ReconArgs R;                           // the stage-2 launch
     const int64_t *job_prefix;
     int64_t total_jobs;
-    int32_t jobs_per_image;                // = MCU columns: a job is a whole column
+    int32_t jobs_per_image;                // x-major: MCU columns (a job is a whole column); row-major: MCU rows x pieces
     int32_t n_prod, n_cons;                // producer wavefronts; consumer wavefronts beside them
-    int32_t ipw;                           // images per workgroup
-    int32_t spi;                           // restart segments (= MCU rows) per image
+    int32_t ipw, n_pass, n_virt;           // images per workgroup and pass; passes per workgroup; virtual workgroups in all
+    int32_t spi;                           // restart segments per image
+    int32_t ri;                            // MCUs per restart segment (the last one of an image may be shorter)
     int32_t n_images;
     // row-major plans (the strip worker runs on the transposed image: its "columns" are the MCU ROWS): a job is a PIECE of one
-    // MCU row — `pieces` per row, each `piece_mcus` MCUs long (the last one shorter) —, ready when its row's wave is past it
-    int32_t pieces, piece_mcus, mcus_per_row;
+    // MCU row — `pieces` per row, each `piece_mcus` MCUs long (the last one shorter) —, ready when the waves that hold its
+    // segments are past it
+    int32_t pieces, piece_mcus, mcus_per_row, mcu_rows;
     // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
     // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
     uint32_t *x_counter;                   // [0] tickets, [1] jobs given up, [2] the clean-up launch's tickets
@@ -80,19 +82,33 @@ typedef uint32_t __attribute__((address_space(3))) *lds_word;
 constexpr unsigned long long kFusedGuardTicks = 200000000ull;      // 2 s
 __device__ __forceinline__ bool guard_expired(unsigned long long t0) { return __builtin_amdgcn_s_memrealtime() - t0 > kFusedGuardTicks; }
 
-// Jobs of this workgroup's images from a ticket counter in LDS, column by column (ticket t = column t / images, image
-// t % images), each gated by the progress of the producer waves that hold the image's rows.  BY_ROWS (row-major plans): piece
-// by piece instead (ticket t = piece t / rows, row t % rows of the workgroup's rows), gated by the one wave that holds the row.
+// Which MCUs a job needs, in terms of restart segments.  An image's MCUs are numbered in raster order, g = row * mpr + column;
+// restart segment s = g / ri holds MCU g as its (g - s * ri)-th, and the wave that walks s reports how many MCUs of it are
+// complete (lock-step: of every segment it holds).  Any restart interval will do — one MCU row per segment (the benchmark's
+// files) is the case where "column m of every row" is "MCU m of every segment".
+struct JobGeo {
+    uint32_t ri, mpr, mcv, spi;
+    uint32_t pieces, piece_mcus;            // row-major plans
+};
+
+// Jobs of this workgroup's images from a ticket counter in LDS.  The workgroup walks its images in passes of `ipp` images (one
+// pass where its producers' lanes hold them all); tickets go pass by pass and, within a pass, column by column (ticket t = column
+// t / images, image t % images), each gated by the progress of the producer waves that hold the MCUs the job needs.  BY_ROWS
+// (row-major plans): piece by piece instead (ticket t = piece t / rows, row t % rows of the pass's MCU rows).
 template <bool BY_ROWS>
 struct FusedSource {
     static constexpr bool kSingleJobs = true;      // a ticket = one job, and consecutive tickets are not consecutive jobs
     uint32_t ctrl;                         // LDS address of the control words
     uint32_t n_tickets;
-    uint32_t images_here, image0;
-    uint32_t jobs_per_image, lpw, spi;
-    uint32_t pieces, piece_mcus, mcus_per_row;      // BY_ROWS
+    uint32_t v0, n_pass, ipp, n_images;    // this workgroup's first virtual workgroup (= its pass 0), its passes, images per pass
+    uint32_t jobs_per_image, lpw;
+    JobGeo g;
     int32_t *status;
     int lane;
+    __device__ __forceinline__ uint32_t images_in(uint32_t pass) const {
+        const uint32_t lo = (v0 + pass) * ipp;
+        return lo >= n_images ? 0u : min(ipp, n_images - lo);
+    }
     __device__ __forceinline__ uint32_t draw() const {
         uint32_t t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add((lds_word)(uintptr_t)ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -100,30 +116,59 @@ struct FusedSource {
     }
     __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
     __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
+        uint32_t pass = 0, ih = images_in(0);
+        for (; pass + 1 < n_pass; ++pass) {             // (tickets of the passes in front of this one's)
+            const uint32_t tp = ih * jobs_per_image;
+            if (ticket < tp) break;
+            ticket -= tp;
+            ih = images_in(pass + 1);
+        }
+        const uint32_t img0 = (v0 + pass) * ipp;
         if constexpr (BY_ROWS) {
-            const uint32_t rows = images_here * spi, pc = ticket / rows, rr = ticket - pc * rows, j = rr / spi, row = rr - j * spi;
-            return (image0 + j) * jobs_per_image + row * pieces + pc;      // (job numbering of the strip worker: row by row, piece by piece)
+            const uint32_t rows = ih * g.mcv, pc = ticket / rows, rr = ticket - pc * rows, j = rr / g.mcv, row = rr - j * g.mcv;
+            return (img0 + j) * jobs_per_image + row * g.pieces + pc;      // (job numbering of the strip worker: row by row, piece by piece)
         } else {
-            const uint32_t m = ticket / images_here, j = ticket - m * images_here;
-            return (image0 + j) * jobs_per_image + m;
+            const uint32_t m = ticket / ih, j = ticket - m * ih;
+            return (img0 + j) * jobs_per_image + m;
         }
     }
     __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
-    // complete MCUs of every row of the job's image > the job's column?
+    // the progress word of the wave that holds segment s of the pass's image j
+    __device__ __forceinline__ uint32_t word(uint32_t j, uint32_t s) const {
+        return *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * ((j * g.spi + s) / lpw));
+    }
+    // every MCU the job needs complete?
     __device__ __forceinline__ bool ready(uint32_t job) const {
-        const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image, j = img - image0;
-        if constexpr (BY_ROWS) {           // MCUs complete in the row's wave >= where the piece ends
-            const uint32_t row = m / pieces, pc = m - row * pieces, w = (j * spi + row) / lpw;
-            const uint32_t done = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)done) >= min((pc + 1u) * piece_mcus, mcus_per_row);
+        const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image, v = img / ipp, j = img - v * ipp;
+        const uint32_t base = (v - v0) << kFusedPassShift;
+        if constexpr (BY_ROWS) {           // MCUs [a, b) of one MCU row: the segment(s) that hold them
+            const uint32_t row = m / g.pieces, pc = m - row * g.pieces, a = pc * g.piece_mcus, b = min(a + g.piece_mcus, g.mpr);
+            const uint32_t g0 = row * g.mpr + a, g1 = row * g.mpr + b - 1u;
+            bool ok = true;
+            for (uint32_t s = g0 / g.ri; s <= g1 / g.ri; ++s) {
+                const uint32_t need = min(g1, (s + 1u) * g.ri - 1u) - s * g.ri;
+                ok = ok && (uint32_t)__builtin_amdgcn_readfirstlane((int)word(j, s)) > base + need;
+            }
+            return ok;
         }
-        const uint32_t w0 = (j * spi) / lpw, w1 = (j * spi + spi - 1u) / lpw;
-        uint32_t least = 0x7FFFFFFFu;
-        for (uint32_t w = w0; w <= w1; ++w) {
-            const uint32_t p = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
-            least = min(least, p);
+        if (g.ri == g.mpr) {               // one MCU row per segment: column m of every row = MCU m of every segment of the image
+            const uint32_t w0 = (j * g.spi) / lpw, w1 = (j * g.spi + g.spi - 1u) / lpw;
+            uint32_t least = 0x7FFFFFFFu;
+            for (uint32_t w = w0; w <= w1; ++w) {
+                const uint32_t p = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
+                least = min(least, p);
+            }
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > base + m;
         }
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > m;
+        bool behind = false;               // column m of every MCU row, one row per lane and turn
+        for (uint32_t r0 = 0; r0 < g.mcv; r0 += 64u) {
+            const uint32_t row = r0 + (uint32_t)lane;
+            if (row < g.mcv) {
+                const uint32_t gi = row * g.mpr + m, s = gi / g.ri;
+                behind = behind || word(j, s) <= base + (gi - s * g.ri);
+            }
+        }
+        return __builtin_amdgcn_ballot_w64(behind) == 0;
     }
     // (bounded by kFusedGuardTicks: on expiry the image is marked MJ_ST_INTERNAL — its blocks were not there — and the wave goes on)
     __device__ __forceinline__ bool wait_ready(uint32_t job) const {
@@ -143,7 +188,7 @@ struct FusedSource {
 // The same when the restart segments are dealt out by length (files of mixed content: the lane launch's striped order): a
 // workgroup's producers then walk segments of images all over the batch, so the jobs are ONE pool for the whole launch — a
 // global ticket counter, column by column over all images (BY_ROWS: piece by piece over all rows) — and a job is ready when
-// the progress words (global memory) of the waves that hold its image's rows say so.  The hand-off across CUs and XCDs is
+// the progress words (global memory) of the waves that hold its MCUs say so.  The hand-off across CUs and XCDs is
 // MI355X_MICROARCH.md's: write-through (sc1) coefficient stores, drained (s_waitcnt vmcnt(0)) before the wave's sc1 progress
 // store; the consumer polls with sc1 loads, then ONE agent-scope acquire (invalidates its CU's vector L1), then plain loads.
 // Every workgroup of the launch is resident at once (one per CU, grid = CUs): a producer never waits, so nobody waits for a
@@ -154,8 +199,8 @@ struct FusedSourceX {
     uint32_t *counter;
     const uint32_t *progress;
     const int32_t *holder;
-    uint32_t n_tickets, n_images, jobs_per_image, spi;
-    uint32_t pieces, piece_mcus, mcus_per_row;
+    uint32_t n_tickets, n_images, jobs_per_image;
+    JobGeo g;
     uint32_t *left_count, *left_list;      // jobs given up: the clean-up launch's work
     uint32_t patience;                     // polls before a job is given up
     int32_t *status;
@@ -168,27 +213,30 @@ struct FusedSourceX {
     __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
     __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
         if constexpr (BY_ROWS) {
-            const uint32_t rows = n_images * spi, pc = ticket / rows, rr = ticket - pc * rows, img = rr / spi, row = rr - img * spi;
-            return img * jobs_per_image + row * pieces + pc;
+            const uint32_t rows = n_images * g.mcv, pc = ticket / rows, rr = ticket - pc * rows, img = rr / g.mcv, row = rr - img * g.mcv;
+            return img * jobs_per_image + row * g.pieces + pc;
         } else {
             const uint32_t m = ticket / n_images, img = ticket - m * n_images;
             return img * jobs_per_image + m;
         }
     }
     __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
+    __device__ __forceinline__ uint32_t word(uint32_t img, uint32_t s) const {
+        return __hip_atomic_load(progress + holder[img * g.spi + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __device__ __forceinline__ bool ready(uint32_t job) const {
         const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image;
-        bool behind = false;               // some row of the image (BY_ROWS: the job's row) is not past what the job needs
+        bool behind = false;               // some MCU the job needs is not complete
         if constexpr (BY_ROWS) {
-            const uint32_t row = m / pieces, pc = m - row * pieces;
-            const uint32_t p = __hip_atomic_load(progress + holder[img * spi + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            behind = p < min((pc + 1u) * piece_mcus, mcus_per_row);
+            const uint32_t row = m / g.pieces, pc = m - row * g.pieces, a = pc * g.piece_mcus, b = min(a + g.piece_mcus, g.mpr);
+            const uint32_t g0 = row * g.mpr + a, g1 = row * g.mpr + b - 1u;
+            for (uint32_t s = g0 / g.ri; s <= g1 / g.ri; ++s) behind = behind || word(img, s) <= min(g1, (s + 1u) * g.ri - 1u) - s * g.ri;
         } else {
-            for (uint32_t r0 = 0; r0 < spi; r0 += 64u) {
+            for (uint32_t r0 = 0; r0 < g.mcv; r0 += 64u) {
                 const uint32_t row = r0 + (uint32_t)lane;
-                if (row < spi) {
-                    const uint32_t p = __hip_atomic_load(progress + holder[img * spi + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    behind = behind || p <= m;
+                if (row < g.mcv) {
+                    const uint32_t gi = row * g.mpr + m, s = gi / g.ri;
+                    behind = behind || word(img, s) <= gi - s * g.ri;
                 }
             }
         }
@@ -235,23 +283,22 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
 
     typename std::conditional<XWG, FusedSourceX<T>, FusedSource<T>>::type src;
     const uint32_t ctrl_lds = lanes13::lds_addr(ctrl);
-    uint32_t image0 = 0;
+    const uint32_t v0 = (uint32_t)blockIdx.x * (uint32_t)F.n_pass;        // this workgroup's first virtual workgroup
+    src.n_images = (uint32_t)F.n_images;
+    src.jobs_per_image = (uint32_t)F.jobs_per_image;
+    src.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus};
     if constexpr (XWG) {
         src.counter = F.x_counter; src.progress = F.x_progress; src.holder = F.x_holder;
         src.left_count = F.x_counter + 1; src.left_list = F.x_left; src.patience = (uint32_t)F.x_patience;
-        src.n_images = (uint32_t)F.n_images;
-        src.jobs_per_image = (uint32_t)F.jobs_per_image;
         src.n_tickets = src.n_images * src.jobs_per_image;
     } else {
         src.ctrl = ctrl_lds;
-        src.image0 = image0 = (uint32_t)blockIdx.x * (uint32_t)F.ipw;
-        src.images_here = min((uint32_t)F.ipw, (uint32_t)F.n_images - src.image0);
-        src.jobs_per_image = (uint32_t)F.jobs_per_image;
-        src.n_tickets = src.images_here * src.jobs_per_image;
+        src.v0 = v0; src.n_pass = (uint32_t)F.n_pass; src.ipp = (uint32_t)F.ipw;
         src.lpw = (uint32_t)F.L.lpw;
+        uint32_t mine = 0;
+        for (uint32_t p = 0; p < src.n_pass; ++p) mine += src.images_in(p);
+        src.n_tickets = mine * src.jobs_per_image;
     }
-    src.pieces = (uint32_t)F.pieces; src.piece_mcus = (uint32_t)F.piece_mcus; src.mcus_per_row = (uint32_t)F.mcus_per_row;
-    src.spi = (uint32_t)F.spi;
     src.lane = lane;
     src.status = F.L.status;
 
@@ -265,7 +312,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = __builtin_amdgcn_s_memrealtime(); }
     unsigned char *my_lds;
     if (wave < n_prod) {
-        lanes13::walk<XWG ? 2 : 1>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
+        if constexpr (XWG) {
+            lanes13::walk<2>(F.L, smem, lane, wave, n_prod, (int)blockIdx.x, (int)gridDim.x, lanes13::lds_addr(ctrl + 2 + wave));
+        } else {
+            // pass by pass: the images of virtual workgroup v0 + p.  No barrier between passes — a wave's rows, windows and
+            // progress word are its own, the tables are read-only —, and the word keeps rising: pass << 20 | MCUs complete
+            for (int p = 0; p < F.n_pass && (int)v0 + p < F.n_virt; ++p)
+                lanes13::walk<1>(F.L, smem, lane, wave, n_prod, (int)v0 + p, F.n_virt, lanes13::lds_addr(ctrl + 2 + wave), (uint32_t)p << kFusedPassShift);
+        }
         __builtin_amdgcn_s_setprio(0);
 #ifdef MJ_DIAGNOSTIC
         if (lane == 0) {
@@ -369,8 +423,8 @@ __global__ __launch_bounds__(256, 3) void k_recon_leftover(FusedArgs F) {
         __syncthreads();
     }
     LeftoverSource<T> src;
-    src.map.n_images = (uint32_t)F.n_images; src.map.jobs_per_image = (uint32_t)F.jobs_per_image; src.map.spi = (uint32_t)F.spi;
-    src.map.pieces = (uint32_t)F.pieces; src.map.piece_mcus = (uint32_t)F.piece_mcus; src.map.mcus_per_row = (uint32_t)F.mcus_per_row;
+    src.map.n_images = (uint32_t)F.n_images; src.map.jobs_per_image = (uint32_t)F.jobs_per_image;
+    src.map.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus};
     src.counter = F.x_counter + 2; src.list = F.x_left; src.n_left = n_left; src.first_undrawn = drawn;
     src.n_tickets = n_left + (all - drawn);
     src.lane = lane;
@@ -398,19 +452,27 @@ static bool fused_budget(FusedShape &s, int n_dc, int hmax, int vmax, int want_c
 }
 
 // How a fused launch would be shaped for `n_images` images of `spi` restart segments each; ok = false: take the two launches.
+// A workgroup's producers have 8 x 64 lanes.  Where every workgroup's share of the batch fits them, whole images per workgroup
+// and every workgroup resident at once (the benchmark: four 1080p images of 68 rows each); where it does not — 1080p 4:2:2 has
+// 135 MCU rows, a restart interval of half a row twice the segments —, a workgroup takes its images in PASSES of as many
+// as fit, one after the other (its consumers go on from one pass's jobs to the next's without a break).
 FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
     FusedShape s{};
     if (transposed) std::swap(hmax, vmax);                     // the strip worker's geometry: that of the transposed image
-    if (n_images < 1 || spi < 1) return s;
-    s.ipw = (n_images + cus - 1) / cus;                        // whole images per workgroup, every workgroup resident at once
+    if (n_images < 1 || spi < 1 || spi > 8 * 64 || cus < 1) return s;
+    const int cap = (8 * 64) / spi;                            // images one pass can hold
+    const int64_t v_min = ((int64_t)n_images + cap - 1) / cap;
+    s.n_pass = (int)((v_min + cus - 1) / cus);
+    if (s.n_pass > 64) return s;
+    s.ipw = (int)(((int64_t)n_images + (int64_t)s.n_pass * cus - 1) / ((int64_t)s.n_pass * cus));     // (<= cap)
+    s.n_virt = (n_images + s.ipw - 1) / s.ipw;
+    s.n_wg = (s.n_virt + s.n_pass - 1) / s.n_pass;
     const int lanes = s.ipw * spi;
-    if (lanes > 8 * 64) return s;
     s.n_prod = std::min(8, std::max(1, (lanes + 33) / 34));
     s.lpw = (lanes + s.n_prod - 1) / s.n_prod;
     s.ring = 64;
     s.ac_total_bytes = ac_total_bytes;
     s.dbits = 8;                                                // (Annex K's DC codes of 9..11 bits — differences beyond +-255 in chroma, +-1023 in luma — take the canonical search)
-    s.n_wg = (n_images + s.ipw - 1) / s.ipw;
     s.ok = fused_budget(s, n_dc, hmax, vmax, want_consumers);
     return s;
 }
@@ -430,7 +492,7 @@ FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vm
     s.dbits = 8;
     s.xwg = true;
     s.n_wg = cus;
-    s.ipw = 0;
+    s.ipw = 0; s.n_pass = 1; s.n_virt = cus;
     s.ok = fused_budget(s, n_dc, hmax, vmax, want_consumers);
     return s;
 }
@@ -438,11 +500,12 @@ FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vm
 }  // namespace mj
 
 extern "C" int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
-                                    int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[6]) {
+                                    int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[8]) {
     if (!out) return MJ_ERR_INVALID;
     const mj::FusedShape s = mj::fused_shape(cus, n_ac * ac_slot_bytes, n_dc, hmax, vmax, transposed != 0, n_images, segments_per_image, want_consumers);
     out[0] = s.ok ? 1 : 0; out[1] = s.ipw; out[2] = s.n_prod; out[3] = s.lpw; out[4] = s.n_cons;
     out[5] = s.ok ? (int32_t)mj::lanes13::lds_bytes(s.ac_total_bytes, n_dc, s.n_prod, s.lpw, s.ring, s.dbits) : 0;
+    out[6] = s.n_pass; out[7] = s.n_wg;
     return MJ_OK;
 }
 
@@ -452,8 +515,10 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                         int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, const int ac_off[4], const int ac_bits[4],
                         int16_t *coef, int32_t *status,
-                        const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
-                        int64_t total_jobs, int jobs_per_image, const int32_t *by_length, const int32_t *holder, uint32_t *x_words) {
+                        const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int restart_interval, int mcus_per_row, int mcu_rows,
+                        const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image, const int32_t *by_length, const int32_t *holder,
+                        uint32_t *x_words) {
+    if (restart_interval < 1 || spi < 1) return hipErrorInvalidValue;
     if (!shape.ok || a.n_images < 1) return hipErrorInvalidValue;
     if (shape.xwg && (!by_length || !holder || !x_words)) return hipErrorInvalidValue;
     FusedArgs F{};
@@ -462,8 +527,9 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
                         {ac_off[0], ac_off[1], ac_off[2], ac_off[3]}, {ac_bits[0], ac_bits[1], ac_bits[2], ac_bits[3]}, shape.ipw * spi, nullptr};
     F.R = a;
     F.job_prefix = job_prefix; F.total_jobs = total_jobs; F.jobs_per_image = jobs_per_image;
-    F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.spi = spi; F.n_images = a.n_images;
-    F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row;
+    F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.n_pass = shape.n_pass; F.n_virt = shape.n_virt;
+    F.spi = spi; F.ri = restart_interval; F.n_images = a.n_images;
+    F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row; F.mcu_rows = mcu_rows;
     if (transposed) {
         // the strip worker's jobs on the transposed image are pieces of an MCU ROW of the original (its own numbering: row by
         // row, piece by piece, `chunk_strips` strips each): about 20 MCUs per piece, so that the consumers work a piece behind
@@ -474,7 +540,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         F.R.chunk_strips = strips;
         F.pieces = (spc + strips - 1) / strips;
         F.piece_mcus = strips * tmw;
-        F.jobs_per_image = spi * F.pieces;
+        F.jobs_per_image = mcu_rows * F.pieces;
         F.total_jobs = (int64_t)a.n_images * F.jobs_per_image;
     }
     unsigned blocks = 0;
@@ -489,7 +555,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         F.L.by_length = by_length; F.L.order_mode = 2; F.L.progress_global = F.x_progress;
         blocks = (unsigned)shape.n_wg;
     } else {
-        blocks = (unsigned)((a.n_images + shape.ipw - 1) / shape.ipw);
+        blocks = (unsigned)shape.n_wg;
     }
     auto go = [&](auto kernel) {
         static OncePerDevice attr_once;

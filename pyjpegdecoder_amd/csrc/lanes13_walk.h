@@ -124,14 +124,17 @@ __device__ __forceinline__ void stage(const Args &A, unsigned char *smem, int ti
 
 // One wavefront's walk: wave `wave` of the `nw` of workgroup `wg` (of `n_wg`).  MODE 0: the stage-1 kernel.  MODE 1 (fused.hip,
 // whole images per workgroup): the wave reports, in the LDS word at `progress_addr`, how many MCUs of its lanes' segments are
-// complete in memory (see the hook behind the AC loop).  MODE 2 (fused.hip, segments dealt out by length — any workgroup's
+// complete in memory (see the hook behind the AC loop) — as progress_base + that number, and progress_base + 2^20 when it is
+// through: a workgroup whose images are more segments than its producers have lanes walks them in passes (`wg` is then the
+// pass's "virtual workgroup"), and progress_base = pass << 20 keeps the word rising from pass to pass.
+// MODE 2 (fused.hip, segments dealt out by length — any workgroup's
 // consumers may need this wave's blocks): the coefficient stores are write-through (sc1) and the report goes to
 // A.progress_global with an sc1 store — MI355X_MICROARCH.md's "sc1 stores, drained, then an sc1 flag" hand-off.
 // Index bits of an AC table's main level: 13 — or, in a fused launch, what A.ac_bits says for its LDS slot (12: half the LDS,
 // 1.5 % of the benchmark's symbols instead of 0.4 % then take the arithmetic step); its second-level tables have 2^(16 - bits) entries
 template <int MODE>
 __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const int lane, const int wave, const int nw, const int wg, const int n_wg,
-                                     const uint32_t progress_addr) {
+                                     const uint32_t progress_addr, const uint32_t progress_base = 0u) {
     const uint32_t *__restrict__ stream = A.stream;
     const int32_t *__restrict__ seg_bits = A.seg_bits;
     const DevSegment *__restrict__ segs = A.segs;
@@ -609,7 +612,7 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
                 if (b == 0) {
                     uint32_t t_prog;
                     if constexpr (MODE == 1)
-                        asm volatile("v_mov_b32 %0, %1\n\tds_write_b32 %2, %0" : "=&v"(t_prog) : "s"((uint32_t)m), "v"(progress_addr) : "memory");
+                        asm volatile("v_mov_b32 %0, %1\n\tds_write_b32 %2, %0" : "=&v"(t_prog) : "s"(progress_base + (uint32_t)m), "v"(progress_addr) : "memory");
                     else        // (write-through stores that have been waited for are in memory: the flag may follow)
                         asm volatile("v_mov_b32 %0, %1\n\tglobal_store_dword %2, %0, off sc1" : "=&v"(t_prog) : "s"((uint32_t)m), "v"(A.progress_global + (wg * nw + wave)) : "memory");
                 }
@@ -745,7 +748,8 @@ __device__ __forceinline__ void walk(const Args &A, unsigned char *smem, const i
     if constexpr (FUSED) {      // the last MCU's blocks: in memory before the wave says "everything"
         uint32_t t_prog;
         if constexpr (MODE == 1)
-            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tds_write_b32 %1, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog) : "v"(progress_addr) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tds_write_b32 %1, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_prog)
+                         : "v"(progress_addr), "s"(progress_base + (1u << kFusedPassShift)) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0x7fffffff\n\tglobal_store_dword %1, %0, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t_prog)
                          : "v"(A.progress_global + (wg * nw + wave)) : "memory");

@@ -296,11 +296,15 @@ int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);
 // Stages 1 + 2 in one launch (fused.hip): producer wavefronts (the lane walk) and consumer wavefronts (stage 2's strip worker)
-// in one workgroup per CU that takes whole images.  fused_shape() says how such a launch would be cut — ok = false: it does not
-// apply (LDS) and the two launches stay.
+// in one workgroup per CU that takes whole images — `ipw` of them at a time, in `n_pass` passes when a workgroup's images hold
+// more restart segments than its producers have lanes (8 x 64).  fused_shape() says how such a launch would be cut — ok =
+// false: it does not apply (LDS) and the two launches stay.
+constexpr int kFusedPassShift = 20;     // a producer's progress word: pass << 20 | MCUs of its segments complete in that pass
 struct FusedShape {
     bool ok;
-    int ipw;            // images per workgroup
+    int ipw;            // images per workgroup and pass
+    int n_pass;         // passes of a workgroup: its "virtual workgroups" n_pass * wg + pass, one after the other
+    int n_virt;         // virtual workgroups in all = ceil(images / ipw)
     int n_prod, lpw;    // producer wavefronts, lanes (restart segments) per producer wavefront
     int n_cons;         // consumer wavefronts beside the producers (every wavefront is one once the producers are through)
     int ring;           // bytes of stream window per lane
@@ -311,13 +315,14 @@ struct FusedShape {
 };
 FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers);
 FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers);
+// spi: restart segments per image; restart_interval: MCUs per segment (any: a job's readiness is worked out per MCU)
 hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,
                         int n_ac, int n_dc, uint64_t ac_slot_pk, uint64_t dc_slot_pk, uint64_t dc_tab_pk, const int ac_off[4], const int ac_bits[4],
                         int16_t *coef, int32_t *status,
-                        const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int mcus_per_row, const int64_t *job_prefix,
-                        int64_t total_jobs, int jobs_per_image, const int32_t *by_length = nullptr, const int32_t *holder = nullptr,
-                        uint32_t *x_words = nullptr);
+                        const ReconArgs &a, int hmax, int vmax, bool transposed, int spi, int restart_interval, int mcus_per_row, int mcu_rows,
+                        const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image, const int32_t *by_length = nullptr,
+                        const int32_t *holder = nullptr, uint32_t *x_words = nullptr);
 // (lut13 of launch_fused: the plan's fused tables, back to back — ac_off / ac_bits per LDS slot)
 // Launch-geometry caches are per device: one process may hold contexts on several GPUs (mijpeg.h: one context per GPU per
 // thread), and a function attribute set on one device says nothing about the next.  Contexts on two threads may make a

@@ -971,6 +971,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             fi.flags = p->flags; fi.seam_or_exact_flags = MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT;
             fi.restart_interval = i0.restart_interval; fi.mcu_count_h = i0.mcu_count_h; fi.mcu_count_v = i0.mcu_count_v;
             fi.jobs_per_image = p->jobs_per_image; fi.n_segs = (int64_t)segs.size(); fi.n_images = b->n_images;
+            for (const mj::DevImage &im : imgs) fi.same_interval = fi.same_interval && im.restart_interval == i0.restart_interval;
+            const int fused_spi = (int)mj::fused_segments_per_image(fi);
             // Restart segments of very different lengths (dealt out by length, seg_order_mode 2: files of mixed content) in
             // blob order — whole images per workgroup — would let the longest wave set the pace of everything (bench.py's mixed
             // content: 11.3 ms fused that way against 10.6 as two launches): they keep their order, and the fused launch's
@@ -993,8 +995,8 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if (allow && want_cons > 0 && mode == 1) {
                 if ((rc = fused_tables(luma13 == 1)) < 0) return rc;
                 if (rc == 0) {
-                    p->fused = mj::fused_shape(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, b->n_images, i0.mcu_count_v, want_cons);
-                    p->fused_spi = i0.mcu_count_v;
+                    p->fused = mj::fused_shape(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, b->n_images, fused_spi, want_cons);
+                    p->fused_spi = fused_spi;
                     p->use_fused = p->fused.ok;
                 }
             } else if (allow && want_cons_x > 0 && mode == 2 && p->d_by_length) {
@@ -1009,7 +1011,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                 // lasts as long as its longest wave's walk, and every consumer beside it slows that walk.  bench.py's mixed content,
                 // ms per step: 12-bit tables all round 2 consumers 10.2, 4: 8.9, 6: 9.1, 8: 10.5; component 0's table at 13 bits
                 // 4: 8.1-8.4, 5: 7.8-7.9, 6: 7.6-7.8; the two launches 10.4)
-                p->fused_spi = i0.mcu_count_v;
+                p->fused_spi = fused_spi;
                 if (p->fused.ok) {
                     // which progress word a segment's wave reports to: the walk deals rank r of the sorted list to wave r mod waves
                     const int64_t n_waves = (int64_t)p->fused.n_wg * p->fused.n_prod;

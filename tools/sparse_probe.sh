@@ -19,10 +19,10 @@ done > "$O/steps.txt" 2>&1
 for l in libmijpeg libmijpeg_xldst; do
   for set in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
     n=$(echo "$set" | cut -c1-14 | tr " " "_")
-    PMC_KERNEL=k_ bash tools/pmc_one.sh "sp_${l}_$n" "$set" --lib pyjpegdecoder_amd/$l.so --distinct 64
+    PMC_KERNEL=k_ bash tools/pmc_one.sh "sp_${l}_$n" "$set" --lib "$R/pyjpegdecoder_amd/$l.so" --distinct 64
   done
 done > "$O/pmc.txt" 2>&1
 cat "$O/steps.txt" "$O/pmc.txt"
 # where the fused launch's time goes now (diagnostic build: per-workgroup stamps)
-MJ_DEBUG_FUSED=1 timeout 300 python3 tools/fused_probe.py --lib pyjpegdecoder_amd/libmijpeg_diag.so --distinct 64 --reps 3 "" > "$O/diag_fused.txt" 2>&1
+MJ_NO_GRAPH=1 MJ_DEBUG_FUSED=1 timeout 300 python3 tools/fused_probe.py --lib pyjpegdecoder_amd/libmijpeg_diag.so --distinct 64 --reps 3 "" > "$O/diag_fused.txt" 2>&1
 tail -12 "$O/diag_fused.txt"
