@@ -253,6 +253,14 @@ int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_
 int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
                          int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[8]);
 
+/* Test hook, host only: which scans of a progressive batch would be walked as scout + parts (csrc/form_select.h:
+ * choose_prog_split, the rule mj_plan_create applies).  mode: MJ_PROG_SPLIT (1 = by the size of the batch); n_bands: band launches
+ * per scan (MCU rows / rows per band); wave_slots: CUs x 32, 0 = MI355X's; parts: MJ_PROG_PARTS or 0 (not set: the rule may
+ * choose); per scan its image, restart segments and entropy-coded bytes (< 0: not a refining AC scan of one component).
+ * split_out[k] = 1: scan k is split; *parts_out = parts per band. */
+int mj_debug_prog_split(int32_t mode, int32_t n_images, int32_t n_bands, int32_t wave_slots, int32_t parts, int32_t n_scans,
+                        const int32_t *image, const int32_t *n_segments, const int64_t *bytes, uint8_t *split_out, int32_t *parts_out);
+
 /* Test hook: every byte of the plan's coefficient store := byte_value (synchronous).  The parity tests poison the store in
  * front of a fused execute: a reconstruction wavefront that read a block before its decoder wavefront had written it would
  * show (a store that still holds the previous execute's blocks of the same files hides exactly that). */

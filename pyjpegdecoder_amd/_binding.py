@@ -28,7 +28,7 @@ EXPORTS = (
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
     "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape", "mj_debug_count_tables",
-    "mj_device_copy_rate", "mj_context_launch_clock",
+    "mj_device_copy_rate", "mj_context_launch_clock", "mj_debug_prog_split",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED, MJ_FORM_COUNT_RESOLVED = 0, 1, 2, 3, 16, 32, 64, 128
 MJ_HOST_DECLINED = 1
@@ -190,6 +190,22 @@ def fused_shape_rule(n_images, segments_per_image, hmax=2, vmax=2, transposed=Fa
         raise ValueError("mj_debug_fused_shape: bad arguments")
     return dict(zip(("ok", "images_per_wg", "producers", "lanes", "consumers", "producer_lds", "passes", "workgroups"),
                     (bool(out[0]),) + tuple(int(x) for x in out[1:])))
+
+
+def prog_split_rule(n_images, scans, mode=1, n_bands=68, wave_slots=0, parts=0):
+    """mj_debug_prog_split (host only): (split flags per scan, parts per band) for a progressive batch whose scans are
+    (image, restart segments, entropy-coded bytes or -1 where the scan is no refining AC scan of one component)."""
+    n = len(scans)
+    img = np.asarray([s[0] for s in scans], dtype=np.int32)
+    seg = np.asarray([s[1] for s in scans], dtype=np.int32)
+    byt = np.asarray([s[2] for s in scans], dtype=np.int64)
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    po = ctypes.c_int32()
+    L = load_library()
+    L.mj_debug_prog_split.argtypes = [ctypes.c_int32] * 6 + [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_int32)]
+    if L.mj_debug_prog_split(mode, n_images, n_bands, wave_slots, parts, n, _ptr(img), _ptr(seg), _ptr(byt), _ptr(out), ctypes.byref(po)) != MJ_OK:
+        raise ValueError("mj_debug_prog_split: bad arguments")
+    return out[:n].astype(bool).tolist(), int(po.value)
 
 
 class UnknownOption(ValueError):

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 namespace mj {
 
@@ -102,14 +103,69 @@ inline bool spread_lengths(const int32_t *seg_len, int64_t n_segs) {
     return (int64_t)top * 4 * n_segs > 5 * sum;
 }
 
+// Progressive batches: which refining AC scans are walked as SCOUT + PARTS (progressive_fast.hip: a scout follows the bit
+// positions alone, a few walks per band place the coefficients one launch behind — a split scan is walked one and a half times,
+// for a chain less than half as long).  Worth it where a band's walk is long (from 1 KiB of entropy-coded bytes per band on) and
+// while the chip has wave slots for the extra walks:
+//   all candidates while their scouts and parts leave a fifth of the chip's wave slots free; past that only each image's LARGEST
+//   refining scan — the last luma refinement, the one a batch waits for — with two parts per band, up to ~1 100 images on
+//   MI355X (3 walks per image within two fifths of the slots); past that none.
+// (libjpeg's script, 1080p, ms per batch, round 5: all split with four parts / largest only with two / none: 384 files 47.4 /
+// 47.8 / 61.3, 512: 48.2 / 48.0 / 61.9, 640: 53.2 / 53.0 / 63.1, 768: 61.3 / 54.0 / 64.8, 896: 65.8 / 61.6 / 66.0, 1 024: 81.5 /
+// 66.2 / 66.7, 1 536: 117 / 99.7 / 79.6.  As many images as fit: worse than either, 99.7 at 1 024.  The thresholds were measured on
+// that one family of files; tests/test_form_select.py pins what the rule says for it.)
+struct ProgSplitInputs {
+    int mode = 1;                          // MJ_PROG_SPLIT: 0 never | 1 this rule | 2 every candidate | 3 each image's largest
+    int64_t n_images = 0, n_bands = 1;
+    int64_t wave_slots = 256 * 32;         // CUs x 32 wavefronts
+    int parts = 4;                         // parts per band of a split scan (MJ_PROG_PARTS)
+    bool parts_given = false;              // ... set by the caller: the rule does not change it
+    int n_scans = 0;
+    const int32_t *image = nullptr;        // per scan: its image,
+    const int32_t *n_segments = nullptr;   // its restart segments,
+    const int64_t *bytes = nullptr;        // its entropy-coded bytes — or < 0: no refining AC scan of one component (never split)
+};
+struct ProgSplitChoice {
+    std::vector<char> split;               // per scan
+    int parts = 4;
+};
+inline ProgSplitChoice choose_prog_split(const ProgSplitInputs &in) {
+    ProgSplitChoice c;
+    c.split.assign((size_t)std::max(in.n_scans, 0), 0);
+    c.parts = in.parts;
+    if (in.mode == 0) return c;
+    std::vector<int> cand;
+    for (int k = 0; k < in.n_scans; ++k)
+        if (in.bytes[k] >= 0 && (in.mode >= 2 || in.bytes[k] / std::max<int64_t>(in.n_bands, 1) >= 1024)) cand.push_back(k);
+    int64_t need_all = 0;
+    for (int k : cand) need_all += (int64_t)in.n_segments[k] * (1 + in.parts);
+    const bool all = in.mode == 2 || (in.mode == 1 && need_all <= in.wave_slots * 4 / 5);
+    const bool largest = in.mode == 3 || (in.mode == 1 && !all && in.n_images * 3 <= in.wave_slots * 2 / 5);
+    if (all) {
+        for (int k : cand) c.split[(size_t)k] = 1;
+    } else if (largest) {
+        std::vector<int64_t> best((size_t)std::max<int64_t>(in.n_images, 0), 0);
+        std::vector<int> which(best.size(), -1);
+        for (int k : cand) {
+            const int im = in.image[k];
+            if (im < 0 || (size_t)im >= best.size()) continue;
+            if (in.bytes[k] > best[(size_t)im]) { best[(size_t)im] = in.bytes[k]; which[(size_t)im] = k; }
+        }
+        for (int k : which) if (k >= 0) c.split[(size_t)k] = 1;
+        if (!in.parts_given) c.parts = 2;
+    }
+    return c;
+}
+
 // One launch for both stages (fused.hip) — the conditions apart from the LDS budget (fused_shape): the resolved-table lane
-// form on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 colour files that all have the SAME restart interval, interleaved
+// form on a uniform batch of 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 / 4:1:1 colour files that all have the SAME restart interval, interleaved
 // pixels, no seam outputs.  A consumer's job is ready when the producer waves that hold its MCUs are past them (fused.hip works
 // that out per MCU, so any interval is correct); what the rule keeps out is where that would be late:
-//   x-major (a job = a whole MCU column of an image): the interval must divide the MCU row — one row (the benchmark's files),
+//   x-major (a job = an MCU column of an image, or a piece of one where it is long): the interval must divide the MCU row — one row (the benchmark's files),
 //     half a row, a third ... —: then column m is the (m mod interval)-th MCU of every segment that holds a piece of it.  With
 //     several rows per segment a column would only be complete when every segment is in its LAST row: no overlap left;
-//   row-major (a job = a piece of one MCU row): any interval — a piece waits for its own segment(s) only.
+//   row-major (a job = a piece of one MCU row): any interval — a piece waits for its own segment(s) only.  Not 4:1:1: the
+//     transposed strip of its 8 x 32 MCUs is 13 KB, two consumers fit beside the walk — 9.8 ms fused against 7.1 as two launches.
 struct FusedInputs {
     bool lanes_resolved = false;           // lane form (not sync) with the resolved tables, 12-bit copies built
     int seg_order_mode = 0;
@@ -127,14 +183,14 @@ inline int64_t fused_segments_per_image(const FusedInputs &f) {
 // 0 = the two launches; 1 = fused, whole images per workgroup (segments in blob order); 2 = fused with the segments dealt out
 // by length (seg_order_mode 2: files of mixed content) — one pool of jobs, hand-off across workgroups.
 inline int fused_applies(const FusedInputs &f) {
-    // x-major: a stage-2 job is a whole MCU column; row-major (the strip worker runs on the transposed image): pieces of an MCU
-    // row, fused.hip cuts them itself
-    const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.jobs_per_image == f.mcu_count_h);
+    // x-major: a stage-2 job is an MCU column or an equal piece of one (the plan's numbering); row-major (the strip worker runs
+    // on the transposed image): pieces of an MCU row, fused.hip cuts them itself
+    const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.mcu_count_h > 0 && f.jobs_per_image % f.mcu_count_h == 0);
     const int64_t spi = fused_segments_per_image(f);
     const bool interval_ok = f.same_interval && spi >= 1 && spi <= 512 && f.n_segs == f.n_images * spi &&
                              (f.transposed || f.mcu_count_h % f.restart_interval == 0);
     const bool ok = f.lanes_resolved && (f.seg_order_mode == 0 || f.seg_order_mode == 2) && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
-                    (f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2) && layout_ok &&
+                    (((f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2)) || (f.hmax == 4 && f.vmax == 1 && !f.transposed)) && layout_ok &&
                     !(f.flags & f.seam_or_exact_flags) && interval_ok;
     return !ok ? 0 : (f.seg_order_mode == 2 ? 2 : 1);
 }

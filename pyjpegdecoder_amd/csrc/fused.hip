@@ -64,6 +64,7 @@ struct FusedArgs {
     // MCU row — `pieces` per row, each `piece_mcus` MCUs long (the last one shorter) —, ready when the waves that hold its
     // segments are past it
     int32_t pieces, piece_mcus, mcus_per_row, mcu_rows;
+    int32_t col_pieces, piece_rows;        // x-major plans: pieces of an MCU column (JobGeo)
     // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
     // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
     uint32_t *x_counter;                   // [0] tickets, [1] jobs given up, [2] the clean-up launch's tickets
@@ -88,7 +89,9 @@ __device__ __forceinline__ bool guard_expired(unsigned long long t0) { return __
 // files) is the case where "column m of every row" is "MCU m of every segment".
 struct JobGeo {
     uint32_t ri, mpr, mcv, spi;
-    uint32_t pieces, piece_mcus;            // row-major plans
+    uint32_t pieces, piece_mcus;            // row-major plans: a job = MCUs [piece * piece_mcus, ...) of one MCU row
+    uint32_t col_pieces, piece_rows;        // x-major plans: a job = MCU rows [piece * piece_rows, ...) of one MCU column (one piece
+                                            // where a column is at most 24 strips: 1080p 4:2:0 has 17, 4:2:2 34 -> two pieces)
 };
 
 // Jobs of this workgroup's images from a ticket counter in LDS.  The workgroup walks its images in passes of `ipp` images (one
@@ -151,20 +154,22 @@ struct FusedSource {
             }
             return ok;
         }
-        if (g.ri == g.mpr) {               // one MCU row per segment: column m of every row = MCU m of every segment of the image
-            const uint32_t w0 = (j * g.spi) / lpw, w1 = (j * g.spi + g.spi - 1u) / lpw;
+        // x-major: the job is piece q of MCU column mc — that column's MCUs of the MCU rows [r_lo, r_hi)
+        const uint32_t mc = m / g.col_pieces, q = m - mc * g.col_pieces, r_lo = q * g.piece_rows, r_hi = min(r_lo + g.piece_rows, g.mcv);
+        if (g.ri == g.mpr) {               // one MCU row per segment: MCU mc of the segments r_lo .. r_hi - 1 of the image
+            const uint32_t w0 = (j * g.spi + r_lo) / lpw, w1 = (j * g.spi + r_hi - 1u) / lpw;
             uint32_t least = 0x7FFFFFFFu;
             for (uint32_t w = w0; w <= w1; ++w) {
                 const uint32_t p = *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * w);
                 least = min(least, p);
             }
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > base + m;
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)least) > base + mc;
         }
-        bool behind = false;               // column m of every MCU row, one row per lane and turn
-        for (uint32_t r0 = 0; r0 < g.mcv; r0 += 64u) {
+        bool behind = false;               // one MCU row per lane and turn
+        for (uint32_t r0 = r_lo; r0 < r_hi; r0 += 64u) {
             const uint32_t row = r0 + (uint32_t)lane;
-            if (row < g.mcv) {
-                const uint32_t gi = row * g.mpr + m, s = gi / g.ri;
+            if (row < r_hi) {
+                const uint32_t gi = row * g.mpr + mc, s = gi / g.ri;
                 behind = behind || word(j, s) <= base + (gi - s * g.ri);
             }
         }
@@ -232,10 +237,11 @@ struct FusedSourceX {
             const uint32_t g0 = row * g.mpr + a, g1 = row * g.mpr + b - 1u;
             for (uint32_t s = g0 / g.ri; s <= g1 / g.ri; ++s) behind = behind || word(img, s) <= min(g1, (s + 1u) * g.ri - 1u) - s * g.ri;
         } else {
-            for (uint32_t r0 = 0; r0 < g.mcv; r0 += 64u) {
+            const uint32_t mc = m / g.col_pieces, q = m - mc * g.col_pieces, r_lo = q * g.piece_rows, r_hi = min(r_lo + g.piece_rows, g.mcv);
+            for (uint32_t r0 = r_lo; r0 < r_hi; r0 += 64u) {
                 const uint32_t row = r0 + (uint32_t)lane;
-                if (row < g.mcv) {
-                    const uint32_t gi = row * g.mpr + m, s = gi / g.ri;
+                if (row < r_hi) {
+                    const uint32_t gi = row * g.mpr + mc, s = gi / g.ri;
                     behind = behind || word(img, s) <= gi - s * g.ri;
                 }
             }
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     const uint32_t v0 = (uint32_t)blockIdx.x * (uint32_t)F.n_pass;        // this workgroup's first virtual workgroup
     src.n_images = (uint32_t)F.n_images;
     src.jobs_per_image = (uint32_t)F.jobs_per_image;
-    src.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus};
+    src.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus,
+                   (uint32_t)F.col_pieces, (uint32_t)F.piece_rows};
     if constexpr (XWG) {
         src.counter = F.x_counter; src.progress = F.x_progress; src.holder = F.x_holder;
         src.left_count = F.x_counter + 1; src.left_list = F.x_left; src.patience = (uint32_t)F.x_patience;
@@ -346,7 +353,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (its strip: from the bottom of LDS, below the strips of the consumers that were there from the start — as many
+        // wavefronts as that leaves room for; 4:1:1 in row-major output has 13 KB strips: twelve fit, not sixteen)
         const int k = wave < n_prod ? wave : wave - n_cons;
+        if (k >= (int)((kFusedLds - kFusedCtrl - G::WTS_BYTES) / G::WAVE_BYTES) - n_cons) return;
         my_lds = smem + k * G::WAVE_BYTES;
     }
     rfast::strips_worker<HS, VS, 3, false, T>(F.R, F.job_prefix, F.total_jobs, F.jobs_per_image, my_lds, wts, lane, (int)blockIdx.x, wave, src);
@@ -424,7 +434,8 @@ __global__ __launch_bounds__(256, 3) void k_recon_leftover(FusedArgs F) {
     }
     LeftoverSource<T> src;
     src.map.n_images = (uint32_t)F.n_images; src.map.jobs_per_image = (uint32_t)F.jobs_per_image;
-    src.map.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus};
+    src.map.g = JobGeo{(uint32_t)F.ri, (uint32_t)F.mcus_per_row, (uint32_t)F.mcu_rows, (uint32_t)F.spi, (uint32_t)F.pieces, (uint32_t)F.piece_mcus,
+                       (uint32_t)F.col_pieces, (uint32_t)F.piece_rows};
     src.counter = F.x_counter + 2; src.list = F.x_left; src.n_left = n_left; src.first_undrawn = drawn;
     src.n_tickets = n_left + (all - drawn);
     src.lane = lane;
@@ -439,6 +450,8 @@ static bool fused_budget(FusedShape &s, int n_dc, int hmax, int vmax, int want_c
     else if (hmax == 2 && vmax == 1) { wave_bytes = rfast::FGeo<2, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<2, 1, 3>::WTS_BYTES; }
     else if (hmax == 1 && vmax == 2) { wave_bytes = rfast::FGeo<1, 2, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 2, 3>::WTS_BYTES; }
     else if (hmax == 1 && vmax == 1) { wave_bytes = rfast::FGeo<1, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 1, 3>::WTS_BYTES; }
+    else if (hmax == 4 && vmax == 1) { wave_bytes = rfast::FGeo<4, 1, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<4, 1, 3>::WTS_BYTES; }
+    else if (hmax == 1 && vmax == 4) { wave_bytes = rfast::FGeo<1, 4, 3>::WAVE_BYTES; wts_bytes = rfast::FGeo<1, 4, 3>::WTS_BYTES; }     // (4:1:1 transposed)
     else return false;
     const size_t prod = lanes13::lds_bytes(s.ac_total_bytes, n_dc, s.n_prod, s.lpw, s.ring, s.dbits);
     const size_t top = (size_t)kFusedLds - kFusedCtrl - wts_bytes;
@@ -447,7 +460,6 @@ static bool fused_budget(FusedShape &s, int n_dc, int hmax, int vmax, int want_c
     int fit = (int)((top - prod) / wave_bytes);
     fit = std::min(fit, waves - s.n_prod);
     s.n_cons = std::max(0, std::min(fit, want_consumers));
-    if ((size_t)waves * wave_bytes > top) return false;      // phase 2: every wave a strip
     return s.n_cons >= 1;
 }
 
@@ -456,7 +468,8 @@ static bool fused_budget(FusedShape &s, int n_dc, int hmax, int vmax, int want_c
 // and every workgroup resident at once (the benchmark: four 1080p images of 68 rows each); where it does not — 1080p 4:2:2 has
 // 135 MCU rows, a restart interval of half a row twice the segments —, a workgroup takes its images in PASSES of as many
 // as fit, one after the other (its consumers go on from one pass's jobs to the next's without a break).
-FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers) {
+FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers,
+                       int want_producers) {
     FusedShape s{};
     if (transposed) std::swap(hmax, vmax);                     // the strip worker's geometry: that of the transposed image
     if (n_images < 1 || spi < 1 || spi > 8 * 64 || cus < 1) return s;
@@ -469,6 +482,7 @@ FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax
     s.n_wg = (s.n_virt + s.n_pass - 1) / s.n_pass;
     const int lanes = s.ipw * spi;
     s.n_prod = std::min(8, std::max(1, (lanes + 33) / 34));
+    if (want_producers > 0) s.n_prod = std::min(8, std::max((lanes + 63) / 64, want_producers));      // (MJ_FUSED_PRODUCERS: fewer, fuller waves)
     s.lpw = (lanes + s.n_prod - 1) / s.n_prod;
     s.ring = 64;
     s.ac_total_bytes = ac_total_bytes;
@@ -530,6 +544,15 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
     F.n_prod = shape.n_prod; F.n_cons = shape.n_cons; F.ipw = shape.ipw; F.n_pass = shape.n_pass; F.n_virt = shape.n_virt;
     F.spi = spi; F.ri = restart_interval; F.n_images = a.n_images;
     F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row; F.mcu_rows = mcu_rows;
+    F.col_pieces = 1; F.piece_rows = mcu_rows;
+    if (!transposed) {
+        // the strip worker's jobs of an x-major plan: an MCU column in pieces of a.chunk_strips strips (the plan's numbering:
+        // column by column, piece by piece) — one piece where the column is at most 24 strips
+        const int tmw = 64 / (8 * hmax), spc = (mcu_rows + tmw - 1) / tmw;
+        F.col_pieces = (spc + a.chunk_strips - 1) / a.chunk_strips;
+        F.piece_rows = a.chunk_strips * tmw;
+        if (jobs_per_image != mcus_per_row * F.col_pieces) return hipErrorInvalidValue;
+    }
     if (transposed) {
         // the strip worker's jobs on the transposed image are pieces of an MCU ROW of the original (its own numbering: row by
         // row, piece by piece, `chunk_strips` strips each): about 20 MCUs per piece, so that the consumers work a piece behind
@@ -570,12 +593,14 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         else if (hmax == 2 && vmax == 1) MJ_GO(2, 1, false);
         else if (hmax == 1 && vmax == 2) MJ_GO(1, 2, false);
         else if (hmax == 1 && vmax == 1) MJ_GO(1, 1, false);
+        else if (hmax == 4 && vmax == 1) MJ_GO(4, 1, false);
         else return hipErrorInvalidValue;
     } else {
         if (hmax == 2 && vmax == 2) MJ_GO(2, 2, true);
         else if (hmax == 2 && vmax == 1) MJ_GO(1, 2, true);
         else if (hmax == 1 && vmax == 2) MJ_GO(2, 1, true);
         else if (hmax == 1 && vmax == 1) MJ_GO(1, 1, true);
+        else if (hmax == 4 && vmax == 1) MJ_GO(1, 4, true);
         else return hipErrorInvalidValue;
     }
 #undef MJ_GO
@@ -588,11 +613,13 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
             if (hmax == 2 && vmax == 2) MJ_LEFT(2, 2, false);
             else if (hmax == 2 && vmax == 1) MJ_LEFT(2, 1, false);
             else if (hmax == 1 && vmax == 2) MJ_LEFT(1, 2, false);
+            else if (hmax == 4 && vmax == 1) MJ_LEFT(4, 1, false);
             else MJ_LEFT(1, 1, false);
         } else {
             if (hmax == 2 && vmax == 2) MJ_LEFT(2, 2, true);
             else if (hmax == 2 && vmax == 1) MJ_LEFT(1, 2, true);
             else if (hmax == 1 && vmax == 2) MJ_LEFT(2, 1, true);
+            else if (hmax == 4 && vmax == 1) MJ_LEFT(1, 4, true);
             else MJ_LEFT(1, 1, true);
         }
 #undef MJ_LEFT

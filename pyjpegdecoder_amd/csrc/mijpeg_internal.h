@@ -314,7 +314,8 @@ struct FusedShape {
     int n_wg;           // ... workgroups of such a launch (= CUs: all resident at once)
 };
 FusedShape fused_shape_x(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int64_t n_segs, int want_consumers);
-FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers);
+FusedShape fused_shape(int cus, int ac_total_bytes, int n_dc, int hmax, int vmax, bool transposed, int n_images, int spi, int want_consumers,
+                       int want_producers = 0);
 // spi: restart segments per image; restart_interval: MCUs per segment (any: a job's readiness is worked out per MCU)
 hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint32_t *dstream, const int32_t *seg_bits, const DevSegment *segs,
                         int64_t n_segs, const DevImage *images, const DevHuff *huff, const uint16_t *lut11, const uint32_t *lut13,

@@ -241,6 +241,19 @@ struct mj_plan {
     uint8_t *last_rgb = nullptr;    // where the most recent execute wrote
 };
 
+// ---- plan_tables.hip: table building (host)
+namespace mj {
+// DHT -> canonical code book + 9-bit LUT (jpeg_decoder.py:366-377)
+void build_dev_huff(const mj_huff_spec &spec, DevHuff &h);
+bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint64_t ac_pk, int n_ac, const int ab_of_slot[4], int fixed_slot_bytes,
+                           std::vector<uint32_t> &out, int slot_off[4], int &total_bytes);
+bool build_count_tables(const mj_batch *b, const std::vector<int> &role, int W, std::vector<uint32_t> &out, int &tab_bytes);
+// ---- plan_progressive.hip: the progressive side of mj_plan_create
+struct ProgScans { std::vector<DevProgScan> pscans; std::vector<DevProgSeg> psegs; };
+int plan_progressive_scans(mj_context *ctx, const mj_batch *b, mj_plan *p, ProgScans &S, int64_t &entropy_bytes);
+int plan_progressive_upload(mj_context *ctx, const mj_batch *b, mj_plan *p, ProgScans &S);
+}  // namespace mj
+
 // (one definition per translation unit: they return through the caller's frame)
 namespace {
 
@@ -261,5 +274,23 @@ int fail(mj_context *ctx, int code, const char *fmt, ...) {
             return fail((ctx), MJ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-}  // namespace
+// a host array into a device buffer from the context's cache — through the plan's pinned arena on the setup stream where it fits
+template <typename T>
+int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
+    MJ_HIP(ctx, ctx->cache.get((void **)dst, n * sizeof(T) + pad_bytes + 16));
+    if (pad_bytes) MJ_HIP(ctx, hipMemsetAsync((char *)*dst + n * sizeof(T), 0, pad_bytes, ctx->setup_stream));
+    const size_t bytes = n * sizeof(T);
+    if (!bytes) return MJ_OK;
+    mj_context::Arena *a = ctx->cur;
+    const size_t at = a ? (a->used + 63) & ~(size_t)63 : 0;
+    if (a && at + bytes <= a->cap) {
+        memcpy(a->base + at, src, bytes);
+        a->used = at + bytes;
+        MJ_HIP(ctx, hipMemcpyAsync(*dst, a->base + at, bytes, hipMemcpyHostToDevice, ctx->setup_stream));
+    } else {
+        MJ_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // big (a host blob) or no arena: the plain way
+    }
+    return MJ_OK;
+}
 
+}  // namespace

@@ -6,28 +6,6 @@
 
 namespace {
 
-// DHT -> canonical code book + 9-bit LUT (jpeg_decoder.py:366-377)
-void build_dev_huff(const mj_huff_spec &spec, mj::DevHuff &h) {
-    memset(&h, 0, sizeof(h));
-    int code = 0, k = 0;
-    for (int l = 1; l <= 16; ++l) {
-        code <<= 1;
-        h.first_code[l] = code;
-        h.count[l] = spec.bits[l - 1];
-        h.first_sym[l] = k;
-        for (int i = 0; i < spec.bits[l - 1] && k < 256; ++i, ++k, ++code) {
-            h.vals[k] = spec.vals[k];
-            if (l <= mj::kLutBits && code < (1 << l)) {
-                int shift = mj::kLutBits - l;
-                for (int f = 0; f < (1 << shift); ++f) {
-                    int idx = (code << shift) | f;
-                    if (h.lut[idx] == 0) h.lut[idx] = (uint16_t)((l << 8) | spec.vals[k]);   // first (shortest) key wins
-                }
-            }
-        }
-    }
-}
-
 // zig-zag index -> natural index v*8+u (row = vertical frequency); blocks and quantisation tables live on the
 // device in this order (see huffman.hip / reconstruct_fast.hip)
 const uint8_t kNatOfZz[64] = {
@@ -58,216 +36,11 @@ bool generic_sampling(const mj_image_desc &d, int &hmax, int &vmax) {
     return blocks <= mj::kMaxBlocksPerMcu;
 }
 
-template <typename T>
-int upload(mj_context *ctx, T **dst, const T *src, size_t n, size_t pad_bytes = 0) {
-    MJ_HIP(ctx, ctx->cache.get((void **)dst, n * sizeof(T) + pad_bytes + 16));
-    if (pad_bytes) MJ_HIP(ctx, hipMemsetAsync((char *)*dst + n * sizeof(T), 0, pad_bytes, ctx->setup_stream));
-    const size_t bytes = n * sizeof(T);
-    if (!bytes) return MJ_OK;
-    mj_context::Arena *a = ctx->cur;
-    const size_t at = a ? (a->used + 63) & ~(size_t)63 : 0;
-    if (a && at + bytes <= a->cap) {
-        memcpy(a->base + at, src, bytes);
-        a->used = at + bytes;
-        MJ_HIP(ctx, hipMemcpyAsync(*dst, a->base + at, bytes, hipMemcpyHostToDevice, ctx->setup_stream));
-    } else {
-        MJ_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // big (a host blob) or no arena: the plain way
-    }
-    return MJ_OK;
-}
 
-
-// Resolved AC tables (huffman_lanes13.hip's entry format) for every table of the batch used as an AC table, table (LDS slot) s with
-// ab_of_slot[s] index bits: a main level of 2^AB entries — the FINISHED symbol wherever code + value bits fit the index
-// (jpeg_decoder.py:834-866 and bin_twos_complement :1636-1646 evaluated here), else what the arithmetic step needs — and second-level
-// tables of 2^(16 - AB) entries for the prefixes of longer codes.  fixed_slot_bytes: the stride of a table in `out` (the stage-1
-// kernel's), or 0: back to back, each as small as its codes allow (a fused launch's).  slot_off / total_bytes: where each lies.
-// false: does not fit.
-bool build_resolved_tables(const mj_batch *b, const std::vector<int> &role, uint64_t ac_pk, int n_ac, const int ab_of_slot[4], int fixed_slot_bytes,
-                           std::vector<uint32_t> &out, int slot_off[4], int &total_bytes) {
-    if (n_ac > 4) return false;
-    int subs_of_slot[4] = {1, 1, 1, 1}, words_of_slot[4] = {0, 0, 0, 0};
-    for (int t = 0; t < b->n_huff; ++t) {
-        if (role[t] != 2) continue;
-        const int slot = (int)((ac_pk >> (8 * t)) & 0xFF), AB = ab_of_slot[slot], AS = 1 << AB, SUB = 1 << (16 - AB);
-        if (fixed_slot_bytes) {
-            subs_of_slot[slot] = (fixed_slot_bytes / 4 - AS) / SUB;
-            words_of_slot[slot] = fixed_slot_bytes / 4;
-            continue;
-        }
-        std::vector<char> seen(AS, 0);
-        int n = 1, code = 0, k = 0;
-        for (int l = 1; l <= 16; ++l) {
-            code <<= 1;
-            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
-                if (code >= (1 << l) || l <= AB) continue;
-                const int prefix = code >> (l - AB);
-                if (!seen[prefix]) { seen[prefix] = 1; ++n; }
-            }
-        }
-        subs_of_slot[slot] = n;
-        words_of_slot[slot] = ((AS + n * SUB) * 4 + 15) / 16 * 4;
-    }
-    int at = 0;
-    for (int sl = 0; sl < n_ac; ++sl) {
-        if ((size_t)words_of_slot[sl] * 4 > 65535u) return false;        // (second-level tables are addressed by a 16-bit byte offset)
-        slot_off[sl] = at * 4;
-        at += words_of_slot[sl];
-    }
-    total_bytes = at * 4;
-    out.assign((size_t)at, 0xFFFFFFFFu);
-    for (int t = 0; t < b->n_huff; ++t) {
-        if (role[t] != 2) continue;
-        const int slot = (int)((ac_pk >> (8 * t)) & 0xFF), AB = ab_of_slot[slot], AS = 1 << AB, SUB = 1 << (16 - AB);
-        const int SLOT = words_of_slot[slot], max_sub = subs_of_slot[slot];
-        uint32_t *tab = out.data() + slot_off[slot] / 4;
-        // second-level tables behind the main one: for the 16 - AB bits that follow an AB-bit prefix of longer codes;
-        // table 0 = "no such code" (where every other unset main entry points as well)
-        int n_sub = 1;
-        for (int i = 0; i < SUB; ++i) tab[AS + i] = 0x8000u;
-        int code = 0, k = 0;
-        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
-            for (uint32_t f = 0; f < count; ++f)
-                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
-        };
-        for (int l = 1; l <= 16; ++l) {
-            code <<= 1;
-            for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
-                if (code >= (1 << l)) continue;
-                const int hv = b->huff[t].vals[k], run = hv >> 4, size = hv & 15;
-                const uint32_t adv = hv == 0 ? 127u : 2u * (uint32_t)(run + 1);
-                const uint32_t open_entry = ((uint32_t)(31 - size) << 24) | ((uint32_t)l << 16) | 0x8000u | ((hv == 0 ? 0u : (uint32_t)(run + 1)) << 8);   // value bits taken arithmetically
-                if (l > AB) {
-                    const uint32_t prefix = (uint32_t)code >> (l - AB);
-                    uint32_t &m = tab[prefix];
-                    if (m == 0xFFFFFFFFu) {                       // first long code under this prefix: a new table
-                        if (n_sub >= max_sub) return false;
-                        for (int j = 0; j < SUB; ++j) tab[AS + n_sub * SUB + j] = 0xFFFFFFFFu;
-                        m = ((uint32_t)(AS * 4 + n_sub * SUB * 4) << 16) | 0xC000u;
-                        ++n_sub;
-                    }
-                    if ((m & 0xC0FFu) != 0xC000u) continue;       // a shorter code owns the prefix (over-subscribed table)
-                    uint32_t *sub = tab + ((m >> 16) / 4);
-                    put(sub, ((uint32_t)code << (16 - l)) & (uint32_t)(SUB - 1), 1u << (16 - l), open_entry);
-                } else if (hv == 0 ? l <= AB : l + size <= AB) {
-                    const int n = hv == 0 ? 0 : size, rest = AB - l - n;
-                    for (uint32_t vb = 0; vb < (1u << n); ++vb) {
-                        // bin_twos_complement (:1636-1646): leading 1 = the value itself, leading 0 = value - (2^n - 1)
-                        const int val = n == 0 ? 0 : ((vb >> (n - 1)) ? (int)vb : (int)vb - ((1 << n) - 1));
-                        put(tab, (((uint32_t)code << n) | vb) << rest, 1u << rest,
-                            ((uint32_t)(uint16_t)(int16_t)val << 16) | (adv << 8) | (uint32_t)(l + n));
-                    }
-                } else {
-                    put(tab, (uint32_t)code << (AB - l), 1u << (AB - l), open_entry);
-                }
-            }
-        }
-        for (int i = 0; i < AS; ++i)
-            if (tab[i] == 0xFFFFFFFFu) tab[i] = ((uint32_t)(AS * 4) << 16) | 0xC000u;          // no such code: the empty second-level table
-        for (int i = AS; i < SLOT; ++i)
-            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x8000u;
-    }
-    return true;
-}
-
-// Every table of a batch of at most 8 as the counting walks of the synchronisation form want it (huffman_sync.hip: k_count): all
-// with W index bits, `tab_bytes` apart.  A 32-bit entry: bits consumed — code AND value — (0..5) | run + 1, 128 = end of block
-// (8..15) | DC tables: the EXTENDed difference (16..30; jpeg_decoder.py:818-820, bin_twos_complement :1636-1646) — finished
-// wherever the code fits the index (AC tables: counting does not look at AC values) or code + value bits do (DC tables).  Bit 31
-// = not finished: bit 30 set = a code longer than the index, (0..15) the byte offset of the second-level table (2^(16 - W)
-// entries for the bits behind the index) for its prefix; else the open form, which second-level tables hold throughout: code
-// length (0..4; 0 = no such code) | run + 1 / 128 (8..15) | size (16..19).  false: does not fit (or a DC size above 15).
-bool build_count_tables(const mj_batch *b, const std::vector<int> &role, int W, std::vector<uint32_t> &out, int &tab_bytes) {
-    if (b->n_huff > 8) return false;
-    const int AS = 1 << W, SUB = 1 << (16 - W);
-    auto walk_codes = [&](const mj_huff_spec &spec, auto &&f) {
-        int code = 0, k = 0;
-        for (int l = 1; l <= 16; ++l) {
-            code <<= 1;
-            for (int i = 0; i < spec.bits[l - 1] && k < 256; ++i, ++k, ++code)
-                if (code < (1 << l)) f(l, code, (int)spec.vals[k]);
-        }
-    };
-    int max_words = AS + SUB;
-    for (int t = 0; t < b->n_huff; ++t) {
-        if (role[t] != 1 && role[t] != 2) return false;
-        std::vector<char> seen((size_t)AS, 0);
-        int n = 1;
-        walk_codes(b->huff[t], [&](int l, int code, int) {
-            if (l > W && !seen[(size_t)(code >> (l - W))]) { seen[(size_t)(code >> (l - W))] = 1; ++n; }
-        });
-        max_words = std::max(max_words, AS + n * SUB);
-    }
-    tab_bytes = (max_words * 4 + 15) / 16 * 16;
-    if (tab_bytes > 65535) return false;
-    const int TW = tab_bytes / 4;
-    out.assign((size_t)b->n_huff * TW, 0xFFFFFFFFu);
-    for (int t = 0; t < b->n_huff; ++t) {
-        uint32_t *tab = out.data() + (size_t)t * TW;
-        const bool is_dc = role[t] == 1;
-        int n_sub = 1;                                            // table 0 = "no such code"
-        for (int i = 0; i < SUB; ++i) tab[AS + i] = 0x80000000u;
-        bool ok = true;
-        auto put = [&](uint32_t *base, uint32_t first, uint32_t count, uint32_t entry) {     // the shortest code wins (first fit)
-            for (uint32_t f = 0; f < count; ++f)
-                if (base[first + f] == 0xFFFFFFFFu) base[first + f] = entry;
-        };
-        walk_codes(b->huff[t], [&](int l, int code, int hv) {
-            const int run = is_dc ? 0 : hv >> 4, size = is_dc ? hv : (hv & 15);
-            if (size > 15) { ok = false; return; }
-            const bool eob = !is_dc && hv == 0;
-            const uint32_t adv = eob ? 128u : (uint32_t)(run + 1);
-            const uint32_t open_entry = 0x80000000u | ((uint32_t)size << 16) | (adv << 8) | (uint32_t)l;
-            if (l > W) {
-                uint32_t &m = tab[(uint32_t)code >> (l - W)];
-                if (m == 0xFFFFFFFFu) {                           // first long code under this prefix: a new table
-                    for (int j = 0; j < SUB; ++j) tab[AS + n_sub * SUB + j] = 0xFFFFFFFFu;
-                    m = 0xC0000000u | (uint32_t)((AS + n_sub * SUB) * 4);
-                    ++n_sub;
-                }
-                if ((m & 0xC0000000u) != 0xC0000000u) return;     // a shorter code owns the prefix (over-subscribed table)
-                put(tab + (m & 0xFFFFu) / 4, ((uint32_t)code << (16 - l)) & (uint32_t)(SUB - 1), 1u << (16 - l), open_entry);
-            } else if (!is_dc) {
-                put(tab, (uint32_t)code << (W - l), 1u << (W - l), (adv << 8) | (uint32_t)(l + size));
-            } else if (l + size <= W) {
-                const int rest = W - l - size;
-                for (uint32_t vb = 0; vb < (1u << size); ++vb) {
-                    const int val = size == 0 ? 0 : ((vb >> (size - 1)) ? (int)vb : (int)vb - ((1 << size) - 1));
-                    put(tab, (((uint32_t)code << size) | vb) << rest, 1u << rest, (((uint32_t)val & 0x7FFFu) << 16) | (adv << 8) | (uint32_t)(l + size));
-                }
-            } else {
-                put(tab, (uint32_t)code << (W - l), 1u << (W - l), open_entry);
-            }
-        });
-        if (!ok) return false;
-        for (int i = 0; i < AS; ++i)
-            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x80000000u;       // no such code
-        for (int i = AS; i < TW; ++i)
-            if (tab[i] == 0xFFFFFFFFu) tab[i] = 0x80000000u;
-    }
-    return true;
-}
 
 }  // namespace
 
 extern "C" {
-
-int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_t *roles, int32_t wbits, uint32_t *out, int64_t cap_words,
-                          int32_t *tab_bytes) {
-    if (!huff || !roles || !tab_bytes || n_huff < 1 || n_huff > 8 || wbits < 10 || wbits > 13) return MJ_ERR_INVALID;
-    mj_batch b{};
-    b.n_huff = n_huff; b.huff = huff;
-    std::vector<int> role(roles, roles + n_huff);
-    std::vector<uint32_t> t;
-    int tb = 0;
-    if (!build_count_tables(&b, role, wbits, t, tb)) return MJ_ERR_UNSUPPORTED;
-    *tab_bytes = tb;
-    if (out) {
-        if ((int64_t)t.size() > cap_words) return MJ_ERR_INVALID;
-        memcpy(out, t.data(), t.size() * 4);
-    }
-    return MJ_OK;
-}
 
 int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
                          int32_t forced_chunk, int32_t out[4]) {
@@ -436,223 +209,9 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
         pix += (int64_t)d.width * d.height;
     }
     mcu_prefix[b->n_images] = mcu;
-    std::vector<mj::DevProgScan> pscans;
-    std::vector<mj::DevProgSeg> psegs;
-    if (prog) {
-        // (what decides the walks' form comes first: the dependency levels below depend on it)
-        p->prog_fast = false;
-        for (int k = 0; k < b->n_scans; ++k)       // every scan of a progressive frame (sequential scans — non-interleaved baseline files — stay with progressive.hip)
-            p->prog_fast = p->prog_fast || !(b->scans[k].ss == 0 && b->scans[k].se == 63);
-        if (const char *e = mj::opt("MJ_PROG_FAST")) p->prog_fast = p->prog_fast && atoi(e) != 0;
-        if (p->hmax == 3 || p->vmax == 3) p->prog_fast = false;      // the stream walks step through a component's blocks with shifts
-        int max_rows = 1;
-        for (int i = 0; i < b->n_images; ++i) max_rows = std::max(max_rows, (int)imgs[i].mcu_count_v);
-        p->prog_banded = true;
-        if (const char *e = mj::opt("MJ_PROG_BANDS")) p->prog_banded = atoi(e) != 0;
-        p->prog_rows_per_band = p->prog_banded ? 1 : max_rows;      // (one frame MCU row per band: 1-2 % faster than two up to 1024 files, equal above)
-        if (const char *e = mj::opt("MJ_PROG_ROWS")) { const int v = atoi(e); if (v >= 1 && p->prog_banded) p->prog_rows_per_band = v; }
-        // Split scans (progressive_fast.hip): a refining AC scan is one serial chain — a batch lasts as long as its longest scan's
-        // walk — and more than half of a block's walk is placing what the symbols say, which needs no order once the bit position
-        // of the block is known.  A scout follows the positions alone; a few walks per band (MJ_PROG_PARTS, 4), one launch
-        // behind, place.  Worth it where a band's walk is long: from 1 KiB of entropy-coded bytes per band on (MJ_PROG_SPLIT: 0 never,
-        // 2 every refining AC scan).
-        int split_mode = 1;
-        if (const char *e = mj::opt("MJ_PROG_SPLIT")) split_mode = atoi(e);
-        if (const char *e = mj::opt("MJ_PROG_PARTS")) p->prog_parts = std::min(std::max(atoi(e), 1), mj::kProgSub);
-        if (!p->prog_fast || !p->prog_banded) split_mode = 0;
-        // The first AC scans of very large batches are cut into self-synchronising chunks and walked one chunk per LANE before the
-        // band pipeline starts (progressive_chunks.hip): they are a third of the wavefront walks' work, which the chip runs out of
-        // instruction issue for — from ~1 800 files on; below that a batch lasts as long as one image's chain through its last
-        // refinement, and the pass in front of the pipeline (4.5 ms per 1 024 files) only adds to it.  1080p, libjpeg's script, ms per
-        // batch without / with: 1 024 files 66.9 / 71.8, 1 536: 79.6 / 84.0, 2 048: 104.2 / 93.5, 3 072: 154.6 / 141.0, 4 096: 204.9 /
-        // 184.1 (profiles/r05_progressive_chunks.txt).  MJ_PROG_CHUNKS: 0 never, 1 from 2 048 images on (the default), 2 always (tests).
-        {
-            int mode = 1;
-            if (const char *e = mj::opt("MJ_PROG_CHUNKS")) mode = atoi(e);
-            p->prog_chunks = p->prog_fast && p->prog_banded && !(b->flags & MJ_FLAG_NO_SYNC) && (mode >= 2 || (mode == 1 && b->n_images >= 2048));
-            if (const char *e = mj::opt("MJ_PROG_CHUNK")) p->pc_chunk_bytes = atoi(e);
-        }
-        auto chunked = [&](int k) { return p->prog_chunks && b->scans[k].ss > 0 && b->scans[k].ah == 0 && b->scans[k].n_comp == 1; };
-        std::vector<char> split_of(b->n_scans, 0);
-        if (split_mode) {
-            // ... and while the chip has wave slots for it: past that the added work — a split scan is walked one and a half
-            // times — costs more than the shorter chain gains.
-            const int64_t n_bands = std::max(1, (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band);
-            std::vector<std::pair<int64_t, int>> cand;        // (bytes, scan)
-            for (int k = 0; k < b->n_scans; ++k) {
-                const mj_scan_desc &sd = b->scans[k];
-                if (sd.ss == 0 || sd.ah == 0 || sd.n_comp != 1) continue;
-                if (sd.first_segment < 0 || sd.n_segments < 1 || sd.first_segment + sd.n_segments > b->n_segments) continue;   // (refused below)
-                int64_t bytes = 0;
-                for (int g = 0; g < sd.n_segments; ++g) bytes += b->seg_end[sd.first_segment + g] - b->seg_begin[sd.first_segment + g];
-                if (split_mode >= 2 || bytes / n_bands >= 1024) cand.push_back({-bytes, k});
-            }
-            // All of them while their scouts and parts leave a fifth of the chip's wave slots free; past that only each image's
-            // LARGEST refining scan — the last luma refinement, the one a batch waits for — with two parts per band, up to ~1 100
-            // images; past that none.  (libjpeg's script, 1080p, ms per batch, round 5: all split with four parts / largest only with
-            // two / none: 384 files 47.4 / 47.8 / 61.3, 512: 48.2 / 48.0 / 61.9, 640: 53.2 / 53.0 / 63.1, 768: 61.3 / 54.0 / 64.8,
-            // 896: 65.8 / 61.6 / 66.0, 1 024: 81.5 / 66.2 / 66.7, 1 536: 117 / 99.7 / 79.6.  As many images as fit: worse than
-            // either, 99.7 at 1 024.)  MJ_PROG_SPLIT: 0 none, 1 this rule, 2 all, 3 the largest of each image.
-            const int64_t slots = (int64_t)mj::device_cus() * 32;
-            int64_t need_all = 0;
-            for (auto &c : cand) need_all += (int64_t)b->scans[c.second].n_segments * (1 + p->prog_parts);
-            const bool parts_given = mj::opt("MJ_PROG_PARTS") != nullptr;
-            const bool all = split_mode == 2 || (split_mode == 1 && need_all <= slots * 4 / 5);
-            const bool largest = split_mode == 3 || (split_mode == 1 && !all && (int64_t)b->n_images * 3 <= slots * 2 / 5);
-            if (all) {
-                for (auto &c : cand) split_of[c.second] = 1;
-            } else if (largest) {
-                std::vector<int64_t> best(b->n_images, 0);
-                std::vector<int> which(b->n_images, -1);
-                for (auto &c : cand) { const int im = b->scans[c.second].image; if (-c.first > best[im]) { best[im] = -c.first; which[im] = c.second; } }
-                for (int i = 0; i < b->n_images; ++i) if (which[i] >= 0) split_of[which[i]] = 1;
-                if (!parts_given) p->prog_parts = 2;
-            }
-        }
-        auto want_split = [&](int k) { return split_of[k] != 0; };
-        std::vector<int> ordinal_of(b->n_scans, 0);
-        std::vector<int> seen(b->n_images, 0);
-        int n_ord = 0;
-        for (int k = 0; k < b->n_scans; ++k) {
-            const mj_scan_desc &sd = b->scans[k];
-            if (sd.image < 0 || sd.image >= b->n_images) return fail(ctx, MJ_ERR_INVALID, "scan %d: image index out of range", k);
-            if (k > 0 && sd.image < b->scans[k - 1].image) return fail(ctx, MJ_ERR_INVALID, "scans must be grouped by image, in file order");
-            // Dependency level instead of file ordinal: a scan must wait only for earlier scans of the same image that
-            // touch the same coefficients (same component, overlapping spectral band).  libjpeg's 10-scan script has
-            // 4 levels: DC | the four first AC scans | the refinements of what is complete | the last luma refinement.
-            {
-                int lvl = 0;
-                for (int j = k - 1; j >= 0 && b->scans[j].image == sd.image; --j) {
-                    const mj_scan_desc &pj = b->scans[j];
-                    if (chunked(j)) continue;                 // (complete before the band pipeline starts)
-                    bool comp_overlap = false;
-                    for (int a1 = 0; a1 < sd.n_comp && a1 < 3; ++a1)
-                        for (int a2 = 0; a2 < pj.n_comp && a2 < 3; ++a2) comp_overlap |= sd.comp[a1] == pj.comp[a2];
-                    // (a split scan's parts run one launch behind its scout: what follows it waits for them)
-                    if (comp_overlap && sd.ss <= pj.se && pj.ss <= sd.se) lvl = std::max(lvl, ordinal_of[j] + 1 + (want_split(j) ? 1 : 0));
-                }
-                ordinal_of[k] = lvl;
-            }
-            (void)seen;
-            if (chunked(k)) ordinal_of[k] = 0;
-            else n_ord = std::max(n_ord, ordinal_of[k] + 1 + (want_split(k) ? 1 : 0));
-            const mj_image_desc &d = b->images[sd.image];
-            const mj::DevImage &im = imgs[sd.image];
-            mj::DevProgScan ps{};
-            ps.image = sd.image; ps.n_comp = sd.n_comp;
-            if (sd.n_comp < 1 || sd.n_comp > d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: %d components", k, sd.n_comp);
-            // ss = 0, se = 63, ah = al = 0: a sequential (baseline) scan of one component — non-interleaved baseline files
-            const bool sequential = sd.ss == 0 && sd.se == 63 && sd.ah == 0 && sd.al == 0;
-            if (sd.ss < 0 || sd.se > 63 || sd.se < sd.ss || sd.al < 0 || sd.al > 13 || (sd.ss == 0 && sd.se != 0 && !sequential))
-                return fail(ctx, MJ_ERR_INVALID, "scan %d: bad spectral selection / successive approximation", k);
-            if ((sd.ss > 0 || sequential) && sd.n_comp != 1)
-                return fail(ctx, sequential ? MJ_ERR_UNSUPPORTED : MJ_ERR_INVALID, "scan %d: an AC or sequential scan has one component here", k);
-            for (int i = 0; i < sd.n_comp; ++i) {
-                if (sd.comp[i] < 0 || sd.comp[i] >= d.ncomp) return fail(ctx, MJ_ERR_INVALID, "scan %d: component out of range", k);
-                ps.comp[i] = sd.comp[i];
-                const bool need_dc = sd.ss == 0 && sd.ah == 0, need_ac = sd.se > 0;
-                if ((need_dc && (sd.dc_sel[i] < 0 || sd.dc_sel[i] >= b->n_huff)) || (need_ac && (sd.ac_sel[i] < 0 || sd.ac_sel[i] >= b->n_huff)))
-                    return fail(ctx, MJ_ERR_INVALID, "scan %d: Huffman table selector out of range", k);
-                ps.dc_tab[i] = need_dc ? sd.dc_sel[i] : 0;
-                ps.ac_tab[i] = need_ac ? sd.ac_sel[i] : 0;
-            }
-            // geometry the kernel relies on
-            int want_h, want_v;
-            if (sd.n_comp > 1) {
-                // (an interleaved DC scan may cover a subset of the components: its MCUs are still the frame's, :591-594, :610-611)
-                want_h = im.mcu_count_h; want_v = im.mcu_count_v;
-            } else {
-                const int c = sd.comp[0];
-                const int h = im.comp_h[c], v = im.comp_v[c];
-                if (sd.ss == 0 && (h > 1 || v > 1))
-                    return fail(ctx, MJ_ERR_UNSUPPORTED, "scan %d: single-component DC scan of a component with sampling > 1 (the reference steps "
-                                "its blocks by the component's MCU size, :993-994, and runs off its array: IndexError)", k);
-                const int cw = (d.width * h + im.hmax - 1) / im.hmax, ch = (d.height * v + im.vmax - 1) / im.vmax;   // ceil(W / ratio)
-                want_h = (cw + 7) / 8; want_v = (ch + 7) / 8;
-                if (d.ncomp == 1) { want_h = (d.width + 7) / 8; want_v = (d.height + 7) / 8; }
-            }
-            if (sd.mcu_count_h != want_h || sd.mcu_count_v != want_v)
-                return fail(ctx, MJ_ERR_INVALID, "scan %d: MCU counts %dx%d, expected %dx%d", k, sd.mcu_count_h, sd.mcu_count_v, want_h, want_v);
-            ps.ss = sd.ss; ps.se = sd.se; ps.ah = sd.ah; ps.al = sd.al;
-            ps.level = ordinal_of[k];
-            ps.split = want_split(k) ? 1 : 0;
-            ps.mcu_count_h = sd.mcu_count_h; ps.mcu_count_v = sd.mcu_count_v;
-            pscans.push_back(ps);
-        }
-        // segments grouped by ordinal
-        // ... and, inside a level, by the kernel that walks them: DC first scans, AC first scans, AC refining scans, the rest
-        auto kind_of = [&](const mj_scan_desc &sd) {
-            const bool sequential = sd.ss == 0 && sd.se == 63;
-            if (sequential) return 3;
-            if (sd.ss == 0) return 0;           // DC scans, first and refining (round 4: the refinement is walked by progressive_fast.hip too)
-            return sd.ah == 0 ? 1 : 2;
-        };
-        p->ordinal_seg_off.assign(n_ord + 1, 0);
-        p->ordinal_kind_off.assign((size_t)n_ord * 4, 0);
-        for (int o = 0; o < n_ord; ++o) {
-            p->ordinal_seg_off[o] = (int64_t)psegs.size();
-          for (int kind = 0; kind < 4; ++kind) {
-            p->ordinal_kind_off[(size_t)o * 4 + kind] = (int64_t)psegs.size();
-            for (int k = 0; k < b->n_scans; ++k) {
-                if (ordinal_of[k] != o || kind_of(b->scans[k]) != kind) continue;
-                const mj_scan_desc &sd = b->scans[k];
-                const int64_t mcus = (int64_t)sd.mcu_count_h * sd.mcu_count_v;
-                const int64_t want = sd.restart_interval > 0 ? (mcus + sd.restart_interval - 1) / sd.restart_interval : 1;
-                if (sd.n_segments != want || sd.first_segment < 0 || sd.first_segment + sd.n_segments > b->n_segments)
-                    return fail(ctx, MJ_ERR_INVALID, "scan %d: %d restart segments given, %lld expected", k, sd.n_segments, (long long)want);
-                for (int sgi = 0; sgi < sd.n_segments; ++sgi) {
-                    const int64_t sb = b->seg_begin[sd.first_segment + sgi], se = b->seg_end[sd.first_segment + sgi];
-                    if (sb < 0 || se < sb || se > b->blob_len) return fail(ctx, MJ_ERR_INVALID, "scan %d segment %d: bad byte range", k, sgi);
-                    mj::DevProgSeg g{};
-                    g.begin = sb; g.len = (int32_t)(se - sb); g.scan = k;
-                    g.mcu0 = sd.restart_interval > 0 ? sgi * sd.restart_interval : 0;
-                    g.n_mcu = (int32_t)(sd.restart_interval > 0 ? std::min<int64_t>(sd.restart_interval, mcus - g.mcu0) : mcus);
-                    g.last = sgi == sd.n_segments - 1;
-                    psegs.push_back(g);
-                    ent += se - sb;
-                }
-            }
-          }
-        }
-        p->ordinal_seg_off[n_ord] = (int64_t)psegs.size();
-        {   // Band pipelining (see progressive_fast.hip): one frame MCU row per band (round 4; two before), launches = bands + levels - 1.  It
-            // shortens the critical path from the sum of the levels' longest scans to about the longest scan — a refining scan
-            // follows one band behind what it refines — and keeps all of an image's scans on the chip at once: faster than one
-            // launch per dependency level at every batch size measured (profiles/r02d_progressive_sweep.txt: 16 x 1080p
-            // 146 -> 80.5 ms, 1024: 184 -> 93 ms, 8192: 728 -> 510 ms with the ordering and the loops of progressive_fast.hip).
-            // MJ_PROG_BANDS=0 keeps one launch per level.  (MJ_PROG_BANDS, MJ_PROG_ROWS, MJ_PROG_FAST, MJ_SYNC_ROUNDS,
-            // MJ_SYNC_CHUNK, MJ_HUFFMAN, MJ_SEG_ORDER and the MJ_LANES_* variables are hooks of the test-suite and of
-            // tools/stage_probe.py: read once, at plan creation or launch; mj_plan_stage1_form() reports the form in effect.)
-            if (p->prog_banded) {
-                // every launch of the pipeline covers all segments, and more workgroups than the chip holds at once: the long
-                // walks go first (a launch lasts as long as its slowest wave; started last, the final luma refinement — half
-                // of a file's bytes — would begin when the short scans' waves leave)
-                // (behind them the segments of the scans progressive.hip walks — DC refinement, sequential scans — so that its
-                // launches cover only those)
-                auto rest = [&](const mj::DevProgSeg &g) { return kind_of(b->scans[g.scan]) == 3; };
-                // (in front of them all the split scans' segments: the kernel finds their parts by position)
-                auto split = [&](const mj::DevProgSeg &g) { return pscans[g.scan].split != 0; };
-                // (and behind everything the segments of the first AC scans that are walked in chunks: no wavefront walk takes them)
-                auto in_chunks = [&](const mj::DevProgSeg &g) { return chunked(g.scan); };
-                std::stable_sort(psegs.begin(), psegs.end(), [&](const mj::DevProgSeg &x, const mj::DevProgSeg &y) {
-                    if (in_chunks(x) != in_chunks(y)) return in_chunks(y);
-                    if (in_chunks(x)) return false;           // (among themselves: as they come — by image, scan, restart segment)
-                    if (rest(x) != rest(y)) return rest(y);
-                    if (split(x) != split(y)) return split(x);
-                    return x.len > y.len;
-                });
-                p->n_split = 0;
-                while (p->n_split < (int64_t)psegs.size() && split(psegs[p->n_split])) ++p->n_split;
-                p->n_psegs_wave = 0;
-                while (p->n_psegs_wave < (int64_t)psegs.size() && !in_chunks(psegs[p->n_psegs_wave])) ++p->n_psegs_wave;
-                p->prog_rest_off = 0;
-                while (p->prog_rest_off < p->n_psegs_wave && !rest(psegs[p->prog_rest_off])) ++p->prog_rest_off;
-            }
-            if (!p->prog_banded) p->n_psegs_wave = (int64_t)psegs.size();
-            const int n_bands = (max_rows + p->prog_rows_per_band - 1) / p->prog_rows_per_band;
-            p->prog_steps = n_bands + std::max(n_ord, 1) - 1;
-        }
-    }
+    mj::ProgScans prog_scans;      // progressive batches: plan_progressive.hip
+    int rc0;
+    if (prog && (rc0 = mj::plan_progressive_scans(ctx, b, p, prog_scans, ent)) != MJ_OK) return rc0;
     p->mcus_per_image = (int32_t)(mcu / b->n_images);
     p->info.total_blocks = blk; p->info.total_mcus = mcu; p->info.total_pixels = pix;
     p->info.rgb_bytes = rgb; p->info.entropy_bytes = ent;
@@ -702,7 +261,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
     }
     if (have_entropy) {
         std::vector<mj::DevHuff> hh(b->n_huff);
-        for (int t = 0; t < b->n_huff; ++t) build_dev_huff(b->huff[t], hh[t]);
+        for (int t = 0; t < b->n_huff; ++t) mj::build_dev_huff(b->huff[t], hh[t]);
         if ((rc = upload(ctx, &p->d_huff, hh.data(), hh.size())) != MJ_OK) return rc;
         p->n_huff = b->n_huff;
         std::vector<int> role(b->n_huff, 0);
@@ -753,7 +312,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     std::vector<uint32_t> l13;
                     const int ab13[4] = {13, 13, 13, 13};
                     int off13[4] = {0, 0, 0, 0}, total13 = 0;
-                    if (!build_resolved_tables(b, role, ac_pk, n_ac, ab13, mj::kLanes13SlotBytes, l13, off13, total13)) goto no_lanes13;
+                    if (!mj::build_resolved_tables(b, role, ac_pk, n_ac, ab13, mj::kLanes13SlotBytes, l13, off13, total13)) goto no_lanes13;
                     if ((rc = upload(ctx, &p->d_lut13, l13.data(), l13.size())) != MJ_OK) return rc;
                     p->n_ac13 = n_ac; p->n_dc13 = n_dc;
                     p->ac_slot_pk = ac_pk; p->dc_slot_pk = dc_pk; p->dc_tab_pk = dct_pk;
@@ -915,7 +474,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
                     for (; ok && wb >= 10; --wb) {
                         std::vector<uint32_t> lc;
                         int tb = 0;
-                        if (!build_count_tables(b, role, wb, lc, tb)) { ok = false; break; }
+                        if (!mj::build_count_tables(b, role, wb, lc, tb)) { ok = false; break; }
                         if ((size_t)tb * (size_t)b->n_huff > 150 * 1024) continue;             // a narrower index fits
                         if ((rc = upload(ctx, &p->d_lutc, lc.data(), lc.size())) != MJ_OK) return rc;
                         p->lutc_tab_bytes = tb; p->lutc_bits = wb;
@@ -983,11 +542,14 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // where four consumers still fit beside it: the long segments of such batches are the ones with large coefficients,
             // whose symbols a 12-bit table finishes least often, and the launch lasts as long as their walk.
             // (0 = built and uploaded, 1 = such tables cannot be built — no fused launch then —, negative = an API error)
+            int acb = 12, want_prod = 0;                         // MJ_FUSED_ACBITS / MJ_FUSED_PRODUCERS: the experiments of profiles/r06_fused_balance.txt
+            if (const char *e = mj::opt("MJ_FUSED_ACBITS")) acb = atoi(e);
+            if (const char *e = mj::opt("MJ_FUSED_PRODUCERS")) want_prod = atoi(e);
             auto fused_tables = [&](bool luma13) -> int {
-                int ab[4] = {12, 12, 12, 12};
+                int ab[4] = {acb, acb, acb, acb};
                 if (luma13) ab[(p->ac_slot_pk >> (8 * imgs[0].tab_index[imgs[0].blk_ac_slot[0]])) & 0xFF] = 13;
                 std::vector<uint32_t> lf;
-                if (!build_resolved_tables(b, role, p->ac_slot_pk, p->n_ac13, ab, 0, lf, p->lutf_off, p->lutf_total)) return 1;
+                if (!mj::build_resolved_tables(b, role, p->ac_slot_pk, p->n_ac13, ab, 0, lf, p->lutf_off, p->lutf_total)) return 1;
                 for (int sl = 0; sl < 4; ++sl) p->lutf_bits[sl] = ab[sl];
                 if (p->d_lut12) { ctx->cache.put(p->d_lut12); p->d_lut12 = nullptr; }
                 return upload(ctx, &p->d_lut12, lf.data(), lf.size());
@@ -995,7 +557,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if (allow && want_cons > 0 && mode == 1) {
                 if ((rc = fused_tables(luma13 == 1)) < 0) return rc;
                 if (rc == 0) {
-                    p->fused = mj::fused_shape(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, b->n_images, fused_spi, want_cons);
+                    p->fused = mj::fused_shape(mj::device_cus(), p->lutf_total, p->n_dc13, p->hmax, p->vmax, p->transposed, b->n_images, fused_spi, want_cons, want_prod);
                     p->fused_spi = fused_spi;
                     p->use_fused = p->fused.ok;
                 }
@@ -1031,112 +593,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             if ((rc = upload(ctx, &p->d_jobs, jobs.data(), jobs.size())) != MJ_OK) return rc;
             p->n_jobs = (int)jobs.size();
         }
-        if (prog) {
-            if ((rc = upload(ctx, &p->d_pscans, pscans.data(), pscans.size())) != MJ_OK) return rc;
-            p->n_psegs = (int64_t)psegs.size();
-            MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pstates, psegs.size() * sizeof(mj::DevProgState) + 16));
-            // DC/AC first scans and AC refining scans walk the stage-0 stream (progressive_fast.hip)
-            // (a plan none of whose scans they take — non-interleaved baseline files, DC refinement only — needs neither the
-            // stage-0 stream nor its pass per execute)
-            if (p->prog_fast) {
-                // stage 0 for every segment of the progressive scans, 16 KiB of source bytes per wavefront.  Stage 0 puts
-                // segment number n at dword (begin >> 2) + n of the stream buffer, which keeps the segments apart only if
-                // they are numbered in blob order — psegs is ordered by dependency level, so each one records its number
-                std::vector<int32_t> order(psegs.size());
-                for (size_t i = 0; i < psegs.size(); ++i) order[i] = (int32_t)i;
-                std::sort(order.begin(), order.end(), [&](int32_t a2, int32_t b2) { return psegs[a2].begin < psegs[b2].begin; });
-                std::vector<mj::DevSegment> ds(psegs.size());
-                std::vector<mj::DevPiece> pcs;
-                for (size_t n = 0; n < psegs.size(); ++n) {
-                    mj::DevProgSeg &g = psegs[order[n]];
-                    g.stream_slot = (int32_t)n;
-                    ds[n] = mj::DevSegment{g.begin, g.len, pscans[g.scan].image, g.mcu0, g.n_mcu, g.last, 0};
-                    const int32_t first = (int32_t)pcs.size();
-                    for (int off = 0; off == 0 || off < g.len; off += 16384)
-                        pcs.push_back(mj::DevPiece{(int32_t)n, first, off, std::min(16384, std::max(0, g.len - off))});
-                }
-                if ((rc = upload(ctx, &p->d_prog_dsegs, ds.data(), ds.size())) != MJ_OK) return rc;
-                p->n_pieces = (int64_t)pcs.size();
-                if ((rc = upload(ctx, &p->d_pieces, pcs.data(), pcs.size())) != MJ_OK) return rc;
-                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_piece_kept, pcs.size() * sizeof(int32_t) + 16));
-                const size_t sbytes = ((size_t)b->blob_len / 4 + psegs.size() + 256) * 4;
-                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stream, sbytes));
-                MJ_HIP(ctx, hipMemsetAsync(p->d_stream, 0, sbytes, ctx->setup_stream));
-                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_seg_bits, (psegs.size() + 1) * sizeof(int32_t)));
-                const int LS = 1 << mj::kProgLutBits;
-                std::vector<uint16_t> lp((size_t)b->n_huff * LS, 0);
-                for (int t = 0; t < b->n_huff; ++t) {
-                    int code = 0, k = 0;
-                    for (int l = 1; l <= 16; ++l) {
-                        code <<= 1;
-                        for (int i = 0; i < b->huff[t].bits[l - 1] && k < 256; ++i, ++k, ++code) {
-                            if (l > mj::kProgLutBits || code >= (1 << l)) continue;
-                            const int shift = mj::kProgLutBits - l;
-                            for (int f = 0; f < (1 << shift); ++f) {
-                                uint16_t &e = lp[(size_t)t * LS + ((code << shift) | f)];
-                                if (e == 0) e = (uint16_t)((l << 8) | b->huff[t].vals[k]);      // the shortest key wins
-                            }
-                        }
-                    }
-                }
-                if ((rc = upload(ctx, &p->d_lut11p, lp.data(), lp.size())) != MJ_OK) return rc;
-                if (p->prog_chunks && p->n_psegs_wave < (int64_t)psegs.size()) {
-                    // the chunked first AC scans (progressive_chunks.hip): their segments, the chunk list — padded to whole wavefronts
-                    // per segment, so that a wavefront's lanes share a table —, and per table the 9-bit LUT + canonical code book
-                    const int cb = std::min(std::max(p->pc_chunk_bytes, 128), 65536) & ~3;
-                    p->pc_chunk_bytes = cb;
-                    std::vector<mj::DevAcSeg> as;
-                    std::vector<mj::DevChunk> ck;
-                    for (size_t i = (size_t)p->n_psegs_wave; i < psegs.size(); ++i) {
-                        const mj::DevProgSeg &g = psegs[i];
-                        const mj::DevProgScan &ps = pscans[g.scan];
-                        mj::DevAcSeg a{};
-                        a.image = ps.image; a.comp = ps.comp[0]; a.ss = ps.ss; a.se = ps.se; a.al = ps.al; a.table = ps.ac_tab[0];
-                        a.stream_slot = g.stream_slot; a.stream_dw = (int32_t)((g.begin >> 2) + g.stream_slot);
-                        a.first_blk = g.mcu0; a.n_blk = g.n_mcu; a.mcu_count_h = ps.mcu_count_h; a.last = g.last;
-                        a.chunk0 = (int32_t)ck.size();
-                        a.n_chunks = std::max(1, (g.len + cb - 1) / cb);
-                        for (int j = 0; j < a.n_chunks; ++j) ck.push_back(mj::DevChunk{(int32_t)as.size(), j});
-                        while (ck.size() % 64) ck.push_back(mj::DevChunk{-1, 0});
-                        as.push_back(a);
-                    }
-                    std::vector<uint8_t> tb((size_t)b->n_huff * (1024 + mj::kProgCanonBytes), 0);
-                    for (int t = 0; t < b->n_huff; ++t) {
-                        uint16_t *l9 = reinterpret_cast<uint16_t *>(tb.data() + (size_t)t * (1024 + mj::kProgCanonBytes));
-                        for (int i = 0; i < 512; ++i) {
-                            const uint16_t e = lp[(size_t)t * LS + ((size_t)i << (mj::kProgLutBits - 9))];
-                            l9[i] = (e >> 8) <= 9 ? e : (uint16_t)0;
-                        }
-                        uint16_t *lim = l9 + 512;
-                        int16_t *base = reinterpret_cast<int16_t *>(lim + 16);
-                        uint8_t *vals = reinterpret_cast<uint8_t *>(base + 16);
-                        int code = 0, k = 0;
-                        for (int l = 1; l <= 16; ++l) {
-                            code <<= 1;
-                            base[l - 1] = (int16_t)(k - code);
-                            const int n = b->huff[t].bits[l - 1];
-                            code += n; k += n;
-                            lim[l - 1] = (uint16_t)std::min<int64_t>((int64_t)code << (16 - l), 65535);
-                        }
-                        for (int i = 0; i < 256; ++i) vals[i] = b->huff[t].vals[i];
-                    }
-                    p->n_acsegs = (int)as.size(); p->n_pc_chunks = (int64_t)ck.size();
-                    if ((rc = upload(ctx, &p->d_acsegs, as.data(), as.size())) != MJ_OK) return rc;
-                    if ((rc = upload(ctx, &p->d_pc_chunks, ck.data(), ck.size())) != MJ_OK) return rc;
-                    if ((rc = upload(ctx, &p->d_pc_tabs, tb.data(), tb.size())) != MJ_OK) return rc;
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_exit, ck.size() * 8 + 16));
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_outs, ck.size() * sizeof(mj::DevChunkOut) + 16));
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_items, ck.size() * 16 + 16));
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_owner, ck.size() * 8 + 128));     // (+ the work list's counter behind it, + a lock word per chunk behind that)
-                    MJ_HIP(ctx, ctx->cache.get((void **)&p->d_pc_vsegs, ck.size() * sizeof(mj::DevVSeg) + 16));
-                } else {
-                    p->prog_chunks = false;
-                }
-            }
-            if ((rc = upload(ctx, &p->d_psegs, psegs.data(), psegs.size())) != MJ_OK) return rc;
-            if (p->n_split)     // by segment (the first n_split of them), two sets: even and odd bands
-                MJ_HIP(ctx, ctx->cache.get((void **)&p->d_psubs, (size_t)p->n_split * 2 * mj::kProgSub * sizeof(mj::DevProgSub)));
-        }
+        if (prog && (rc = mj::plan_progressive_upload(ctx, b, p, prog_scans)) != MJ_OK) return rc;
         if (b->blob_mem == MJ_MEM_HOST) {
             if ((rc = upload(ctx, &p->d_blob_owned, b->blob, (size_t)b->blob_len, 1024)) != MJ_OK) return rc;
             p->d_blob = p->d_blob_owned;

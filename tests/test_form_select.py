@@ -88,18 +88,27 @@ def test_segments_are_dealt_out_by_length_only_when_they_differ():
 
 
 def test_fused_launch_shapes():
-    """How a fused launch is cut (fused.hip: fused_shape): whole images per workgroup, every workgroup resident at once, 8
-    producer wavefronts of at most 64 lanes, as many consumers as the LDS left beside them holds (8 320 B each for 4:2:0)."""
+    """How a fused launch is cut (fused.hip: fused_shape): whole images per workgroup, 8 producer wavefronts of at most 64 lanes,
+    as many consumers as the LDS left beside them holds (8 320 B each for 4:2:0) — every workgroup resident at once where the
+    batch fits the chip's lanes, and in PASSES (a workgroup's images a few at a time) where it does not."""
     c3 = B.fused_shape_rule(1024, 68)
-    assert c3 == dict(ok=True, images_per_wg=4, producers=8, lanes=34, consumers=8, producer_lds=c3["producer_lds"]) and c3["producer_lds"] <= 92 * 1024
+    assert c3 == dict(ok=True, images_per_wg=4, producers=8, lanes=34, consumers=8, producer_lds=c3["producer_lds"], passes=1, workgroups=256)
+    assert c3["producer_lds"] <= 92 * 1024
     c4 = B.fused_shape_rule(1250, 68)                   # config 4's share: 5 images per workgroup, 340 lanes
-    assert (c4["ok"], c4["images_per_wg"], c4["producers"], c4["lanes"]) == (True, 5, 8, 43) and 4 <= c4["consumers"] < 8
+    assert (c4["ok"], c4["images_per_wg"], c4["producers"], c4["lanes"], c4["passes"]) == (True, 5, 8, 43, 1) and 4 <= c4["consumers"] < 8
     half = B.fused_shape_rule(512, 68)
-    assert (half["images_per_wg"], half["producers"], half["lanes"], half["consumers"]) == (2, 4, 34, 8)
+    assert (half["images_per_wg"], half["producers"], half["lanes"], half["consumers"], half["workgroups"]) == (2, 4, 34, 8, 256)
     one = B.fused_shape_rule(200, 68)
-    assert (one["images_per_wg"], one["producers"], one["lanes"]) == (1, 2, 34)
-    assert not B.fused_shape_rule(2048, 68)["ok"]       # 544 segments per workgroup: more than 8 x 64 lanes
-    assert not B.fused_shape_rule(1024, 135)["ok"]      # 2160p in rows: 540 lanes
+    assert (one["images_per_wg"], one["producers"], one["lanes"], one["workgroups"]) == (1, 2, 34, 200)
+    # more segments than 8 x 64 lanes per workgroup: round 5 refused these, now the workgroup takes its images in passes
+    two = B.fused_shape_rule(2048, 68)                  # 8 images per workgroup = 544 segments: 2 passes of 4
+    assert (two["ok"], two["images_per_wg"], two["passes"], two["workgroups"], two["lanes"]) == (True, 4, 2, 256, 34)
+    uhd = B.fused_shape_rule(1024, 135, hmax=2, vmax=1)  # 1080p 4:2:2 (or 2160p 4:2:0) in rows: 4 images = 540 segments: 2 passes of 2
+    assert (uhd["ok"], uhd["images_per_wg"], uhd["passes"], uhd["workgroups"], uhd["producers"] * uhd["lanes"] >= 270) == (True, 2, 2, 256, True)
+    halfrow = B.fused_shape_rule(1024, 270, hmax=1, vmax=1)   # 1080p 4:4:4, restart interval half an MCU row: one image per pass, four passes
+    assert (halfrow["ok"], halfrow["images_per_wg"], halfrow["passes"], halfrow["workgroups"]) == (True, 1, 4, 256)
+    assert not B.fused_shape_rule(64, 513)["ok"]        # one image's segments must fit the producers' lanes
+    assert not B.fused_shape_rule(200000, 68)["ok"]     # (more than 64 passes: the two launches)
     assert B.fused_shape_rule(1024, 68, want_consumers=3)["consumers"] == 3
     assert not B.fused_shape_rule(1024, 68, want_consumers=0)["ok"]
     # three 13-bit-sized tables would not leave room: the budget is what decides
@@ -107,8 +116,48 @@ def test_fused_launch_shapes():
     # row-major: the strip worker's geometry is the transposed image's (4:2:2 becomes 4:4:0 and back)
     a, b = B.fused_shape_rule(1000, 45, hmax=2, vmax=1, transposed=True), B.fused_shape_rule(1000, 45, hmax=1, vmax=2)
     assert a == b and a["ok"]
-    for n, spi in ((1024, 68), (1250, 68), (777, 30), (1021, 60), (64, 17)):
+    for n, spi in ((1024, 68), (1250, 68), (777, 30), (1021, 60), (64, 17), (3000, 68), (1500, 135), (5, 400)):
         s = B.fused_shape_rule(n, spi)
         if s["ok"]:
-            assert s["images_per_wg"] * 256 >= n and s["producers"] * s["lanes"] >= s["images_per_wg"] * spi
+            assert s["images_per_wg"] * s["passes"] * s["workgroups"] >= n and s["workgroups"] <= 256
+            assert s["producers"] * s["lanes"] >= s["images_per_wg"] * spi and s["images_per_wg"] * spi <= 512
             assert s["producers"] + s["consumers"] <= 16 and s["lanes"] <= 64
+            # no workgroup without work, no pass more than needed
+            assert (s["workgroups"] - 1) * s["passes"] * s["images_per_wg"] < n
+
+
+def test_progressive_split_tiers():
+    """Which refining AC scans of a progressive batch are walked as scout + parts (form_select.h: choose_prog_split): all of them
+    while the chip has wave slots for the extra walks, then each image's largest with two parts, then none — libjpeg's 10-scan
+    script on 1080p files (one segment per scan), the family the thresholds were measured on (384 .. 1536 files)."""
+    def batch(n, sizes=(75000, 72000, 110000, 290000)):       # refining AC scans per image (bytes): Cb, Cr, luma's first refinement, luma's last
+        scans = []
+        for i in range(n):
+            scans += [(i, 1, -1)] * 5                            # DC, three first AC scans, DC refinement ... : never candidates
+            scans += [(i, 1, b) for b in sizes]
+            scans += [(i, 1, -1)]
+        return scans
+    cand = [5, 6, 7, 8]
+    # 8 192 wave slots: four scouts + 16 parts per image fit four fifths of them up to 327 images, three walks per image two fifths up to 1 092
+    for n, want in ((16, "all"), (327, "all"), (328, "largest"), (768, "largest"), (1024, "largest"), (1092, "largest"), (1093, "none"), (2048, "none")):
+        split, parts = B.prog_split_rule(n, batch(n))
+        per_image = [[split[i * 10 + c] for c in cand] for i in (0, n - 1)]
+        if want == "all":
+            assert per_image == [[True] * 4] * 2 and parts == 4, (n, per_image)
+            assert sum(split) == 4 * n
+        elif want == "largest":
+            assert per_image == [[False, False, False, True]] * 2 and parts == 2, (n, per_image)     # the last luma refinement
+        else:
+            assert not any(split) and parts == 4, n
+    # a band's walk must be long enough: 68 bands x 1 KiB
+    split, _ = B.prog_split_rule(4, batch(4, sizes=(69631, 69632, 1000, 200000)))
+    assert [split[c] for c in cand] == [False, True, False, True]
+    # the switches: never / every candidate / the largest of each image; a caller's parts are kept
+    assert not any(B.prog_split_rule(4, batch(4), mode=0)[0])
+    assert sum(B.prog_split_rule(2048, batch(2048, sizes=(10, 20, 30, 40)), mode=2)[0]) == 4 * 2048
+    split, parts = B.prog_split_rule(2048, batch(2048), mode=3, parts=3)
+    assert sum(split) == 2048 and parts == 3 and split[8]
+    assert B.prog_split_rule(700, batch(700), parts=8)[1] == 8
+    # a smaller chip runs out of slots sooner
+    small = B.prog_split_rule(200, batch(200), wave_slots=64 * 32)[0]
+    assert small[8] and not small[5]

@@ -2097,7 +2097,7 @@ def _fused_batch(ss, W, H, n, distinct, seed, ri=None, gpu_segment=False, layout
     from pyjpegdecoder_amd import _binding as B
     from pyjpegdecoder_amd import parse_jpeg
     from pyjpegdecoder_amd.batch import prepare_batch
-    mw = 16 if ss in ("420", "422") else 8
+    mw = 32 if ss == "411" else (16 if ss in ("420", "422") else 8)
     ri = (W + mw - 1) // mw if ri is None else ri
     blob, offs = synth.synth_batch(distinct, seed, W, H, 85, ss, ri)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
@@ -2307,15 +2307,17 @@ def test_fused_launches_of_several_plans_at_once(dec, mixed, tune):
 
 
 def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
-    """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): a restart interval that is not
-    one MCU row, planar pixels, seam outputs, the exact-order stage 2, restart segments of very different lengths (dealt out
-    by length), MJ_FUSED=0 — and whatever it is, the pixels are the oracle's."""
+    """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): in x-major output a restart
+    interval that does not divide the MCU row (two rows per segment: a column would only be complete when every segment is in
+    its last row; 25 MCUs on a row of 40), planar pixels, seam outputs, the exact-order stage 2, MJ_FUSED=0 — and whatever
+    it is, the pixels are the oracle's.  (Round 5 also kept out half rows and every interval in row-major output: those fuse now,
+    test_fused_launch_any_restart_interval.)"""
     torch = pytest.importorskip("torch")
     from oracle import oracle
     from pyjpegdecoder_amd import _binding as B
     W, H, n, distinct = 640, 480, 800, 5
-    for kind in ("half_rows", "two_rows", "planar", "seams", "exact", "off"):
-        ri = {"half_rows": 20, "two_rows": 80}.get(kind)
+    for kind in ("two_rows", "odd_interval", "planar", "seams", "exact", "off"):
+        ri = {"two_rows": 80, "odd_interval": 25}.get(kind)
         layout = B.MJ_LAYOUT_PLANAR_XMAJOR if kind == "planar" else None
         flags = {"seams": B.MJ_FLAG_KEEP_IDCT, "exact": B.MJ_FLAG_EXACT_ONLY}.get(kind, 0)
         raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000, ri=ri, layout=layout, flags=flags)
@@ -2329,6 +2331,81 @@ def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
     raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000)
     _, _, form = _decode_plan(dec.ctx, prep, n, torch, [("MJ_HUFFMAN", "lanes")])
     assert form & B.MJ_FORM_FUSED
+
+
+@pytest.mark.parametrize("layout,ss,W,H,n,distinct,ri", [
+    ("xmajor", "420", 640, 480, 800, 5, 20),          # half an MCU row per segment (round 5: two launches)
+    ("xmajor", "444", 640, 480, 700, 6, 20),          # a quarter of a row; 240 segments per image: two passes on 256 CUs
+    ("xmajor", "422", 800, 608, 900, 7, 10),          # a fifth of a row: 380 segments per image, one image per pass, four passes
+    ("rowmajor", "420", 640, 480, 800, 5, 20),        # row-major: pieces of rows behind half-row segments
+    ("rowmajor", "420", 640, 480, 800, 5, 80),        # ... two rows per segment
+    ("rowmajor", "444", 640, 480, 600, 6, 25),        # ... an interval with no relation to the row (80 MCUs): pieces straddle segments
+    ("rowmajor", "440", 512, 512, 700, 9, 100),       # ... longer than a row and not a multiple of it; the last segment short
+    ("rowmajor", "422", 800, 608, 650, 4, 8),         # ... shorter than a piece (16 MCUs): several segments per piece; 475 per image, three passes
+    ("rowmajor", "422", 800, 608, 650, 4, 7),         # ... 543 segments per image: more than a workgroup's producers have lanes -> the two launches
+    ("xmajor", "411", 640, 480, 600, 5, 20),          # 4:1:1 (32-pixel MCUs: 20 per row), one row per segment — round 6: fused as well
+    ("rowmajor", "411", 640, 480, 600, 5, 40),        # ... row-major 4:1:1 keeps the two launches (form_select.h)
+])
+def test_fused_launch_any_restart_interval(dec, layout, ss, W, H, n, distinct, ri, tune):
+    """Round 6: the fused launch no longer needs one restart interval per MCU row.  A consumer's job is ready when the producer
+    waves that hold its MCUs are past them, worked out per MCU (fused.hip: JobGeo): x-major plans take every interval that
+    divides the row, row-major plans any.  Against the two launches byte for byte (coefficient store poisoned, three executes),
+    every distinct file against the oracle, 1 / 8 consumers, markers found on the host and on the GPU."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    raws, files, prep = _fused_batch(ss, W, H, n, distinct, 99000 + W + ri, ri=ri, layout=lay)
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0"), ("MJ_HUFFMAN", "lanes")])
+    assert not st2.any() and not form2 & B.MJ_FORM_FUSED
+    per = W * H * 3
+    imgs = two.view(n, per)
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        i = next(k for k in range(n) if (5 * k + k // distinct) % distinct == d)
+        got = imgs[i].cpu().numpy()
+        got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
+        assert np.array_equal(got, want), d
+    mw, mh = (32 if ss == "411" else (16 if ss in ("420", "422") else 8)), (16 if ss in ("420", "440") else 8)
+    spi = -(-(-(-W // mw) * -(-H // mh)) // ri)
+    want_fused = spi <= 512 and not (ss == "411" and layout == "rowmajor")     # (4:1:1 transposed: 13 KB strips, no room beside the walk)
+    for cons in (None, "1", "8"):
+        opts = [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED_CONSUMERS", cons)] if cons else [])
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, opts)
+        assert bool(form & B.MJ_FORM_FUSED) == want_fused, (form, cons, spi)
+        assert not st.any() and torch.equal(fused, two), cons
+    _, _, prep_g = _fused_batch(ss, W, H, n, distinct, 99000 + W + ri, ri=ri, gpu_segment=True, layout=lay)
+    fused, st, form = _decode_plan(dec.ctx, prep_g, n, torch, [("MJ_HUFFMAN", "lanes")])
+    assert bool(form & B.MJ_FORM_FUSED) == want_fused and not st.any() and torch.equal(fused, two)
+
+
+@pytest.mark.parametrize("layout", ["xmajor", "rowmajor"])
+@pytest.mark.parametrize("ss,W,H,n,distinct", [("422", 1920, 1080, 1024, 8), ("420", 640, 480, 4400, 6), ("444", 96, 1096, 1601, 5)])
+def test_fused_launch_in_passes(dec, layout, ss, W, H, n, distinct, tune):
+    """Round 6: a workgroup whose images hold more restart segments than its producers have lanes (8 x 64) takes them in PASSES —
+    1024 x 1080p 4:2:2 (135 MCU rows: four images = 540 segments; round 5: two launches, 9.1 ms against 6.3 for 4:2:0), 4400 small
+    files (18 per workgroup), tall narrow files (137 rows, ragged: the last workgroup has fewer passes).  The consumers go from one
+    pass's jobs to the next's; a producer's progress word keeps rising (pass << 20 | MCUs).  Against the two launches byte for
+    byte, every distinct file against the oracle."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    raws, files, prep = _fused_batch(ss, W, H, n, distinct, 55000 + W, layout=lay)
+    two, st2, form2 = _decode_plan(dec.ctx, prep, n, torch, [("MJ_FUSED", "0"), ("MJ_HUFFMAN", "lanes")])
+    assert not st2.any() and not form2 & B.MJ_FORM_FUSED
+    per = W * H * 3
+    imgs = two.view(n, per)
+    for d, want in enumerate(oracle_rgb_all(raws)):
+        i = next(k for k in range(n) if (5 * k + k // distinct) % distinct == d)
+        got = imgs[i].cpu().numpy()
+        got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
+        assert np.array_equal(got, want), d
+    mh = 16 if ss in ("420", "440") else 8
+    shape = B.fused_shape_rule(n, -(-H // mh), hmax=2 if ss in ("420", "422") else 1, vmax=2 if ss in ("420", "440") else 1, transposed=layout == "rowmajor")
+    assert shape["ok"] and shape["passes"] >= 2, shape
+    for cons in (None, "2"):
+        opts = [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED_CONSUMERS", cons)] if cons else [])
+        fused, st, form = _decode_plan(dec.ctx, prep, n, torch, opts)
+        assert form & B.MJ_FORM_FUSED, (form, cons)
+        assert not st.any() and torch.equal(fused, two), cons
 
 
 def test_fused_launch_damaged_files_do_not_stall_their_workgroup(dec, tune):
