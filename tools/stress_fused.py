@@ -1,0 +1,107 @@
+"""One-off stress run on the GPU box for the fused launch (fused.hip) after round 6 generalised it: random UNIFORM batches — sampling
+layout, image size, image count, restart interval (one row, fractions of a row, several rows, unrelated to the row), pixel layout,
+who finds the markers, number of consumers — each decoded by the plan's own execute (one fused launch where form_select.h allows
+it) and by the two launches (MJ_FUSED=0), coefficient store poisoned before every execute; outputs compared byte for byte, every
+distinct file against the oracle.  Not part of the test suite (minutes):
+    python tools/stress_fused.py [n_trials] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from oracle import oracle
+from pyjpegdecoder_amd import _binding as B
+from pyjpegdecoder_amd import parse_jpeg
+from pyjpegdecoder_amd.batch import prepare_batch
+from tools import synth
+
+n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda", 0)
+ctx = B.Context(0)
+
+
+def decode(prep, n, opts):
+    for k, v in opts:
+        B.set_option(k, v)
+    try:
+        d_blob = torch.from_numpy(prep.blob).to(dev)
+        torch.cuda.synchronize()
+        plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+        try:
+            out = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+            keep = None
+            for poison in (0x5A, 0xC3):
+                out.zero_()
+                torch.cuda.synchronize()
+                plan.fill_coef(poison)
+                plan.execute(0, out.data_ptr())
+                plan.sync()
+                if keep is None:
+                    keep = out.clone()
+                elif not torch.equal(out, keep):
+                    return None, None, plan.stage1_form()
+            return keep, plan.read(rgb=False)["status"], plan.stage1_form()
+        finally:
+            plan.close()
+    finally:
+        for k, _ in opts:
+            B.set_option(k, None)
+
+
+bad = fused_n = 0
+t0 = time.time()
+for trial in range(n_trials):
+    ss = str(rng.choice(["420", "422", "440", "444", "411"]))
+    mw = 32 if ss == "411" else (16 if ss in ("420", "422") else 8)
+    mh = 16 if ss in ("420", "440") else 8
+    W, H = int(rng.integers(64, 1500)), int(rng.integers(48, 1200))
+    mpr, mcv = -(-W // mw), -(-H // mh)
+    kind = int(rng.integers(0, 6))
+    divs = [d for d in range(2, 9) if mpr % d == 0]
+    if kind == 0 or (kind == 1 and not divs):
+        ri = mpr
+    elif kind == 1:
+        ri = mpr // int(rng.choice(divs))
+    elif kind == 2:
+        ri = mpr * int(rng.integers(2, 4))
+    else:
+        ri = int(rng.integers(max(4, mpr // 6), 3 * mpr))
+    spi = -(-(mpr * mcv) // ri)
+    # enough segments for the lane form, not more pixels than ~3 GB of output
+    n_lo = max(8, -(-1100 // spi))
+    n_hi = max(n_lo + 1, min(4000, int(3e9 // (W * H * 3))))
+    n = int(rng.integers(n_lo, n_hi))
+    distinct = int(rng.integers(2, 5))
+    layout = str(rng.choice(["xmajor", "rowmajor"]))
+    lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
+    gpu_seg = bool(rng.integers(0, 2))
+    cons = rng.choice([None, "1", "3", "8"])
+    blob, offs = synth.synth_batch(distinct, int(rng.integers(0, 1 << 30)), W, H, int(rng.choice([60, 85, 95])), ss, ri)
+    raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
+    files = [raws[(3 * i + i // distinct) % distinct] for i in range(n)]
+    parsed = [parse_jpeg(f, headers_only=True) for f in files] if gpu_seg else None
+    prep = prepare_batch(files, lay, 0, parsed)
+    base = [("MJ_HUFFMAN", "lanes")]
+    two, st2, form2 = decode(prep, n, base + [("MJ_FUSED", "0")])
+    one, st1, form1 = decode(prep, n, base + ([("MJ_FUSED_CONSUMERS", cons)] if cons else []))
+    per = W * H * 3
+    ok = two is not None and one is not None and not st2.any() and not st1.any() and bool(torch.equal(one, two))
+    if ok:
+        imgs = two.view(n, per)
+        for d in range(distinct):
+            i = next(k for k in range(n) if (3 * k + k // distinct) % distinct == d)
+            got = imgs[i].cpu().numpy()
+            got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
+            ok = ok and np.array_equal(got, oracle.decode(raws[d])["rgb"])
+    fused = bool(form1 & B.MJ_FORM_FUSED)
+    fused_n += fused
+    bad += not ok
+    print(f"trial {trial:3d}: {ss} {W}x{H} x{n} ri={ri} ({mpr} MCUs per row, {spi} segments per image) {layout} markers by {'gpu' if gpu_seg else 'host'} "
+          f"consumers {cons}: {'fused' if fused else 'two launches'} (form {form1}) {'ok' if ok else 'MISMATCH'}", flush=True)
+print(f"{n_trials} trials, {fused_n} of them through a fused launch, {bad} mismatches, {time.time() - t0:.0f} s")
+ctx.close()
+sys.exit(1 if bad else 0)
