@@ -355,8 +355,9 @@ hipError_t launch_destuff_pieces(hipStream_t stream, const uint8_t *blob, const 
 // rank-sorted and thread r writes segment r.  More markers than the list holds: MJ_ST_TAIL, the host segments it.
 namespace {
 constexpr int kScanCap = 2048;
+constexpr int kScanThreads = 512;        // eight wavefronts per image (round 6; four before: 16 wavefronts per CU left the loads' latency exposed)
 }
-__global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict__ blob, const DevScanJob *__restrict__ jobs,
+__global__ __launch_bounds__(kScanThreads) void k_scan_markers(const uint8_t *__restrict__ blob, const DevScanJob *__restrict__ jobs,
                                                      int n_jobs, DevSegment *__restrict__ segs, int32_t *__restrict__ status) {
     __shared__ uint32_t s_pos[kScanCap], s_sorted[kScanCap];
     __shared__ uint32_t s_count, s_term;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict_
     const uint32_t len32 = (uint32_t)(end - begin);
     if (tid == 0) { s_count = 0; s_term = len32; }
     __syncthreads();
-    for (int64_t c0 = abase + (int64_t)wave * 4096; c0 < end; c0 += 4 * 4096) {
+    for (int64_t c0 = abase + (int64_t)wave * 4096; c0 < end; c0 += (kScanThreads / 64) * 4096) {
         // everything behind the terminator is somebody else's data (wave-uniform test; the value only ever drops)
         if (c0 > begin && (uint32_t)(c0 - begin) > *(volatile uint32_t *)&s_term) break;
         uint4 w[4];
@@ -385,6 +386,23 @@ __global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict_
             uint32_t nb = __shfl_down(d[0], 1) & 0xFFu;
             const uint32_t wrap = q < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)w[q < 3 ? q + 1 : 3].x) & 0xFFu : tail;
             nb = lane == 63 ? wrap : nb;
+            // Nearly every 0xFF of entropy-coded data is followed by its stuffed 0x00: the byte-by-byte look below is only
+            // needed where some lane holds an 0xFF in front of a NON-zero byte (a marker, fill bytes, damage) — about one
+            // wavefront row in ten of a file with a restart marker per MCU row.  Four dwords per lane, word-parallel: bytes
+            // equal to 0xFF, bytes whose successor is not zero (round 6: 0.26 -> 0.1x ms per 1024 x 1080p; the loop below
+            // costs ~130 instructions per 16 bytes, this filter ~40)
+            {
+                uint32_t hit = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const uint32_t wd = d[k2], nxt = k2 < 3 ? d[k2 + 1] : nb;
+                    const uint32_t nx = __builtin_amdgcn_alignbit(nxt, wd, 8);                       // each byte's successor
+                    const uint32_t ff = ((wd & 0x7F7F7F7Fu) + 0x01010101u) & wd & 0x80808080u;       // 0x80 where the byte is 0xFF
+                    const uint32_t nz = (((nx & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nx) & 0x80808080u;     // 0x80 where the successor is not 0
+                    hit |= ff & nz;
+                }
+                if (__builtin_amdgcn_ballot_w64(hit != 0u) == 0) continue;
+            }
             uint32_t rstm = 0, termm = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict_
         return;
     }
     // rank sort of the markers in front of the terminator (positions are distinct)
-    for (uint32_t i = tid; i < n_found; i += 256) {
+    for (uint32_t i = tid; i < n_found; i += kScanThreads) {
         const uint32_t p = s_pos[i];
         if (p >= T) continue;
         uint32_t r = 0;
@@ -430,12 +448,12 @@ __global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict_
     __syncthreads();
     {
         uint32_t mine = 0;
-        for (uint32_t i = tid; i < n_found; i += 256) mine += s_pos[i] < T ? 1u : 0u;
+        for (uint32_t i = tid; i < n_found; i += kScanThreads) mine += s_pos[i] < T ? 1u : 0u;
         if (mine) atomicAdd(&s_m, mine);
     }
     __syncthreads();
     const int m = (int)s_m;                          // markers = segments that end at one
-    for (int r = tid; r < n_seg; r += 256) {
+    for (int r = tid; r < n_seg; r += kScanThreads) {
         DevSegment *g = segs + first + r;
         if (r < m && r < n_seg - 1) {
             const uint32_t b0 = r == 0 ? 0u : s_sorted[r - 1] + 2u;
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(256) void k_scan_markers(const uint8_t *__restrict_
 hipError_t launch_scan_markers(hipStream_t stream, const uint8_t *blob, const DevScanJob *jobs, int n_jobs, DevSegment *segs,
                                int32_t *status) {
     if (n_jobs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_markers, dim3((unsigned)n_jobs), dim3(256), 0, stream, blob, jobs, n_jobs, segs, status);
+    hipLaunchKernelGGL(k_scan_markers, dim3((unsigned)n_jobs), dim3(kScanThreads), 0, stream, blob, jobs, n_jobs, segs, status);
     return hipGetLastError();
 }
 

@@ -77,10 +77,16 @@ for trial in range(n_trials):
     n = int(rng.integers(n_lo, n_hi))
     distinct = int(rng.integers(2, 5))
     layout = str(rng.choice(["xmajor", "rowmajor"]))
+    if layout == "xmajor" and mpr % ri != 0 and rng.integers(0, 3) > 0:
+        layout = "rowmajor"                     # (x-major plans only fuse intervals that divide the row: keep most trials on fused ground)
     lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
     gpu_seg = bool(rng.integers(0, 2))
     cons = rng.choice([None, "1", "3", "8"])
-    blob, offs = synth.synth_batch(distinct, int(rng.integers(0, 1 << 30)), W, H, int(rng.choice([60, 85, 95])), ss, ri)
+    fseed, q = int(rng.integers(0, 1 << 30)), int(rng.choice([50, 75, 85, 92]))
+    try:
+        blob, offs = synth.synth_batch(distinct, fseed, W, H, q, ss, ri)
+    except RuntimeError:                        # (the writer's output buffer is one byte per pixel: 4:4:4 at high quality can exceed it)
+        blob, offs = synth.synth_batch(distinct, fseed, W, H, 60, ss, ri)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
     files = [raws[(3 * i + i // distinct) % distinct] for i in range(n)]
     parsed = [parse_jpeg(f, headers_only=True) for f in files] if gpu_seg else None
