@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2400 -- 'bash tools/final_round.sh r05e'
-TAG=${1:-r05e}
+# Everything the round's committed evidence comes from, in one gpurun call:  gpurun --timeout 2700 -- 'bash tools/final_round.sh r06e'
+TAG=${1:-r06e}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1
@@ -17,5 +17,9 @@ bash "$R/tools/layout_sweep.sh" > /dev/null 2>&1
 ( cd "$R" && bash tools/nodri_stats.sh 256 > "$O/nodri_stats_$TAG.txt" 2>&1 )
 ( cd "$R" && timeout 300 python3 tools/stage_probe.py --ri 0 --batch 1 --distinct 1 "" > "$O/nodri_sizes_$TAG.txt" 2>&1; for n in 16 64 256 1024; do timeout 300 python3 tools/stage_probe.py --ri 0 --batch $n --distinct 16 "" MJ_SYNC_COUNT=classic 2>&1 | tail -2 | sed "s/^/$n files: /" >> "$O/nodri_sizes_$TAG.txt"; done )
 ( cd "$R" && timeout 200 python3 tools/single_file_probe.py 120 > "$O/single_file_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 900 python3 tools/stress_fused.py 120 61 > "$O/stress_fused_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 900 python3 tools/stress_parity.py 600 62 > "$O/stress_parity_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 900 python3 tools/stress_progressive.py > "$O/stress_progressive_$TAG.txt" 2>&1 )
+( cd "$R" && timeout 900 python3 tools/stress_crafted.py 600 63 > "$O/stress_crafted_$TAG.txt" 2>&1 )
 ( cd "$R" && { [ -x tools/step_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm tools/step_probe.hip -o tools/step_probe.bin; } && timeout 300 ./tools/step_probe.bin > "$O/step_probe_$TAG.txt" 2>&1 )
 ls "$O" | tail -20

@@ -19,9 +19,22 @@ dst = ROOT / "profiles"
 bench = (src / "bench.json").read_text().strip().splitlines()[-1]
 json.loads(bench)
 (dst / f"{tag}_bench_n1.json").write_text(bench + "\n")
-stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))
+stats = sorted(glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv")), key=lambda f: -Path(f).stat().st_size)     # (the traced process's own: the largest)
 if stats:
     shutil.copy(stats[0], dst / f"{tag}_kernel_stats_batch1024.csv")
+    # the line the traced process itself printed (tools/profile_round.sh): the trace's averages are held against THIS line
+    sl = src / "stats_bench_line.json"
+    if sl.exists() and sl.read_text().strip():
+        line = sl.read_text().strip().splitlines()[-1]
+        d = json.loads(line)
+        (dst / f"{tag}_kernel_stats_bench_line.json").write_text(line + "\n")
+        rows = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(stats[0]))}
+        dom = [k for k in rows if "fused" in k] or [k for k in rows if "reconstruct_fast" in k]
+        if dom:
+            r = rows[dom[0]]
+            print(f"same process: {dom[0][:50]} rocprof average {float(r['AverageNs']) / 1e6:.3f} ms over {r['Calls']} calls (min {float(r['MinNs']) / 1e6:.3f}); "
+                  f"the line: ms_per_step {d['ms_per_step']}, HIP-event launch {d['roofline']['avg_launch_ms']} ms, "
+                  f"shader clock {d['roofline'].get('shader_clock_mhz')} MHz")
 
 
 def per_kernel(pattern):
