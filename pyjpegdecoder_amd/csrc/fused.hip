@@ -548,7 +548,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
     if (!transposed) {
         // the strip worker's jobs of an x-major plan: an MCU column in pieces of a.chunk_strips strips (the plan's numbering:
         // column by column, piece by piece) — one piece where the column is at most 24 strips
-        const int tmw = 64 / (8 * hmax), spc = (mcu_rows + tmw - 1) / tmw;
+        const int tmw = fast_tile_mcus(hmax, vmax, 3, false), spc = (mcu_rows + tmw - 1) / tmw;
         F.col_pieces = (spc + a.chunk_strips - 1) / a.chunk_strips;
         F.piece_rows = a.chunk_strips * tmw;
         if (jobs_per_image != mcus_per_row * F.col_pieces) return hipErrorInvalidValue;
@@ -557,7 +557,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         // the strip worker's jobs on the transposed image are pieces of an MCU ROW of the original (its own numbering: row by
         // row, piece by piece, `chunk_strips` strips each): about 20 MCUs per piece, so that the consumers work a piece behind
         // the walk instead of a row behind it (an LDS ticket costs nothing: the stage-2 kernel's global counter wants big jobs)
-        const int tmw = 64 / (8 * vmax);                       // MCUs per strip (the worker's HS is the image's vmax)
+        const int tmw = fast_tile_mcus(hmax, vmax, 3, true);    // MCUs per strip (the worker's HS is the image's vmax)
         const int strips = std::max(1, 20 / tmw);
         const int spc = (mcus_per_row + tmw - 1) / tmw;
         F.R.chunk_strips = strips;

@@ -292,6 +292,8 @@ hipError_t launch_reconstruct_generic(hipStream_t stream, const ReconArgs &a);
 // fast form: strips of fast_tile_mcus() MCUs in column-major MCU order.  transposed = the kernel runs on the transposed
 // image (blocks and tables stored [u][v]), so its x-major output is the row-major image (MJ_LAYOUT_ROWMAJOR)
 int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed);
+// how many times the 64 lanes' MCUs a strip is tall (FGeo::SV): MCUs of 8 pixel rows whose column runs would be under 192 bytes
+constexpr int strip_sv(int mw, int mh, int nc) { return mh != 8 ? 1 : ((64 / mw) * 8 * nc >= 192 ? 1 : ((64 / mw) * 8 * nc == 64 ? 4 : 2)); }
 // jobs: pieces of at most a.chunk_strips strips of one MCU column, numbered image by image (job_prefix[i] = first job of image i)
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,
                                    const int64_t *job_prefix, int64_t total_jobs, int jobs_per_image);

@@ -101,7 +101,8 @@ static hipError_t launch_fast_t(hipStream_t stream, const ReconArgs &a, const in
 
 // hmax/vmax are the ORIGINAL image's sampling factors; a transposed plan runs the kernel with them swapped
 int fast_tile_mcus(int hmax, int vmax, int ncomp, bool transposed) {
-    return 64 / (ncomp == 1 ? 8 : 8 * (transposed ? vmax : hmax));
+    const int mw = ncomp == 1 ? 8 : 8 * (transposed ? vmax : hmax), mh = ncomp == 1 ? 8 : 8 * (transposed ? hmax : vmax);
+    return 64 / mw * strip_sv(mw, mh, ncomp == 1 ? 1 : 3);
 }
 
 hipError_t launch_reconstruct_fast(hipStream_t stream, const ReconArgs &a, int hmax, int vmax, int ncomp, bool transposed,

@@ -123,14 +123,20 @@ struct FGeo {
     static constexpr int NB = NC == 1 ? 1 : NBY + 2;
     static constexpr int MW = NC == 1 ? 8 : 8 * HS;
     static constexpr int MH = NC == 1 ? 8 : 8 * VS;
-    static constexpr int TMW = 64 / MW;                  // MCUs per wave strip
+    static constexpr int TML = 64 / MW;                  // MCUs the 64 lanes cover in the pixel phase (lane = pixel column x MCU)
+    // MCUs of 8 pixel rows (greyscale; VS = 1 in the kernel's geometry: 4:2:2 and 4:1:1 in x-major output, 4:4:0 in row-major)
+    // make short column runs — TML * 8 * NC bytes: 96 for 4:2:2, 48 for 4:1:1, 64 for greyscale, against 192 for 4:2:0 and 4:4:4 —,
+    // whose ends share their 64-byte sectors with the strips above and below.  Such strips are SV times as tall (strip_sv,
+    // mijpeg_internal.h): a lane does SV MCUs in the pixel phase, and the runs are 192 / 96 / 256 bytes (round 6)
+    static constexpr int SV = strip_sv(MW, MH, NC);
+    static constexpr int TMW = TML * SV;                 // MCUs per wave strip
     static constexpr int NBT = TMW * NB;                 // blocks of a strip
     static constexpr int ROUNDS = (NBT + 7) / 8;         // 8 blocks per round; 4:1:1's 12 blocks leave half of the second round idle
     static constexpr int MCU_STRIDE = NB * 64 + 32;      // int16 elements; +64 B makes phase B's 16-byte reads conflict-free
     static constexpr bool SUB = NC == 3 && NBY > 1;
     static constexpr int STRIP_BYTES = TMW * MCU_STRIDE * 2;
     // per-wave scratch: the transposes of phase A (8 groups x 576 B), then the wave's 64 pixel runs on their way out
-    static constexpr int SCR_BYTES = 64 * MH * NC > 8 * 576 ? 64 * MH * NC : 8 * 576;
+    static constexpr int SCR_BYTES = 64 * MH * NC * SV > 8 * 576 ? 64 * MH * NC * SV : 8 * 576;
     static constexpr int QT_BYTES = 3 * 128;              // this wave's image's quantisation tables
     static constexpr int WAVE_BYTES = STRIP_BYTES + SCR_BYTES + QT_BYTES;
     static constexpr int WTS_ROW = MH + 1;                // float4 per row, padded against bank conflicts
@@ -342,8 +348,8 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
     uint16_t *s_qt = reinterpret_cast<uint16_t *>(wave_lds + G::STRIP_BYTES + G::SCR_BYTES);
     const int grp = lane >> 3, j = lane & 7;
 
-    // phase-B identity of this lane: column px of MCU pk of the strip
-    const int px = lane / G::TMW, pk = lane % G::TMW;
+    // phase-B identity of this lane: column px of MCU pk0 (+ TML per turn) of the strip
+    const int px = lane / G::TML, pk0 = lane % G::TML;
 
     // A strip = TMW vertically adjacent MCUs of one MCU column (strips never wrap to the next column, so a
     // lane's MCU row is strip*TMW + k and every index below is either wave-uniform or a 24-bit multiply).
@@ -440,7 +446,7 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
     if constexpr (!SEAMS) {
         // as many stores behind the first fetch as every later fetch has behind it (see the store phase): otherwise the
         // loop entry is the path "no store after the loads" and the wait in front of phase A becomes vmcnt(0) for every strip
-        constexpr int NT0 = (4 * G::MH * NC + 63) / 64;
+        constexpr int NT0 = (G::MW * G::TMW * G::MH * NC / 16 + 63) / 64;
         unsigned char *dump0 = a.dump + ((size_t)(dump_slot & 4095) * 64 + lane) * 16;
 #pragma unroll
         for (int t = 0; t < NT0; ++t) *reinterpret_cast<volatile u32x4_a4 *>(dump0) = u32x4_a4{0u, 0u, 0u, (uint32_t)t};
@@ -700,7 +706,18 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
         MJ_STAMP(1);          // level 3, next strip's geometry and fetch
 #endif
         // ================= phase B: pixels ==================
+        // A lane is one pixel column of one MCU (64 lanes = MW columns x TML MCUs); where the strip is SV times as tall as that
+        // (MCUs of 8 pixel rows: FGeo), it does SV MCUs one after the other — MCU pk0 + sv * TML of the strip in turn sv — and
+        // the store phase behind the turns moves the whole strip's runs.
         {
+            constexpr int NBYTES = G::MH * NC;
+            unsigned char *const s_out = wave_lds + G::STRIP_BYTES;
+            uint32_t ob[(NBYTES + 3) / 4];
+            constexpr int RGB = G::MH / 8;               // bits of a turn's `rg`: one per 8-row half of the MCU
+            int act_m = 0, slow_m = 0, rg_m = 0;         // per turn: bit sv = lane active / slow; RGB bits from bit RGB * sv = rg
+#pragma unroll
+          for (int sv = 0; sv < G::SV; ++sv) {
+            const int pk = pk0 + sv * G::TML;
 #ifdef MJ_DIAGNOSTIC
             const bool have = pk < n_valid && a.debug != 2 && !(dm & 2);
 #else
@@ -710,7 +727,6 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
             const int16_t *mt = s_strip + pk * G::MCU_STRIDE;
             const int nrows = min(G::MH, H - gy0);
             unsigned char *dst = col_dst + (int64_t)px * hnc_i + gy0 * NC;
-            constexpr int NBYTES = G::MH * NC;
 
             if constexpr (SEAMS) {
                 if (have && gx < W)
@@ -719,7 +735,6 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
                                                    a.planes ? a.planes + (im->pix_off + (T ? (int64_t)gy0 * W + gx : (int64_t)gx * H + gy0)) * NC : nullptr,
                                                    T ? W * NC : NC);
             } else {
-                uint32_t ob[(NBYTES + 3) / 4];
 #pragma unroll
                 for (int i = 0; i < (NBYTES + 3) / 4; ++i) ob[i] = 0;
                 bool slow = false;
@@ -846,7 +861,24 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
                 }
                 }   // have
                 const bool active = have && gx < W;
-                const bool fast = active && !slow;
+                act_m |= active ? 1 << sv : 0;
+                slow_m |= slow ? 1 << sv : 0;
+                rg_m |= rg << (RGB * sv);
+                // the lane's bytes of this MCU into the staging area, in run order: column px's run is its TMW MCUs back to back
+                {
+                    unsigned char *mine = s_out + (px * G::TMW + pk) * NBYTES;
+                    if constexpr (NBYTES % 16 == 0) {
+#pragma unroll
+                        for (int i = 0; i < NBYTES / 16; ++i)
+                            reinterpret_cast<uint4 *>(mine)[i] = make_uint4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NBYTES / 8; ++i) reinterpret_cast<uint2 *>(mine)[i] = make_uint2(ob[2 * i], ob[2 * i + 1]);
+                    }
+                }
+            }
+          }   // sv
+            if constexpr (!SEAMS) {
 #ifdef MJ_DIAGNOSTIC
                 MJ_STAMP(2);      // pixel arithmetic
 #endif
@@ -855,13 +887,13 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
                 if (dbg_nostore) { uint32_t acc = 0;
 #pragma unroll
                     for (int i = 0; i < (NBYTES + 3) / 4; ++i) acc ^= ob[i];
-                    if (acc == 0x12345678u && slow) dst[0] = 1; }
+                    if (acc == 0x12345678u && slow_m) *(col_dst) = 1; }
 #else
                 constexpr bool dbg_nostore = false;
 #endif
                 if (!dbg_nostore) {
-                // ---- stores.  A lane holds NBYTES consecutive bytes of one image column and the TMW lanes of a column
-                // hold one contiguous run; written lane by lane, one store instruction would touch 64 separate
+                // ---- stores.  A lane holds NBYTES consecutive bytes of one image column per MCU and the TMW MCUs of a column
+                // are one contiguous run; written lane by lane, one store instruction would touch 64 separate
                 // 16-byte pieces.  So the wave's bytes go through LDS (the transpose scratch is free now) and come back
                 // as 16-byte pieces in run order: consecutive lanes write consecutive addresses.
                 // The NT store instructions below are executed for EVERY strip, branch-free: pieces that must not land in
@@ -873,27 +905,22 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
                 // bytes of a column run that lie inside the image (the bottom strip of an image whose height is no multiple of
                 // the strip's: its last piece is stored as the 16 bytes that END at the image's edge — rewriting a few bytes of its
                 // predecessor with the same values — so the store stays one 16-byte instruction per piece)
-                constexpr int RUN = G::TMW * NBYTES, NPIECE = 4 * NBYTES;
+                constexpr int RUN = G::TMW * NBYTES, NPIECE = G::MW * RUN / 16;
                 const int runv = min(RUN, (H - y_first * G::MH) * NC);
-                const bool staged = runv >= 16 && (hnc_i & 3) == 0 && (rgb_off & 3) == 0 && __ballot(active && !fast) == 0;
+                const bool staged = runv >= 16 && (hnc_i & 3) == 0 && (rgb_off & 3) == 0 && __ballot((act_m & slow_m) != 0) == 0;
                 {
                     static_assert(RUN % 16 == 0 && NBYTES % 8 == 0, "column runs are whole 16-byte pieces");
-                    unsigned char *s_out = wave_lds + G::STRIP_BYTES;
-                    unsigned char *mine = s_out + lane * NBYTES;
-                    if constexpr (NBYTES % 16 == 0) {
-#pragma unroll
-                        for (int i = 0; i < NBYTES / 16; ++i)
-                            reinterpret_cast<uint4 *>(mine)[i] = make_uint4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NBYTES / 8; ++i) reinterpret_cast<uint2 *>(mine)[i] = make_uint2(ob[2 * i], ob[2 * i + 1]);
-                    }
                     if constexpr (NC == 3) {
                         // green again where the fp32 quotient may be one off or sits on a tie (about 6 % of the strips have such a
                         // pixel in some lane): patched into the staged bytes, all in LDS
-                        if (staged && __builtin_amdgcn_ballot_w64(fast && rg != 0) != 0) {
-                            if (fast && rg != 0)
-                                green_fix_lds<HS, VS, T>(lds_off(mt), lds_off(s_wts + px * G::WTS_ROW), lds_off(mine), px, rg);
+                        if (staged && __builtin_amdgcn_ballot_w64(act_m != 0 && rg_m != 0) != 0) {
+#pragma unroll
+                            for (int sv = 0; sv < G::SV; ++sv) {
+                                const int pk = pk0 + sv * G::TML, rg = (rg_m >> (RGB * sv)) & ((1 << RGB) - 1);
+                                if (((act_m >> sv) & 1) && rg != 0)
+                                    green_fix_lds<HS, VS, T>(lds_off(s_strip + pk * G::MCU_STRIDE), lds_off(s_wts + px * G::WTS_ROW),
+                                                             lds_off(s_out + (px * G::TMW + pk) * NBYTES), px, rg);
+                            }
                         }
                     }
                     // Every lane stores one 16-byte piece per instruction, whatever the strip looks like.  Pieces that do not exist
@@ -948,20 +975,27 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
 #ifdef MJ_DIAGNOSTIC
                 MJ_STAMP(3);      // staging through LDS + the NT stores
 #endif
-                if (!staged && active) {
-                    if (slow || rg != 0 || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
-                        pixel_run_exact<HS, VS, NC, T>(mt, px, dst, nrows, nullptr, 0);
-                    } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
+                if (!staged && act_m != 0) {
+                    // the per-lane way (rare: a lane that fp32 cannot decide, an image whose columns are not dword aligned): every
+                    // MCU of the lane's turns from its staged bytes — or, where those are not final, through the exact routine
 #pragma unroll
-                        for (int i = 0; i < NBYTES / 16; ++i)
-                            reinterpret_cast<uint4 *>(dst)[i] = make_uint4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
-                    } else if (NBYTES % 8 == 0 && ((uintptr_t)dst & 7) == 0) {
+                    for (int sv = 0; sv < G::SV; ++sv) {
+                        if (!((act_m >> sv) & 1)) continue;
+                        const int pk = pk0 + sv * G::TML, gy0 = (y_first + pk) * G::MH, nrows = min(G::MH, H - gy0);
+                        unsigned char *dst = col_dst + (int64_t)px * hnc_i + gy0 * NC;
+                        const unsigned char *mine = s_out + (px * G::TMW + pk) * NBYTES;
+                        if (((slow_m >> sv) & 1) || ((rg_m >> (RGB * sv)) & ((1 << RGB) - 1)) != 0 || nrows != G::MH || ((uintptr_t)dst & 3) != 0) {
+                            pixel_run_exact<HS, VS, NC, T>(s_strip + pk * G::MCU_STRIDE, px, dst, nrows, nullptr, 0);
+                        } else if (NBYTES % 16 == 0 && ((uintptr_t)dst & 15) == 0) {
 #pragma unroll
-                        for (int i = 0; i < NBYTES / 8; ++i)
-                            reinterpret_cast<uint2 *>(dst)[i] = make_uint2(ob[2 * i], ob[2 * i + 1]);
-                    } else {
+                            for (int i = 0; i < NBYTES / 16; ++i) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(mine)[i];
+                        } else if (NBYTES % 8 == 0 && ((uintptr_t)dst & 7) == 0) {
 #pragma unroll
-                        for (int i = 0; i < NBYTES / 4; ++i) reinterpret_cast<uint32_t *>(dst)[i] = ob[i];
+                            for (int i = 0; i < NBYTES / 8; ++i) reinterpret_cast<uint2 *>(dst)[i] = reinterpret_cast<const uint2 *>(mine)[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NBYTES / 4; ++i) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(mine)[i];
+                        }
                     }
                 }
                 }   // !dbg_nostore

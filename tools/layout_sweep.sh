@@ -7,14 +7,12 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/layout_sweep.txt
 : > "$O"
 for ss in 420 422 440 444 411 grey; do
-  case $ss in 420|422) row=120;; 411) row=60;; *) row=240;; esac
-  for ri in 120 $row; do
-    [ "$ri" = 120 ] && [ "$row" = 120 ] && [ "$first_done_$ss" = 1 ] && continue
+  case $ss in 420|422) intervals="120";; 411) intervals="120 60";; *) intervals="120 240";; esac
+  for ri in $intervals; do
     for lay in xmajor rowmajor; do
       echo "== $ss $lay DRI=$ri" >> "$O"
       timeout 300 python3 "$R/tools/stage_probe.py" --subsampling $ss --layout $lay --batch 1024 --iters 10 --ri $ri >> "$O" 2>&1
     done
-    [ "$row" = 120 ] && break
   done
 done
 cat "$O"
