@@ -65,6 +65,7 @@ struct FusedArgs {
     // segments are past it
     int32_t pieces, piece_mcus, mcus_per_row, mcu_rows;
     int32_t col_pieces, piece_rows;        // x-major plans: pieces of an MCU column (JobGeo)
+    int32_t simd_split;                    // experiment (MJ_FUSED_SIMD_SPLIT): producers on SIMDs 0-1, consumers on SIMDs 2-3
     // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
     // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
     uint32_t *x_counter;                   // [0] tickets, [1] jobs given up, [2] the clean-up launch's tickets
@@ -278,8 +279,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
     using G = rfast::FGeo<HS, VS, 3>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_prod = F.n_prod, n_cons = F.n_cons;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (F.simd_split) {
+        // a workgroup's wavefront w sits on SIMD w % 4: with this the walking wavefronts have SIMDs 0 and 1 to themselves (four
+        // each) and the reconstructing ones SIMDs 2 and 3 — the role a wavefront plays follows from its SIMD, its number within
+        // the role from its slot there (profiles/r06_fused_balance.txt)
+        const int simd = wave & 3, slot = wave >> 2, r = slot * 2 + (simd & 1);
+        if (simd < 2) wave = r < n_prod ? r : n_prod + n_cons + (r - n_prod);
+        else wave = r < n_cons ? n_prod + r : n_prod + n_cons + (8 - min(n_prod, 8)) + (r - n_cons);
+        wave = min(wave, kFusedThreads / 64 - 1);
+    }
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem + kFusedLds - kFusedCtrl);
     float4 *wts = reinterpret_cast<float4 *>(smem + kFusedLds - kFusedCtrl - G::WTS_BYTES);
     if (tid < kFusedCtrl / 4) ctrl[tid] = 0;
@@ -545,6 +555,7 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
     F.spi = spi; F.ri = restart_interval; F.n_images = a.n_images;
     F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row; F.mcu_rows = mcu_rows;
     F.col_pieces = 1; F.piece_rows = mcu_rows;
+    if (const char *e = opt("MJ_FUSED_SIMD_SPLIT")) F.simd_split = atoi(e) != 0 && shape.n_prod <= 8 && shape.n_cons <= 8;
     if (!transposed) {
         // the strip worker's jobs of an x-major plan: an MCU column in pieces of a.chunk_strips strips (the plan's numbering:
         // column by column, piece by piece) — one piece where the column is at most 24 strips

@@ -626,6 +626,75 @@ def test_two_contexts_on_one_device_from_two_threads():
             assert np.array_equal(img, oracle.decode(f)["rgb"])
 
 
+def test_first_launches_of_every_form_from_two_threads_in_a_fresh_process(tmp_path):
+    """The launchers raise a kernel's dynamic-LDS limit and size their persistent grids at a kernel's FIRST launch on a device —
+    once per (kernel, device), under std::call_once / atomics since round 6 (round 5: plain static flags).  By the time a test of
+    this suite runs, every kernel has been launched; so this one starts a FRESH process whose first act is two threads, a context
+    each, creating and executing plans of different forms at the same moment (a barrier in front of every execute): the fused
+    launch (x-major and row-major), the lane kernels of the two launches, the synchronisation form, the wave form — crossed over,
+    so that both threads make the same kernel's first launch in the same round.  Every image against the oracle."""
+    import subprocess
+    import sys
+    script = tmp_path / "two_threads.py"
+    script.write_text(
+        "import sys, threading\n"
+        "import numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import torch\n"
+        "from oracle import oracle\n"
+        "from tools import synth\n"
+        "from pyjpegdecoder_amd import _binding as B\n"
+        "from pyjpegdecoder_amd.batch import prepare_batch\n"
+        "def batch(kind, seed):\n"
+        "    if kind == 'fused' or kind == 'fused_rm' or kind == 'two':\n"
+        "        raws = [synth.synth_jpeg(seed + i, 160, 128, 85, '420', 10) for i in range(4)]; n = 400\n"
+        "    elif kind == 'sync':\n"
+        "        raws = [synth.synth_jpeg(seed + i, 640, 480, 85, '420', 0) for i in range(4)]; n = 24\n"
+        "    else:\n"
+        "        raws = [synth.synth_jpeg(seed + i, 96, 80, 85, '444', 3) for i in range(4)]; n = 6\n"
+        "    files = [raws[i % 4] for i in range(n)]\n"
+        "    lay = B.MJ_LAYOUT_ROWMAJOR if kind == 'fused_rm' else B.MJ_LAYOUT_XMAJOR\n"
+        "    return raws, files, prepare_batch(files, lay, 0), lay\n"
+        "orders = [['fused', 'sync', 'two', 'wave', 'fused_rm'], ['sync', 'fused', 'fused_rm', 'two', 'wave']]\n"
+        "work = [[batch(k, 1000 * t + 100 * j) + (k,) for j, k in enumerate(orders[t])] for t in range(2)]\n"
+        "gate = threading.Barrier(2)\n"
+        "errs = []\n"
+        "def run(t):\n"
+        "    try:\n"
+        "        ctx = B.Context(0)\n"
+        "        for raws, files, prep, lay, kind in work[t]:\n"
+        "            gate.wait(timeout=120)\n"
+        "            plan = B.Plan(ctx, prep.to_c(), {'prep': prep, 'n_images': len(files)})\n"
+        "            try:\n"
+        "                if kind == 'two': plan.execute_stage1(); plan.execute_stage2()      # (the stages' own kernels, no process-wide switch)\n"
+        "                else: plan.execute()\n"
+        "                plan.sync()\n"
+        "                out = plan.read(rgb=True)\n"
+        "                form = plan.stage1_form()\n"
+        "            finally:\n"
+        "                plan.close()\n"
+        "            assert not out['status'].any(), (t, kind)\n"
+        "            if kind.startswith('fused'): assert form & B.MJ_FORM_FUSED, (kind, form)\n"
+        "            if kind == 'sync': assert (form & 15) == B.MJ_FORM_SYNC, form\n"
+        "            off = 0\n"
+        "            for i, (f, (w, h, nc)) in enumerate(zip(files, prep.shapes)):\n"
+        "                if i < 8:\n"
+        "                    ref = oracle.decode(f)['rgb']\n"
+        "                    got = out['rgb'][off:off + w * h * nc]\n"
+        "                    got = got.reshape(ref.shape) if lay == B.MJ_LAYOUT_XMAJOR else np.swapaxes(got.reshape(h, w, nc), 0, 1)\n"
+        "                    assert np.array_equal(got, ref), (t, kind, i)\n"
+        "                off += w * h * nc\n"
+        "        ctx.close()\n"
+        "    except BaseException as exc:\n"
+        "        errs.append(repr(exc)); gate.abort()\n"
+        "ths = [threading.Thread(target=run, args=(t,)) for t in range(2)]\n"
+        "[th.start() for th in ths]; [th.join(timeout=600) for th in ths]\n"
+        "print('ERRORS', errs) if errs else print('OK two threads')\n"
+        "sys.exit(1 if errs else 0)\n")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK two threads" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
 def test_the_environment_does_not_choose_the_stage1_form(dec, monkeypatch):
     """The library's switches are set through mj_set_option only: a stray MJ_HUFFMAN in the environment of a production
     process changes nothing (round 3's library read it with getenv at every plan creation)."""
