@@ -311,7 +311,11 @@ int mj_context_launch_clock(mj_context *ctx, float *shader_mhz, float *launch_ms
  *   MJ_LANES_WAVES    1..16   MJ_LANES_PER_WAVE  1..64 (the 11-bit lane form reads 1 as 2)   MJ_LANES_RING  64 | 128
  *   MJ_STAGE2_CHUNK   1..4096 strips per stage-2 job
  *   MJ_FUSED          0 | 1  (0 = mj_plan_execute always launches the stages separately)
- *   MJ_FUSED_CONSUMERS 0..8  reconstruction wavefronts beside the lane walk of a fused launch (as many as LDS allows)
+ *   MJ_FUSED_CONSUMERS 0..15  reconstruction wavefronts beside the lane walk of a fused launch (8, or as many as LDS allows)
+ *   MJ_FUSED_PRODUCERS 1..8   walking wavefronts of a fused launch (fewer, fuller ones: 272 segments as 6 x 46 lanes instead of 8 x 34)
+ *   MJ_FUSED_ACBITS    10..13  index bits of a fused launch's AC tables (12; 11 frees 16 KB of LDS for two more strips)
+ *   MJ_FUSED_SIMD_SPLIT 0 | 1  the walking wavefronts on SIMDs 0-1, the reconstructing ones on SIMDs 2-3 (default 0: mixed)
+ *                     (the last three: the balance experiments of profiles/r06_fused_balance.txt — measured, defaults unchanged)
  *   MJ_FUSED_LUMA13   0 | 1  component 0's AC table of a fused launch with a 13-bit main level (default: only where the segments are
  *                     dealt out by length) or with 12 bits like the others
  *   MJ_FUSED_PATIENCE 0..1000000  polls before a consumer of a fused launch whose jobs cross workgroups gives a job up to the
