@@ -454,6 +454,8 @@ def main():
     ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
                     help="process group for the barrier / MAX of timings (gloo: nothing of this job needs RCCL)")
     ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses cuda:0")
+    ap.add_argument("--tune-placement", type=int, default=4,
+                    help="coefficient stores the plan tries before the timed region (mj_plan_tune_placement; 1 = keep what the allocator gave)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks.  It has not imported torch and has not
@@ -519,11 +521,13 @@ def main():
 
     ctx = B.Context(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+    placement = None
     t0 = time.perf_counter()
     if queue_mode:
         # (across_passes: a pass — the rank's share of one job — hands over to the next without draining the GPU: the next
         # pass's plan is created while this pass's kernels run, as the next job's would be in a service; the fence drains)
-        queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank, across_passes=True)
+        queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank, across_passes=True,
+                                 tune_placement=args.tune_placement)
         torch.cuda.synchronize()
         host_prep_s, h2d_s = time.perf_counter() - t0, None
 
@@ -548,6 +552,26 @@ def main():
 
         def step():
             plan.execute(stream, d_rgb.data_ptr())
+        # Placement (round 6, profiles/r06_placement.txt): where the plan's coefficient store lies relative to the output buffer puts
+        # the fused launch into one of two classes 8-9 % apart, by the luck of two allocations.  A plan that is executed many times
+        # into one buffer — this loop; a service's output slot — tries a few stores and keeps the fastest (mj_plan_tune_placement:
+        # a few timed executes each, outside the timed region, after a second of warm-up so that no candidate is timed on a cold clock).
+        if args.tune_placement > 1 and plan.stage1_form() & B.MJ_FORM_FUSED:
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 1.0:
+                step()
+                torch.cuda.synchronize()
+            cand_ms, kept = plan.tune_placement(stream, d_rgb.data_ptr(), args.tune_placement)
+            placement = {"candidates_ms_per_execute": [round(x, 3) for x in cand_ms if x > 0], "kept": kept,
+                         "note": "mj_plan_tune_placement before the warm-up: coefficient stores tried (the plan's own first), ms per execute "
+                                 "(stage 0 + fused launch, HIP events), and which one the plan kept"}
+
+    if queue_mode and args.tune_placement > 1:      # (a second of passes first: no candidate is timed on a cold clock)
+        qt = DeviceImageQueue(ctx, files[:min(len(files), args.queue_batch)], args.queue_batch, layout, 1, device=local_rank)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 1.0:
+            qt.run()
+        del qt
 
     def fence():
         if queue_mode:
@@ -656,6 +680,8 @@ def main():
                        "parallelism": f"image-sharded x{world}, no collective on the data path (gloo barrier + MAX of timings only)"},
             "timed_region_s": round(dt, 3),
             "parity": parity,
+            "placement": placement if not queue_mode else {str(k): {"candidates_ms_per_execute": [round(x, 3) for x in v[0] if x > 0], "kept": v[1]}
+                                                            for k, v in queue.placement.items()},
             "host": {"synth_encode_s": round(gen_s, 2), "parse_segment_assemble_s": round(host_prep_s, 2),
                      "h2d_blob_s": None if h2d_s is None else round(h2d_s, 3),
                      "note": "outside the timed region; inputs are HBM-resident when timing starts"},

@@ -28,7 +28,7 @@ EXPORTS = (
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
     "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape", "mj_debug_count_tables",
-    "mj_device_copy_rate", "mj_context_launch_clock", "mj_debug_prog_split",
+    "mj_device_copy_rate", "mj_context_launch_clock", "mj_debug_prog_split", "mj_plan_tune_placement",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED, MJ_FORM_COUNT_RESOLVED = 0, 1, 2, 3, 16, 32, 64, 128
 MJ_HOST_DECLINED = 1
@@ -361,6 +361,16 @@ class Plan:
         f, m = ctypes.c_float(), ctypes.c_float()
         self.ctx.check(self.ctx.lib.mj_plan_time_execute(self.handle, iters, rgb_device or None, ctypes.byref(f), ctypes.byref(m)))
         return f.value, m.value
+
+    def tune_placement(self, stream: int = 0, rgb_device: int = 0, candidates: int = 4):
+        """mj_plan_tune_placement: tries `candidates` coefficient stores for a fused plan that will be executed many times into
+        `rgb_device`, keeps the fastest.  Returns (ms per execute of every candidate tried, index of the one that stayed)."""
+        ms = (ctypes.c_float * candidates)()
+        chosen = ctypes.c_int32()
+        self.ctx.lib.mj_plan_tune_placement.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
+        self.ctx.check(self.ctx.lib.mj_plan_tune_placement(self.handle, stream or None, rgb_device or None, candidates, ms, ctypes.byref(chosen)))
+        return [float(x) for x in ms], int(chosen.value)
 
     def close(self):
         if getattr(self, "handle", None):

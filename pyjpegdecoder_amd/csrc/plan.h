@@ -65,6 +65,12 @@ struct DevBufferCache {
             }
         (void)hipFree(ptr);             // not one of ours
     }
+    // hand a live block back to the device instead of keeping it for the next plan (mj_plan_tune_placement's losing candidates)
+    void drop(void *ptr) {
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].ptr == ptr) { live[i] = live.back(); live.pop_back(); break; }
+        (void)hipFree(ptr);
+    }
     void trim(size_t keep) {
         while (cached_bytes > keep && !free_blocks.empty()) {
             int old = 0;

@@ -54,12 +54,16 @@ class DeviceImageQueue:
     """``files``: this rank's share (a list of file bytes).  ``depth`` plans are in flight at once, each on its own stream
     and with its own output buffer.
 
+    ``tune_placement=n`` (n > 1): the first plan that goes to each output slot tries n coefficient stores against it and keeps
+    the fastest (``placement``); later plans of the slot inherit it through the context's buffer cache.
+
     ``across_passes=True`` keeps ``depth`` slots even when the share is fewer batches than that, so that with
     ``run(wait=False)`` the plan of the next pass (the next job's files, in a service) is created — host work — while the
     current pass's kernels run; ``drain()`` collects what is still in flight."""
 
     def __init__(self, ctx, files: Sequence[bytes], batch_size: int, layout: int, depth: int = 2, device=None, backend=None,
-                 prepare: Optional[Callable] = None, on_collect: Optional[Callable] = None, across_passes: bool = False):
+                 prepare: Optional[Callable] = None, on_collect: Optional[Callable] = None, across_passes: bool = False,
+                 tune_placement: int = 0):
         if batch_size < 1 or depth < 1:
             raise ValueError("batch_size and depth must be at least 1")
         if prepare is None:
@@ -86,6 +90,13 @@ class DeviceImageQueue:
         # called as on_collect(batch number, slot, plan) when a plan's pixels are in HBM, before the plan is destroyed;
         # statuses[batch number] then says which of its images (if any) are not valid
         self.on_collect = on_collect
+        # Placement (mj_plan_tune_placement): where a plan's coefficient store lies relative to its output slot decides, by the
+        # luck of two allocations, whether its fused launch runs 8-9 % slower.  The context recycles the stores from plan to plan
+        # and the queue pairs them with its slots in a fixed rhythm, so the FIRST plan that goes to a slot tries `tune_placement`
+        # stores against that slot (a few timed decodes each, once) and every later plan of the slot inherits the winner.
+        self.tune_placement = tune_placement
+        self._slot_tuned = [False] * self.depth
+        self.placement = {}               # slot -> (ms per execute of the candidates tried, which one stayed)
         self._flying = []                 # (batch number, plan), oldest first — across run() calls with wait=False
         self._seq = 0                     # plans submitted since the queue last ran dry: plan number `seq` uses slot seq % depth
         self._slot = {}                   # batch number -> slot of its latest submission
@@ -158,6 +169,9 @@ class DeviceImageQueue:
                 self._seq += 1
                 self._slot[k] = slot
                 self._flying.append((k, plan))
+                if self.tune_placement > 1 and not self._slot_tuned[slot] and hasattr(plan, "tune_placement"):
+                    self._slot_tuned[slot] = True
+                    self.placement[slot] = plan.tune_placement(self.streams[slot][1], self.out[slot][1], self.tune_placement)
                 plan.execute(self.streams[slot][1], self.out[slot][1])
             if wait:
                 self.drain()

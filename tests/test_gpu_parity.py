@@ -2477,6 +2477,57 @@ def test_fused_launch_in_passes(dec, layout, ss, W, H, n, distinct, tune):
         assert not st.any() and torch.equal(fused, two), cons
 
 
+def test_placement_tuning_keeps_the_pixels_and_one_store(dec):
+    """mj_plan_tune_placement: a fused plan tries a few coefficient stores (fresh allocations) and keeps the fastest — the output
+    is what it was, a captured graph does not survive with the old store's address in it, the stores that lost are gone (the
+    device's free memory is not down by more than one store), and a plan that is not fused is left alone."""
+    torch = pytest.importorskip("torch")
+    from pyjpegdecoder_amd import _binding as B
+    W, H, n, distinct = 640, 480, 800, 5
+    raws, files, prep = _fused_batch("420", W, H, n, distinct, 41000)
+    dev = torch.device("cuda", 0)
+    d_blob = torch.from_numpy(prep.blob).to(dev)
+    B.set_option("MJ_HUFFMAN", "lanes")
+    try:
+        plan = B.Plan(dec.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": n})
+    finally:
+        B.set_option("MJ_HUFFMAN", None)
+    try:
+        assert plan.stage1_form() & B.MJ_FORM_FUSED
+        out = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):                                   # (the third execute replays a captured graph)
+            plan.execute(stream, out.data_ptr())
+        plan.sync()
+        want = out.clone()
+        store0 = plan.device_buffers()["coef"]
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        ms, kept = plan.tune_placement(stream, out.data_ptr(), 4)
+        assert len(ms) == 4 and all(m > 0 for m in ms) and 0 <= kept < 4
+        assert (plan.device_buffers()["coef"] == store0) == (kept == 0)
+        # (the candidates that lost went back to the device — blocks the context's cache had kept from earlier plans may have been
+        # among them, so free memory can only have grown, or shrunk by the one store that replaced a cached one)
+        assert free0 - torch.cuda.mem_get_info()[0] <= plan.info.total_blocks * 128 + (64 << 20)
+        for poison in (0x3C, 0xA5, 0x69):                    # plain, captured, replayed — each on a poisoned store
+            out.zero_()
+            torch.cuda.synchronize()
+            plan.fill_coef(poison)
+            plan.execute(stream, out.data_ptr())
+            plan.sync()
+            assert torch.equal(out, want) and not plan.read(rgb=False)["status"].any()
+    finally:
+        plan.close()
+    raw, _ = load_golden("64x64_420_pil")
+    prep1 = __import__("pyjpegdecoder_amd.batch", fromlist=["prepare_batch"]).prepare_batch([raw] * 4, B.MJ_LAYOUT_XMAJOR, 0)
+    small = B.Plan(dec.ctx, prep1.to_c(), {"prep": prep1, "n_images": 4})
+    try:
+        ms, kept = small.tune_placement(0, 0, 3)
+        assert ms == [0.0, 0.0, 0.0] and kept == 0
+    finally:
+        small.close()
+
+
 def test_fused_launch_damaged_files_do_not_stall_their_workgroup(dec, tune):
     """Files of a fused batch with entropy-coded bytes overwritten (markers left where they are): the statuses are those of the
     two launches, damaged files that still decode give the same pixels, every other image of the batch — the damaged files'
