@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--segment", default="host", choices=["host", "gpu"])
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--mixed", action="store_true", help="files of mixed content (bench.py's mixed_content family)")
+    ap.add_argument("--tune", type=int, default=4, help="coefficient stores a fused plan tries before it is timed (1 = none)")
     ap.add_argument("--lib", default=None, help="another build of the library (pyjpegdecoder_amd/libmijpeg_diag.so + MJ_DEBUG_FUSED=1: phase times)")
     ap.add_argument("exps", nargs="*", default=[""])
     args = ap.parse_args()
@@ -52,16 +53,25 @@ def main():
     d_blob = torch.from_numpy(prep.blob).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # ONE output buffer for every experiment (round 6: which block the allocator hands out decides between two classes of step,
+    # 5-9 % apart — profiles/r06_placement.txt), and every fused plan picks its coefficient store against it before it is timed
+    keep = {}
+
     def run(opts):
         for k, v in opts:
             B.set_option(k, v)
         plan = B.Plan(ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": args.batch})
-        out = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        if "out" not in keep:
+            keep["out"] = torch.zeros(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+        out = keep["out"]
+        out.zero_()
         try:
             form = plan.stage1_form()
             for _ in range(10):
                 plan.execute(stream, out.data_ptr())
             torch.cuda.synchronize()
+            if args.tune > 1:
+                plan.tune_placement(stream, out.data_ptr(), args.tune)
             t0 = time.perf_counter()
             for _ in range(args.reps):
                 plan.execute(stream, out.data_ptr())
@@ -75,6 +85,7 @@ def main():
                 B.set_option(k, None)
         return out, ms, form, st, parts
     ref, ms0, form0, st0, parts0 = run([("MJ_FUSED", "0")])
+    ref = ref.clone()
     print(f"{'two launches (MJ_FUSED=0)':50s} form {form0:3d}  {ms0:7.3f} ms per step ({parts0[0]:.3f} + {parts0[1]:.3f})   statuses not ok: {int((st0 != 0).sum())}", flush=True)
     for exp in args.exps:
         opts = [kv.split("=", 1) for kv in exp.split(",") if kv]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warm", type=int, default=15, help="untimed executes before the timed ones (clock ramp)")
+    ap.add_argument("--tune", type=int, default=4, help="coefficient stores a fused plan tries before it is timed (mj_plan_tune_placement; 1 = none)")
     ap.add_argument("--mixed", action="store_true", help="the heterogeneous family of bench.py's mixed_content instead of the homogeneous one")
     ap.add_argument("exps", nargs="*", default=[""])
     args = ap.parse_args()
@@ -65,6 +66,12 @@ def main():
         torch.cuda.synchronize()
         import time
         st = torch.cuda.current_stream().cuda_stream
+        if args.tune > 1 and plan.stage1_form() & B.MJ_FORM_FUSED:      # (the fast placement class for every line of a sweep: profiles/r06_placement.txt)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.7:
+                plan.execute(st, d_rgb.data_ptr())
+                torch.cuda.synchronize()
+            plan.tune_placement(st, d_rgb.data_ptr(), args.tune)
         t0 = time.perf_counter()
         for _ in range(args.iters):
             plan.execute(st, d_rgb.data_ptr())
