@@ -561,14 +561,20 @@ def main():
         # into one buffer — this loop; a service's output slot — tries a few stores and keeps the fastest (mj_plan_tune_placement:
         # a few timed executes each, outside the timed region, after a second of warm-up so that no candidate is timed on a cold clock).
         if args.tune_placement > 1 and plan.stage1_form() & B.MJ_FORM_FUSED:
+            from pyjpegdecoder_amd.placement import tuned_output
             t_w = time.perf_counter()
             while time.perf_counter() - t_w < 1.0:
                 step()
                 torch.cuda.synchronize()
-            cand_ms, kept = plan.tune_placement(stream, d_rgb.data_ptr(), args.tune_placement)
-            placement = {"candidates_ms_per_execute": [round(x, 3) for x in cand_ms if x > 0], "kept": kept,
-                         "note": "mj_plan_tune_placement before the warm-up: coefficient stores tried (the plan's own first), ms per execute "
-                                 "(stage 0 + fused launch, HIP events), and which one the plan kept"}
+            keep = [d_rgb]
+
+            def alloc(nbytes):          # (the buffer that exists first; then others — all held until the choice is made, or torch hands the same block out again)
+                t = keep.pop() if keep else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                return t, t.data_ptr()
+            d_rgb, _, placement = tuned_output(plan, stream, plan.info.rgb_bytes, alloc, out_candidates=3, store_candidates=args.tune_placement)
+            placement["note"] = ("pyjpegdecoder_amd.placement.tuned_output before the warm-up: output buffers tried, for each the coefficient stores "
+                                 "(and stage-0 stream buffers) the plan tried against it (mj_plan_tune_placement: ms per execute = stage 0 + fused "
+                                 "launch, HIP events), and which pair stayed")
 
     if queue_mode and args.tune_placement > 1:      # (a second of passes first: no candidate is timed on a cold clock)
         qt = DeviceImageQueue(ctx, files[:min(len(files), args.queue_batch)], args.queue_batch, layout, 1, device=local_rank)
@@ -684,8 +690,7 @@ def main():
                        "parallelism": f"image-sharded x{world}, no collective on the data path (gloo barrier + MAX of timings only)"},
             "timed_region_s": round(dt, 3),
             "parity": parity,
-            "placement": placement if not queue_mode else {str(k): {"candidates_ms_per_execute": [round(x, 3) for x in v[0] if x > 0], "kept": v[1]}
-                                                            for k, v in queue.placement.items()},
+            "placement": placement if not queue_mode else {f"slot {k}": v for k, v in queue.placement.items()},
             "host": {"synth_encode_s": round(gen_s, 2), "parse_segment_assemble_s": round(host_prep_s, 2),
                      "h2d_blob_s": None if h2d_s is None else round(h2d_s, 3),
                      "note": "outside the timed region; inputs are HBM-resident when timing starts"},

@@ -286,9 +286,13 @@ int mj_plan_time_execute(mj_plan *plan, int iters, uint8_t *rgb_device, float *f
  * Where the plan's coefficient store lies relative to that buffer — physically: nothing the virtual addresses show — puts the
  * fused launch (MJ_FORM_FUSED) into one of two classes 8-9 % apart (profiles/r06_placement.txt).  Tries `candidates` (1..16)
  * stores — the plan's own, then fresh allocations —, each with a few timed executes into rgb_device on `stream` (NULL: the
- * context's), keeps the fastest and releases the others.  ms_out[candidates] (may be NULL): ms per execute of each candidate tried
- * (0 = not tried); *chosen (may be NULL): which one stayed.  Plans that are not fused are left alone (all zeros).  Synchronous. */
-int mj_plan_tune_placement(mj_plan *plan, void *stream, uint8_t *rgb_device, int32_t candidates, float *ms_out, int32_t *chosen);
+ * context's), keeps the fastest and releases the others; then the same for the plan's stage-0 stream buffer (the other buffer
+ * the launch's traffic runs through).  ms_out[candidates] (may be NULL): ms per execute of each coefficient store tried (0 = not
+ * tried); *chosen (may be NULL): which one stayed; *best_ms (may be NULL): ms per execute with what the plan ends up with.  The
+ * output buffer is the caller's: a caller that owns several can call this for each and keep the best pair (bench.py does).  Plans
+ * that are not fused are left alone (all zeros).  Synchronous. */
+int mj_plan_tune_placement(mj_plan *plan, void *stream, uint8_t *rgb_device, int32_t candidates, float *ms_out, int32_t *chosen,
+                           float *best_ms);
 
 /* The plain device-to-device copy the rooflines are held against (SURVEY 8d's second denominator): `bytes` (a multiple of 16)
  * copied `iters` times between two buffers of the context's own by a kernel that moves sixteen bytes per lane; average

@@ -364,12 +364,15 @@ class Plan:
 
     def tune_placement(self, stream: int = 0, rgb_device: int = 0, candidates: int = 4):
         """mj_plan_tune_placement: tries `candidates` coefficient stores for a fused plan that will be executed many times into
-        `rgb_device`, keeps the fastest.  Returns (ms per execute of every candidate tried, index of the one that stayed)."""
+        `rgb_device` (then as many stage-0 stream buffers), keeps the fastest.  Returns (ms per execute of every store tried, index
+        of the one that stayed); `best_ms` afterwards = ms per execute with what the plan ended up with."""
         ms = (ctypes.c_float * candidates)()
-        chosen = ctypes.c_int32()
+        chosen, best = ctypes.c_int32(), ctypes.c_float()
         self.ctx.lib.mj_plan_tune_placement.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
-                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
-        self.ctx.check(self.ctx.lib.mj_plan_tune_placement(self.handle, stream or None, rgb_device or None, candidates, ms, ctypes.byref(chosen)))
+                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
+        self.ctx.check(self.ctx.lib.mj_plan_tune_placement(self.handle, stream or None, rgb_device or None, candidates, ms, ctypes.byref(chosen),
+                                                           ctypes.byref(best)))
+        self.best_ms = float(best.value)
         return [float(x) for x in ms], int(chosen.value)
 
     def close(self):

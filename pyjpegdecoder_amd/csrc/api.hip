@@ -638,8 +638,9 @@ int mj_device_copy_rate(mj_context *ctx, int64_t bytes, int iters, float *ms_per
 // "the headline depends on the board" was mostly this.  The store is the plan's own, so the plan can try a few: each candidate
 // a fresh hipMalloc, a handful of timed executes (HIP events), the fastest stays.  Worth it for a plan that is executed many
 // times into one output buffer (a decode service's slot, a benchmark's step); a one-shot decode should not bother.
-int mj_plan_tune_placement(mj_plan *p, void *stream, uint8_t *rgb_device, int32_t candidates, float *ms_out, int32_t *chosen) {
+int mj_plan_tune_placement(mj_plan *p, void *stream, uint8_t *rgb_device, int32_t candidates, float *ms_out, int32_t *chosen, float *best_out) {
     if (!p || candidates < 1 || candidates > 16) return MJ_ERR_INVALID;
+    if (best_out) *best_out = 0.f;
     mj_context *ctx = p->ctx;
     if (chosen) *chosen = 0;
     if (ms_out) for (int i = 0; i < candidates; ++i) ms_out[i] = 0.f;
@@ -666,32 +667,41 @@ int mj_plan_tune_placement(mj_plan *p, void *stream, uint8_t *rgb_device, int32_
         ms /= 5.f;
         return rc;
     };
-    const size_t bytes = (size_t)p->info.total_blocks * 64 * sizeof(int16_t) + 16;
-    int16_t *best = p->d_coef;
+    // Two of the plan's buffers carry the launch's traffic: the coefficient store (written, read back) and the stage-0 stream (read
+    // by the walk).  Each is tried in turn against everything else as it stands: the plan's own first, then `candidates - 1` others.
+    // Candidates come through the context's buffer cache — a block it holds from an earlier plan is as good a candidate as a fresh
+    // one, and the winner is then a block the cache knows: when this plan goes, the next plan of its size gets it back (most
+    // recently released first), which is how a queue of plans into one output slot keeps what was tuned for that slot.  The losers
+    // go back to the device: kept, they would be the next plan's buffers.
     float best_ms = 0.f;
     if (int rc = timed(best_ms)) return rc;
     if (ms_out) ms_out[0] = best_ms;
-    for (int c = 1; c < candidates; ++c) {
-        // candidates come through the context's buffer cache — a block it holds from an earlier plan is as good a candidate as a
-        // fresh one, and the winner is then a block the cache knows: when this plan goes, the next plan of its size gets it back
-        // (most recently released first), which is how a queue of plans into one output slot keeps what was tuned for that slot.
-        // The losers go back to the device: kept, they would be the next plan's store.
-        int16_t *cand = nullptr;
-        if (ctx->cache.get((void **)&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }     // (no room for another: what we have stands)
-        p->d_coef = cand;
-        float ms = 0.f;
-        const int rc = timed(ms);
-        if (ms_out) ms_out[c] = ms;
-        if (rc == MJ_OK && ms < best_ms * 0.99f) {           // (the classes are 8 % apart: one per cent is noise)
-            ctx->cache.drop(best);
-            best = cand; best_ms = ms;
-            if (chosen) *chosen = c;
-        } else {
-            ctx->cache.drop(cand);
+    auto try_buffers = [&](void **slot, size_t bytes, bool clear, int which) -> int {
+        void *best = *slot;
+        for (int c = 1; c < candidates; ++c) {
+            void *cand = nullptr;
+            if (ctx->cache.get(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }     // (no room for another: what we have stands)
+            if (clear) MJ_HIP(ctx, hipMemsetAsync(cand, 0, bytes, s));
+            *slot = cand;
+            float ms = 0.f;
+            const int rc = timed(ms);
+            if (ms_out && which == 0) ms_out[c] = ms;
+            if (rc == MJ_OK && ms < best_ms * 0.99f) {       // (the classes are 5-9 % apart: one per cent is noise)
+                ctx->cache.drop(best);
+                best = cand; best_ms = ms;
+                if (chosen && which == 0) *chosen = c;
+            } else {
+                ctx->cache.drop(cand);
+            }
+            *slot = best;
+            if (rc != MJ_OK) return rc;
         }
-        p->d_coef = best;
-        if (rc != MJ_OK) return rc;
-    }
+        return MJ_OK;
+    };
+    if (int rc = try_buffers(reinterpret_cast<void **>(&p->d_coef), (size_t)p->info.total_blocks * 64 * sizeof(int16_t) + 16, false, 0)) return rc;
+    if (p->stream_bytes)
+        if (int rc = try_buffers(reinterpret_cast<void **>(&p->d_stream), p->stream_bytes, true, 1)) return rc;
+    if (best_out) *best_out = best_ms;
     // whatever graph was captured holds the old store's address
     if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
     p->graph_stream = nullptr; p->prev_stream = nullptr; p->last_was_graph = false;

@@ -152,6 +152,7 @@ struct mj_plan {
     int32_t *d_wg_tabs_lanes = nullptr, *d_wg_tabs_count = nullptr;
     int wg_slots_lanes = 0, wg_slots_count = 0;      // 8 or 16 LUTs per workgroup
     uint32_t *d_stream = nullptr;       // stage 0 output (destuff.hip): big-endian dwords per restart segment
+    size_t stream_bytes = 0;            // ... its size (mj_plan_tune_placement tries other buffers of that size)
     int32_t *d_seg_bits = nullptr;      // [n_segs] bits per segment after stage 0
     // long restart segments (files without DRI): synchronisation passes + virtual segments (huffman_sync.hip)
     bool use_sync = false;

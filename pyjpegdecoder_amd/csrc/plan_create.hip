@@ -444,6 +444,7 @@ int mj_plan_create(mj_context *ctx, const mj_batch *b, mj_plan **out) {
             // stage 0 output: segment i's kept bytes start at dword (begin_i >> 2) + i, so regions never overlap
             const size_t sbytes = ((size_t)b->blob_len / 4 + segs.size() + 256) * 4;
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_stream, sbytes));
+            p->stream_bytes = sbytes;
             MJ_HIP(ctx, hipMemsetAsync(p->d_stream, 0, sbytes, ctx->setup_stream));
             MJ_HIP(ctx, ctx->cache.get((void **)&p->d_seg_bits, (segs.size() + 1) * sizeof(int32_t)));
             if (want_sync) {

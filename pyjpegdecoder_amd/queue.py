@@ -81,6 +81,7 @@ class DeviceImageQueue:
             self._files.append(part)
         cap = max((sum(w * h * nc for (w, h, nc) in b[0].shapes) for b in self.batches), default=0)
         self.depth = max(1, depth if across_passes else min(depth, len(self.batches)))
+        self._slot_bytes = cap
         self.out = [self.backend.empty(cap) for _ in range(self.depth)]           # (handle, pointer) per slot
         self.streams = [self.backend.stream() for _ in range(self.depth)]        # (handle, raw stream) per slot
         self.n_images = len(files)
@@ -93,10 +94,11 @@ class DeviceImageQueue:
         # Placement (mj_plan_tune_placement): where a plan's coefficient store lies relative to its output slot decides, by the
         # luck of two allocations, whether its fused launch runs 8-9 % slower.  The context recycles the stores from plan to plan
         # and the queue pairs them with its slots in a fixed rhythm, so the FIRST plan that goes to a slot tries `tune_placement`
-        # stores against that slot (a few timed decodes each, once) and every later plan of the slot inherits the winner.
+        # stores — and up to three buffers for the slot itself — (a few timed decodes each, once: placement.tuned_output) and every
+        # later plan of the slot inherits the winners.
         self.tune_placement = tune_placement
         self._slot_tuned = [False] * self.depth
-        self.placement = {}               # slot -> (ms per execute of the candidates tried, which one stayed)
+        self.placement = {}               # slot -> placement.tuned_output's report (output buffers and stores tried, what stayed)
         self._flying = []                 # (batch number, plan), oldest first — across run() calls with wait=False
         self._seq = 0                     # plans submitted since the queue last ran dry: plan number `seq` uses slot seq % depth
         self._slot = {}                   # batch number -> slot of its latest submission
@@ -171,7 +173,15 @@ class DeviceImageQueue:
                 self._flying.append((k, plan))
                 if self.tune_placement > 1 and not self._slot_tuned[slot] and hasattr(plan, "tune_placement"):
                     self._slot_tuned[slot] = True
-                    self.placement[slot] = plan.tune_placement(self.streams[slot][1], self.out[slot][1], self.tune_placement)
+                    from .placement import tuned_output
+                    have = [self.out[slot]]
+
+                    def alloc(nbytes, have=have):           # the slot's own buffer first, then others of its size
+                        return have.pop() if have else self.backend.empty(self._slot_bytes)
+                    handle, ptr, report = tuned_output(plan, self.streams[slot][1], self._slot_bytes, alloc, out_candidates=3,
+                                                       store_candidates=self.tune_placement)
+                    self.out[slot] = (handle, ptr)
+                    self.placement[slot] = report
                 plan.execute(self.streams[slot][1], self.out[slot][1])
             if wait:
                 self.drain()

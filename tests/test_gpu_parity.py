@@ -2506,9 +2506,13 @@ def test_placement_tuning_keeps_the_pixels_and_one_store(dec):
         ms, kept = plan.tune_placement(stream, out.data_ptr(), 4)
         assert len(ms) == 4 and all(m > 0 for m in ms) and 0 <= kept < 4
         assert (plan.device_buffers()["coef"] == store0) == (kept == 0)
-        # (the candidates that lost went back to the device — blocks the context's cache had kept from earlier plans may have been
-        # among them, so free memory can only have grown, or shrunk by the one store that replaced a cached one)
-        assert free0 - torch.cuda.mem_get_info()[0] <= plan.info.total_blocks * 128 + (64 << 20)
+        assert plan.best_ms > 0 and plan.best_ms <= min(ms) * 1.05
+        # (the candidates that lost went back to the device — which hands freed memory on lazily: what is pinned is that the call
+        # does not keep them, i.e. a second call does not take free memory further down)
+        free1 = torch.cuda.mem_get_info()[0]
+        plan.tune_placement(stream, out.data_ptr(), 4)
+        torch.cuda.synchronize()
+        assert free1 - torch.cuda.mem_get_info()[0] <= plan.info.total_blocks * 128 + (64 << 20), (free0, free1, torch.cuda.mem_get_info()[0])
         for poison in (0x3C, 0xA5, 0x69):                    # plain, captured, replayed — each on a poisoned store
             out.zero_()
             torch.cuda.synchronize()

@@ -166,3 +166,39 @@ def test_statuses_are_kept_unsettled_images_go_round_again_and_internal_errors_r
     with pytest.raises(BackendError):
         q.run()
     assert all(p.closed for p in be.plans)
+
+
+def test_tuned_output_keeps_the_fastest_pair_and_retunes_for_it():
+    """pyjpegdecoder_amd.placement.tuned_output without a GPU: output buffers are tried in turn, the plan picks its stores against
+    each, the fastest pair stays — and when that is not the last one tried, the plan picks its stores once more against it."""
+    from pyjpegdecoder_amd.placement import tuned_output
+
+    class P:
+        def __init__(self, ms_by_ptr):
+            self.ms_by_ptr, self.calls, self.best_ms = ms_by_ptr, [], 0.0
+
+        def tune_placement(self, stream, ptr, candidates):
+            self.calls.append(ptr)
+            self.best_ms = self.ms_by_ptr[ptr]
+            return [self.best_ms + 0.3] + [self.best_ms] * (candidates - 1), 1
+    n = [0]
+
+    def alloc(nbytes):
+        n[0] += 1
+        return ("buf", n[0]), 100 + n[0]
+    plan = P({101: 6.30, 102: 5.80, 103: 5.79})             # (103 is within one per cent of 102: the earlier one stays)
+    handle, ptr, rep = tuned_output(plan, 7, 1 << 20, alloc, out_candidates=3, store_candidates=4)
+    assert (handle, ptr) == (("buf", 2), 102) and rep["kept"] == 1 and rep["output_candidates_ms_per_execute"] == [6.3, 5.8, 5.79]
+    assert plan.calls == [101, 102, 103, 102] and rep["ms_per_execute"] == 5.8          # re-tuned against the one that stays
+    plan = P({101: 5.7})
+    n[0] = 0
+    _, ptr, rep = tuned_output(plan, 7, 1 << 20, alloc, out_candidates=1)
+    assert ptr == 101 and plan.calls == [101] and rep["kept"] == 0
+    plan = P({101: 0.0})                                     # not a fused plan: the first buffer, nothing else allocated
+    m = [0]
+
+    def alloc2(nbytes):
+        m[0] += 1
+        return None, 100 + m[0]
+    _, ptr, rep = tuned_output(plan, 7, 64, alloc2, out_candidates=3)
+    assert ptr == 101 and m[0] == 1 and rep["kept"] == 0

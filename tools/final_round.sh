@@ -3,7 +3,7 @@
 TAG=${1:-r06e}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
-bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1
+( time bash "$R/tools/profile_round.sh" "$TAG" > /dev/null 2>&1 ) 2> "$O/profile_round_time_$TAG.txt"
 mkdir -p "$O/prog_$TAG"
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prog_$TAG/stats" -- python3 "$R/tools/prog_batch_probe.py" 1024 > "$O/prog_$TAG/stats.log" 2>&1 )
 ( cd "$R" && timeout 600 python3 bench.py --total-images 1250 --no-cpu-baseline --no-progressive > "$O/config4_1gpu_share_$TAG.json" 2> "$O/config4_1gpu_share_$TAG.err" )
