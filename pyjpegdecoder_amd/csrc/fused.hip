@@ -30,6 +30,7 @@
 // output whose restart interval is one MCU row, decoded with the resolved 13-bit tables in blob order (api.hip: fused_ok).
 // Everything else — and mj_plan_execute_stage1 / _stage2, MJ_FLAG_KEEP_* — takes the two launches as before.
 #include <stdio.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -46,7 +47,8 @@ namespace mj {
 namespace {
 
 constexpr int kFusedLds = 160 * 1024;
-constexpr int kFusedCtrl = 128;            // control words at the very top of LDS: ticket, producers done, progress per producer wave
+constexpr int kFusedCtrl = 384;            // control words at the very top of LDS: ticket, producers done, progress per producer wave (128 B),
+constexpr int kFusedBitmap = 128;          // ... and behind them 64 words of claimed-job bits (the newest-first order)
 constexpr int kFusedThreads = 1024;        // 16 wavefronts = 4 per SIMD, 128 registers each: 8 producers and up to 8 consumers beside them
 
 struct FusedArgs {
@@ -66,6 +68,7 @@ struct FusedArgs {
     int32_t pieces, piece_mcus, mcus_per_row, mcu_rows;
     int32_t col_pieces, piece_rows;        // x-major plans: pieces of an MCU column (JobGeo)
     int32_t simd_split;                    // experiment (MJ_FUSED_SIMD_SPLIT): producers on SIMDs 0-1, consumers on SIMDs 2-3
+    int32_t newest;                        // consumers take the NEWEST complete column instead of the next one (FusedSource::claim)
     // segments dealt out by length (XWG): any workgroup's consumers may need any wave's blocks — one ticket counter and the
     // producers' progress words in global memory, and for every restart segment the progress word of the wave that walks it
     uint32_t *x_counter;                   // [0] tickets, [1] jobs given up, [2] the clean-up launch's tickets
@@ -76,6 +79,7 @@ struct FusedArgs {
 };
 
 typedef uint32_t __attribute__((address_space(3))) *lds_word;
+typedef uint32_t __attribute__((address_space(3))) *lds_word_t;
 
 // The waits of a fused launch are for wavefronts that never wait themselves (a producer walks its segments and ends), so
 // they always end; what bounds them only guards the GPU against a defect in this file.  The bound is WALL-CLOCK time (the
@@ -109,6 +113,42 @@ struct FusedSource {
     JobGeo g;
     int32_t *status;
     int lane;
+    // Newest first (round 6; x-major, one pass, one MCU row per segment, whole columns).  In ticket order the consumers fall
+    // behind the walk — by its end they are at column ~60 of 120 — and read coefficient blocks that left every cache long ago.
+    // Taking the newest complete column instead (and leaving the old ones to phase 2, which reads from memory anyway) they read
+    // what the walk wrote tens of microseconds before: while the launch moves ~4.4 TB/s the 256 MiB Infinity Cache turns over in
+    // ~60 us.  Which columns are taken is a bitmap in LDS (one bit per image and column), claimed with an atomic OR.
+    uint32_t newest, wpi, n_prod_w, pref;  // on / bitmap words per image / producer wavefronts / the image this wave looks at first
+    __device__ __forceinline__ uint32_t ctl_word(uint32_t addr) const {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)addr);
+    }
+    __device__ __forceinline__ uint32_t claim() const {        // a job nobody has taken whose column is complete; ~0: none left
+        const uint32_t ih = images_in(0);
+        for (;;) {
+            const bool all_done = ctl_word(ctrl + 4u) >= n_prod_w;       // (looked at BEFORE the progress words)
+            for (uint32_t jj = 0; jj < ih; ++jj) {
+                const uint32_t j = pref + jj < ih ? pref + jj : pref + jj - ih;
+                uint32_t r = g.mpr;                                       // columns [0, r) of image j are complete
+                if (!all_done) {
+                    const uint32_t w0 = (j * g.spi) / lpw, w1 = (j * g.spi + g.spi - 1u) / lpw;
+                    for (uint32_t w = w0; w <= w1; ++w) r = min(r, ctl_word(ctrl + 8u + 4u * w));
+                }
+                while (r > 0u) {
+                    const uint32_t w = (r - 1u) >> 5, hi = r - (w << 5);  // bits [0, hi) of word w, hi = 1..32
+                    const uint32_t addr = ctrl + (uint32_t)kFusedBitmap + 4u * (j * wpi + w);
+                    const uint32_t avail = ~ctl_word(addr) & (hi >= 32u ? 0xFFFFFFFFu : (1u << hi) - 1u);
+                    if (avail == 0u) { r = w << 5; continue; }             // all taken down to this word's first column
+                    const uint32_t b = 31u - (uint32_t)__builtin_clz(avail);
+                    uint32_t old = 0;
+                    if (lane == 0) old = __hip_atomic_fetch_or((lds_word_t)(uintptr_t)addr, 1u << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                    if (!(old & (1u << b))) return (v0 * ipp + j) * jobs_per_image + (w << 5) + b;
+                }
+            }
+            if (all_done) return ~0u;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
     __device__ __forceinline__ uint32_t images_in(uint32_t pass) const {
         const uint32_t lo = (v0 + pass) * ipp;
         return lo >= n_images ? 0u : min(ipp, n_images - lo);
@@ -120,6 +160,7 @@ struct FusedSource {
     }
     __device__ __forceinline__ uint32_t take(uint32_t t) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); }
     __device__ __forceinline__ uint32_t first_job(uint32_t ticket) const {
+        if constexpr (!BY_ROWS) { if (newest) return claim(); }     // (one call per ticket: the ticket only counts the claims)
         uint32_t pass = 0, ih = images_in(0);
         for (; pass + 1 < n_pass; ++pass) {             // (tickets of the passes in front of this one's)
             const uint32_t tp = ih * jobs_per_image;
@@ -136,13 +177,14 @@ struct FusedSource {
             return (img0 + j) * jobs_per_image + m;
         }
     }
-    __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return first_job(ticket) + 1u; }
+    __device__ __forceinline__ uint32_t end_job(uint32_t ticket, uint32_t) const { return newest ? 0u : first_job(ticket) + 1u; }   // (unused: single jobs)
     // the progress word of the wave that holds segment s of the pass's image j
     __device__ __forceinline__ uint32_t word(uint32_t j, uint32_t s) const {
         return *(volatile uint32_t __attribute__((address_space(3))) *)(uintptr_t)(ctrl + 8u + 4u * ((j * g.spi + s) / lpw));
     }
     // every MCU the job needs complete?
     __device__ __forceinline__ bool ready(uint32_t job) const {
+        if (newest) return true;           // (a claimed column is a complete one)
         const uint32_t img = job / jobs_per_image, m = job - img * jobs_per_image, v = img / ipp, j = img - v * ipp;
         const uint32_t base = (v - v0) << kFusedPassShift;
         if constexpr (BY_ROWS) {           // MCUs [a, b) of one MCU row: the segment(s) that hold them
@@ -312,6 +354,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_fused(FusedArgs F) {
         src.ctrl = ctrl_lds;
         src.v0 = v0; src.n_pass = (uint32_t)F.n_pass; src.ipp = (uint32_t)F.ipw;
         src.lpw = (uint32_t)F.L.lpw;
+        src.newest = (uint32_t)F.newest; src.wpi = ((uint32_t)F.mcus_per_row + 31u) >> 5; src.n_prod_w = (uint32_t)n_prod;
+        src.pref = (uint32_t)wave % max(1u, src.images_in(0));
         uint32_t mine = 0;
         for (uint32_t p = 0; p < src.n_pass; ++p) mine += src.images_in(p);
         src.n_tickets = mine * src.jobs_per_image;
@@ -556,6 +600,11 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
     F.pieces = 1; F.piece_mcus = mcus_per_row; F.mcus_per_row = mcus_per_row; F.mcu_rows = mcu_rows;
     F.col_pieces = 1; F.piece_rows = mcu_rows;
     if (const char *e = opt("MJ_FUSED_SIMD_SPLIT")) F.simd_split = atoi(e) != 0 && shape.n_prod <= 8 && shape.n_cons <= 8;
+    // newest-first consumers (FusedSource::claim): where a column is one job and one test — x-major, one pass, one MCU row per segment
+    F.newest = !shape.xwg && !transposed && shape.n_pass == 1 && restart_interval == mcus_per_row && F.col_pieces == 1 &&
+               shape.ipw * ((mcus_per_row + 31) / 32) <= (kFusedCtrl - kFusedBitmap) / 4;
+    if (const char *e = opt("MJ_FUSED_ORDER")) F.newest = F.newest && !strcmp(e, "newest");
+    else F.newest = 0;
     if (!transposed) {
         // the strip worker's jobs of an x-major plan: an MCU column in pieces of a.chunk_strips strips (the plan's numbering:
         // column by column, piece by piece) — one piece where the column is at most 24 strips

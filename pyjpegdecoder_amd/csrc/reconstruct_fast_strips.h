@@ -437,6 +437,7 @@ __device__ __forceinline__ void strips_worker(const ReconArgs &a, const int64_t 
     uint32_t ticket = src.take(src.draw());
     if (ticket >= src.n_tickets) return;
     uint32_t job = src.first_job(ticket);
+    if (job >= n_jobs) return;            // (sources that hand out what is left: nothing was)
     const DevImage *qt_owner = nullptr;
     uint4 cw[G::ROUNDS];
   for (;;) {        // (gated sources only come round again: a job whose blocks were not there yet when its turn to be fetched came)
