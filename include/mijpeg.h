@@ -295,8 +295,10 @@ int mj_plan_tune_placement(mj_plan *plan, void *stream, uint8_t *rgb_device, int
                            float *best_ms);
 
 /* The plain device-to-device copy the rooflines are held against (SURVEY 8d's second denominator): `bytes` (a multiple of 16)
- * copied `iters` times between two buffers of the context's own by a kernel that moves sixteen bytes per lane; average
- * device time per copy in ms (HIP events on the context's stream).  2 * bytes / ms = the chip's achieved copy rate. */
+ * copied `iters` times between two buffers of the context's own by a kernel that moves sixteen bytes per lane, in each of a few
+ * launch shapes (workgroups per CU, loads in flight, temporal or not: what a copy reaches on this chip depends on them by
+ * 20 %); device time per copy in ms of the BEST shape (HIP events on the context's stream).  2 * bytes / ms = the copy rate
+ * the chip reaches between these two buffers — a ceiling to hold the decode kernels against, not an average. */
 int mj_device_copy_rate(mj_context *ctx, int64_t bytes, int iters, float *ms_per_copy);
 /* The shader clock (MHz) the chip held during the context's latest fused launch (MJ_FORM_FUSED) and that launch's duration as
  * its first workgroup saw it: the launch leaves the shader-clock counter and the 100 MHz counter at its start and end.  The

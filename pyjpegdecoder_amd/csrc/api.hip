@@ -620,13 +620,18 @@ int mj_device_copy_rate(mj_context *ctx, int64_t bytes, int iters, float *ms_per
     MJ_HIP(ctx, hipEventCreate(&h.e1));
     hipStream_t s = ctx->stream;
     MJ_HIP(ctx, mj::launch_fill_words(s, h.a, 0x01020304u, bytes / 4));
-    for (int i = 0; i < 3; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes));      // warm
-    MJ_HIP(ctx, hipEventRecord(h.e0, s));
-    for (int i = 0; i < iters; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes));
-    MJ_HIP(ctx, hipEventRecord(h.e1, s));
-    MJ_HIP(ctx, hipEventSynchronize(h.e1));
-    float ms = 0.f;
-    MJ_HIP(ctx, hipEventElapsedTime(&ms, h.e0, h.e1));
+    float best = 0.f;
+    for (int v = 0; v < mj::copy16_variants(); ++v) {          // every launch shape: the best one is the ceiling (util_kernels.hip)
+        for (int i = 0; i < 3; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes, v));      // warm
+        MJ_HIP(ctx, hipEventRecord(h.e0, s));
+        for (int i = 0; i < iters; ++i) MJ_HIP(ctx, mj::launch_copy16(s, h.a, h.b, bytes, v));
+        MJ_HIP(ctx, hipEventRecord(h.e1, s));
+        MJ_HIP(ctx, hipEventSynchronize(h.e1));
+        float t = 0.f;
+        MJ_HIP(ctx, hipEventElapsedTime(&t, h.e0, h.e1));
+        if (best == 0.f || t < best) best = t;
+    }
+    float ms = best;
     *ms_per_copy = ms / iters;
     return MJ_OK;
 }

@@ -358,7 +358,8 @@ inline int device_cus() {
 hipError_t launch_planes_from_interleaved(hipStream_t stream, const DevImage *images, int n_images, int64_t max_pixels,
                                           const uint8_t *interleaved, uint8_t *planar);
 // dst[0 .. bytes) = src[0 .. bytes), sixteen bytes per lane (bytes a multiple of 16): the plain copy the rooflines are held against
-hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes);
+hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes, int variant);     // variant 0 .. copy16_variants() - 1: launch shapes
+int copy16_variants();
 // p[0 .. n_words) = value, as a kernel (why not hipMemsetAsync: api.hip)
 hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_t n_words);
 // 64-entry permutation of every block: dst[b*64 + i] = src[b*64 + table[i]]

@@ -33,22 +33,39 @@ hipError_t launch_fill_words(hipStream_t stream, void *p, uint32_t value, int64_
     return hipGetLastError();
 }
 // The copy SURVEY 8d's second denominator asks for ("what a plain device-to-device copy achieves here"): every lane moves 16
-// bytes per instruction, a wavefront 1 KiB of consecutive addresses, four loads in flight per lane, a grid that fills the chip
-// eight workgroups deep.  (torch's uint8 copy_ moved 2.1 TB/s on this chip — below what the decode kernels themselves move.)
-__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n16) {
+// bytes per instruction, a wavefront 1 KiB of consecutive addresses.  What such a copy reaches depends on its shape more than one
+// would like (tools/copy_probe.hip, one MI355X box, 2 GiB, TB/s read + written: 1 024 workgroups with one load in flight per lane
+// 5.50, 2 048 with four 4.48, 16 384 with four non-temporal 5.08, hipMemcpyAsync 4.82; torch's uint8 copy_ 2.1) and on which
+// two buffers it runs between (4.45-4.86 for one shape over seven destinations): mj_device_copy_rate runs the shapes below and
+// reports the best — a ceiling, not an average.
+typedef unsigned int mj_cu32x4 __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_copy16(const mj_cu32x4 *__restrict__ src, mj_cu32x4 *__restrict__ dst, int64_t n16) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        mj_cu32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride); else dst[i + u * stride] = v[u]; }
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
-hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes) {
+int copy16_variants() { return 4; }
+hipError_t launch_copy16(hipStream_t stream, const void *src, void *dst, int64_t bytes, int variant) {
     if (bytes <= 0) return hipSuccess;
-    const int64_t n16 = bytes / 16, want = (n16 + 1023) / 1024;
-    const int64_t cap = (int64_t)device_cus() * 8;
-    hipLaunchKernelGGL(k_copy16, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+    const int64_t n16 = bytes / 16;
+    const mj_cu32x4 *s = static_cast<const mj_cu32x4 *>(src);
+    mj_cu32x4 *d = static_cast<mj_cu32x4 *>(dst);
+    const int cus = device_cus();
+    auto grid = [&](int per_cu) { const int64_t want = (n16 + 255) / 256, cap = (int64_t)cus * per_cu; return dim3((unsigned)(want < cap ? want : cap)); };
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((k_copy16<1, false>), grid(4), dim3(256), 0, stream, s, d, n16); break;      // four workgroups per CU, one load in flight per lane
+        case 1: hipLaunchKernelGGL((k_copy16<4, false>), grid(8), dim3(256), 0, stream, s, d, n16); break;      // eight, four in flight
+        case 2: hipLaunchKernelGGL((k_copy16<4, true>), grid(32), dim3(256), 0, stream, s, d, n16); break;      // 32, four non-temporal
+        default: hipLaunchKernelGGL((k_copy16<4, true>), grid(64), dim3(256), 0, stream, s, d, n16); break;     // 64, four non-temporal
+    }
     return hipGetLastError();
 }
 hipError_t launch_permute_blocks(hipStream_t stream, const int16_t *src, int16_t *dst, int64_t n_blocks, int to_natural,
