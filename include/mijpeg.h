@@ -253,6 +253,15 @@ int mj_debug_count_tables(const mj_huff_spec *huff, int32_t n_huff, const int32_
 int mj_debug_fused_shape(int32_t cus, int32_t n_ac, int32_t n_dc, int32_t ac_slot_bytes, int32_t hmax, int32_t vmax, int32_t transposed,
                          int32_t n_images, int32_t segments_per_image, int32_t want_consumers, int32_t out[8]);
 
+/* Test hook, host only: would mj_plan_execute of such a batch be ONE fused launch (csrc/form_select.h: fused_applies, the rule
+ * mj_plan_create applies before it asks mj_debug_fused_shape's question)?  layout: MJ_LAYOUT_*; every image mcus_per_row x
+ * mcu_rows MCUs with one restart interval (0: none); traits: 1 not the lane form on resolved tables, 2 segments dealt out by length
+ * (files of mixed content), 4 segments in another order, 8 images of several geometries, 16 a sampling layout outside the common
+ * five, 32 progressive, 64 images with different restart intervals; flags: the plan's MJ_FLAG_*.
+ * *mode_out = 0 the two launches, 1 fused with whole images per workgroup, 2 fused with the hand-off across workgroups. */
+int mj_debug_fused_applies(int32_t layout, int32_t ncomp, int32_t hmax, int32_t vmax, int32_t mcus_per_row, int32_t mcu_rows,
+                           int32_t restart_interval, int32_t n_images, uint32_t traits, uint32_t flags, int32_t *mode_out);
+
 /* Test hook, host only: which scans of a progressive batch would be walked as scout + parts (csrc/form_select.h:
  * choose_prog_split, the rule mj_plan_create applies).  mode: MJ_PROG_SPLIT (1 = by the size of the batch); n_bands: band launches
  * per scan (MCU rows / rows per band); wave_slots: CUs x 32, 0 = MI355X's; parts: MJ_PROG_PARTS or 0 (not set: the rule may

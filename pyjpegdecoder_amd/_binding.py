@@ -28,7 +28,7 @@ EXPORTS = (
     "mj_plan_execute", "mj_plan_execute_stage1", "mj_plan_execute_stage2", "mj_plan_sync",
     "mj_plan_device_buffers", "mj_plan_read", "mj_plan_write_coef", "mj_plan_fill_coef",
     "mj_decode_baseline_batch", "mj_idct_batch", "mj_plan_time_stages", "mj_plan_time_execute", "mj_plan_idct_levels", "mj_host_idct_table", "mj_host_assemble", "mj_plan_stage1_form", "mj_set_option", "mj_get_option", "mj_debug_stage1_form", "mj_debug_fused_shape", "mj_debug_count_tables",
-    "mj_device_copy_rate", "mj_context_launch_clock", "mj_debug_prog_split", "mj_plan_tune_placement",
+    "mj_device_copy_rate", "mj_context_launch_clock", "mj_debug_prog_split", "mj_debug_fused_applies", "mj_plan_tune_placement",
 )
 MJ_FORM_WAVE, MJ_FORM_LANES, MJ_FORM_SYNC, MJ_FORM_SCANS, MJ_FORM_WG_TABLES, MJ_FORM_RESOLVED, MJ_FORM_FUSED, MJ_FORM_COUNT_RESOLVED = 0, 1, 2, 3, 16, 32, 64, 128
 MJ_HOST_DECLINED = 1
@@ -190,6 +190,16 @@ def fused_shape_rule(n_images, segments_per_image, hmax=2, vmax=2, transposed=Fa
         raise ValueError("mj_debug_fused_shape: bad arguments")
     return dict(zip(("ok", "images_per_wg", "producers", "lanes", "consumers", "producer_lds", "passes", "workgroups"),
                     (bool(out[0]),) + tuple(int(x) for x in out[1:])))
+
+
+def fused_applies_rule(layout, hmax, vmax, mcus_per_row, mcu_rows, restart_interval, n_images=1024, ncomp=3, traits=0, flags=0):
+    """mj_debug_fused_applies (host only): 0 the two launches, 1 one fused launch, 2 fused with the hand-off across workgroups."""
+    L = load_library()
+    out = ctypes.c_int32(-1)
+    L.mj_debug_fused_applies.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_uint32] * 2 + [ctypes.POINTER(ctypes.c_int32)]
+    if L.mj_debug_fused_applies(layout, ncomp, hmax, vmax, mcus_per_row, mcu_rows, restart_interval, n_images, traits, flags, ctypes.byref(out)) != MJ_OK:
+        raise ValueError("mj_debug_fused_applies: bad arguments")
+    return out.value
 
 
 def prog_split_rule(n_images, scans, mode=1, n_bands=68, wave_slots=0, parts=0):

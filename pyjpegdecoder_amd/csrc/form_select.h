@@ -184,11 +184,16 @@ inline int64_t fused_segments_per_image(const FusedInputs &f) {
 // by length (seg_order_mode 2: files of mixed content) — one pool of jobs, hand-off across workgroups.
 inline int fused_applies(const FusedInputs &f) {
     // x-major: a stage-2 job is an MCU column or an equal piece of one (the plan's numbering); row-major (the strip worker runs
-    // on the transposed image): pieces of an MCU row, fused.hip cuts them itself
+    // on the transposed image): pieces of an MCU row, fused.hip cuts them itself.
+    // Which intervals (measured, 1024 x 1080p, EXPERIMENTS.md round 6): row-major jobs need one row's segments, so any interval
+    // overlaps; an x-major column needs every MCU row — with a fraction of a row per segment it is complete early in every walk,
+    // with TWO rows per segment in the second half of them (-4..-11 % against the two launches), with three rows in the last
+    // third (+3 %: the walk beside consumers is slower than alone) and with an interval unrelated to the row only when nearly
+    // every segment is done (+3 %).
     const bool layout_ok = f.transposed ? f.layout == 1 : (f.layout == 0 && f.mcu_count_h > 0 && f.jobs_per_image % f.mcu_count_h == 0);
     const int64_t spi = fused_segments_per_image(f);
     const bool interval_ok = f.same_interval && spi >= 1 && spi <= 512 && f.n_segs == f.n_images * spi &&
-                             (f.transposed || f.mcu_count_h % f.restart_interval == 0);
+                             (f.transposed || f.mcu_count_h % f.restart_interval == 0 || f.restart_interval == 2 * f.mcu_count_h);
     const bool ok = f.lanes_resolved && (f.seg_order_mode == 0 || f.seg_order_mode == 2) && f.uniform && !f.generic && !f.progressive && f.ncomp == 3 &&
                     (((f.hmax == 1 || f.hmax == 2) && (f.vmax == 1 || f.vmax == 2)) || (f.hmax == 4 && f.vmax == 1 && !f.transposed)) && layout_ok &&
                     !(f.flags & f.seam_or_exact_flags) && interval_ok;

@@ -42,6 +42,21 @@ bool generic_sampling(const mj_image_desc &d, int &hmax, int &vmax) {
 
 extern "C" {
 
+int mj_debug_fused_applies(int32_t layout, int32_t ncomp, int32_t hmax, int32_t vmax, int32_t mcus_per_row, int32_t mcu_rows,
+                           int32_t restart_interval, int32_t n_images, uint32_t traits, uint32_t flags, int32_t *mode_out) {
+    if (!mode_out || mcus_per_row < 1 || mcu_rows < 1 || n_images < 1) return MJ_ERR_INVALID;
+    mj::FusedInputs f;
+    f.lanes_resolved = !(traits & 1u); f.seg_order_mode = (traits & 2u) ? 2 : ((traits & 4u) ? 1 : 0);
+    f.uniform = !(traits & 8u); f.generic = (traits & 16u) != 0; f.progressive = (traits & 32u) != 0; f.same_interval = !(traits & 64u);
+    f.layout = layout; f.transposed = (layout & 1) != 0; f.ncomp = ncomp; f.hmax = hmax; f.vmax = vmax;
+    f.flags = flags; f.seam_or_exact_flags = MJ_FLAG_EXACT_ONLY | MJ_FLAG_KEEP_PLANES | MJ_FLAG_KEEP_IDCT;
+    f.restart_interval = restart_interval; f.mcu_count_h = mcus_per_row; f.mcu_count_v = mcu_rows;
+    f.jobs_per_image = mcus_per_row;        // (x-major plans number their jobs column by column, whole or in equal pieces)
+    f.n_images = n_images; f.n_segs = (int64_t)n_images * mj::fused_segments_per_image(f);
+    *mode_out = mj::fused_applies(f);
+    return MJ_OK;
+}
+
 int mj_debug_stage1_form(const int32_t *seg_len, int64_t n_segs, uint64_t blob_len, int32_t n_huff, uint32_t traits, const char *force,
                          int32_t forced_chunk, int32_t out[4]) {
     if (!out || (n_segs > 0 && !seg_len) || n_segs < 0) return MJ_ERR_INVALID;

@@ -161,3 +161,35 @@ def test_progressive_split_tiers():
     # a smaller chip runs out of slots sooner
     small = B.prog_split_rule(200, batch(200), wave_slots=64 * 32)[0]
     assert small[8] and not small[5]
+
+
+def test_which_batches_take_the_fused_launch():
+    """form_select.h: fused_applies — the rule in front of the fused launch (mj_plan_create asks it, then fused_shape for the LDS):
+    uniform colour batches of the common samplings in the resolved-table lane form, interleaved pixels, no seam outputs; the
+    restart interval decides by pixel layout (x-major: a divisor of the MCU row, or two rows — measured, EXPERIMENTS.md;
+    row-major: any), at most 512 segments per image."""
+    X, R, PX = B.MJ_LAYOUT_XMAJOR, B.MJ_LAYOUT_ROWMAJOR, B.MJ_LAYOUT_PLANAR_XMAJOR
+    rule = B.fused_applies_rule
+    # 1080p 4:2:0: 120 x 68 MCUs
+    assert rule(X, 2, 2, 120, 68, 120) == 1 and rule(R, 2, 2, 120, 68, 120) == 1
+    for ri, x_major in ((60, 1), (40, 1), (24, 1), (240, 1), (360, 0), (100, 0), (50, 0), (480, 0)):
+        assert rule(X, 2, 2, 120, 68, ri) == x_major, ri
+        assert rule(R, 2, 2, 120, 68, ri) == 1, ri
+    assert rule(X, 2, 2, 120, 68, 0) == 0                       # no restart markers: the synchronisation form's
+    assert rule(X, 2, 2, 120, 68, 15) == 0 and rule(R, 2, 2, 120, 68, 15) == 0     # 544 segments per image: more than a workgroup's lanes
+    assert rule(X, 2, 2, 120, 68, 16) == 0 and rule(R, 2, 2, 120, 68, 16) == 1     # 510 fit; 16 does not divide 120
+    # samplings: 4:4:4 / 4:2:2 / 4:4:0 both ways, 4:1:1 in x-major output only, nothing outside those
+    for h, v in ((1, 1), (2, 1), (1, 2)):
+        assert rule(X, h, v, 120, 68, 120) == 1 and rule(R, h, v, 120, 68, 120) == 1
+    assert rule(X, 4, 1, 60, 135, 60) == 1 and rule(X, 4, 1, 60, 135, 120) == 1 and rule(R, 4, 1, 60, 135, 60) == 0
+    assert rule(X, 1, 4, 240, 34, 240) == 0 and rule(X, 4, 2, 60, 68, 60) == 0
+    assert rule(X, 1, 1, 240, 135, 240, ncomp=1) == 0           # greyscale
+    # files of mixed content (segments dealt out by length): the form with the hand-off across workgroups
+    assert rule(X, 2, 2, 120, 68, 120, traits=2) == 2 and rule(R, 2, 2, 120, 68, 60, traits=2) == 2
+    for traits in (1, 4, 8, 16, 32, 64):                        # not the lane form / another order / several geometries / generic / progressive / intervals differ
+        assert rule(X, 2, 2, 120, 68, 120, traits=traits) == 0, traits
+    assert rule(PX, 2, 2, 120, 68, 120) == 0                    # planar pixels
+    for flags in (B.MJ_FLAG_EXACT_ONLY, B.MJ_FLAG_KEEP_PLANES, B.MJ_FLAG_KEEP_IDCT):
+        assert rule(X, 2, 2, 120, 68, 120, flags=flags) == 0
+    assert rule(X, 2, 2, 120, 68, 120, flags=B.MJ_FLAG_GPU_SEGMENT) == 1
+

@@ -2377,16 +2377,16 @@ def test_fused_launches_of_several_plans_at_once(dec, mixed, tune):
 
 def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
     """What a fused launch cannot take keeps the two launches (mj_plan_stage1_form says which): in x-major output a restart
-    interval that does not divide the MCU row (two rows per segment: a column would only be complete when every segment is in
-    its last row; 25 MCUs on a row of 40), planar pixels, seam outputs, the exact-order stage 2, MJ_FUSED=0 — and whatever
-    it is, the pixels are the oracle's.  (Round 5 also kept out half rows and every interval in row-major output: those fuse now,
-    test_fused_launch_any_restart_interval.)"""
+    interval of three MCU rows (a column is only complete when every segment is in its last row — the last third of the walks:
+    measured slower than the two launches, form_select.h) or unrelated to the row (25 MCUs on a row of 40), planar pixels, seam
+    outputs, the exact-order stage 2, MJ_FUSED=0 — and whatever it is, the pixels are the oracle's.  (Round 5 also kept out half
+    rows, two rows and every interval in row-major output: those fuse now, test_fused_launch_any_restart_interval.)"""
     torch = pytest.importorskip("torch")
     from oracle import oracle
     from pyjpegdecoder_amd import _binding as B
     W, H, n, distinct = 640, 480, 800, 5
-    for kind in ("two_rows", "odd_interval", "planar", "seams", "exact", "off"):
-        ri = {"two_rows": 80, "odd_interval": 25}.get(kind)
+    for kind in ("three_rows", "odd_interval", "planar", "seams", "exact", "off"):
+        ri = {"three_rows": 120, "odd_interval": 25}.get(kind)
         layout = B.MJ_LAYOUT_PLANAR_XMAJOR if kind == "planar" else None
         flags = {"seams": B.MJ_FLAG_KEEP_IDCT, "exact": B.MJ_FLAG_EXACT_ONLY}.get(kind, 0)
         raws, files, prep = _fused_batch("420", W, H, n, distinct, 31000, ri=ri, layout=layout, flags=flags)
@@ -2406,6 +2406,9 @@ def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
     ("xmajor", "420", 640, 480, 800, 5, 20),          # half an MCU row per segment (round 5: two launches)
     ("xmajor", "444", 640, 480, 700, 6, 20),          # a quarter of a row; 240 segments per image: two passes on 256 CUs
     ("xmajor", "422", 800, 608, 900, 7, 10),          # a fifth of a row: 380 segments per image, one image per pass, four passes
+    ("xmajor", "420", 640, 480, 800, 5, 80),          # TWO rows per segment: a column is complete in the second half of the walks
+    ("xmajor", "444", 328, 200, 900, 6, 82),          # ... 41 MCUs per row, 25 rows: the last segment holds one row
+    ("xmajor", "440", 640, 480, 800, 5, 240),         # ... three rows: the two launches
     ("rowmajor", "420", 640, 480, 800, 5, 20),        # row-major: pieces of rows behind half-row segments
     ("rowmajor", "420", 640, 480, 800, 5, 80),        # ... two rows per segment
     ("rowmajor", "444", 640, 480, 600, 6, 25),        # ... an interval with no relation to the row (80 MCUs): pieces straddle segments
@@ -2418,7 +2421,7 @@ def test_fused_launch_only_where_it_applies(dec, dec_rm, tune):
 def test_fused_launch_any_restart_interval(dec, layout, ss, W, H, n, distinct, ri, tune):
     """Round 6: the fused launch no longer needs one restart interval per MCU row.  A consumer's job is ready when the producer
     waves that hold its MCUs are past them, worked out per MCU (fused.hip: JobGeo): x-major plans take every interval that
-    divides the row, row-major plans any.  Against the two launches byte for byte (coefficient store poisoned, three executes),
+    divides the row and the interval of two rows, row-major plans any.  Against the two launches byte for byte (coefficient store poisoned, three executes),
     every distinct file against the oracle, 1 / 8 consumers, markers found on the host and on the GPU."""
     torch = pytest.importorskip("torch")
     from pyjpegdecoder_amd import _binding as B
@@ -2435,7 +2438,9 @@ def test_fused_launch_any_restart_interval(dec, layout, ss, W, H, n, distinct, r
         assert np.array_equal(got, want), d
     mw, mh = (32 if ss == "411" else (16 if ss in ("420", "422") else 8)), (16 if ss in ("420", "440") else 8)
     spi = -(-(-(-W // mw) * -(-H // mh)) // ri)
+    mpr = -(-W // mw)
     want_fused = spi <= 512 and not (ss == "411" and layout == "rowmajor")     # (4:1:1 transposed: 13 KB strips, no room beside the walk)
+    want_fused = want_fused and (layout == "rowmajor" or mpr % ri == 0 or ri == 2 * mpr)
     for cons in (None, "1", "8"):
         opts = [("MJ_HUFFMAN", "lanes")] + ([("MJ_FUSED_CONSUMERS", cons)] if cons else [])
         fused, st, form = _decode_plan(dec.ctx, prep, n, torch, opts)

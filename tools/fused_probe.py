@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--ri", type=int, default=0, help="restart interval in MCUs (0 = one MCU row)")
     ap.add_argument("--segment", default="host", choices=["host", "gpu"])
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--mixed", action="store_true", help="files of mixed content (bench.py's mixed_content family)")
@@ -39,9 +40,9 @@ def main():
     dev = torch.device("cuda", 0)
     mcus_per_row = (args.width + (15 if args.subsampling in ("420", "422") else 7)) // (16 if args.subsampling in ("420", "422") else 8)
     if args.mixed:
-        blob, offs = synth.synth_mixed_batch(args.distinct, 900000, args.width, args.height, args.subsampling, mcus_per_row)
+        blob, offs = synth.synth_mixed_batch(args.distinct, 900000, args.width, args.height, args.subsampling, args.ri or mcus_per_row)
     else:
-        blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, mcus_per_row)
+        blob, offs = synth.synth_batch(args.distinct, 0, args.width, args.height, 85, args.subsampling, args.ri or mcus_per_row)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(args.distinct)]
     files = [raws[i % args.distinct] for i in range(args.batch)]
     layout = B.MJ_LAYOUT_XMAJOR if args.layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR

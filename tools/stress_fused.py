@@ -77,8 +77,8 @@ for trial in range(n_trials):
     n = int(rng.integers(n_lo, n_hi))
     distinct = int(rng.integers(2, 5))
     layout = str(rng.choice(["xmajor", "rowmajor"]))
-    if layout == "xmajor" and mpr % ri != 0 and rng.integers(0, 3) > 0:
-        layout = "rowmajor"                     # (x-major plans only fuse intervals that divide the row: keep most trials on fused ground)
+    if layout == "xmajor" and mpr % ri != 0 and ri != 2 * mpr and rng.integers(0, 3) > 0:
+        layout = "rowmajor"                     # (x-major plans only fuse intervals that divide the row, or of two rows: keep most trials on fused ground)
     lay = B.MJ_LAYOUT_XMAJOR if layout == "xmajor" else B.MJ_LAYOUT_ROWMAJOR
     gpu_seg = bool(rng.integers(0, 2))
     cons = rng.choice([None, "1", "3", "8"])
