@@ -339,6 +339,7 @@ int mj_context_launch_clock(mj_context *ctx, float *shader_mhz, float *launch_ms
  *   MJ_FUSED_ACBITS    10..13  index bits of a fused launch's AC tables (12; 11 frees 16 KB of LDS for two more strips)
  *   MJ_FUSED_SIMD_SPLIT 0 | 1  the walking wavefronts on SIMDs 0-1, the reconstructing ones on SIMDs 2-3 (default 0: mixed)
  *                     (the last three: the balance experiments of profiles/r06_fused_balance.txt — measured, defaults unchanged)
+ *   MJ_FUSED_PIECE    1..4096  MCUs per job of a row-major fused launch (its jobs are pieces of MCU rows; 20, rounded down to strips)
  *   MJ_FUSED_LUMA13   0 | 1  component 0's AC table of a fused launch with a 13-bit main level (default: only where the segments are
  *                     dealt out by length) or with 12 bits like the others
  *   MJ_FUSED_PATIENCE 0..1000000  polls before a consumer of a fused launch whose jobs cross workgroups gives a job up to the

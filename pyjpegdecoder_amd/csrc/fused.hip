@@ -618,7 +618,9 @@ hipError_t launch_fused(hipStream_t stream, const FusedShape &shape, const uint3
         // row, piece by piece, `chunk_strips` strips each): about 20 MCUs per piece, so that the consumers work a piece behind
         // the walk instead of a row behind it (an LDS ticket costs nothing: the stage-2 kernel's global counter wants big jobs)
         const int tmw = fast_tile_mcus(hmax, vmax, 3, true);    // MCUs per strip (the worker's HS is the image's vmax)
-        const int strips = std::max(1, 20 / tmw);
+        int piece = 20;
+        if (const char *e = opt("MJ_FUSED_PIECE")) piece = atoi(e);
+        const int strips = std::max(1, piece / tmw);
         const int spc = (mcus_per_row + tmw - 1) / tmw;
         F.R.chunk_strips = strips;
         F.pieces = (spc + strips - 1) / strips;

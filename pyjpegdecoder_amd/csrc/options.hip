@@ -21,6 +21,7 @@ const OptionRule kOptionRules[] = {
     {"MJ_FUSED", nullptr, 0, 1, 1},          {"MJ_FUSED_CONSUMERS", nullptr, 0, 15, 1},  {"MJ_FUSED_PATIENCE", nullptr, 0, 1000000, 1},
     {"MJ_FUSED_LUMA13", nullptr, 0, 1, 1},   {"MJ_SYNC_COUNT", "classic|resolved", 0, 0, 1}, {"MJ_SYNC_BITS", nullptr, 10, 13, 1},
     {"MJ_FUSED_ACBITS", nullptr, 10, 13, 1}, {"MJ_FUSED_PRODUCERS", nullptr, 1, 8, 1}, {"MJ_FUSED_SIMD_SPLIT", nullptr, 0, 1, 1}, {"MJ_FUSED_ORDER", "ticket|newest", 0, 0, 1},
+    {"MJ_FUSED_PIECE", nullptr, 1, 4096, 1},
     {"MJ_PROG_CHUNKS", nullptr, 0, 2, 1},    {"MJ_PROG_CHUNK", nullptr, 128, 65536, 4},
 };
 constexpr int kNumOptions = (int)(sizeof(kOptionRules) / sizeof(kOptionRules[0]));
