@@ -5,7 +5,7 @@ it) and by the two launches (MJ_FUSED=0), coefficient store poisoned before ever
 distinct file against the oracle.  With `damage` as third argument a few files of every batch get entropy-coded bytes overwritten
 (no marker made or unmade): the statuses must be the two launches', no MJ_ST_INTERNAL (a consumer that gave up waiting), the
 images that still decode identical, and no execute may take as long as the consumers' guard.  Not part of the test suite (minutes):
-    python tools/stress_fused.py [n_trials] [seed] [damage]"""
+    python tools/stress_fused.py [n_trials] [seed] [damage] [mixed]"""
 import os
 import sys
 import time
@@ -21,7 +21,8 @@ from tools import synth
 
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-damage = len(sys.argv) > 3 and sys.argv[3] == "damage"
+damage = "damage" in sys.argv[3:]
+mixed_too = "mixed" in sys.argv[3:]          # every third trial on files of mixed content
 slowest = 0.0
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
@@ -90,10 +91,15 @@ for trial in range(n_trials):
     gpu_seg = bool(rng.integers(0, 2))
     cons = rng.choice([None, "1", "3", "8"])
     fseed, q = int(rng.integers(0, 1 << 30)), int(rng.choice([50, 75, 85, 92]))
-    try:
-        blob, offs = synth.synth_batch(distinct, fseed, W, H, q, ss, ri)
-    except RuntimeError:                        # (the writer's output buffer is one byte per pixel: 4:4:4 at high quality can exceed it)
-        blob, offs = synth.synth_batch(distinct, fseed, W, H, 60, ss, ri)
+    mixed = mixed_too and trial % 3 == 2       # files of mixed content: the segments are dealt out by length, the hand-off crosses workgroups
+    if mixed:
+        distinct = int(rng.integers(8, 33))
+        blob, offs = synth.synth_mixed_batch(distinct, fseed, W, H, ss, ri)
+    else:
+        try:
+            blob, offs = synth.synth_batch(distinct, fseed, W, H, q, ss, ri)
+        except RuntimeError:                    # (the writer's output buffer is one byte per pixel: 4:4:4 at high quality can exceed it)
+            blob, offs = synth.synth_batch(distinct, fseed, W, H, 60, ss, ri)
     raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(distinct)]
     files = [raws[(3 * i + i // distinct) % distinct] for i in range(n)]
     hurt = []
@@ -128,7 +134,9 @@ for trial in range(n_trials):
     if ok:
         imgs = two.view(n, per)
         for d in range(distinct):
-            i = next(k for k in range(n) if (3 * k + k // distinct) % distinct == d and k not in hurt)
+            i = next((k for k in range(n) if (3 * k + k // distinct) % distinct == d and k not in hurt), None)
+            if i is None:                       # (every instance of this file was damaged)
+                continue
             got = imgs[i].cpu().numpy()
             got = got.reshape(W, H, 3) if layout == "xmajor" else np.swapaxes(got.reshape(H, W, 3), 0, 1)
             ok = ok and np.array_equal(got, oracle.decode(raws[d])["rgb"])
@@ -137,7 +145,7 @@ for trial in range(n_trials):
     if trial == 0:
         slowest = 0.0                           # (the first executes load the code object)
     bad += not ok
-    print(f"trial {trial:3d}: {ss} {W}x{H} x{n} ri={ri} ({mpr} MCUs per row, {spi} segments per image) {layout} markers by {'gpu' if gpu_seg else 'host'} "
+    print(f"trial {trial:3d}: {ss} {W}x{H} x{n} ri={ri} ({mpr} MCUs per row, {spi} segments per image) {'mixed content ' if mixed else ''}{layout} markers by {'gpu' if gpu_seg else 'host'} "
           f"consumers {cons}: {'fused' if fused else 'two launches'} (form {form1}) {'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"{n_trials} trials{' with damaged files' if damage else ''}, {fused_n} of them through a fused launch, {bad} mismatches, "
       f"slowest execute {slowest * 1e3:.0f} ms, {time.time() - t0:.0f} s")
