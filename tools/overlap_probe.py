@@ -1,5 +1,7 @@
 """Can stage 1 of one part of a batch run under stage 2 of another?  The config-3 batch as P plans of 1024 / P images each, stage 1 on
-one stream, stage 2 on a second one behind an event per part, against the one-plan execute.  python tools/overlap_probe.py [2 4 8]"""
+one stream, stage 2 on a second one behind an event per part, against the one-plan execute.
+    python tools/overlap_probe.py [2 4 8]            OVERLAP_RI=0 (files without restart markers), OVERLAP_N=1024 in the environment"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -11,9 +13,10 @@ from pyjpegdecoder_amd import _binding as B                       # noqa: E402
 from pyjpegdecoder_amd.batch import prepare_batch                 # noqa: E402
 from tools import synth                                           # noqa: E402
 
-N, ND, W, H = 1024, 64, 1920, 1080
+N, ND, W, H = int(os.environ.get("OVERLAP_N", "1024")), 64, 1920, 1080
+RI = int(os.environ.get("OVERLAP_RI", "120"))
 dev = torch.device("cuda", 0)
-blob, offs = synth.synth_batch(ND, 0, W, H, 85, "420", 120)
+blob, offs = synth.synth_batch(ND, 0, W, H, 85, "420", RI)
 raws = [blob[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(ND)]
 files = [raws[i % ND] for i in range(N)]
 ctx = B.Context(0)
@@ -37,7 +40,7 @@ for _ in range(20):
     whole.execute(s_main, d_rgb.data_ptr())
 torch.cuda.synchronize()
 base = (time.perf_counter() - t) / 20
-print(f"one plan of {N}: {base * 1e3:.3f} ms per batch", flush=True)
+print(f"DRI={RI}: one plan of {N}: {base * 1e3:.3f} ms per batch", flush=True)
 ref = d_rgb.clone()
 
 for parts in [int(a) for a in sys.argv[1:]] or [2, 4]:
