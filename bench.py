@@ -860,7 +860,7 @@ def main():
                 pass
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n_it = 8
+            n_it = 16
             for out3 in bd.decode_device_iter(files3 for _ in range(n_it)):
                 pass
             torch.cuda.synchronize()

@@ -583,23 +583,27 @@ class BatchDecoder:
                     item[2].close()
         return results
 
-    def decode_device_iter(self, batches):
-        """Decode a stream of batches (an iterable of lists of file bytes) with the host work and the upload of batch
-        k+1 overlapping the GPU work of batch k; yields, per batch and in order, what :meth:`decode_device` returns.
+    def decode_device_iter(self, batches, depth=2):
+        """Decode a stream of batches (an iterable of lists of file bytes) with the host work and the upload of the next
+        batches overlapping the GPU work of the ones before; yields, per batch and in order, what :meth:`decode_device` returns.
 
-        Per batch: the native host front end assembles the blob in one of two pinned buffers (host threads), the upload is
-        queued on a copy stream, the plan is created (its buffer clears run on the context's setup stream), its kernels
+        Per batch: the native host front end assembles the blob in one of ``depth + 1`` pinned buffers (host threads), the upload
+        is queued on a copy stream, the plan is created (its buffer clears run on the context's setup stream), its kernels
         are queued on the context's stream behind the previous batch's, waiting for the upload by event — and only then is the
-        previous batch collected (``mj_plan_sync`` waits for that plan's own work) and handed out.  The GPU goes from one
-        batch's kernels straight into the next's.  Batches the front end declines are decoded by :meth:`decode_device`
-        in place (no overlap for those)."""
+        batch ``depth`` places back collected (``mj_plan_sync`` waits for that plan's own work) and handed out.  With one batch
+        in flight (round 5) the host waited for batch k's kernels before it started assembling batch k + 2, and the copy engine
+        idled meanwhile: 512 x 1080p took the front end's 4.3 ms PLUS the upload's 6.1 ms per batch; with two the three —
+        host threads, copy engine, GPU — run side by side and the batch takes what the slowest of them takes.  Batches the front
+        end declines are decoded by :meth:`decode_device` in place, behind everything in flight (no overlap for those)."""
+        import collections
         import torch
         dev = torch.device("cuda", self.ctx.device)
         copy_stream = torch.cuda.Stream(device=dev)
-        pinned = [None, None]
-        uploaded = [None, None]     # event behind the latest upload out of each pinned buffer
+        depth = max(1, int(depth))
+        pinned = [None] * (depth + 1)
+        uploaded = [None] * (depth + 1)     # event behind the latest upload out of each pinned buffer
         turn = 0
-        pending = None              # ((plan, prep, d_rgb, d_blob), files) of the batch in flight
+        pending = collections.deque()       # ((plan, prep, d_rgb, d_blob), files) of the batches in flight, oldest first
 
         def finish(job):
             plan, prep, d_rgb, _ = job
@@ -627,51 +631,49 @@ class BatchDecoder:
                     out[int(i)] = img
             return out
 
-        for files in batches:
-            files = list(files)
-            prep = None
-            if self.gpu_segment and self.native_host and files:
-                buf, turn = turn, turn ^ 1
-                need = sum(map(len, files)) + 3 * len(files) + 1024
-                if uploaded[buf] is not None:
-                    uploaded[buf].synchronize()                   # two batches ago: long done
-                if pinned[buf] is None or pinned[buf].numel() < need:
-                    pinned[buf] = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
-                prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned[buf].numpy())
-            if not isinstance(prep, PreparedBatch):               # declined, or several plans' worth: the one-call path sorts it out
+        try:
+            for files in batches:
+                files = list(files)
                 prep = None
-            if prep is None:
-                if pending is not None:
-                    job, pending = pending, None
-                    yield collect(job)
-                yield self.decode_device(files)
-                continue
-            with torch.cuda.stream(copy_stream):
-                d_blob = pinned[buf][:prep.blob.size].to(dev, non_blocking=True)
-                uploaded[buf] = torch.cuda.Event()
-                uploaded[buf].record(copy_stream)
-            plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
-            try:
-                # (both tensors outlive the kernels that touch them: they stay in `pending` until the plan has been collected)
-                d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
-                self.ctx.wait_event(uploaded[buf].cuda_event)
-                ev = torch.cuda.Event()                            # see decode_device: the context's stream waits for whatever
-                ev.record(torch.cuda.current_stream(dev))          # the current stream still does with a recycled block
-                self.ctx.wait_event(ev.cuda_event)
-                plan.execute(0, d_rgb.data_ptr())
-            except BaseException:
-                plan.close()
-                raise
-            job, pending = pending, ((plan, prep, d_rgb, d_blob), files)
-            if job is not None:
+                if self.gpu_segment and self.native_host and files:
+                    buf, turn = turn, (turn + 1) % (depth + 1)
+                    need = sum(map(len, files)) + 3 * len(files) + 1024
+                    if uploaded[buf] is not None:
+                        uploaded[buf].synchronize()               # depth + 1 batches ago: long done
+                    if pinned[buf] is None or pinned[buf].numel() < need:
+                        pinned[buf] = torch.empty(need + need // 4, dtype=torch.uint8, pin_memory=True)
+                    prep = prepare_batch_native(files, self.layout, self.base_flags, staging=pinned[buf].numpy())
+                if not isinstance(prep, PreparedBatch):           # declined, or several plans' worth: the one-call path sorts it out
+                    prep = None
+                if prep is None:
+                    while pending:
+                        yield collect(pending.popleft())
+                    yield self.decode_device(files)
+                    continue
+                with torch.cuda.stream(copy_stream):
+                    d_blob = pinned[buf][:prep.blob.size].to(dev, non_blocking=True)
+                    uploaded[buf] = torch.cuda.Event()
+                    uploaded[buf].record(copy_stream)
+                plan = B.Plan(self.ctx, prep.to_c(d_blob.data_ptr()), {"prep": prep, "n_images": len(files)})
                 try:
-                    done = collect(job)
+                    # (both tensors outlive the kernels that touch them: they stay in `pending` until the plan has been collected)
+                    d_rgb = torch.empty(plan.info.rgb_bytes, dtype=torch.uint8, device=dev)
+                    self.ctx.wait_event(uploaded[buf].cuda_event)
+                    ev = torch.cuda.Event()                        # see decode_device: the context's stream waits for whatever
+                    ev.record(torch.cuda.current_stream(dev))      # the current stream still does with a recycled block
+                    self.ctx.wait_event(ev.cuda_event)
+                    plan.execute(0, d_rgb.data_ptr())
                 except BaseException:
-                    pending[0][0].close()
+                    plan.close()
                     raise
-                yield done
-        if pending is not None:
-            yield collect(pending)
+                pending.append(((plan, prep, d_rgb, d_blob), files))
+                while len(pending) > depth:
+                    yield collect(pending.popleft())
+            while pending:
+                yield collect(pending.popleft())
+        finally:
+            while pending:                                        # (an error, or a consumer that stopped early: nothing stays open)
+                pending.popleft()[0][0].close()
 
     def close(self):
         self.ctx.close()

@@ -800,8 +800,10 @@ def test_native_host_front_end_through_decode_device(dec_gs, monkeypatch):
         dec_gs.decode_device(files[:2] + [b"not a jpeg at all"])
 
 
-def test_pipelined_stream_of_batches(dec_gs):
-    """decode_device_iter: batch k+1 is assembled and uploaded while batch k is on the GPU; results come in order and are
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_pipelined_stream_of_batches(dec_gs, depth):
+    """decode_device_iter: the next batches are assembled and uploaded while the ones before are on the GPU (`depth` of them in
+    flight — round 6: two by default, so that host threads, copy engine and GPU run side by side); results come in order and are
     the same pixels, also when a batch is declined by the front end, has a tail behind a scan, or is empty-handed."""
     from tools import synth
     from oracle import oracle
@@ -820,7 +822,7 @@ def test_pipelined_stream_of_batches(dec_gs):
                 yield [pool[0], with_com, pool[2]]
             else:
                 yield [pool[i] for i in b]
-    outs = list(dec_gs.decode_device_iter(gen()))
+    outs = list(dec_gs.decode_device_iter(gen(), depth=depth))
     assert len(outs) == len(batches)
     for b, o in zip(batches, outs):
         if b == "prog":
@@ -837,8 +839,14 @@ def test_pipelined_stream_of_batches(dec_gs):
     s0 = pool[1].find(b"\xff\xda")
     broken = pool[1][:s0 + 40] + bytes(200) + pool[1][s0 + 240:]
     with pytest.raises(CorruptedJpeg):
-        list(dec_gs.decode_device_iter([[pool[0]], [broken, pool[2]], [pool[3]]]))
+        list(dec_gs.decode_device_iter([[pool[0]], [broken, pool[2]], [pool[3]], [pool[5]], [pool[6]]], depth=depth))
     assert np.array_equal(dec_gs.decode_device([pool[4]])[0].cpu().numpy(), want[4])      # the decoder is still usable
+    # a consumer that stops early leaves nothing open
+    it = dec_gs.decode_device_iter(([pool[i]] for i in range(8)), depth=depth)
+    first = next(it)
+    assert np.array_equal(first[0].cpu().numpy(), want[0])
+    it.close()
+    assert np.array_equal(dec_gs.decode_device([pool[7]])[0].cpu().numpy(), want[7])
 
 
 @pytest.mark.parametrize("cache_mb", ["0", "1", "64"])

@@ -36,8 +36,11 @@ dec = BatchDecoder(0, segment="gpu")
 for _ in dec.decode_device_iter([files[:8], files, files]): pass
 torch.cuda.synchronize()
 nb = 24
-t = time.perf_counter()
-for out in dec.decode_device_iter(files for _ in range(nb)): pass
-torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nb
-print("%-42s decode_device_iter, %d batches of 512 x 1080p: %.4f s per batch = %.0f MP/s" % ("pipelined, native host front end", nb, dt, 512 * W * H / 1e6 / dt))
+for depth in (1, 2, 3):          # batches in flight (1: round 5's pipeline — the host waited for batch k before it assembled k + 2)
+    for _ in dec.decode_device_iter((files for _ in range(3)), depth=depth): pass
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for out in dec.decode_device_iter((files for _ in range(nb)), depth=depth): pass
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nb
+    print("%-42s decode_device_iter, %d batches of 512 x 1080p, %d in flight: %.4f s per batch = %.0f MP/s" % ("pipelined, native host front end", nb, depth, dt, 512 * W * H / 1e6 / dt))
 dec.close()
