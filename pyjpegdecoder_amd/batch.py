@@ -466,15 +466,26 @@ class BatchDecoder:
             self._staging = np.empty(need + need // 4, dtype=np.uint8)
         return self._staging
 
-    def decode_device(self, files: Sequence[bytes]):
+    def decode_device(self, files: Sequence[bytes], parts: Optional[int] = None):
         """Like :meth:`decode`, but the pixels stay in HBM: a list of ``torch.uint8`` tensors on this decoder's GPU,
         views into one packed buffer per plan (zero-copy for any DLPack consumer via ``tensor.__dlpack__()``).
         torch is only the allocator here; import it before this package.
 
         With ``segment="gpu"`` a batch of everyday baseline files never meets the Python parser: libmijpeg.so's host
         front end (``mj_host_assemble``) reads the headers and assembles the batch on host threads; whatever it declines
-        takes the Python path below, which raises the reference's exceptions."""
+        takes the Python path below, which raises the reference's exceptions.  A large batch on that route goes as ``parts``
+        plans of 256 files or more (up to four) through :meth:`decode_device_iter`, so that one part's upload runs under the
+        assembly of the next and under the kernels of the one before — inside one call the three would otherwise add up."""
         import torch
+        if parts is None:
+            parts = min(4, len(files) // 256) if (self.native_host and self._gpu_segment_for(files)) else 1
+        if parts > 1:
+            n = len(files)
+            cut = [n * i // parts for i in range(parts + 1)]
+            out: List["torch.Tensor"] = []
+            for part in self.decode_device_iter((files[cut[i]:cut[i + 1]] for i in range(parts)), depth=2):
+                out += part
+            return out
         dev = torch.device("cuda", self.ctx.device)
         results: List[Optional["torch.Tensor"]] = [None] * len(files)
         parsed: Dict[int, ParsedJpeg] = {}
@@ -626,7 +637,7 @@ class BatchDecoder:
         def collect(job):
             out, again = finish(job[0])
             if again.size:                                        # only the files concerned take the long way (host parse)
-                redo = self.decode_device([job[1][int(i)] for i in again])
+                redo = self.decode_device([job[1][int(i)] for i in again], parts=1)
                 for i, img in zip(again, redo):
                     out[int(i)] = img
             return out
@@ -648,7 +659,7 @@ class BatchDecoder:
                 if prep is None:
                     while pending:
                         yield collect(pending.popleft())
-                    yield self.decode_device(files)
+                    yield self.decode_device(files, parts=1)
                     continue
                 with torch.cuda.stream(copy_stream):
                     d_blob = pinned[buf][:prep.blob.size].to(dev, non_blocking=True)

@@ -849,6 +849,43 @@ def test_pipelined_stream_of_batches(dec_gs, depth):
     assert np.array_equal(dec_gs.decode_device([pool[7]])[0].cpu().numpy(), want[7])
 
 
+def test_one_call_in_overlapped_parts(dec_gs):
+    """decode_device(files, parts=k): a large batch goes as k plans through the pipelined route (one part's upload under the next
+    part's assembly and the kernels of the one before; by default from 512 files on).  Same tensors in the same order, also with
+    a progressive file and a file with a tail behind its scan among them (those parts take the long way), and the reference's
+    exception for a corrupt file."""
+    from tools import synth
+    from oracle import oracle
+    from pyjpegdecoder_amd import CorruptedJpeg
+    pool = [synth.synth_jpeg(700 + i, 96 + 8 * (i % 4), 64 + 8 * (i % 3), 75, "420", (0, 3, 6)[i % 3], 12.0) for i in range(12)]
+    want = [oracle.decode(f)["rgb"] for f in pool]
+    praw, pvec = load_golden(prog_names()[0])
+    files = [pool[i % 12] for i in range(40)]
+    for parts in (1, 2, 3, 4):
+        got = dec_gs.decode_device(files, parts=parts)
+        assert len(got) == 40
+        for i, g in enumerate(got):
+            assert g.is_cuda and np.array_equal(g.cpu().numpy(), want[i % 12]), (parts, i)
+    mixed = list(files)
+    mixed[7] = praw
+    mixed[29] = pool[5][:-2] + b"\xff\xfe\x00\x06abcd" + b"\xff\xd9"
+    got = dec_gs.decode_device(mixed, parts=4)
+    for i, g in enumerate(got):
+        assert np.array_equal(g.cpu().numpy(), pvec["rgb"] if i == 7 else want[i % 12]), i
+    s0 = pool[1].find(b"\xff\xda")
+    broken = list(files)
+    broken[33] = pool[1][:s0 + 40] + bytes(200) + pool[1][s0 + 240:]
+    with pytest.raises(CorruptedJpeg):
+        dec_gs.decode_device(broken, parts=4)
+    # the default: parts of 256 files or more
+    many = [pool[i % 12] for i in range(520)]
+    got = dec_gs.decode_device(many)
+    assert len(got) == 520 and got[0].data_ptr() != got[519].data_ptr()
+    for i in (0, 259, 260, 519):
+        assert np.array_equal(got[i].cpu().numpy(), want[i % 12])
+    assert sum(g.numel() for g in got[:260]) <= (got[259].data_ptr() - got[0].data_ptr()) + got[259].numel()      # one buffer per part
+
+
 @pytest.mark.parametrize("cache_mb", ["0", "1", "64"])
 def test_device_buffer_cache_limits(cache_mb, monkeypatch):
     """A context keeps the device buffers of destroyed plans for the next plan (bounded, MJ_CACHE_MB).  Whatever the bound

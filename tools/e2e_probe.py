@@ -31,6 +31,23 @@ for label, kw in (("host segmentation, Python host code", dict(segment="host")),
         pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
     dec.close()
 
+# one call, as one plan or in overlapped parts (round 6: the default from 512 files on), 512 and 1024 files of 256 distinct ones
+blob2, offs2 = synth.synth_batch(256, 1000, W, H, 85, "420", 120)
+raws2 = [blob2[int(offs2[i]):int(offs2[i + 1])].tobytes() for i in range(256)]
+dec = BatchDecoder(0, segment="gpu")
+for n in (512, 1024):
+    fs = [raws2[i % 256] for i in range(n)]
+    for parts in (1, 2, 4, None):
+        dec.decode_device(fs, parts=parts)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter(); out = dec.decode_device(fs, parts=parts); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+        del out
+        ts.sort()
+        print("one call, %4d files, parts=%-4s  median %.4f s (min %.4f) = %.0f MP/s" % (n, parts, ts[2], ts[0], n * W * H / 1e6 / ts[2]))
+dec.close()
+
 # a serving loop: batches back to back, host work and upload of the next batch under the GPU work of the current one
 dec = BatchDecoder(0, segment="gpu")
 for _ in dec.decode_device_iter([files[:8], files, files]): pass
