@@ -446,6 +446,9 @@ def main():
                     help="images per plan in the per-GPU queue (--total-images): stage 1 lasts as long as one restart segment's walk "
                          "whatever the plan holds, up to ~1400 1080p images, so plans are as large as the share allows")
     ap.add_argument("--queue-depth", type=int, default=2, help="plans in flight at once in the per-GPU queue, one stream each")
+    ap.add_argument("--queue-collect-first", action="store_true",
+                    help="A/B: the queue collects a slot's previous plan before it creates the next one (the new plan then takes over its "
+                         "buffers: a fixed pairing of coefficient store and output slot; measured 3 %% slower)")
     ap.add_argument("--layout", default="xmajor", choices=["xmajor", "rowmajor"])
     ap.add_argument("--segment", default="host", choices=["host", "gpu"],
                     help="who finds the restart markers: the host parser (default) or stage 0 on the GPU (then inside the timed step)")
@@ -531,7 +534,7 @@ def main():
         # (across_passes: a pass — the rank's share of one job — hands over to the next without draining the GPU: the next
         # pass's plan is created while this pass's kernels run, as the next job's would be in a service; the fence drains)
         queue = DeviceImageQueue(ctx, files, args.queue_batch, layout, args.queue_depth, device=local_rank, across_passes=True,
-                                 tune_placement=args.tune_placement)
+                                 tune_placement=args.tune_placement, collect_first=args.queue_collect_first)
         torch.cuda.synchronize()
         host_prep_s, h2d_s = time.perf_counter() - t0, None
 
